@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the *reference itself* (imported read-only from
+/root/reference, CPU) and stores inputs + expected outputs as small .npz fixtures
+under tests/golden/.  Runs only in the build container; the GPU box never sees the
+reference.  Re-run:  python oracle/gen_golden.py
+
+Shims (no reference source is modified or copied):
+  * SPUIGACF.py:342,367,370 hard-code device='cuda' -> a TorchFunctionMode maps
+    device='cuda' to 'cpu'; models are built with useCuda=False.
+  * metrics.py:52,77 use np.asfarray (gone in NumPy 2) -> aliased to np.asarray(float).
+  * dropout sites are pinned by replacing the layer *instance's* .dropout attribute
+    with a fixed-mask module and by patching F.dropout while a fixed-mask run is on.
+"""
+import hashlib
+import os
+import sys
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.overrides import TorchFunctionMode
+
+if not hasattr(np, "asfarray"):
+    np.asfarray = lambda a, dtype=np.float64: np.asarray(a, dtype=dtype)
+
+import graphattention.SPUIGACF as R          # noqa: E402
+import graphattention.SPGA as RS             # noqa: E402
+import graphattention.BPRLoss as RB          # noqa: E402
+import graphattention.metrics as RM          # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+class CpuDevice(TorchFunctionMode):
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = dict(kwargs or {})
+        if kwargs.get("device", None) == "cuda":
+            kwargs["device"] = "cpu"
+        return func(*args, **kwargs)
+
+
+class FixedMask(torch.nn.Module):
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, x):
+        return x * self.mask
+
+
+def toy_graph(U=50, I=40, E=320, seed=7):
+    """3 isolated items (37,38,39), user 0 has degree 1, item 0 is a hub."""
+    rs = np.random.RandomState(seed)
+    pairs = {(0, 0)}
+    for u in range(1, U):
+        pairs.add((u, int(rs.randint(0, I - 3))))        # every user >= 1 edge
+    for u in range(1, U, 2):
+        pairs.add((u, 0))                                 # hub item 0
+    while len(pairs) < E:
+        u, i = int(rs.randint(1, U)), int(rs.randint(0, I - 3))
+        pairs.add((u, i))
+    arr = np.array(sorted(pairs), dtype=np.int64).T      # row-major sorted = coalesce() order
+    return arr
+
+
+def sd_numpy(module):
+    return {k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def g1_layers(edge, U, I):
+    """G1: one SpUIGraphAttentionLayer, k=8/concat and k=64/no-concat, with e_rowsum/e_colsum."""
+    for tag, k, concat in (("k8_concat", 8, True), ("k64_noconcat", 64, False)):
+        torch.manual_seed(11 + k)
+        layer = R.SpUIGraphAttentionLayer(64, k, dropout=0.0, alpha=0.2, concat=concat).eval()
+        X = torch.randn(U + I, 64) * 0.5
+        e_t = torch.from_numpy(edge)
+        with CpuDevice():
+            out = layer(torch.arange(U), torch.arange(I) + U, X, e_t)
+        # recompute the two normalisers with the reference's own ops for the fixture
+        u_h, i_h = X[:U] @ layer.W_u, X[U:] @ layer.W_i
+        eh = torch.cat((u_h[e_t[0]], i_h[e_t[1]]), 1).t()
+        ee = torch.exp(-layer.leakyrelu(layer.a.mm(eh).squeeze()))
+        A = torch.sparse_coo_tensor(e_t, ee, (U, I))
+        rs = torch.sparse.mm(A, torch.ones(I, 1))
+        cs = torch.sparse.mm(A.t(), torch.ones(U, 1))
+        save("g1_layer_" + tag, X=X.numpy(), W_u=layer.W_u.detach().numpy(), W_i=layer.W_i.detach().numpy(),
+             a=layer.a.detach().numpy(), edge=edge, U=U, I=I, out=out.detach().numpy(),
+             e_rowsum=rs.detach().numpy().ravel(), e_colsum=cs.detach().numpy().ravel())
+
+
+def g2_g3_g4_model(edge, U, I, multi, tag):
+    """G2/G5 stack output, G3 scores + BPR loss, G4 all parameter grads (droprate 0, train mode),
+    fp32 and a float64 re-run for tolerance calibration."""
+    cls = R.SPUIMultiGACF if multi else R.SPUIGACF
+    rs = np.random.RandomState(3)
+    B = 32
+    u = rs.randint(0, U, B).astype(np.int64)
+    pos = rs.randint(0, I, B).astype(np.int64)
+    neg = rs.randint(0, I, B).astype(np.int64)
+    out = {}
+    state32 = None
+    for dt_name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.set_default_dtype(dt)
+        torch.manual_seed(5)
+        m = cls(U, I, 64, [64, 64], 0.0, useCuda=False)
+        if state32 is None:
+            with torch.no_grad():              # embeddings scaled up so gradients are not ~1e-9
+                m.uEmbd.weight.mul_(30.0)
+                m.iEmbd.weight.mul_(30.0)
+            state32 = {k_: v.clone() for k_, v in m.state_dict().items()}
+        else:                                  # identical parameters, promoted to float64
+            m.load_state_dict({k_: v.double() for k_, v in state32.items()})
+        m.train()
+        e_t = torch.from_numpy(edge)
+        with CpuDevice():
+            _, _, feats = m.getFeatureMat()
+            Fout = m.gat(torch.arange(U), torch.arange(I) + U, feats, e_t)
+            ps = m(torch.from_numpy(u), torch.from_numpy(pos), e_t)
+            ns = m(torch.from_numpy(u), torch.from_numpy(neg), e_t)
+            loss = RB.BPRLoss()(ps, ns)
+            loss.backward()
+        if dt_name == "f32":
+            for k_, v in sd_numpy(m).items():
+                out["p." + k_] = v
+        out["F_" + dt_name] = Fout.detach().numpy()
+        out["pos_" + dt_name] = ps.detach().numpy()
+        out["neg_" + dt_name] = ns.detach().numpy()
+        out["loss_" + dt_name] = loss.detach().numpy()
+        for k_, p in m.named_parameters():
+            out["g_%s.%s" % (dt_name, k_)] = p.grad.detach().numpy()
+    torch.set_default_dtype(torch.float32)
+    save("g234_" + tag, edge=edge, U=U, I=I, u=u, pos=pos, neg=neg, **out)
+
+
+def g4b_fixed_dropout(edge, U, I):
+    """Train-mode SPUIGACF with *pinned* dropout masks at all three sites; pins the
+    'numerators only' semantics (SPUIGACF.py:375) and the feature dropout (:208,:213)."""
+    torch.manual_seed(9)
+    p = 0.25
+    m = R.SPUIGACF(U, I, 64, [64, 64], p, useCuda=False)
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30.0)
+        m.iEmbd.weight.mul_(30.0)
+    m.train()
+    rs = np.random.RandomState(21)
+    E = edge.shape[1]
+    keep = 1.0 / (1.0 - p)
+    emasks = (rs.rand(9, E) >= p).astype(np.float32) * keep
+    fmasks = (rs.rand(2, U + I, 64) >= p).astype(np.float32) * keep
+    layers = [getattr(m.gat, "attention_%d" % h) for h in range(8)] + [m.gat.out_att]
+    for l, em in zip(layers, emasks):
+        l.dropout = FixedMask(torch.from_numpy(em))
+    calls = {"n": 0}
+    real = F.dropout
+
+    def fake(x, p=0.5, training=True, inplace=False):
+        i = calls["n"] % 2
+        calls["n"] += 1
+        return x * torch.from_numpy(fmasks[i])
+    B = 32
+    u = rs.randint(0, U, B).astype(np.int64)
+    it = rs.randint(0, I, B).astype(np.int64)
+    R.F.dropout = fake
+    try:
+        with CpuDevice():
+            sc = m(torch.from_numpy(u), torch.from_numpy(it), torch.from_numpy(edge))
+            sc.sum().backward()
+    finally:
+        R.F.dropout = real
+    out = {"p." + k_: v for k_, v in sd_numpy(m).items() if "mask" not in k_}
+    for k_, p_ in m.named_parameters():
+        out["g." + k_] = p_.grad.detach().numpy()
+    save("g4b_fixed_dropout", edge=edge, U=U, I=I, u=u, item=it, emasks=emasks, fmasks=fmasks,
+         scores=sc.detach().numpy(), **out)
+
+
+def g6_spga():
+    torch.manual_seed(13)
+    N = 60
+    rs = np.random.RandomState(4)
+    adj = (rs.rand(N, N) < 0.08)
+    adj[np.arange(N), np.arange(N)] = True               # every row non-empty
+    adj_t = torch.from_numpy(adj.astype(np.float32))
+    X = torch.randn(N, 64) * 0.5
+    res = {}
+    for tag, k, concat in (("k8", 8, True), ("k64", 64, False)):
+        l = RS.SpGraphAttentionLayer(64, k, dropout=0.0, alpha=0.2, concat=concat).eval()
+        out = l(X, adj_t)
+        res.update({"W_" + tag: l.W.detach().numpy(), "a_" + tag: l.a.detach().numpy(),
+                    "out_" + tag: out.detach().numpy()})
+    save("g6_spga_layer", X=X.numpy(), edge=np.stack(np.nonzero(adj)).astype(np.int64), N=N, **res)
+
+
+def g7_static_spmm(edge, U, I):
+    """GPLayer (L + I) @ X with L = mean_adj built by the reference's buildLaplacianMat."""
+    import pandas as pd
+    from data.loadGowalla import buildLaplacianMat, scipySP_torchSP
+    rt = pd.DataFrame({"userId": edge[0], "itemId": edge[1], "rating": np.ones(edge.shape[1])})
+    L = buildLaplacianMat(rt, U, I, "mean_adj")
+    Lt = scipySP_torchSP(L).coalesce()
+    N = U + I
+    torch.manual_seed(17)
+    X = torch.randn(N, 64)
+    eye = torch.sparse_coo_tensor(torch.arange(N).repeat(2, 1), torch.ones(N), (N, N))
+    out = torch.sparse.mm(Lt + eye, X)
+    save("g7_static_spmm", edge=edge, U=U, I=I, X=X.numpy(), L_row=Lt.indices()[0].numpy(),
+         L_col=Lt.indices()[1].numpy(), L_val=Lt.values().numpy(), out=out.numpy())
+
+
+def g8_metrics():
+    import train_eval_Gowalla as TE
+    rs = np.random.RandomState(8)
+    rvecs = [np.array([1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1]),
+             np.zeros(20, dtype=np.int64), np.ones(20, dtype=np.int64),
+             np.array([0] * 19 + [1]), (rs.rand(20) < 0.3).astype(np.int64),
+             np.array([0, 1, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0])]
+    Ks = [1, 5, 10, 20]
+    npos = [7, 3, 25, 1, 9, 3]
+    res = np.zeros((len(rvecs), 4, 4))
+    for j, (r, n) in enumerate(zip(rvecs, npos)):
+        perf = TE.get_performance(list(range(n)), list(r), 0.0, Ks)
+        for c, key in enumerate(("precision", "recall", "ndcg", "hit_ratio")):
+            res[j, c] = perf[key]
+    # ranklist_by_heapq with score ties
+    ratings = np.round(rs.rand(50), 1)                    # many ties
+    test_items = [int(x) for x in rs.permutation(50)[:35]]
+    user_pos = [int(x) for x in rs.permutation(50)[:6]]
+    r, _ = TE.ranklist_by_heapq(user_pos, test_items, list(ratings), Ks)
+    save("g8_metrics", rvecs=np.stack(rvecs), npos=np.array(npos), perf=res, ratings=ratings,
+         test_items=np.array(test_items), user_pos=np.array(user_pos), r=np.array(r))
+
+
+def g9_g10_ml100k():
+    """ml100k ui_mat digest (no file is written next to the reference data: the matrix is
+    built in memory with the reference's buildLaplacianMat + coalesce) and a medium-graph
+    SpUIGAT eval output."""
+    import pandas as pd
+    from data.loadGowalla import buildLaplacianMat, scipySP_torchSP
+    rt = pd.read_table(REF + "/data/1K/u.data", sep="\t", names=["userId", "itemId", "rating", "timestamp"])
+    U, I = int(rt["userId"].max()), int(rt["itemId"].max())
+    rt["userId"] -= 1
+    rt["itemId"] -= 1
+    adj = scipySP_torchSP(buildLaplacianMat(rt, U, I, "ui_mat")).coalesce()
+    idx = adj.indices().numpy()
+    digest = hashlib.sha256(np.ascontiguousarray(idx).tobytes()).hexdigest()
+    # raw interactions in file order (data, small ints) so the GPU box can rebuild everything
+    save("ml100k_interactions", userId=rt["userId"].values.astype(np.int16),
+         itemId=rt["itemId"].values.astype(np.int16), rating=rt["rating"].values.astype(np.int8))
+    torch.manual_seed(2019)
+    m = R.SPUIGACF(U, I, 64, [64, 64], 0.1, useCuda=False).eval()
+    emb = (np.random.RandomState(2019).randn(U + I, 64) * 0.01).astype(np.float32)   # N(0, 0.01^2), :27-28
+    with torch.no_grad():
+        m.uEmbd.weight.copy_(torch.from_numpy(emb[:U]))
+        m.iEmbd.weight.copy_(torch.from_numpy(emb[U:]))
+    with CpuDevice():
+        _, _, feats = m.getFeatureMat()
+        Fout = m.gat(torch.arange(U), torch.arange(I) + U, feats, adj.indices())
+    Fo = Fout.detach().numpy()
+    rows = np.random.RandomState(1).permutation(U + I)[:256]
+    gat = {"p." + k_: v for k_, v in sd_numpy(m).items() if k_.startswith("gat.")}
+    save("g9_g10_ml100k", shape=np.array([U, I]), nnz=idx.shape[1], sha256=np.array(digest),
+         first16=idx[:, :16], last16=idx[:, -16:], emb_seed=2019,
+         rows=rows, F_rows=Fo[rows], F_sum=np.float64(Fo.astype(np.float64).sum()),
+         F_abs_sum=np.float64(np.abs(Fo.astype(np.float64)).sum()), **gat)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    edge = toy_graph()
+    U, I = 50, 40
+    g1_layers(edge, U, I)
+    g2_g3_g4_model(edge, U, I, multi=False, tag="spuigacf")
+    g2_g3_g4_model(edge, U, I, multi=True, tag="spuimultigacf")
+    g4b_fixed_dropout(edge, U, I)
+    g6_spga()
+    g7_static_spmm(edge[:, edge[1] < 37], U, 37)      # buildLaplacianMat infers shapes from max ids
+    g8_metrics()
+    g9_g10_ml100k()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""Pins oracle/ngacf_oracle.py to the fixtures the reference itself produced
+(oracle/gen_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, params_of
+from oracle import ngacf_oracle as O
+
+
+def _maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+@pytest.mark.parametrize("tag,concat", [("k8_concat", True), ("k64_noconcat", False)])
+def test_g1_layer(tag, concat):
+    g = load_golden("g1_layer_" + tag)
+    U, I = int(g["U"]), int(g["I"])
+    f = O.layer_forward(g["X"], g["W_u"], g["W_i"], g["a"], g["edge"], U, I, 0.2, concat)
+    assert _maxabs(f["out"], g["out"]) < 2e-6
+    assert _maxabs(f["R"], g["e_rowsum"]) < 1e-5
+    assert _maxabs(f["C"], g["e_colsum"]) < 1e-5
+    assert (g["e_colsum"][37:] == 0).all()          # the three isolated items
+    assert np.array_equal(f["out"][U + 37:], f["i_h"][37:] if not concat else O.elu(f["i_h"][37:]))
+
+
+@pytest.mark.parametrize("tag,multi", [("spuigacf", False), ("spuimultigacf", True)])
+def test_g234_stack_scores_loss_grads(tag, multi):
+    g = load_golden("g234_" + tag)
+    U, I = int(g["U"]), int(g["I"])
+    p32 = params_of(g)
+    # fp32 forward vs reference fp32
+    F = O.spuigat_forward(p32, O.features_of(p32), g["edge"], U, I, multi=multi)
+    assert _maxabs(F, g["F_f32"]) < 5e-6
+    # float64 run vs reference float64: the restatement is exact to rounding
+    p64 = {k: v.astype(np.float64) for k, v in p32.items()}
+    loss, pos, neg, grads = O.bpr_step_grads(p64, g["u"], g["pos"], g["neg"], g["edge"], multi=multi)
+    assert _maxabs(pos, g["pos_f64"]) < 1e-12
+    assert _maxabs(neg, g["neg_f64"]) < 1e-12
+    assert abs(loss - float(g["loss_f64"])) < 1e-12
+    for k, v in grads.items():
+        ref = g["g_f64." + k]
+        assert _maxabs(v, ref) <= 1e-11 * max(1.0, float(np.abs(ref).max())), k
+    assert set(grads) == {k[len("g_f64."):] for k in g if k.startswith("g_f64.")}
+    # fp32 grads of the reference sit within fp32 noise of the float64 truth
+    for k in grads:
+        scale = max(float(np.abs(g["g_f64." + k]).max()), 1e-12)
+        assert _maxabs(g["g_f32." + k], g["g_f64." + k]) / scale < 1e-3
+
+
+def test_g4b_fixed_dropout_forward_and_grads():
+    g = load_golden("g4b_fixed_dropout")
+    U, I = int(g["U"]), int(g["I"])
+    p = {k: v.astype(np.float64) for k, v in params_of(g).items()}
+    em = [[g["emasks"][h].astype(np.float64) for h in range(8)], [g["emasks"][8].astype(np.float64)]]
+    fm = [g["fmasks"][0].astype(np.float64), g["fmasks"][1].astype(np.float64)]
+    X = O.features_of(p)
+    F, tape = O.spuigat_forward(p, X, g["edge"], U, I, feat_masks=fm, edge_masks=em, keep=True)
+    sc = np.sum(F[g["u"]] * F[g["item"] + U], 1)
+    assert _maxabs(sc, g["scores"]) < 1e-5
+    gF = np.zeros_like(F)
+    np.add.at(gF, g["u"], F[g["item"] + U])
+    np.add.at(gF, g["item"] + U, F[g["u"]])
+    dX, grads = O.spuigat_backward(gF, tape, p, g["edge"], U, I, feat_masks=fm, edge_masks=em)
+    grads["uEmbd.weight"], grads["iEmbd.weight"] = dX[:U], dX[U:]
+    for k, v in grads.items():
+        ref = g["g." + k]
+        assert _maxabs(v, ref) <= 2e-4 * max(float(np.abs(ref).max()), 1e-6), k     # reference ran in fp32
+
+
+def test_g6_spga_layer():
+    g = load_golden("g6_spga_layer")
+    for tag, concat in (("k8", True), ("k64", False)):
+        out = O.spga_layer_forward(g["X"], g["W_" + tag], g["a_" + tag], g["edge"], 0.2, concat)
+        assert _maxabs(out, g["out_" + tag]) < 5e-6
+
+
+def test_g7_static_spmm_and_mean_adj():
+    g = load_golden("g7_static_spmm")
+    U, I = int(g["U"]), int(g["I"])
+    out = O.static_spmm(g["L_row"], g["L_col"], g["L_val"], g["X"])
+    assert _maxabs(out, g["out"]) < 5e-6
+    r, c, v = O.mean_adj(g["edge"], U, I)
+    import scipy.sparse as sp
+    mine = sp.coo_matrix((v, (r, c)), shape=(U + I, U + I)).toarray()
+    ref = sp.coo_matrix((g["L_val"], (g["L_row"], g["L_col"])), shape=(U + I, U + I)).toarray()
+    assert _maxabs(mine, ref) < 1e-6
+
+
+def test_g8_metrics_and_ranking():
+    g = load_golden("g8_metrics")
+    Ks = (1, 5, 10, 20)
+    for r, n, perf in zip(g["rvecs"], g["npos"], g["perf"]):
+        p = O.performance(list(range(int(n))), list(r), Ks)
+        for c, key in enumerate(("precision", "recall", "ndcg", "hit_ratio")):
+            assert np.allclose(p[key], perf[c], atol=1e-12), key
+    # the inflated-NDCG quirk: a single hit at rank 20 still scores 1/log2(21)/1
+    assert abs(O.ndcg_at_k([0] * 19 + [1], 20) - (1 / np.log2(21)) / 1.0) < 1e-12
+    r = O.ranklist(list(g["user_pos"]), [int(x) for x in g["test_items"]], list(g["ratings"]), Ks)
+    assert r == list(g["r"])
+
+
+def test_g9_ml100k_adjacency_digest():
+    g = load_golden("g9_g10_ml100k")
+    d = load_golden("ml100k_interactions")
+    u, i = d["userId"].astype(np.int64), d["itemId"].astype(np.int64)
+    U, I = int(g["shape"][0]), int(g["shape"][1])
+    assert (U, I) == (943, 1682) and int(g["nnz"]) == 100000
+    key = np.unique(u * I + i)                                   # coalesce(): row-major sorted, unique
+    idx = np.stack([key // I, key % I])
+    assert idx.shape[1] == 100000
+    assert hashlib.sha256(np.ascontiguousarray(idx).tobytes()).hexdigest() == str(g["sha256"])
+    assert np.array_equal(idx[:, :16], g["first16"]) and np.array_equal(idx[:, -16:], g["last16"])
+
+
+def test_g10_ml100k_medium_graph_eval_output():
+    g = load_golden("g9_g10_ml100k")
+    d = load_golden("ml100k_interactions")
+    U, I = int(g["shape"][0]), int(g["shape"][1])
+    key = np.unique(d["userId"].astype(np.int64) * I + d["itemId"].astype(np.int64))
+    edge = np.stack([key // I, key % I])
+    X = (np.random.RandomState(int(g["emb_seed"])).randn(U + I, 64) * 0.01).astype(np.float32)
+    p = params_of(g)
+    F = O.spuigat_forward(p, X, edge, U, I)
+    assert _maxabs(F[g["rows"]], g["F_rows"]) < 1e-6
+    assert abs(float(F.astype(np.float64).sum()) - float(g["F_sum"])) < 1e-3
+    assert abs(float(np.abs(F.astype(np.float64)).sum()) - float(g["F_abs_sum"])) < 1e-3
