@@ -1,0 +1,141 @@
+/*
+ * ngacf.h -- C ABI of the MI355X (gfx950) graph-attention propagation library.
+ *
+ * The reference (cleverer123/NGACF) has no FFI: its hot path is a chain of ATen
+ * calls inside nn.Module.forward.  Each entry point below replaces one such chain;
+ * the citation names the reference lines it stands in for (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated; the library owns nothing;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it;
+ *   - return value: 0 on success, a negative NGACF_E_* code for a rejected
+ *     argument (nothing was launched), or a positive hipError_t from the launch;
+ *   - no global mutable state: safe from several host threads on different devices.
+ *
+ * Node numbering: users are 0..U-1, items are U..U+I-1 (N = U+I), exactly the
+ * `features = cat([userEmbd, itemEmbd])` order of graphattention/SPUIGACF.py:38-39.
+ *
+ * Graph plan (built once per adjacency by the host, see ngacf_amd/plan.py):
+ *   col   int32[2E]      source node (global id) of every directed edge; the 2E entries
+ *                        are the CSR of the user rows followed by the CSC of the item rows
+ *   segs  int32[nseg][4] work items {dst row, first edge, one-past-last edge, part}:
+ *                        part < 0  -> the segment is the whole row, finished in place;
+ *                        part >= 0 -> slice of a long row, partial sums go to slot `part`
+ *   split int32[nsplit][3] {dst row, first part slot, number of slots} for the long rows
+ */
+#ifndef NGACF_H
+#define NGACF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGACF_F32  0
+#define NGACF_BF16 1
+
+/* flags of ngacf_prop_* */
+#define NGACF_ELU        1   /* apply ELU to h + agg (SPUIGACF.py:395-397 and the outer F.elu :214) */
+#define NGACF_RESIDUAL   2   /* out = h_dst + agg (SPUIGACF.py:383,390); clear for SPGA.py:405-409 */
+#define NGACF_SCORE_ROW  4   /* recompute the source score a_src . h_src from the gathered row
+                                instead of reading S_src (saves 4*heads bytes per edge) */
+
+#define NGACF_TBWD_BLOCKS 256 /* workgroups of the dW reduction in ngacf_transform_bwd */
+
+#define NGACF_E_ARG     (-1)  /* null pointer / negative size */
+#define NGACF_E_SHAPE   (-2)  /* unsupported (d, heads, dtype) combination */
+
+const char* ngacf_version(void);
+
+/* Row transform + per-node attention scores.
+ * Replaces torch.mm(features[uidx], W_u), torch.mm(features[iidx], W_i) (SPUIGACF.py:356-357)
+ * for all heads of a stage at once, the feature dropout in front of the stage (:208,:213), and
+ * the node halves of a.mm(edge_h) (:359-361):  S[n,h] = sum_{c in head h} H[n,c] * avec[type(n)][c].
+ *   X     [N,din]   x_dtype          W    float[2][din][dout]  (0 = W_u heads side by side, 1 = W_i)
+ *   avec  float[2][dout]  (0 = the a[:, :k] halves of the heads, 1 = the a[:, k:] halves)
+ *   H     [N,dout]  h_dtype          S    float[N][heads]
+ * feat_drop_p > 0 multiplies X by the counter-hash dropout mask keyed by (seed, n, c). */
+int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, const float* avec,
+                        void* H, int h_dtype, float* S,
+                        int U, int I, int din, int dout, int heads,
+                        float feat_drop_p, uint64_t seed, void* stream);
+
+/* Attention propagation, forward, both directions in one launch.
+ * Replaces SPUIGACF.py:359-393 (edge gather, exp(-leakyrelu), e_rowsum/e_colsum, edge dropout,
+ * the two numerator sparse.mm, div, NaN->0, residual) plus the ELU of :397/:214.
+ *   H      [N,d] dtype     S_dst,S_src float[N][heads] (may alias; S_src unused with NGACF_SCORE_ROW)
+ *   avec   float[2][d]     (as in ngacf_transform_fwd; used only with NGACF_SCORE_ROW)
+ *   out    [N,d] dtype     agg float[N][d] / R float[N][heads]: normalised aggregate and
+ *                          denominators, saved for the backward (both may be NULL)
+ *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for long rows
+ * drop_p > 0 applies the edge dropout of :375 (numerators only), mask keyed by
+ * (seed, head, user, item) so both directions see the same mask. */
+int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                   const int32_t* col, const void* H, int dtype,
+                   const float* S_dst, const float* S_src, const float* avec,
+                   void* out, float* agg, float* R, float* part_acc, float* part_r,
+                   int U, int N, int d, int heads, float alpha,
+                   float drop_p, uint64_t seed, int flags, void* stream);
+
+/* Backward of ngacf_prop_fwd (autograd of SPUIGACF.py:359-397; formulas SURVEY.md §8(a) A4b).
+ * Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  t[n,h] = (g . agg)_h / R
+ * Step 2 (per edge, pull):  dH[n] = g[n] + sum_src m e Gn[src] + dS[n,h] * avec[type(n)]
+ *                           dS[n,h] = sum_src -e * lrelu'(s) * (m Gn[n].H[src] - t[n] + m Gn[src].H[n] - t[src])
+ *   gout [N,d] float   out [N,d] dtype (forward output)   agg, R: as saved by the forward
+ *   G, Gn float[N][d], t float[N][heads]: workspace        dH float[N][d], dS float[N][heads]: results
+ *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for long rows */
+int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                   const int32_t* col, const void* H, int dtype,
+                   const float* S_dst, const float* S_src, const float* avec,
+                   const void* out, const float* agg, const float* R, const float* gout,
+                   float* G, float* Gn, float* t, float* dH, float* dS,
+                   float* part_acc, float* part_r,
+                   int U, int N, int d, int heads, float alpha,
+                   float drop_p, uint64_t seed, int flags, void* stream);
+
+/* Backward of ngacf_transform_fwd (autograd of SPUIGACF.py:356-357 and the a.mm of :361).
+ *   dX   float[N][din]          = mask * (dH @ W[type]^T)
+ *   dW   float[2][din][dout]    = (mask * X)[type rows]^T @ dH[type rows]
+ *   davec float[2][dout]        = sum_n dS[n,head(c)] * H[n,c]
+ *   work  float[NGACF_TBWD_BLOCKS][din*dout + dout]: per-workgroup partial sums, reduced in
+ *         workgroup order (no atomics: results are bitwise reproducible)
+ * dH already contains the dS*avec term (ngacf_prop_bwd adds it). */
+int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
+                        const float* dH, const float* dS,
+                        float* dX, float* dW, float* davec, float* work,
+                        int U, int I, int din, int dout, int heads,
+                        float feat_drop_p, uint64_t seed, void* stream);
+
+/* Pair scoring: score[b] = sum_c F[u[b],c] * F[U + i[b],c]   (SPUIGACF.py:49-52). */
+int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
+                    float* score, int B, int U, int d, void* stream);
+/* gF[u[b]] += g[b] * F[U+i[b]],  gF[U+i[b]] += g[b] * F[u[b]]   (float atomics; gF float[N][d]) */
+int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
+                    const float* gscore, float* gF, int B, int U, int d, void* stream);
+
+/* BPR loss  -mean(log(sigmoid(pos - neg)))  (graphattention/BPRLoss.py:8-9).
+ * loss is a single float, accumulated with atomics: zero it first. */
+int ngacf_bpr_fwd(const float* pos, const float* neg, float* loss, int B, void* stream);
+/* gpos[b] = -gloss * sigmoid(neg-pos) / B ; gneg = -gpos */
+int ngacf_bpr_bwd(const float* pos, const float* neg, const float* gloss,
+                  float* gpos, float* gneg, int B, void* stream);
+
+/* Static-weight propagation  out[n] = (self_loop ? X[n] : 0) + sum_e val[e] * X[col[e]]
+ * (GPLayer.forward, SPUIGACF.py:178-185: torch.sparse.mm(L + I, features)). */
+int ngacf_spmm_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                   const int32_t* col, const float* val, const void* X, int dtype,
+                   void* out, float* part_acc, int N, int d, int self_loop, void* stream);
+
+/* Counter-hash dropout mask bits, exposed so tests can pin the device RNG against the
+ * host restatement: bits[k] = the 32-bit hash the kernels compare against drop_p * 2^32.
+ * kind 0: feature mask, a = node, b = column.  kind 1: edge mask, a = user, b = item (global id), c = head. */
+int ngacf_dropout_bits(int kind, uint64_t seed, const int32_t* a, const int32_t* b, const int32_t* c,
+                       uint32_t* bits, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGACF_H */

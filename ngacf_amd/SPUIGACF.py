@@ -1,0 +1,243 @@
+"""Drop-in module surface of the reference's graphattention/SPUIGACF.py, backed by the
+HIP library.  Constructor signatures, forward signatures, parameter names/shapes and
+therefore state_dict keys are the reference's:
+
+  SPUIGACF(userNum, itemNum, embedSize, layers, droprate, useCuda=True)        SPUIGACF.py:7
+      .forward(userIdx[B], itemIdx[B], mask[2,E] | [1,2,E]) -> scores[B]       SPUIGACF.py:41
+  SPUIMultiGACF (three propagation stages)                                     SPUIGACF.py:54
+  SPUIGAGPCF  (+ GPLayer static-weight propagation and Linear/ReLU stack)      SPUIGACF.py:103
+  SpUIGAT(nfeat, nhid, nclass, dropout, alpha, nheads).forward(uidx, iidx, features, adj)   :187
+  SPUIMultiGAT                                                                 :217
+  SpUIGraphAttentionLayer(in_dim, out_dim, dropout, alpha, concat)
+      .forward(uidx, iidx, features, indices)                                  :258,:340
+
+What differs from the reference is only *how* a stage is computed: the eight heads of a
+stage run as one fused 64-wide pass (weights concatenated on the fly, so checkpoints stay
+interchangeable), and dropout masks come from a counter hash instead of torch's RNG.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as NF
+from .plan import build_plan
+
+_PLAN_CACHE_MAX = 4
+
+
+class _PlanCache:
+    """Per-module cache of graph plans keyed by the identity of the `mask` tensor the
+    caller passes on every forward (train_eval_Gowalla.py:131-132 passes the same `adj`)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, indices, U, I, seg_len):
+        key = (indices.data_ptr(), tuple(indices.shape), str(indices.device), indices._version, U, I, seg_len)
+        p = self._d.get(key)
+        if p is None:
+            if len(self._d) >= _PLAN_CACHE_MAX:
+                self._d.pop(next(iter(self._d)))
+            p = build_plan(indices, U, I, seg_len=seg_len, device=indices.device if indices.is_cuda else None)
+            self._d[key] = p
+        return p
+
+
+def _fresh_seed():
+    # torch's CPU generator: reproducible under torch.manual_seed (run_Gowalla.py:191), no device sync
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def _fuse(layers):
+    """Concatenate the heads of a stage: W [2,din,dout], avec [2,dout]."""
+    k = layers[0].out_dim
+    Wu = torch.cat([l.W_u for l in layers], 1)
+    Wi = torch.cat([l.W_i for l in layers], 1)
+    au = torch.cat([l.a[0, :k] for l in layers])
+    ai = torch.cat([l.a[0, k:] for l in layers])
+    return torch.stack([Wu, Wi]), torch.stack([au, ai])
+
+
+class SpUIGraphAttentionLayer(nn.Module):
+    """Parameter holder + standalone layer call (SPUIGACF.py:258-403)."""
+
+    def __init__(self, in_dim, out_dim, dropout, alpha, concat=True):
+        super().__init__()
+        self.in_dim, self.out_dim, self.alpha, self.concat = in_dim, out_dim, alpha, concat
+        self.W_u = nn.Parameter(torch.zeros(in_dim, out_dim))
+        nn.init.xavier_normal_(self.W_u.data, gain=1.414)            # :270-273
+        self.W_i = nn.Parameter(torch.zeros(in_dim, out_dim))
+        nn.init.xavier_normal_(self.W_i.data, gain=1.414)
+        self.a = nn.Parameter(torch.zeros(1, 2 * out_dim))
+        nn.init.xavier_normal_(self.a.data, gain=1.414)              # :277-278
+        self.droprate = dropout
+        self._plans = _PlanCache()
+        self.seg_len = 256
+
+    def forward(self, uidx, iidx, features, indices):
+        U, I = int(uidx.numel()), int(iidx.numel())
+        plan = self._plans.get(indices.squeeze(), U, I, self.seg_len)
+        p = self.droprate if self.training else 0.0
+        k = self.out_dim
+        if k in (64, 128):
+            W, avec = _fuse([self])
+            return NF.stage(features, W, avec, plan, 1, self.alpha, self.concat, p, 0.0, _fresh_seed())
+        if k != 8:
+            raise ValueError("standalone layer supports out_dim 8, 64 or 128 (got %d)" % k)
+        # a lone 8-wide head = head 0 of a fused 8-head stage whose other heads have zero weights
+        pad = features.new_zeros(self.in_dim, 56)
+        W = torch.stack([torch.cat([self.W_u, pad], 1), torch.cat([self.W_i, pad], 1)])
+        z = features.new_zeros(56)
+        avec = torch.stack([torch.cat([self.a[0, :k], z]), torch.cat([self.a[0, k:], z])])
+        out = NF.stage(features, W, avec, plan, 8, self.alpha, self.concat, p, 0.0, _fresh_seed())
+        return out[:, :k]
+
+    def __repr__(self):
+        return self.__class__.__name__ + " (" + str(self.in_dim) + " -> " + str(self.out_dim) + ")"
+
+
+class _GATBase(nn.Module):
+    """Shared stage runner.  `self._stages` lists the layer groups in execution order."""
+
+    compute_dtype = torch.float32    # storage type of H and of the stage outputs (fp32 | bf16)
+    seg_len = 256
+
+    def _run(self, uidx, iidx, features, adj):
+        U, I = int(uidx.numel()), int(iidx.numel())
+        plan = self._plans.get(adj.squeeze(), U, I, self.seg_len)
+        p = self.dropout if self.training else 0.0
+        base = _fresh_seed() if p > 0 else 0
+        x = features
+        for s, layers in enumerate(self._stages()):
+            W, avec = _fuse(layers)
+            # feature dropout in front of every stage (:208,:213) and the ELU behind it (:397 inside
+            # the concat layers, :214 around out_att) are fused into the stage
+            x = NF.stage(x, W, avec, plan, len(layers), layers[0].alpha, True, p, p,
+                         NF.stage_seed(base, s), self.compute_dtype)
+        return x
+
+
+class SpUIGAT(_GATBase):
+    def __init__(self, nfeat, nhid, nclass, dropout, alpha, nheads):
+        super().__init__()
+        self.dropout = dropout
+        self.attentions = [SpUIGraphAttentionLayer(nfeat, nhid, dropout=dropout, alpha=alpha, concat=True)
+                           for _ in range(nheads)]
+        for i, attention in enumerate(self.attentions):
+            self.add_module("attention_{}".format(i), attention)
+        self.out_att = SpUIGraphAttentionLayer(nhid * nheads, nclass, dropout=dropout, alpha=alpha, concat=False)
+        self._plans = _PlanCache()
+
+    def _stages(self):
+        return [self.attentions, [self.out_att]]
+
+    def forward(self, uidx, iidx, features, adj):
+        return self._run(uidx, iidx, features, adj)
+
+
+class SPUIMultiGAT(_GATBase):
+    def __init__(self, nfeat, nhid, nclass, dropout, alpha, nheads):
+        super().__init__()
+        self.dropout = dropout
+        self.attentions1 = [SpUIGraphAttentionLayer(nfeat, nhid, dropout=dropout, alpha=alpha, concat=True)
+                            for _ in range(nheads)]
+        self.attentions2 = [SpUIGraphAttentionLayer(nfeat, nhid, dropout=dropout, alpha=alpha, concat=True)
+                            for _ in range(nheads)]
+        for i, attention in enumerate(self.attentions1):
+            self.add_module("attention1_{}".format(i), attention)
+        for i, attention in enumerate(self.attentions2):
+            self.add_module("attention2_{}".format(i), attention)
+        self.out_att = SpUIGraphAttentionLayer(nhid * nheads, nclass, dropout=dropout, alpha=alpha, concat=False)
+        self._plans = _PlanCache()
+
+    def _stages(self):
+        return [self.attentions1, self.attentions2, [self.out_att]]
+
+    def forward(self, uidx, iidx, features, adj):
+        return self._run(uidx, iidx, features, adj)
+
+
+class StackedSpUIGAT(_GATBase):
+    """Generalised depth (BASELINE config "d=128 L=4"): n_hidden 8-head stages + the out layer.
+    Not in the reference; state_dict keys follow SPUIMultiGAT's numbering (attention{s}_{h})."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout, alpha, nheads, n_hidden):
+        super().__init__()
+        self.dropout = dropout
+        self.hidden = []
+        for s in range(n_hidden):
+            grp = [SpUIGraphAttentionLayer(nfeat if s == 0 else nhid * nheads, nhid, dropout=dropout, alpha=alpha,
+                                           concat=True) for _ in range(nheads)]
+            for h, l in enumerate(grp):
+                self.add_module("attention{}_{}".format(s + 1, h), l)
+            self.hidden.append(grp)
+        self.out_att = SpUIGraphAttentionLayer(nhid * nheads, nclass, dropout=dropout, alpha=alpha, concat=False)
+        self._plans = _PlanCache()
+
+    def _stages(self):
+        return self.hidden + [[self.out_att]]
+
+    def forward(self, uidx, iidx, features, adj):
+        return self._run(uidx, iidx, features, adj)
+
+
+class _CFBase(nn.Module):
+    def _init_weight_(self):
+        nn.init.normal_(self.uEmbd.weight, std=0.01)                 # SPUIGACF.py:26-28
+        nn.init.normal_(self.iEmbd.weight, std=0.01)
+
+    def getFeatureMat(self):
+        """SPUIGACF.py:30-39 without the per-call Python index lists."""
+        dev = self.uEmbd.weight.device
+        uidx = torch.arange(self.userNum, device=dev)
+        iidx = torch.arange(self.itemNum, device=dev)
+        features = torch.cat([self.uEmbd.weight, self.iEmbd.weight], dim=0)
+        return uidx, iidx + self.userNum, features
+
+    def propagate(self, mask):
+        uidx, iidx, features = self.getFeatureMat()
+        return self.gat(uidx, iidx, features, mask.squeeze())        # :42-46
+
+    def forward(self, userIdx, itemIdx, mask):
+        features = self.propagate(mask)
+        return NF.score(features, userIdx, itemIdx, self.userNum)    # :49-52
+
+
+class SPUIGACF(_CFBase):
+    def __init__(self, userNum, itemNum, embedSize, layers, droprate, useCuda=True):
+        super().__init__()
+        self.useCuda, self.userNum, self.itemNum, self.droprate = useCuda, userNum, itemNum, droprate
+        self.uEmbd = nn.Embedding(userNum, embedSize)
+        self.iEmbd = nn.Embedding(itemNum, embedSize)
+        self.gat = SpUIGAT(nfeat=embedSize, nhid=8, nclass=embedSize, dropout=droprate, nheads=8, alpha=0.2)
+        self._init_weight_()
+
+
+class SPUIMultiGACF(_CFBase):
+    def __init__(self, userNum, itemNum, embedSize, layers, droprate, useCuda=True):
+        super().__init__()
+        self.useCuda, self.userNum, self.itemNum, self.droprate = useCuda, userNum, itemNum, droprate
+        self.uEmbd = nn.Embedding(userNum, embedSize)
+        self.iEmbd = nn.Embedding(itemNum, embedSize)
+        self.gat = SPUIMultiGAT(nfeat=embedSize, nhid=8, nclass=embedSize, dropout=droprate, nheads=8, alpha=0.2)
+        self._init_weight_()
+
+
+class SPUIStackedGACF(_CFBase):
+    """Depth-generalised model for the BASELINE "L=4" config (stages = n_hidden + 1)."""
+
+    def __init__(self, userNum, itemNum, embedSize, layers, droprate, useCuda=True, stages=4):
+        super().__init__()
+        self.useCuda, self.userNum, self.itemNum, self.droprate = useCuda, userNum, itemNum, droprate
+        self.uEmbd = nn.Embedding(userNum, embedSize)
+        self.iEmbd = nn.Embedding(itemNum, embedSize)
+        self.gat = StackedSpUIGAT(embedSize, 8, embedSize, droprate, 0.2, 8, stages - 1)
+        self._init_weight_()
+
+
+def set_compute_dtype(model, dtype):
+    """bf16 storage of H / stage outputs (fp32 accumulate) for every GAT stack inside `model`."""
+    for m in model.modules():
+        if isinstance(m, _GATBase):
+            m.compute_dtype = dtype
+    return model

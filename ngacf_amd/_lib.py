@@ -1,0 +1,72 @@
+"""ctypes binding of the C ABI declared in include/ngacf.h.
+
+There is no CPU fallback: if libngacf_hip.so is missing the import of any product
+module fails here, loudly.  PyTorch only provides device memory and the stream.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  -- must come first: the library has to bind to the HIP runtime torch already
+              # loaded (torch bundles its own libamdhip64); two runtimes in one process cannot share pointers
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libngacf_hip.so")
+
+F32, BF16 = 0, 1
+FLAG_ELU, FLAG_RESIDUAL, FLAG_SCORE_ROW = 1, 2, 4
+TBWD_BLOCKS = 256
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_u64 = ctypes.c_uint64
+
+# name -> argtypes, exactly the prototypes of include/ngacf.h
+SIGNATURES = {
+    "ngacf_transform_fwd": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _u64, _p],
+    "ngacf_prop_fwd": [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p,
+                       _i, _i, _i, _i, _f, _f, _u64, _i, _p],
+    "ngacf_prop_bwd": [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
+                       _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u64, _i, _p],
+    "ngacf_transform_bwd": [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p],
+    "ngacf_score_fwd": [_p, _i, _p, _p, _p, _i, _i, _i, _p],
+    "ngacf_score_bwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    "ngacf_bpr_fwd": [_p, _p, _p, _i, _p],
+    "ngacf_bpr_bwd": [_p, _p, _p, _p, _p, _i, _p],
+    "ngacf_spmm_fwd": [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p],
+    "ngacf_dropout_bits": [_i, _u64, _p, _p, _p, _p, _i, _p],
+}
+
+
+class NgacfError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "ngacf_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.ngacf_version.restype = ctypes.c_char_p
+    lib.ngacf_version.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library disagree
+        fn.restype = ctypes.c_int
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def version():
+    return lib.ngacf_version().decode()
+
+
+_ERRS = {-1: "NGACF_E_ARG (null pointer or bad size)", -2: "NGACF_E_SHAPE (unsupported d/heads/dtype)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NgacfError("%s failed: %s" % (what, _ERRS.get(rc, "hipError_t %d" % rc)))

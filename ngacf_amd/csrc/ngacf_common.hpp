@@ -1,0 +1,111 @@
+// Shared device helpers for the gfx950 kernels: 16-byte row-slice I/O for fp32 and
+// bf16 storage, wave64 cross-lane moves, the counter-hash dropout RNG.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ngacf.h"
+
+namespace ngacf {
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------
+// storage types.  A lane always moves 16 bytes: 4 fp32 or 8 bf16 columns.
+// ---------------------------------------------------------------------------
+struct bf16_t { uint16_t bits; };
+
+template <typename T> struct Slice;
+
+template <> struct Slice<float> {
+    static constexpr int VEC = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&f)[4]) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&f)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    }
+    static __device__ __forceinline__ float round(float x) { return x; }
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+// round-to-nearest-even through the hardware convert (keeps NaN a NaN)
+__device__ __forceinline__ uint32_t f32_to_bf16(float x) {
+    const __bf16 h = static_cast<__bf16>(x);
+    return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h));
+}
+
+template <> struct Slice<bf16_t> {
+    static constexpr int VEC = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&f)[8]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j]     = __uint_as_float(w[j] << 16);
+            f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&f)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = f32_to_bf16(f[2 * j]) | (f32_to_bf16(f[2 * j + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    static __device__ __forceinline__ float round(float x) { return bf16_to_f32(f32_to_bf16(x)); }
+};
+
+// ---------------------------------------------------------------------------
+// wave64 cross-lane helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float xor_add(float v, int mask) { return v + __shfl_xor(v, mask, WAVE); }
+
+// sum over the lanes that differ only in the bits [lo, hi) of the lane id
+template <int LO, int HI>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int m = LO; m < HI; m <<= 1) v = xor_add(v, m);
+    return v;
+}
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---------------------------------------------------------------------------
+// counter-hash dropout RNG (host restatement: ngacf_amd/rng.py; pinned by tests)
+//   bits = lowbias32(a * K1 ^ (b * K2 + salt)),  keep iff bits >= floor(p * 2^32)
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+constexpr uint32_t RNG_K1 = 0x9E3779B1u, RNG_K2 = 0x85EBCA77u, RNG_K3 = 0xC2B2AE3Du;
+
+__host__ __device__ __forceinline__ uint32_t salt_of(uint64_t seed, uint32_t stream) {
+    return lowbias32(static_cast<uint32_t>(seed) ^ lowbias32(static_cast<uint32_t>(seed >> 32) + stream * RNG_K3));
+}
+// feature mask of element (node n, column c)
+__host__ __device__ __forceinline__ uint32_t feat_bits(uint32_t salt, uint32_t n, uint32_t c) {
+    return lowbias32((n * RNG_K1) ^ (c * RNG_K2 + salt));
+}
+// edge mask of (user u, item i as global id, head h); salt_h = salt_of(seed, 1 + h)
+__host__ __device__ __forceinline__ uint32_t edge_bits(uint32_t salt_h, uint32_t u, uint32_t i) {
+    return lowbias32((u * RNG_K1) ^ (i * RNG_K2 + salt_h));
+}
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+    const double t = static_cast<double>(p) * 4294967296.0;
+    return t >= 4294967295.0 ? 0xffffffffu : static_cast<uint32_t>(t);
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
+
+#define NGACF_CHECK_LAUNCH()                                   \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        if (e__ != hipSuccess) return static_cast<int>(e__);   \
+    } while (0)
+
+}  // namespace ngacf

@@ -1,0 +1,158 @@
+// Pair scoring (SPUIGACF.py:49-52), BPR loss (BPRLoss.py:8-9) and the dropout-RNG probe.
+#include "ngacf_common.hpp"
+
+namespace ngacf {
+
+// LPR lanes per pair: each lane multiplies a 16-byte slice of the user row with the item row's.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void score_fwd_kernel(const T* __restrict__ F, const int64_t* __restrict__ u,
+                                                        const int64_t* __restrict__ it, float* __restrict__ score,
+                                                        int B, int U) {
+    constexpr int VEC = Slice<T>::VEC, LPR = D / VEC, PPW = WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = wave * PPW + lane / LPR, q = lane % LPR;
+    const bool ok = b < B;
+    const int bb = ok ? b : B - 1;
+    float x[VEC], y[VEC];
+    Slice<T>::load(F + (size_t)u[bb] * D + q * VEC, x);
+    Slice<T>::load(F + (size_t)(it[bb] + U) * D + q * VEC, y);
+    float p = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) p = fmaf(x[j], y[j], p);
+    p = group_sum<1, LPR>(p);
+    if (ok && q == 0) score[b] = p;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void score_bwd_kernel(const T* __restrict__ F, const int64_t* __restrict__ u,
+                                                        const int64_t* __restrict__ it, const float* __restrict__ g,
+                                                        float* __restrict__ gF, int B, int U) {
+    constexpr int VEC = Slice<T>::VEC, LPR = D / VEC, PPW = WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = wave * PPW + lane / LPR, q = lane % LPR;
+    if (b >= B) return;
+    const size_t ur = (size_t)u[b], ir = (size_t)(it[b] + U);
+    float x[VEC], y[VEC];
+    Slice<T>::load(F + ur * D + q * VEC, x);
+    Slice<T>::load(F + ir * D + q * VEC, y);
+    const float gb = g[b];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        atomicAdd(gF + ur * D + q * VEC + j, gb * y[j]);
+        atomicAdd(gF + ir * D + q * VEC + j, gb * x[j]);
+    }
+}
+
+__device__ __forceinline__ float log_sigmoid(float x) {       // log(1/(1+exp(-x))), stable for both signs
+    return fminf(x, 0.f) - log1pf(__expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(256) void bpr_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ neg,
+                                                      float* __restrict__ loss, int B) {
+    float s = 0.f;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) s -= log_sigmoid(pos[b] - neg[b]);
+    s = group_sum<1, WAVE>(s);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (ws[0] + ws[1] + ws[2] + ws[3]) / (float)B);
+}
+
+__global__ __launch_bounds__(256) void bpr_bwd_kernel(const float* __restrict__ pos, const float* __restrict__ neg,
+                                                      const float* __restrict__ gloss, float* __restrict__ gpos,
+                                                      float* __restrict__ gneg, int B) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float x = pos[b] - neg[b];
+    const float sg = 1.f / (1.f + __expf(x));                  // sigmoid(-x)
+    const float g = -gloss[0] * sg / (float)B;
+    gpos[b] = g;
+    gneg[b] = -g;
+}
+
+__global__ void dropout_bits_kernel(int kind, uint64_t seed, const int* a, const int* b, const int* c, uint32_t* bits, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (kind == 0) bits[k] = feat_bits(salt_of(seed, 0u), a[k], b[k]);
+    else bits[k] = edge_bits(salt_of(seed, 1u + c[k]), a[k], b[k]);
+}
+
+}  // namespace ngacf
+
+using namespace ngacf;
+
+extern "C" const char* ngacf_version(void) { return "ngacf-hip 0.1 (gfx950)"; }
+
+extern "C" int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
+                               float* score, int B, int U, int d, void* stream) {
+    if (B < 0) return NGACF_E_ARG;
+    if (B == 0) return 0;
+    if (!F || !u || !i || !score) return NGACF_E_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NGACF_CASE(T, D)                                                                                   \
+    {                                                                                                      \
+        constexpr int PPB = 4 * WAVE / (D / Slice<T>::VEC);                                                \
+        hipLaunchKernelGGL((score_fwd_kernel<T, D>), dim3((B + PPB - 1) / PPB), dim3(256), 0, st,          \
+                           static_cast<const T*>(F), u, i, score, B, U);                                   \
+        NGACF_CHECK_LAUNCH();                                                                              \
+        return 0;                                                                                          \
+    }
+    if (dtype == NGACF_F32 && d == 64) NGACF_CASE(float, 64)
+    if (dtype == NGACF_F32 && d == 128) NGACF_CASE(float, 128)
+    if (dtype == NGACF_BF16 && d == 64) NGACF_CASE(bf16_t, 64)
+    if (dtype == NGACF_BF16 && d == 128) NGACF_CASE(bf16_t, 128)
+#undef NGACF_CASE
+    return NGACF_E_SHAPE;
+}
+
+extern "C" int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
+                               const float* gscore, float* gF, int B, int U, int d, void* stream) {
+    if (B < 0) return NGACF_E_ARG;
+    if (B == 0) return 0;
+    if (!F || !u || !i || !gscore || !gF) return NGACF_E_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NGACF_CASE(T, D)                                                                                   \
+    {                                                                                                      \
+        constexpr int PPB = 4 * WAVE / (D / Slice<T>::VEC);                                                \
+        hipLaunchKernelGGL((score_bwd_kernel<T, D>), dim3((B + PPB - 1) / PPB), dim3(256), 0, st,          \
+                           static_cast<const T*>(F), u, i, gscore, gF, B, U);                              \
+        NGACF_CHECK_LAUNCH();                                                                              \
+        return 0;                                                                                          \
+    }
+    if (dtype == NGACF_F32 && d == 64) NGACF_CASE(float, 64)
+    if (dtype == NGACF_F32 && d == 128) NGACF_CASE(float, 128)
+    if (dtype == NGACF_BF16 && d == 64) NGACF_CASE(bf16_t, 64)
+    if (dtype == NGACF_BF16 && d == 128) NGACF_CASE(bf16_t, 128)
+#undef NGACF_CASE
+    return NGACF_E_SHAPE;
+}
+
+extern "C" int ngacf_bpr_fwd(const float* pos, const float* neg, float* loss, int B, void* stream) {
+    if (B <= 0 || !pos || !neg || !loss) return NGACF_E_ARG;
+    const int nb = (B + 255) / 256 < 64 ? (B + 255) / 256 : 64;
+    hipLaunchKernelGGL(bpr_fwd_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), pos, neg, loss, B);
+    NGACF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ngacf_bpr_bwd(const float* pos, const float* neg, const float* gloss,
+                             float* gpos, float* gneg, int B, void* stream) {
+    if (B <= 0 || !pos || !neg || !gloss || !gpos || !gneg) return NGACF_E_ARG;
+    hipLaunchKernelGGL(bpr_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       pos, neg, gloss, gpos, gneg, B);
+    NGACF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ngacf_dropout_bits(int kind, uint64_t seed, const int32_t* a, const int32_t* b, const int32_t* c,
+                                  uint32_t* bits, int n, void* stream) {
+    if (n < 0 || (kind != 0 && kind != 1)) return NGACF_E_ARG;
+    if (n == 0) return 0;
+    if (!a || !b || !bits || (kind == 1 && !c)) return NGACF_E_ARG;
+    hipLaunchKernelGGL(dropout_bits_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       kind, seed, a, b, c, bits, n);
+    NGACF_CHECK_LAUNCH();
+    return 0;
+}

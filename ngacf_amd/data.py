@@ -1,0 +1,92 @@
+"""Adjacency sources for the propagation path.
+
+  * synthetic_bipartite: the power-law bipartite generator of SURVEY.md §8(d) at Gowalla /
+    Yelp / 1e9-edge shapes (the train CSVs of the reference's datasets are not available);
+  * load_ml100k / ui_mat_indices: the reference's `ui_mat` adjacency (data/loadGowalla.py:
+    184-253): coo(userId, itemId) over train+test interactions, coalesced -> [2,E] indices.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+SHAPES = {          # (U, I, E) -- SURVEY.md §8
+    "ml100k": (943, 1682, 100000),
+    "gowalla": (29858, 40981, 1027370),
+    "yelp": (45919, 45538, 1185065),
+    "synthetic1b": (10_000_000, 5_000_000, 1_000_000_000),
+}
+
+
+def synthetic_bipartite(U, I, E, seed=2019, device="cpu", alpha_pop=0.8, sigma=1.0, chunk=1 << 26):
+    """[2,E'] int64 indices, row-major sorted and unique (E' within ~1 % of E).  Item popularity
+    p_i ~ (rank+1)^-alpha_pop, user degree ~ lognormal(sigma) rescaled to the target, every user
+    has at least one edge (reference precondition, SPUIGACF.py:368), items may stay isolated."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    deg = torch.exp(sigma * torch.randn(U, device=dev, generator=g, dtype=torch.float64))
+    over = 1.06                                            # duplicates are merged below
+    deg = torch.clamp((deg * (E * over / float(deg.sum()))).round().long(), min=1, max=I)
+    pop = torch.pow(torch.arange(1, I + 1, device=dev, dtype=torch.float64), -alpha_pop)
+    perm = torch.randperm(I, device=dev, generator=g)      # popularity rank -> item id
+    cdf = torch.cumsum(pop / pop.sum(), 0)
+    total = int(deg.sum())
+    users = torch.repeat_interleave(torch.arange(U, device=dev), deg)
+    keys = []
+    for s in range(0, total, chunk):
+        n = min(chunk, total - s)
+        r = torch.rand(n, device=dev, generator=g, dtype=torch.float64)
+        items = perm[torch.searchsorted(cdf, r).clamp_(max=I - 1)]
+        keys.append(torch.unique(users[s:s + n] * I + items))
+    key = torch.unique(torch.cat(keys)) if len(keys) > 1 else keys[0]
+    extra = key.numel() - E
+    if extra > 0:                                          # thin out, never a user's first edge
+        u = key // I
+        first = torch.ones_like(u, dtype=torch.bool)
+        first[1:] = u[1:] != u[:-1]
+        cand = torch.nonzero(~first).squeeze(1)
+        drop = cand[torch.randperm(cand.numel(), device=dev, generator=g)[:extra]]
+        keep = torch.ones_like(first)
+        keep[drop] = False
+        key = key[keep]
+    return torch.stack([key // I, key % I])
+
+
+def uniform_bipartite(U, I, E, seed=2019, device="cpu"):
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    u = torch.cat([torch.arange(U, device=dev), torch.randint(0, U, (max(E - U, 0),), device=dev, generator=g)])
+    i = torch.randint(0, I, (u.numel(),), device=dev, generator=g)
+    key = torch.unique(u * I + i)
+    return torch.stack([key // I, key % I])
+
+
+def ui_mat_indices(user_ids, item_ids, I):
+    """`.coalesce().indices()` of coo(userId, itemId): row-major sorted, duplicates merged."""
+    key = np.unique(np.asarray(user_ids, dtype=np.int64) * I + np.asarray(item_ids, dtype=np.int64))
+    return np.stack([key // I, key % I])
+
+
+def load_ml100k(path=None):
+    """(userId, itemId, rating) zero-based, in file order.  `path` may be the reference's
+    data/1K/u.data (tab separated, data/loadGowalla.py:19-21) or the committed fixture
+    tests/golden/ml100k_interactions.npz (same rows, same order)."""
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                            "tests", "golden", "ml100k_interactions.npz")
+    if path.endswith(".npz"):
+        d = np.load(path)
+        return d["userId"].astype(np.int64), d["itemId"].astype(np.int64), d["rating"].astype(np.int64)
+    raw = np.loadtxt(path, dtype=np.int64, delimiter="\t")
+    return raw[:, 0] - 1, raw[:, 1] - 1, raw[:, 2]
+
+
+def algorithmic_bytes_stage(U, I, E, din, dout, elem_bytes):
+    """forward bytes of one propagation stage."""
+    N = U + I
+    trav = 2 * E * (4 + dout * elem_bytes) + N * (2 * dout * elem_bytes + 8)
+    trans = N * (din + dout) * elem_bytes
+    return trav, trans

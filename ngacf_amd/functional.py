@@ -1,0 +1,87 @@
+"""autograd glue: one torch.autograd.Function per C-ABI forward/backward pair.  The math
+lives in the HIP library; these classes only route tensors and saved state."""
+import torch
+
+from . import ops
+
+_STAGE_SEED_STRIDE = 0x9E3779B97F4A7C15
+
+
+class _Stage(torch.autograd.Function):
+    """One propagation stage: transform (X @ W per node type, scores) + attention
+    propagation over both directions.  Mirrors what one list-comprehension over
+    SpUIGraphAttentionLayer heads computes in SPUIGACF.py:212 (or the out_att call :214)."""
+
+    @staticmethod
+    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype):
+        X = X.contiguous()
+        W = W.contiguous().float()
+        avec = avec.contiguous().float()
+        H, S = ops.transform_fwd(X, W, avec, plan.U, plan.I, heads, h_dtype, feat_drop_p, seed)
+        need = any(ctx.needs_input_grad[:3])
+        if need:
+            out, agg, R = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, True, None, drop_p, seed, save=True)
+            ctx.save_for_backward(X, W, avec, H, S, out, agg, R)
+            ctx.cfg = (plan, heads, alpha, elu, drop_p, feat_drop_p, seed)
+        else:
+            out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, True, None, drop_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        X, W, avec, H, S, out, agg, R = ctx.saved_tensors
+        plan, heads, alpha, elu, drop_p, feat_drop_p, seed = ctx.cfg
+        gout = gout.contiguous().float()
+        dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, alpha, elu, True, None, drop_p, seed)
+        dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed)
+        return dX.to(X.dtype), dW, da, None, None, None, None, None, None, None, None
+
+
+def stage(X, W, avec, plan, heads, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=0.0, seed=0, h_dtype=None):
+    return _Stage.apply(X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed,
+                        X.dtype if h_dtype is None else h_dtype)
+
+
+def stage_seed(base, s):
+    return (base + (s + 1) * _STAGE_SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF
+
+
+class _Score(torch.autograd.Function):
+    """SPUIGACF.py:49-52: sum(features[userIdx] * features[itemIdx + U], dim=1)."""
+
+    @staticmethod
+    def forward(ctx, F, u, i, U):
+        F = F.contiguous()
+        u, i = u.contiguous().long(), i.contiguous().long()
+        ctx.save_for_backward(F, u, i)
+        ctx.U = U
+        return ops.score_fwd(F, u, i, U)
+
+    @staticmethod
+    def backward(ctx, g):
+        F, u, i = ctx.saved_tensors
+        gF = ops.score_bwd(F, u, i, g.contiguous().float(), ctx.U)
+        return gF.to(F.dtype), None, None, None
+
+
+def score(F, u, i, U):
+    return _Score.apply(F, u, i, U)
+
+
+class _BPR(torch.autograd.Function):
+    """graphattention/BPRLoss.py:8-9."""
+
+    @staticmethod
+    def forward(ctx, pos, neg):
+        pos, neg = pos.contiguous().float(), neg.contiguous().float()
+        ctx.save_for_backward(pos, neg)
+        return ops.bpr_fwd(pos, neg)
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, neg = ctx.saved_tensors
+        return ops.bpr_bwd(pos, neg, g)
+
+
+def bpr_loss(pos, neg):
+    return _BPR.apply(pos, neg)

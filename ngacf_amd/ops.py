@@ -1,0 +1,216 @@
+"""Checked wrappers around the C ABI (include/ngacf.h).  Each wrapper verifies device,
+dtype, contiguity and element counts of every tensor before a raw pointer crosses the
+boundary -- a wrong size would be an out-of-bounds access on the GPU, not a Python error --
+then launches on the caller's current stream.  No torch math happens here.
+"""
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, FLAG_ELU, FLAG_RESIDUAL, FLAG_SCORE_ROW, lib
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+SUPPORTED_D = (64, 128)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype, numel, dev):
+    if t is None:
+        raise ValueError("%s is required" % name)
+    if not t.is_cuda or t.device != dev:
+        raise ValueError("%s must live on %s, is on %s" % (name, dev, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError("%s must be %s, is %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if t.numel() != numel:
+        raise ValueError("%s must have %d elements, has %d" % (name, numel, t.numel()))
+    if t.data_ptr() % 16:
+        raise ValueError("%s must be 16-byte aligned" % name)
+    return t.data_ptr()
+
+
+def _heads_ok(d, heads):
+    if d not in SUPPORTED_D or heads not in (1, d // 8):
+        raise ValueError("unsupported row width / heads: d=%d heads=%d (d in %s, heads in {1, d/8})" % (d, heads, SUPPORTED_D))
+
+
+def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.0, seed=0):
+    """H[N,dout], S[N,heads] = ngacf_transform_fwd(X[N,din], W[2,din,dout], avec[2,dout])."""
+    dev, N = X.device, U + I
+    din, dout = W.shape[1], W.shape[2]
+    _heads_ok(dout, heads)
+    if din not in SUPPORTED_D:
+        raise ValueError("unsupported din=%d" % din)
+    xp = _chk(X, "X", None, N * din, dev)
+    if X.dtype not in _DT:
+        raise ValueError("X dtype %s" % X.dtype)
+    wp = _chk(W, "W", torch.float32, 2 * din * dout, dev)
+    ap = _chk(avec, "avec", torch.float32, 2 * dout, dev)
+    H = torch.empty(N, dout, dtype=h_dtype, device=dev)
+    S = torch.empty(N, heads, dtype=torch.float32, device=dev)
+    _lib.check(lib.ngacf_transform_fwd(xp, _DT[X.dtype], wp, ap, H.data_ptr(), _DT[h_dtype], S.data_ptr(),
+                                       U, I, din, dout, heads, float(feat_drop_p), int(seed), _stream()),
+               "ngacf_transform_fwd")
+    return H, S
+
+
+def _plan_ptrs(plan, dev):
+    if plan.device != dev:
+        raise ValueError("plan is on %s, tensors on %s" % (plan.device, dev))
+    segs = _chk(plan.segs, "plan.segs", torch.int32, plan.nseg * 4, dev) if plan.nseg else 0
+    split = _chk(plan.split, "plan.split", torch.int32, plan.nsplit * 3, dev) if plan.nsplit else 0
+    col = _chk(plan.col, "plan.col", torch.int32, plan.n_edges_directed, dev) if plan.n_edges_directed else 0
+    return segs, split, col
+
+
+def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
+             drop_p=0.0, seed=0, save=False, out=None):
+    """One propagation stage over plan's dst rows.  Returns out (and agg, R when save=True)."""
+    dev, N, d = H.device, plan.N, H.shape[1]
+    _heads_ok(d, heads)
+    if score_from_row is None:
+        score_from_row = heads > 1
+    hp = _chk(H, "H", None, N * d, dev)
+    if H.dtype not in _DT:
+        raise ValueError("H dtype %s" % H.dtype)
+    sd = _chk(S_dst, "S_dst", torch.float32, N * heads, dev)
+    ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
+    ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
+    segs, split, col = _plan_ptrs(plan, dev)
+    if out is None:
+        out = torch.empty(N, d, dtype=H.dtype, device=dev)
+    op = _chk(out, "out", H.dtype, N * d, dev)
+    agg = torch.empty(N, d, dtype=torch.float32, device=dev) if save else None
+    R = torch.empty(N, heads, dtype=torch.float32, device=dev) if save else None
+    pa = torch.empty(max(plan.nparts, 1), d, dtype=torch.float32, device=dev)
+    pr = torch.empty(max(plan.nparts, 1), heads, dtype=torch.float32, device=dev)
+    flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
+    _lib.check(lib.ngacf_prop_fwd(segs, plan.nseg, split, plan.nsplit, col, hp, _DT[H.dtype], sd, ss, ap,
+                                  op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
+                                  pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
+                                  float(drop_p), int(seed), flags, _stream()), "ngacf_prop_fwd")
+    return (out, agg, R) if save else out
+
+
+def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, elu=True, residual=True,
+             score_from_row=None, drop_p=0.0, seed=0):
+    """Returns dH [N,d] fp32 (with the dS*avec term) and dS [N,heads]."""
+    dev, N, d = H.device, plan.N, H.shape[1]
+    _heads_ok(d, heads)
+    if score_from_row is None:
+        score_from_row = heads > 1
+    hp = _chk(H, "H", None, N * d, dev)
+    sd = _chk(S_dst, "S_dst", torch.float32, N * heads, dev)
+    ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
+    ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
+    op = _chk(out, "out", H.dtype, N * d, dev)
+    gp = _chk(agg, "agg", torch.float32, N * d, dev)
+    rp = _chk(R, "R", torch.float32, N * heads, dev)
+    go = _chk(gout, "gout", torch.float32, N * d, dev)
+    segs, split, col = _plan_ptrs(plan, dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    G, Gn, dH = torch.empty(N, d, **f32), torch.empty(N, d, **f32), torch.empty(N, d, **f32)
+    t, dS = torch.empty(N, heads, **f32), torch.empty(N, heads, **f32)
+    pa = torch.empty(max(plan.nparts, 1), d, **f32)
+    pr = torch.empty(max(plan.nparts, 1), heads, **f32)
+    if plan.row_lo != 0 or plan.row_hi != N:
+        dH.zero_()
+        dS.zero_()
+    flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
+    _lib.check(lib.ngacf_prop_bwd(segs, plan.nseg, split, plan.nsplit, col, hp, _DT[H.dtype], sd, ss, ap,
+                                  op, gp, rp, go, G.data_ptr(), Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
+                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
+                                  float(drop_p), int(seed), flags, _stream()), "ngacf_prop_bwd")
+    return dH, dS
+
+
+def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0):
+    """Returns dX [N,din], dW [2,din,dout], davec [2,dout] (all fp32)."""
+    dev, N = X.device, U + I
+    din, dout = W.shape[1], W.shape[2]
+    _heads_ok(dout, heads)
+    xp = _chk(X, "X", None, N * din, dev)
+    wp = _chk(W, "W", torch.float32, 2 * din * dout, dev)
+    hp = _chk(H, "H", None, N * dout, dev)
+    gp = _chk(dH, "dH", torch.float32, N * dout, dev)
+    sp = _chk(dS, "dS", torch.float32, N * heads, dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    dX = torch.empty(N, din, **f32)
+    dW = torch.empty(2, din, dout, **f32)
+    da = torch.empty(2, dout, **f32)
+    work = torch.empty(_lib.TBWD_BLOCKS, din * dout + dout, **f32)
+    _lib.check(lib.ngacf_transform_bwd(xp, _DT[X.dtype], wp, hp, _DT[H.dtype], gp, sp, dX.data_ptr(), dW.data_ptr(),
+                                       da.data_ptr(), work.data_ptr(), U, I, din, dout, heads,
+                                       float(feat_drop_p), int(seed), _stream()), "ngacf_transform_bwd")
+    return dX, dW, da
+
+
+def _idx(t, name, B, dev, hi):
+    p = _chk(t, name, torch.int64, B, dev)
+    return p
+
+
+def score_fwd(F, u, i, U):
+    dev, d, B = F.device, F.shape[1], u.numel()
+    if d not in SUPPORTED_D or F.dtype not in _DT:
+        raise ValueError("unsupported F: d=%d dtype=%s" % (d, F.dtype))
+    fp = _chk(F, "F", None, F.shape[0] * d, dev)
+    score = torch.empty(B, dtype=torch.float32, device=dev)
+    if B:
+        _lib.check(lib.ngacf_score_fwd(fp, _DT[F.dtype], _idx(u, "userIdx", B, dev, U), _idx(i, "itemIdx", B, dev, 0),
+                                       score.data_ptr(), B, U, d, _stream()), "ngacf_score_fwd")
+    return score
+
+
+def score_bwd(F, u, i, gscore, U):
+    dev, d, B = F.device, F.shape[1], u.numel()
+    fp = _chk(F, "F", None, F.shape[0] * d, dev)
+    gF = torch.zeros(F.shape[0], d, dtype=torch.float32, device=dev)
+    if B:
+        gp = _chk(gscore, "gscore", torch.float32, B, dev)
+        _lib.check(lib.ngacf_score_bwd(fp, _DT[F.dtype], _idx(u, "userIdx", B, dev, U), _idx(i, "itemIdx", B, dev, 0),
+                                       gp, gF.data_ptr(), B, U, d, _stream()), "ngacf_score_bwd")
+    return gF
+
+
+def bpr_fwd(pos, neg):
+    dev, B = pos.device, pos.numel()
+    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    _lib.check(lib.ngacf_bpr_fwd(_chk(pos, "pos", torch.float32, B, dev), _chk(neg, "neg", torch.float32, B, dev),
+                                 loss.data_ptr(), B, _stream()), "ngacf_bpr_fwd")
+    return loss
+
+
+def bpr_bwd(pos, neg, gloss):
+    dev, B = pos.device, pos.numel()
+    gpos, gneg = torch.empty_like(pos), torch.empty_like(neg)
+    gl = gloss.reshape(1).contiguous().float()
+    _lib.check(lib.ngacf_bpr_bwd(_chk(pos, "pos", torch.float32, B, dev), _chk(neg, "neg", torch.float32, B, dev),
+                                 gl.data_ptr(), gpos.data_ptr(), gneg.data_ptr(), B, _stream()), "ngacf_bpr_bwd")
+    return gpos, gneg
+
+
+def spmm_fwd(plan, val, X, self_loop=True):
+    dev, N, d = X.device, plan.N, X.shape[1]
+    if d not in SUPPORTED_D or X.dtype not in _DT:
+        raise ValueError("unsupported X: d=%d dtype=%s" % (d, X.dtype))
+    xp = _chk(X, "X", None, N * d, dev)
+    vp = _chk(val, "val", torch.float32, plan.n_edges_directed, dev)
+    segs, split, col = _plan_ptrs(plan, dev)
+    out = torch.empty_like(X)
+    pa = torch.empty(max(plan.nparts, 1), d, dtype=torch.float32, device=dev)
+    _lib.check(lib.ngacf_spmm_fwd(segs, plan.nseg, split, plan.nsplit, col, vp, xp, _DT[X.dtype], out.data_ptr(),
+                                  pa.data_ptr(), N, d, int(bool(self_loop)), _stream()), "ngacf_spmm_fwd")
+    return out
+
+
+def dropout_bits(kind, seed, a, b, c=None):
+    dev, n = a.device, a.numel()
+    bits = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.check(lib.ngacf_dropout_bits(kind, int(seed), _chk(a, "a", torch.int32, n, dev), _chk(b, "b", torch.int32, n, dev),
+                                      _chk(c, "c", torch.int32, n, dev) if c is not None else 0,
+                                      bits.data_ptr(), n, _stream()), "ngacf_dropout_bits")
+    return bits

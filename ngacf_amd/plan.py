@@ -1,0 +1,117 @@
+"""Graph plan: the reference's COO `indices` ([2,E] int64, row 0 user id, row 1 item id,
+as returned by data/loadGowalla.py:253 `.coalesce().indices()` and kept by
+run_Gowalla.py:94) turned once into the traversal layout of include/ngacf.h:
+
+  col    int32[2E]   CSR of the user rows followed by the CSC of the item rows, sources
+                     as global node ids (items offset by U)
+  segs   int32[S,4]  {dst row, beg, end, part}: rows longer than `seg_len` edges are cut
+                     into slices with their own partial-sum slot; longest segments first
+  split  int32[P,3]  {dst row, first slot, slot count} of the cut rows
+
+Everything is a torch tensor on the graph's device (PyTorch owns the memory).  Built
+with torch ops so a 1e9-edge graph can be planned on the GPU; the builder checks the
+invariants the kernels rely on, because a bad index is a GPU fault, not an exception.
+"""
+import torch
+
+
+class GraphPlan:
+    def __init__(self, U, I, E, rowptr, col, segs, split, nparts, seg_len, row_lo=0, row_hi=None):
+        self.U, self.I, self.N, self.E = U, I, U + I, E
+        self.rowptr, self.col, self.segs, self.split = rowptr, col, segs, split
+        self.nseg, self.nsplit, self.nparts = int(segs.shape[0]), int(split.shape[0]), int(nparts)
+        self.seg_len = seg_len
+        self.row_lo, self.row_hi = row_lo, (U + I if row_hi is None else row_hi)
+        self.device = col.device
+        self.n_edges_directed = int(col.shape[0])
+
+    @property
+    def degrees(self):
+        return self.rowptr[1:] - self.rowptr[:-1]
+
+    def to(self, device):
+        return GraphPlan(self.U, self.I, self.E, self.rowptr.to(device), self.col.to(device),
+                         self.segs.to(device), self.split.to(device), self.nparts, self.seg_len,
+                         self.row_lo, self.row_hi)
+
+
+def _segments(rowptr, rows, seg_len):
+    """rows: int64 tensor of the dst rows to cover (global ids); rowptr is indexed by global id."""
+    dev = rowptr.device
+    beg_r, end_r = rowptr[rows], rowptr[rows + 1]
+    deg = end_r - beg_r
+    npr = torch.clamp((deg + seg_len - 1) // seg_len, min=1)          # an empty row still needs its epilogue
+    nseg = int(npr.sum())
+    ridx = torch.repeat_interleave(torch.arange(rows.numel(), device=dev), npr)
+    first = torch.cumsum(npr, 0) - npr
+    k = torch.arange(nseg, device=dev) - first[ridx]
+    beg = beg_r[ridx] + k * seg_len
+    end = torch.minimum(beg + seg_len, end_r[ridx])
+    cut = npr[ridx] > 1
+    part = torch.where(cut, torch.cumsum(cut.long(), 0) - 1, torch.full_like(beg, -1))
+    segs = torch.stack([rows[ridx], beg, end, part], 1)
+    order = torch.sort(end - beg, descending=True, stable=True).indices   # longest first: short tail
+    segs = segs[order].to(torch.int32).contiguous()
+    cut_rows = npr > 1
+    first_part = torch.cumsum(torch.where(cut_rows, npr, torch.zeros_like(npr)), 0) - npr
+    split = torch.stack([rows[cut_rows], first_part[cut_rows], npr[cut_rows]], 1).to(torch.int32).contiguous()
+    return segs, split, int(cut.sum())
+
+
+def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None):
+    """indices: [2,E] (or [1,2,E], run under DataParallel: SPUIGACF.py:42 squeezes it) integer
+    tensor.  Duplicate pairs are merged like `.coalesce()`.  `row_range=(lo,hi)` keeps only
+    the dst rows lo..hi-1 (node partition of ngacf_amd/dist.py); sources stay global."""
+    indices = indices.squeeze()
+    if indices.dim() != 2 or indices.shape[0] != 2:
+        raise ValueError("indices must be [2,E], got %s" % (tuple(indices.shape),))
+    dev = torch.device(device) if device is not None else indices.device
+    idx = indices.to(dev).long()
+    N = U + I
+    if 2 * idx.shape[1] >= 2 ** 31:
+        raise ValueError("2E must stay below 2^31 (int32 edge offsets)")
+    if idx.shape[1]:
+        if int(idx[0].min()) < 0 or int(idx[0].max()) >= U or int(idx[1].min()) < 0 or int(idx[1].max()) >= I:
+            raise ValueError("edge endpoint out of range for U=%d, I=%d" % (U, I))
+    key = torch.unique(idx[0] * I + idx[1])                  # row-major sorted + unique == coalesce()
+    eu, ei = key // I, key % I
+    E = int(key.numel())
+    deg_u = torch.bincount(eu, minlength=U)
+    deg_i = torch.bincount(ei, minlength=I)
+    if require_user_edges and U and int(deg_u.min()) == 0:
+        # the reference asserts e_rowsum != 0 for every user (SPUIGACF.py:368)
+        raise ValueError("user %d has no interaction: the reference asserts on a zero attention row-sum"
+                         % int(torch.argmin(deg_u)))
+    rowptr = torch.zeros(N + 1, dtype=torch.long, device=dev)
+    rowptr[1:] = torch.cumsum(torch.cat([deg_u, deg_i]), 0)
+    by_item = torch.sort(ei * U + eu).values                 # CSC order: item-major, users ascending
+    col = torch.cat([ei + U, by_item % U]).to(torch.int32).contiguous()
+    lo, hi = (0, N) if row_range is None else row_range
+    rows = torch.arange(lo, hi, device=dev)
+    segs, split, nparts = _segments(rowptr, rows, seg_len)
+    plan = GraphPlan(U, I, E, rowptr, col, segs, split, nparts, seg_len, lo, hi)
+    validate_plan(plan)
+    return plan
+
+
+def validate_plan(p):
+    """Host-side check of every bound the kernels assume."""
+    n2e = p.col.numel()
+    if n2e:
+        assert int(p.col.min()) >= 0 and int(p.col.max()) < p.N, "source id out of range"
+    if p.nseg:
+        s = p.segs.long()
+        assert int(s[:, 0].min()) >= 0 and int(s[:, 0].max()) < p.N, "segment row out of range"
+        assert bool((s[:, 1] <= s[:, 2]).all()) and int(s[:, 1].min()) >= 0 and int(s[:, 2].max()) <= n2e, \
+            "segment edge range out of bounds"
+        assert int(s[:, 3].max()) < max(p.nparts, 1) and int(s[:, 3].min()) >= -1, "partial-sum slot out of range"
+        # user rows only see item sources and vice versa
+        urow = s[:, 0] < p.U
+        nonempty = s[:, 1] < s[:, 2]
+        if bool((urow & nonempty).any()):
+            assert int(p.col[s[urow & nonempty, 1]].min()) >= p.U
+        if bool((~urow & nonempty).any()):
+            assert int(p.col[s[~urow & nonempty, 1]].max()) < p.U
+    if p.nsplit:
+        sp = p.split.long()
+        assert int((sp[:, 1] + sp[:, 2]).max()) <= p.nparts and int(sp[:, 1].min()) >= 0

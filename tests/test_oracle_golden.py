@@ -126,3 +126,16 @@ def test_g10_ml100k_medium_graph_eval_output():
     assert _maxabs(F[g["rows"]], g["F_rows"]) < 1e-6
     assert abs(float(F.astype(np.float64).sum()) - float(g["F_sum"])) < 1e-3
     assert abs(float(np.abs(F.astype(np.float64)).sum()) - float(g["F_abs_sum"])) < 1e-3
+
+
+@pytest.mark.parametrize("tag,multi", [("spuigacf", False), ("spuimultigacf", True)])
+def test_cpu_baseline_matches_goldens(tag, multi):
+    """bench.py's CPU leg (reference operator order, torch CPU) reproduces the reference output."""
+    import torch
+    from oracle import cpu_baseline as CB
+    g = load_golden("g234_" + tag)
+    U, I = int(g["U"]), int(g["I"])
+    p = {k: torch.from_numpy(v) for k, v in params_of(g).items()}
+    x = torch.cat([p["uEmbd.weight"], p["iEmbd.weight"]])
+    out = CB.forward(p, x, torch.from_numpy(g["edge"]), U, I, O.stage_names(multi))
+    assert _maxabs(out.numpy(), g["F_f32"]) < 5e-6
