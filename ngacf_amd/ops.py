@@ -16,6 +16,38 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Opt-in per-launch timing of one entry point with events on the launch stream
+    (bench.py's roofline leg).  `with KernelTimer("ngacf_prop_fwd") as t: ...; t.durations_ms()`."""
+    active = None
+
+    def __init__(self, name):
+        self.name, self.pairs = name, []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def durations_ms(self):
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self.pairs]
+
+
+def _timed(name, fn, *args):
+    t = KernelTimer.active
+    if t is None or t.name != name:
+        return fn(*args)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    rc = fn(*args)
+    b.record()
+    t.pairs.append((a, b))
+    return rc
+
+
 def _chk(t, name, dtype, numel, dev):
     if t is None:
         raise ValueError("%s is required" % name)
@@ -88,10 +120,10 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     pa = torch.empty(max(plan.nparts, 1), d, dtype=torch.float32, device=dev)
     pr = torch.empty(max(plan.nparts, 1), heads, dtype=torch.float32, device=dev)
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
-    _lib.check(lib.ngacf_prop_fwd(segs, plan.nseg, split, plan.nsplit, col, hp, _DT[H.dtype], sd, ss, ap,
-                                  op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
-                                  pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
-                                  float(drop_p), int(seed), flags, _stream()), "ngacf_prop_fwd")
+    _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, segs, plan.nseg, split, plan.nsplit, col, hp,
+                      _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
+                      pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
+                      float(drop_p), int(seed), flags, _stream()), "ngacf_prop_fwd")
     return (out, agg, R) if save else out
 
 
