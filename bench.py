@@ -169,7 +169,8 @@ def main():
     if not args.no_cpu_baseline:
         from oracle import cpu_baseline as CB
         from oracle import ngacf_oracle as O
-        ncores = os.cpu_count() or 1
+        # the GPU box gives one GPU's share of the host: 16 cores (more threads only oversubscribe)
+        ncores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(ncores)
         names = stage_layer_names(model)
         p_cpu = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}

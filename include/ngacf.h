@@ -20,10 +20,13 @@
  * Graph plan (built once per adjacency by the host, see ngacf_amd/plan.py):
  *   col   int32[2E]      source node (global id) of every directed edge; the 2E entries
  *                        are the CSR of the user rows followed by the CSC of the item rows
- *   segs  int32[nseg][4] work items {dst row, first edge, one-past-last edge, part}:
+ *   rowptr int32[N+1]    edge range of every dst row in `col`
+ *   srow  int32[nshort]  the short dst rows (degree <= plan.short_max), sorted by degree,
+ *                        descending: traversed one lane group per row
+ *   segs  int32[nseg][4] work items of the long rows {dst row, first edge, one-past-last edge, part}:
  *                        part < 0  -> the segment is the whole row, finished in place;
- *                        part >= 0 -> slice of a long row, partial sums go to slot `part`
- *   split int32[nsplit][3] {dst row, first part slot, number of slots} for the long rows
+ *                        part >= 0 -> slice of a hub row, partial sums go to slot `part`
+ *   split int32[nsplit][3] {dst row, first part slot, number of slots} for the hub rows
  */
 #ifndef NGACF_H
 #define NGACF_H
@@ -74,6 +77,7 @@ int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, const float*
  * drop_p > 0 applies the edge dropout of :375 (numerators only), mask keyed by
  * (seed, head, user, item) so both directions see the same mask. */
 int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                   const int32_t* srow, int nshort, const int32_t* rowptr,
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
                    void* out, float* agg, float* R, float* part_acc, float* part_r,
@@ -81,17 +85,18 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    float drop_p, uint64_t seed, int flags, void* stream);
 
 /* Backward of ngacf_prop_fwd (autograd of SPUIGACF.py:359-397; formulas SURVEY.md §8(a) A4b).
- * Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  t[n,h] = (g . agg)_h / R
+ * Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  ST[n,h] = { S_src[n,h], (g . agg)_h / R }
  * Step 2 (per edge, pull):  dH[n] = g[n] + sum_src m e Gn[src] + dS[n,h] * avec[type(n)]
- *                           dS[n,h] = sum_src -e * lrelu'(s) * (m Gn[n].H[src] - t[n] + m Gn[src].H[n] - t[src])
+ *                           dS[n,h] = sum_src -e * lrelu'(s) * (m (Gn[n].H[src] + Gn[src].H[n])_h - t[n] - t[src])
  *   gout [N,d] float   out [N,d] dtype (forward output)   agg, R: as saved by the forward
- *   G, Gn float[N][d], t float[N][heads]: workspace        dH float[N][d], dS float[N][heads]: results
- *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for long rows */
+ *   G, Gn float[N][d], ST float[N][heads][2]: workspace    dH float[N][d], dS float[N][heads]: results
+ *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows */
 int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                   const int32_t* srow, int nshort, const int32_t* rowptr,
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
                    const void* out, const float* agg, const float* R, const float* gout,
-                   float* G, float* Gn, float* t, float* dH, float* dS,
+                   float* G, float* Gn, float* ST, float* dH, float* dS,
                    float* part_acc, float* part_r,
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, int flags, void* stream);

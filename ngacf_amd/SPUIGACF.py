@@ -48,14 +48,52 @@ def _fresh_seed():
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
+class _FuseHeads(torch.autograd.Function):
+    """Per-head parameters (the reference's state_dict layout) -> the fused stage operands
+    W [2,din,dout] and avec [2,dout].  The backward hands every head its slice of dW/davec as a
+    view, so no zero-fill/copy kernels run per head.  Nothing is saved: it may run twice."""
+
+    @staticmethod
+    def forward(ctx, k, *params):
+        h = len(params) // 3
+        Wu = torch.cat(params[:h], 1)
+        Wi = torch.cat(params[h:2 * h], 1)
+        A = torch.cat(params[2 * h:], 0)                                  # [h, 2k]
+        ctx.k, ctx.h = k, h
+        return torch.stack([Wu, Wi]), torch.stack([A[:, :k].reshape(-1), A[:, k:].reshape(-1)])
+
+    @staticmethod
+    def backward(ctx, dW, da):
+        k, h = ctx.k, ctx.h
+        gu = [dW[0][:, j * k:(j + 1) * k] for j in range(h)]
+        gi = [dW[1][:, j * k:(j + 1) * k] for j in range(h)]
+        dA = torch.cat([da[0].view(h, k), da[1].view(h, k)], 1)           # [h, 2k]
+        ga = [dA[j:j + 1] for j in range(h)]
+        return (None, *gu, *gi, *ga)
+
+
 def _fuse(layers):
     """Concatenate the heads of a stage: W [2,din,dout], avec [2,dout]."""
-    k = layers[0].out_dim
-    Wu = torch.cat([l.W_u for l in layers], 1)
-    Wi = torch.cat([l.W_i for l in layers], 1)
-    au = torch.cat([l.a[0, :k] for l in layers])
-    ai = torch.cat([l.a[0, k:] for l in layers])
-    return torch.stack([Wu, Wi]), torch.stack([au, ai])
+    ps = [l.W_u for l in layers] + [l.W_i for l in layers] + [l.a for l in layers]
+    return _FuseHeads.apply(layers[0].out_dim, *ps)
+
+
+class _FusedCache:
+    """(W, avec) of a stage, reused while no parameter of the stage changed (both forwards of a
+    BPR step, every forward of an evaluation).  Keyed by the parameters' version counters."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, s, layers):
+        ps = [l.W_u for l in layers] + [l.W_i for l in layers] + [l.a for l in layers]
+        key = (tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps), torch.is_grad_enabled(),
+               any(p.requires_grad for p in ps))
+        hit = self._d.get(s)
+        if hit is None or hit[0] != key:
+            hit = (key, _FuseHeads.apply(layers[0].out_dim, *ps))
+            self._d[s] = hit
+        return hit[1]
 
 
 class SpUIGraphAttentionLayer(nn.Module):
@@ -108,8 +146,10 @@ class _GATBase(nn.Module):
         p = self.dropout if self.training else 0.0
         base = _fresh_seed() if p > 0 else 0
         x = features
+        if not hasattr(self, "_fused"):
+            self._fused = _FusedCache()
         for s, layers in enumerate(self._stages()):
-            W, avec = _fuse(layers)
+            W, avec = self._fused.get(s, layers)
             # feature dropout in front of every stage (:208,:213) and the ELU behind it (:397 inside
             # the concat layers, :214 around out_att) are fused into the stage
             x = NF.stage(x, W, avec, plan, len(layers), layers[0].alpha, True, p, p,

@@ -72,6 +72,25 @@ __device__ __forceinline__ float group_sum(float v) {
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// DPP moves run at VALU rate and need no LDS: quad_perm / row_half_mirror / row_mirror (gfx9 encodings)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+    return v + __int_as_float(m);
+}
+
+// all-reduce (sum) over aligned groups of N consecutive lanes, N a power of two
+template <int N>
+__device__ __forceinline__ float lanes_sum(float v) {
+    if constexpr (N >= 2) v = dpp_add<0xB1>(v);          // quad_perm [1,0,3,2]
+    if constexpr (N >= 4) v = dpp_add<0x4E>(v);          // quad_perm [2,3,0,1]
+    if constexpr (N >= 8) v = dpp_add<0x141>(v);         // row_half_mirror
+    if constexpr (N >= 16) v = dpp_add<0x140>(v);        // row_mirror
+    if constexpr (N >= 32) v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (0x10 << 10) | 0x1f));
+    if constexpr (N >= 64) v = xor_add(v, 32);
+    return v;
+}
+
 // ---------------------------------------------------------------------------
 // counter-hash dropout RNG (host restatement: ngacf_amd/rng.py; pinned by tests)
 //   bits = lowbias32(a * K1 ^ (b * K2 + salt)),  keep iff bits >= floor(p * 2^32)

@@ -1,0 +1,377 @@
+// Attention propagation, backward (pull-only, no atomics): autograd of
+// graphattention/SPUIGACF.py:359-397; formulas SURVEY.md 8(a) row A4b.
+//
+// Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  ST[n,h] = { S_src[n,h], (g . agg)_h / R }
+// Step 2 (per directed edge, pulled by the destination row n, source c):
+//     e  = exp(-lrelu(S_dst[n] + S_src[c]))          m = edge dropout multiplier
+//     de = m * (Gn[n].H[c] + Gn[c].H[n])_h - t[n] - t[c]
+//     dS[n,h] += -e * lrelu'(s) * de                  acc[n] += m e Gn[c]
+//   epilogue: dH[n] = g[n] + acc[n] + dS[n,h] * avec[type(n)]
+//
+// Same two traversal modes as the forward (propagate.hip); a lane owns 4 columns, so a slot is
+// LPR = d/4 lanes and carries the fp32 gradient row (16 B) next to the bf16/fp32 feature row.
+#include "ngacf_common.hpp"
+
+namespace ngacf {
+
+constexpr int UNROLL = 4;
+
+struct PropBwdArgs {
+    const int4* segs;
+    int nseg;
+    const int* srow;
+    int nshort;
+    const int* rowptr;
+    const int* col;
+    const void* H;
+    const float* S_dst;
+    const float* S_src;
+    const float* avec;
+    const void* out;
+    const float* agg;
+    const float* R;
+    const float* gout;
+    float* G;
+    float* Gn;
+    float2* ST;
+    float* dH;
+    float* dS;
+    float* part_acc;
+    float* part_r;
+    int U, N;
+    int nb_long;
+    float alpha;
+    uint32_t drop_thr;
+    float drop_scale;
+    uint64_t seed;
+    int flags;
+};
+
+// 4 consecutive columns of a T row as floats
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&f)[4]) { Slice<float>::load(p, f); }
+};
+template <> struct Quad<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&f)[4]) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+};
+
+template <typename T, int D, int HEADS>
+struct BShape {
+    static constexpr int LPR = D / 4, EPI = WAVE / LPR, HW = D / HEADS, LPH = HW / 4;
+    static constexpr int HSHIFT = D * sizeof(T) == 128 ? 7 : D * sizeof(T) == 256 ? 8 : 9;   // H row bytes
+    static constexpr int GSHIFT = D == 64 ? 8 : 9;                                            // fp32 row bytes
+    static_assert(LPR >= 8, "column-index broadcast uses lanes 0..7 of a slot");
+};
+
+template <typename T, int D, int HEADS>
+__device__ __forceinline__ void load_h(const void* base, int c, int q, float (&f)[4]) {
+    const uint32_t off = (static_cast<uint32_t>(c) << BShape<T, D, HEADS>::HSHIFT) | (static_cast<uint32_t>(q) * (4u * sizeof(T)));
+    Quad<T>::load(reinterpret_cast<const T*>(static_cast<const char*>(base) + off), f);
+}
+template <typename T, int D, int HEADS>
+__device__ __forceinline__ void load_g(const float* base, int c, int q, float (&f)[4]) {
+    const uint32_t off = (static_cast<uint32_t>(c) << BShape<T, D, HEADS>::GSHIFT) | (static_cast<uint32_t>(q) << 4);
+    Slice<float>::load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off), f);
+}
+
+template <int LPR, int J>
+__device__ __forceinline__ int slot_bcast_b(int v) {
+    constexpr int and_mask = (~(LPR - 1)) & 0x1f;
+    return __builtin_amdgcn_ds_swizzle(v, (J << 5) | and_mask);
+}
+
+// Step 1, per node.  One lane per 4 columns.
+template <typename T, int D, int HEADS>
+__global__ __launch_bounds__(256) void prop_bwd_node_kernel(const PropBwdArgs a) {
+    using SH = BShape<T, D, HEADS>;
+    constexpr int LPR = SH::LPR, HW = SH::HW;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = gid / LPR;
+    const int q = (int)(gid % LPR);
+    const bool ok = n < (size_t)a.N;
+    const size_t nn = ok ? n : 0;
+    const int head = (q * 4) / HW;
+    float g[4], o[4], ag[4];
+    Slice<float>::load(a.gout + nn * D + q * 4, g);
+    Slice<float>::load(a.agg + nn * D + q * 4, ag);
+    if (a.flags & NGACF_ELU) {
+        Quad<T>::load(static_cast<const T*>(a.out) + nn * D + q * 4, o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] *= o[j] > 0.f ? 1.f : o[j] + 1.f;   // ELU' = exp(pre) = out + 1 on the negative side
+    }
+    const float r = a.R[nn * HEADS + head];
+    const float inv = r > 0.f ? 1.f / r : 0.f;                // isolated node: the aggregate is a constant 0
+    float gn[4], p = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        gn[j] = g[j] * inv;
+        p = fmaf(gn[j], ag[j], p);
+    }
+    p = lanes_sum<SH::LPH>(p);
+    if (!ok) return;
+    Slice<float>::store(a.G + n * D + q * 4, g);
+    Slice<float>::store(a.Gn + n * D + q * 4, gn);
+    if ((q * 4) % HW == 0) a.ST[n * HEADS + head] = make_float2(a.S_src[n * HEADS + head], p);
+}
+
+struct RowCtx {
+    float h_own[4], gn_own[4], av[4];
+    float s_dst, t_own;
+    uint32_t row_key, salt_h;
+    bool dst_is_user;
+};
+
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
+__device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, int head, RowCtx& x) {
+    x.dst_is_user = row < a.U;
+    load_h<T, D, HEADS>(a.H, row, q, x.h_own);
+    load_g<T, D, HEADS>(a.Gn, row, q, x.gn_own);
+    x.s_dst = a.S_dst[(size_t)row * HEADS + head];
+    x.t_own = a.ST[(size_t)row * HEADS + head].y;
+    if (FROM_ROW) {
+        const float* ap = a.avec + (x.dst_is_user ? D : 0) + q * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x.av[j] = ap[j];
+    }
+    x.salt_h = x.row_key = 0;
+    if (DROP) {
+        x.salt_h = salt_of(a.seed, 1u + head);
+        x.row_key = x.dst_is_user ? (uint32_t)row * RNG_K1 : (uint32_t)row * RNG_K2 + x.salt_h;
+    }
+}
+
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
+__device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx& x, const float (&hv)[4], const float (&gv)[4],
+                                            float2 st, bool ok, int c, float (&acc)[4], float& dsum) {
+    constexpr int LPH = BShape<T, D, HEADS>::LPH;
+    float dot = 0.f, s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        dot = fmaf(x.gn_own[j], hv[j], dot);
+        dot = fmaf(gv[j], x.h_own[j], dot);
+        if (FROM_ROW) s = fmaf(hv[j], x.av[j], s);
+    }
+    dot = lanes_sum<LPH>(dot);
+    s = FROM_ROW ? lanes_sum<LPH>(s) : st.x;
+    s += x.s_dst;
+    const float lr = fmaxf(s, a.alpha * s);
+    const float ev = ok ? __expf(-lr) : 0.f;
+    float m = 1.f;
+    if (DROP) {
+        const uint32_t other = x.dst_is_user ? (uint32_t)c * RNG_K2 + x.salt_h : (uint32_t)c * RNG_K1;
+        m = lowbias32(x.row_key ^ other) >= a.drop_thr ? a.drop_scale : 0.f;
+    }
+    const float de = m * dot - x.t_own - st.y;
+    dsum -= ev * de * (s > 0.f ? 1.f : a.alpha);
+    const float wgt = m * ev;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = fmaf(wgt, gv[j], acc[j]);
+}
+
+template <int D, int HEADS>
+__device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[4], float dsum) {
+    constexpr int HW = D / HEADS;
+    float g[4], o[4];
+    if (a.flags & NGACF_RESIDUAL) Slice<float>::load(a.G + (size_t)row * D + q * 4, g);
+    else g[0] = g[1] = g[2] = g[3] = 0.f;
+    const float* ao = a.avec + (row < a.U ? 0 : D) + q * 4;        // the node's own type
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = g[j] + acc[j] + dsum * ao[j];
+    Slice<float>::store(a.dH + (size_t)row * D + q * 4, o);
+    if ((q * 4) % HW == 0) a.dS[(size_t)row * HEADS + head] = dsum;
+}
+
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
+__global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
+    using SH = BShape<T, D, HEADS>;
+    constexpr int LPR = SH::LPR, EPI = SH::EPI, HW = SH::HW;
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / LPR, q = lane % LPR;
+    const int head = (q * 4) / HW;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float dsum = 0.f;
+    RowCtx x;
+
+    if ((int)blockIdx.x >= a.nb_long) {
+        // ------------------------------------------------------------------ short rows: slot per row
+        const int w = (blockIdx.x - a.nb_long) * 4 + (threadIdx.x >> 6);
+        if (w * EPI >= a.nshort) return;
+        const int ridx = w * EPI + slot;
+        const bool live = ridx < a.nshort;
+        const int row = a.srow[live ? ridx : a.nshort - 1];
+        const int beg = a.rowptr[row];
+        const int deg = live ? a.rowptr[row + 1] - beg : 0;
+        const int maxdeg = uniform(deg);
+        load_ctx<T, D, HEADS, FROM_ROW, DROP>(a, row, q, head, x);
+        const int last = deg > 0 ? beg + deg - 1 : 0;
+        int colv = a.col[min(beg + (q & 7), last)];
+        for (int k0 = 0; k0 < maxdeg; k0 += 8) {
+            const int coln = a.col[min(beg + k0 + 8 + (q & 7), last)];
+            int c[8];
+            c[0] = slot_bcast_b<LPR, 0>(colv); c[1] = slot_bcast_b<LPR, 1>(colv);
+            c[2] = slot_bcast_b<LPR, 2>(colv); c[3] = slot_bcast_b<LPR, 3>(colv);
+            c[4] = slot_bcast_b<LPR, 4>(colv); c[5] = slot_bcast_b<LPR, 5>(colv);
+            c[6] = slot_bcast_b<LPR, 6>(colv); c[7] = slot_bcast_b<LPR, 7>(colv);
+#pragma unroll
+            for (int h0 = 0; h0 < 8; h0 += UNROLL) {
+                if (h0 > 0 && k0 + h0 >= maxdeg) break;
+                float hv[UNROLL][4], gv[UNROLL][4];
+                float2 st[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    load_h<T, D, HEADS>(a.H, c[h0 + u], q, hv[u]);
+                    load_g<T, D, HEADS>(a.Gn, c[h0 + u], q, gv[u]);
+                    st[u] = a.ST[(size_t)c[h0 + u] * HEADS + head];
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+                    edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], st[u], k0 + h0 + u < deg, c[h0 + u], acc, dsum);
+            }
+            colv = coln;
+        }
+        if (live) finish_row_b<D, HEADS>(a, row, q, head, acc, dsum);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- long rows: wave per segment
+    const int w = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= a.nseg) return;
+    const int4 sg = a.segs[w];
+    const int row = uniform(sg.x), beg = uniform(sg.y), end = uniform(sg.z), part = uniform(sg.w);
+    load_ctx<T, D, HEADS, FROM_ROW, DROP>(a, row, q, head, x);
+    for (int base = beg; base < end; base += EPI * UNROLL) {
+        int c[UNROLL];
+        bool ok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int e = base + u * EPI + slot;
+            ok[u] = e < end;
+            c[u] = a.col[ok[u] ? e : end - 1];
+        }
+        float hv[UNROLL][4], gv[UNROLL][4];
+        float2 st[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            load_h<T, D, HEADS>(a.H, c[u], q, hv[u]);
+            load_g<T, D, HEADS>(a.Gn, c[u], q, gv[u]);
+            st[u] = a.ST[(size_t)c[u] * HEADS + head];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], st[u], ok[u], c[u], acc, dsum);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
+    dsum = group_sum<LPR, WAVE>(dsum);
+    if (slot != 0) return;
+    if (part >= 0) {
+        Slice<float>::store(a.part_acc + (size_t)part * D + q * 4, acc);
+        if ((q * 4) % HW == 0) a.part_r[(size_t)part * HEADS + head] = dsum;
+        return;
+    }
+    finish_row_b<D, HEADS>(a, row, q, head, acc, dsum);
+}
+
+template <int D, int HEADS>
+__global__ __launch_bounds__(256) void prop_bwd_split_kernel(const PropBwdArgs a, const int* __restrict__ split, int nsplit) {
+    constexpr int LPR = D / 4, EPI = WAVE / LPR, HW = D / HEADS;
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= nsplit) return;
+    const int row = split[3 * w], p0 = split[3 * w + 1], np = split[3 * w + 2];
+    const int slot = lane / LPR, q = lane % LPR, head = (q * 4) / HW;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, dsum = 0.f;
+#pragma unroll 4
+    for (int p = p0 + slot; p < p0 + np; p += EPI) {
+        float v[4];
+        Slice<float>::load(a.part_acc + (size_t)p * D + q * 4, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j];
+        dsum += a.part_r[(size_t)p * HEADS + head];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
+    dsum = group_sum<LPR, WAVE>(dsum);
+    if (slot != 0) return;
+    finish_row_b<D, HEADS>(a, row, q, head, acc, dsum);
+}
+
+template <typename T, int D, int HEADS>
+static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st) {
+    constexpr int EPI = BShape<T, D, HEADS>::EPI;
+    {
+        const size_t threads = (size_t)a.N * (D / 4);
+        hipLaunchKernelGGL((prop_bwd_node_kernel<T, D, HEADS>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
+        NGACF_CHECK_LAUNCH();
+    }
+    a.nb_long = (a.nseg + 3) / 4;
+    const int nw_short = (a.nshort + EPI - 1) / EPI;
+    const int nb = a.nb_long + (nw_short + 3) / 4;
+    if (nb > 0) {
+        const dim3 grid(nb), block(256);
+        if (from_row) {
+            if (drop) hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, true>), grid, block, 0, st, a);
+            else      hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, false>), grid, block, 0, st, a);
+        } else {
+            if (drop) hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, false, true>), grid, block, 0, st, a);
+            else      hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, false, false>), grid, block, 0, st, a);
+        }
+        NGACF_CHECK_LAUNCH();
+    }
+    if (nsplit > 0) {
+        hipLaunchKernelGGL((prop_bwd_split_kernel<D, HEADS>), dim3((nsplit + 3) / 4), dim3(256), 0, st, a, split, nsplit);
+        NGACF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+}  // namespace ngacf
+
+using namespace ngacf;
+
+extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                              const int32_t* srow, int nshort, const int32_t* rowptr,
+                              const int32_t* col, const void* H, int dtype,
+                              const float* S_dst, const float* S_src, const float* avec,
+                              const void* out, const float* agg, const float* R, const float* gout,
+                              float* G, float* Gn, float* ST, float* dH, float* dS,
+                              float* part_acc, float* part_r,
+                              int U, int N, int d, int heads, float alpha,
+                              float drop_p, uint64_t seed, int flags, void* stream) {
+    if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
+    if (N == 0) return 0;
+    if (!col || !rowptr || !H || !S_dst || !S_src || !avec || !out || !agg || !R || !gout || !G || !Gn || !ST || !dH || !dS)
+        return NGACF_E_ARG;
+    if ((nseg > 0 && !segs) || (nshort > 0 && !srow)) return NGACF_E_ARG;
+    if (nsplit > 0 && (!split || !part_acc || !part_r)) return NGACF_E_ARG;
+    if (!(drop_p >= 0.f && drop_p < 1.f) || !(alpha > 0.f && alpha < 1.f)) return NGACF_E_ARG;
+    if ((uint64_t)N * (uint64_t)d * 4ull >= (1ull << 32)) return NGACF_E_SHAPE;   // 32-bit row offsets (fp32 gradient rows)
+    const bool from_row = (flags & NGACF_SCORE_ROW) != 0;
+    PropBwdArgs a;
+    a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
+    a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R; a.gout = gout;
+    a.G = G; a.Gn = Gn; a.ST = reinterpret_cast<float2*>(ST); a.dH = dH; a.dS = dS; a.part_acc = part_acc; a.part_r = part_r;
+    a.U = U; a.N = N; a.nb_long = 0; a.alpha = alpha;
+    a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.flags = flags;
+    const bool drop = drop_p > 0.f;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NGACF_CASE(T, D, HD) return launch_bwd<T, D, HD>(a, split, nsplit, from_row, drop, st)
+    if (dtype == NGACF_F32) {
+        if (d == 64 && heads == 8) NGACF_CASE(float, 64, 8);
+        if (d == 64 && heads == 1) NGACF_CASE(float, 64, 1);
+        if (d == 128 && heads == 1) NGACF_CASE(float, 128, 1);
+        if (d == 128 && heads == 16) NGACF_CASE(float, 128, 16);
+    } else if (dtype == NGACF_BF16) {
+        if (d == 64 && heads == 8) NGACF_CASE(bf16_t, 64, 8);
+        if (d == 64 && heads == 1) NGACF_CASE(bf16_t, 64, 1);
+        if (d == 128 && heads == 1) NGACF_CASE(bf16_t, 128, 1);
+        if (d == 128 && heads == 16) NGACF_CASE(bf16_t, 128, 16);
+    }
+#undef NGACF_CASE
+    return NGACF_E_SHAPE;
+}

@@ -356,15 +356,31 @@ __global__ __launch_bounds__(256) void transform_bwd_dw_kernel(const TransBwdArg
 #pragma unroll
                 for (int j = 0; j < RJ; ++j) acc[i][j] = fmaf(xa[i], gb[j], acc[i][j]);
         }
-        if (tid < DOUT) {
-            const int nr = rend - row0 < TM ? rend - row0 : TM;
-            for (int r = 0; r < nr; ++r) {
-                const size_t n = (size_t)(row0 + r);
+        {   // davec: thread (rg, c) walks rows rg, rg+RG, ... of the tile; loads are independent
+            constexpr int RG = 256 / DOUT;
+            const int c = tid % DOUT, rg = tid / DOUT;
+#pragma unroll 8
+            for (int r = rg; r < TM; r += RG) {
+                const int row = row0 + r;
+                const bool ok = row < rend;
+                const size_t n = (size_t)(ok ? row : rend - 1);
                 float h;
-                if constexpr (sizeof(TH) == 4) h = reinterpret_cast<const float*>(Hg)[n * DOUT + tid];
-                else h = bf16_to_f32(reinterpret_cast<const uint16_t*>(Hg)[n * DOUT + tid]);
-                da = fmaf(a.dS[n * HEADS + tid / HW], h, da);
+                if constexpr (sizeof(TH) == 4) h = reinterpret_cast<const float*>(Hg)[n * DOUT + c];
+                else h = bf16_to_f32(reinterpret_cast<const uint16_t*>(Hg)[n * DOUT + c]);
+                const float s = a.dS[n * HEADS + c / HW];
+                da = fmaf(ok ? s : 0.f, h, da);
             }
+        }
+    }
+    {   // fold the row groups of davec through LDS
+        constexpr int RG = 256 / DOUT;
+        __syncthreads();
+        lds[tid] = da;
+        __syncthreads();
+        if (tid < DOUT) {
+            da = 0.f;
+#pragma unroll
+            for (int g = 0; g < RG; ++g) da += lds[g * DOUT + tid];
         }
     }
     float* wk = a.work + (size_t)blockIdx.x * (DIN * DOUT + DOUT);
@@ -380,12 +396,20 @@ __global__ __launch_bounds__(256) void transform_bwd_dw_kernel(const TransBwdArg
 // dW[type], davec[type] = sum of the partials of that type's workgroups, in workgroup order
 __global__ __launch_bounds__(256) void transform_bwd_reduce_kernel(const float* __restrict__ work, float* __restrict__ dW,
                                                                    float* __restrict__ davec, int nbu, int nbi, int wsz, int dwsz) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;      // over [2][wsz]
-    if (idx >= 2 * wsz) return;
-    const int type = idx / wsz, k = idx % wsz;
+    // 64 outputs per workgroup; the 4 waves take interleaved quarters of the partials, then fold in LDS
+    __shared__ float red[256];
+    const int o = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;                  // over [2][wsz]
+    const bool ok = idx < 2 * wsz;
+    const int type = ok ? idx / wsz : 0, k = ok ? idx % wsz : 0;
     const int b0 = type == 0 ? 0 : nbu, b1 = type == 0 ? nbu : nbu + nbi;
     float s = 0.f;
-    for (int b = b0; b < b1; ++b) s += work[(size_t)b * wsz + k];
+#pragma unroll 8
+    for (int b = b0 + pg; b < b1; b += 4) s += work[(size_t)b * wsz + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pg != 0 || !ok) return;
+    s = (red[o] + red[64 + o]) + (red[128 + o] + red[192 + o]);
     if (k < dwsz) dW[(size_t)type * dwsz + k] = s;
     else davec[(size_t)type * (wsz - dwsz) + (k - dwsz)] = s;
 }
@@ -429,7 +453,7 @@ static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool dr
         }
         NGACF_CHECK_LAUNCH();
         constexpr int wsz = DIN * DOUT + DOUT;
-        hipLaunchKernelGGL(transform_bwd_reduce_kernel, dim3((2 * wsz + 255) / 256), dim3(256), 0, st,
+        hipLaunchKernelGGL(transform_bwd_reduce_kernel, dim3((2 * wsz + 63) / 64), dim3(256), 0, st,
                            a.work, dW, davec, a.nbu, a.nbi, wsz, DIN * DOUT);
         NGACF_CHECK_LAUNCH();
     }

@@ -95,7 +95,9 @@ def _plan_ptrs(plan, dev):
     segs = _chk(plan.segs, "plan.segs", torch.int32, plan.nseg * 4, dev) if plan.nseg else 0
     split = _chk(plan.split, "plan.split", torch.int32, plan.nsplit * 3, dev) if plan.nsplit else 0
     col = _chk(plan.col, "plan.col", torch.int32, plan.n_edges_directed, dev) if plan.n_edges_directed else 0
-    return segs, split, col
+    srow = _chk(plan.srow, "plan.srow", torch.int32, plan.nshort, dev) if plan.nshort else 0
+    rowptr = _chk(plan.rowptr32, "plan.rowptr32", torch.int32, plan.N + 1, dev)
+    return (segs, plan.nseg, split, plan.nsplit, srow, plan.nshort, rowptr, col)
 
 
 def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
@@ -111,7 +113,7 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     sd = _chk(S_dst, "S_dst", torch.float32, N * heads, dev)
     ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
     ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
-    segs, split, col = _plan_ptrs(plan, dev)
+    pp = _plan_ptrs(plan, dev)
     if out is None:
         out = torch.empty(N, d, dtype=H.dtype, device=dev)
     op = _chk(out, "out", H.dtype, N * d, dev)
@@ -120,7 +122,7 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     pa = torch.empty(max(plan.nparts, 1), d, dtype=torch.float32, device=dev)
     pr = torch.empty(max(plan.nparts, 1), heads, dtype=torch.float32, device=dev)
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
-    _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, segs, plan.nseg, split, plan.nsplit, col, hp,
+    _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, *pp, hp,
                       _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
                       pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
                       float(drop_p), int(seed), flags, _stream()), "ngacf_prop_fwd")
@@ -142,17 +144,17 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     gp = _chk(agg, "agg", torch.float32, N * d, dev)
     rp = _chk(R, "R", torch.float32, N * heads, dev)
     go = _chk(gout, "gout", torch.float32, N * d, dev)
-    segs, split, col = _plan_ptrs(plan, dev)
+    pp = _plan_ptrs(plan, dev)
     f32 = dict(dtype=torch.float32, device=dev)
     G, Gn, dH = torch.empty(N, d, **f32), torch.empty(N, d, **f32), torch.empty(N, d, **f32)
-    t, dS = torch.empty(N, heads, **f32), torch.empty(N, heads, **f32)
+    t, dS = torch.empty(N, heads, 2, **f32), torch.empty(N, heads, **f32)
     pa = torch.empty(max(plan.nparts, 1), d, **f32)
     pr = torch.empty(max(plan.nparts, 1), heads, **f32)
     if plan.row_lo != 0 or plan.row_hi != N:
         dH.zero_()
         dS.zero_()
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
-    _lib.check(lib.ngacf_prop_bwd(segs, plan.nseg, split, plan.nsplit, col, hp, _DT[H.dtype], sd, ss, ap,
+    _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, ss, ap,
                                   op, gp, rp, go, G.data_ptr(), Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
                                   dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
                                   float(drop_p), int(seed), flags, _stream()), "ngacf_prop_bwd")
@@ -231,10 +233,14 @@ def spmm_fwd(plan, val, X, self_loop=True):
         raise ValueError("unsupported X: d=%d dtype=%s" % (d, X.dtype))
     xp = _chk(X, "X", None, N * d, dev)
     vp = _chk(val, "val", torch.float32, plan.n_edges_directed, dev)
-    segs, split, col = _plan_ptrs(plan, dev)
+    segs_t, split_t, nparts = plan.all_rows_segments()
+    nseg, nsplit = int(segs_t.shape[0]), int(split_t.shape[0])
+    segs = _chk(segs_t, "segs", torch.int32, nseg * 4, dev) if nseg else 0
+    split = _chk(split_t, "split", torch.int32, nsplit * 3, dev) if nsplit else 0
+    col = _chk(plan.col, "plan.col", torch.int32, plan.n_edges_directed, dev)
     out = torch.empty_like(X)
-    pa = torch.empty(max(plan.nparts, 1), d, dtype=torch.float32, device=dev)
-    _lib.check(lib.ngacf_spmm_fwd(segs, plan.nseg, split, plan.nsplit, col, vp, xp, _DT[X.dtype], out.data_ptr(),
+    pa = torch.empty(max(nparts, 1), d, dtype=torch.float32, device=dev)
+    _lib.check(lib.ngacf_spmm_fwd(segs, nseg, split, nsplit, col, vp, xp, _DT[X.dtype], out.data_ptr(),
                                   pa.data_ptr(), N, d, int(bool(self_loop)), _stream()), "ngacf_spmm_fwd")
     return out
 

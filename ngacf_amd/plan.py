@@ -16,7 +16,8 @@ import torch
 
 
 class GraphPlan:
-    def __init__(self, U, I, E, rowptr, col, segs, split, nparts, seg_len, row_lo=0, row_hi=None):
+    def __init__(self, U, I, E, rowptr, col, segs, split, nparts, seg_len, row_lo=0, row_hi=None,
+                 srow=None, short_max=0):
         self.U, self.I, self.N, self.E = U, I, U + I, E
         self.rowptr, self.col, self.segs, self.split = rowptr, col, segs, split
         self.nseg, self.nsplit, self.nparts = int(segs.shape[0]), int(split.shape[0]), int(nparts)
@@ -24,15 +25,27 @@ class GraphPlan:
         self.row_lo, self.row_hi = row_lo, (U + I if row_hi is None else row_hi)
         self.device = col.device
         self.n_edges_directed = int(col.shape[0])
+        # short rows (degree <= short_max), sorted by degree descending: one lane group per row
+        self.srow = srow if srow is not None else torch.empty(0, dtype=torch.int32, device=col.device)
+        self.nshort, self.short_max = int(self.srow.shape[0]), short_max
+        self.rowptr32 = rowptr.to(torch.int32).contiguous()
 
     @property
     def degrees(self):
         return self.rowptr[1:] - self.rowptr[:-1]
 
+    def all_rows_segments(self):
+        """(segs, split, nparts) covering EVERY dst row of the range as wave-per-segment work
+        items (used by the static-weight SpMM path)."""
+        if getattr(self, "_all", None) is None:
+            rows = torch.arange(self.row_lo, self.row_hi, device=self.device)
+            self._all = _segments(self.rowptr, rows, self.seg_len)
+        return self._all
+
     def to(self, device):
         return GraphPlan(self.U, self.I, self.E, self.rowptr.to(device), self.col.to(device),
                          self.segs.to(device), self.split.to(device), self.nparts, self.seg_len,
-                         self.row_lo, self.row_hi)
+                         self.row_lo, self.row_hi, self.srow.to(device), self.short_max)
 
 
 def _segments(rowptr, rows, seg_len):
@@ -58,7 +71,7 @@ def _segments(rowptr, rows, seg_len):
     return segs, split, int(cut.sum())
 
 
-def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None):
+def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None, short_max=64):
     """indices: [2,E] (or [1,2,E], run under DataParallel: SPUIGACF.py:42 squeezes it) integer
     tensor.  Duplicate pairs are merged like `.coalesce()`.  `row_range=(lo,hi)` keeps only
     the dst rows lo..hi-1 (node partition of ngacf_amd/dist.py); sources stay global."""
@@ -88,8 +101,12 @@ def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True,
     col = torch.cat([ei + U, by_item % U]).to(torch.int32).contiguous()
     lo, hi = (0, N) if row_range is None else row_range
     rows = torch.arange(lo, hi, device=dev)
-    segs, split, nparts = _segments(rowptr, rows, seg_len)
-    plan = GraphPlan(U, I, E, rowptr, col, segs, split, nparts, seg_len, lo, hi)
+    deg = rowptr[rows + 1] - rowptr[rows]
+    is_short = deg <= short_max
+    order = torch.sort(deg[is_short], descending=True, stable=True).indices
+    srow = rows[is_short][order].to(torch.int32).contiguous()
+    segs, split, nparts = _segments(rowptr, rows[~is_short], seg_len)
+    plan = GraphPlan(U, I, E, rowptr, col, segs, split, nparts, seg_len, lo, hi, srow, short_max)
     validate_plan(plan)
     return plan
 
@@ -115,3 +132,11 @@ def validate_plan(p):
     if p.nsplit:
         sp = p.split.long()
         assert int((sp[:, 1] + sp[:, 2]).max()) <= p.nparts and int(sp[:, 1].min()) >= 0
+    if p.nshort:
+        sr = p.srow.long()
+        assert int(sr.min()) >= 0 and int(sr.max()) < p.N, "short row out of range"
+        d = p.rowptr[sr + 1] - p.rowptr[sr]
+        assert int(d.max()) <= p.short_max and bool((d[1:] <= d[:-1]).all()), "short rows must be sorted by degree, descending"
+    assert int(p.rowptr[-1]) == n2e and int(p.rowptr[-1]) < 2 ** 31
+    covered = p.nshort + (int(torch.unique(p.segs[:, 0]).numel()) if p.nseg else 0)
+    assert covered == p.row_hi - p.row_lo, "every dst row of the range must be covered exactly once"

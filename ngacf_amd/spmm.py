@@ -17,7 +17,7 @@ def build_square_plan(rows, cols, vals, N, seg_len=256):
     rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=N), 0)
     segs, split, nparts = _segments(rowptr, torch.arange(N, device=dev), seg_len)
     plan = GraphPlan(N, 0, int(uniq.numel()), rowptr, c.to(torch.int32).contiguous(), segs, split, nparts, seg_len)
-    plan.n_edges_directed = int(uniq.numel())
+    plan._all = (segs, split, nparts)
     validate_square(plan)
     return plan, val.contiguous()
 

@@ -71,7 +71,10 @@ def test_library_loaded_and_rejects_bad_shapes(dev):
     from ngacf_amd import _lib
     assert "gfx950" in ngacf_amd.version()
     # unsupported row width is refused before any launch
-    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 2, 48, 1, 0.2, 0.0, 0, 3, 0)
+    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 2, 48, 1, 0.2, 0.0, 0, 3, 0)
+    assert rc == -2
+    # a table of 2^32 bytes or more does not fit the 32-bit row offsets: refused, not wrapped
+    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1 << 24, 64, 8, 0.2, 0.0, 0, 3, 0)
     assert rc == -2
     assert _lib.lib.ngacf_score_fwd(0, 0, 0, 0, 0, 5, 1, 64, 0) == -1
 
@@ -156,14 +159,18 @@ def test_split_rows_match_unsplit(dev):
     H, S = ops.transform_fwd(X, W, avec, U, I, 8)
     g = torch.randn(U + I, 64, device=dev)
     ref = None
-    for seg in (1 << 20, 64, 8):
-        plan = build_plan(_t(edge, dev), U, I, seg_len=seg)
-        if seg == 8:
-            assert plan.nsplit > 100
+    # (seg_len, short_max): all rows as whole-wave segments / cut into slices / every mix of the
+    # slot-per-row mode with the long mode / all rows in the slot-per-row mode
+    for seg, short in ((1 << 20, -1), (64, -1), (8, 4), (256, 64), (16, 30), (1 << 20, 1 << 20)):
+        plan = build_plan(_t(edge, dev), U, I, seg_len=seg, short_max=short)
+        if (seg, short) == (8, 4):
+            assert plan.nsplit > 100 and plan.nshort > 0
+        if short == 1 << 20:
+            assert plan.nseg == 0 and plan.nshort == U + I
         out, agg, R = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)
         dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, g, 8)
         if ref is None:
-            assert plan.nsplit == 0
+            assert plan.nsplit == 0 and plan.nshort == 0
             ref = (out, R, dH, dS)
             continue
         assert float((out - ref[0]).abs().max()) < 1e-5
