@@ -89,14 +89,14 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  * Step 2 (per edge, pull):  dH[n] = g[n] + sum_src m e Gn[src] + dS[n,h] * avec[type(n)]
  *                           dS[n,h] = sum_src -e * lrelu'(s) * (m (Gn[n].H[src] + Gn[src].H[n])_h - t[n] - t[src])
  *   gout [N,d] float   out [N,d] dtype (forward output)   agg, R: as saved by the forward
- *   G, Gn float[N][d], ST float[N][heads][2]: workspace    dH float[N][d], dS float[N][heads]: results
+ *   G float[N][d], Gn [N][d] dtype, ST float[N][heads][2]: workspace    dH float[N][d], dS float[N][heads]: results
  *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows */
 int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                    const int32_t* srow, int nshort, const int32_t* rowptr,
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
                    const void* out, const float* agg, const float* R, const float* gout,
-                   float* G, float* Gn, float* ST, float* dH, float* dS,
+                   float* G, void* Gn, float* ST, float* dH, float* dS,
                    float* part_acc, float* part_r,
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, int flags, void* stream);

@@ -8,8 +8,9 @@
 //     dS[n,h] += -e * lrelu'(s) * de                  acc[n] += m e Gn[c]
 //   epilogue: dH[n] = g[n] + acc[n] + dS[n,h] * avec[type(n)]
 //
-// Same two traversal modes as the forward (propagate.hip); a lane owns 4 columns, so a slot is
-// LPR = d/4 lanes and carries the fp32 gradient row (16 B) next to the bf16/fp32 feature row.
+// Same two traversal modes and lane layout as the forward (propagate.hip): a lane owns a 16-byte
+// slice of the feature row H[c] AND of the normalised-gradient row Gn[c], which is stored in the
+// same type T as H (bf16 storage halves the dominant gather of the backward too).
 #include "ngacf_common.hpp"
 
 namespace ngacf {
@@ -32,7 +33,7 @@ struct PropBwdArgs {
     const float* R;
     const float* gout;
     float* G;
-    float* Gn;
+    void* Gn;
     float2* ST;
     float* dH;
     float* dS;
@@ -47,36 +48,33 @@ struct PropBwdArgs {
     int flags;
 };
 
-// 4 consecutive columns of a T row as floats
-template <typename T> struct Quad;
-template <> struct Quad<float> {
-    static __device__ __forceinline__ void load(const float* p, float (&f)[4]) { Slice<float>::load(p, f); }
-};
-template <> struct Quad<bf16_t> {
-    static __device__ __forceinline__ void load(const bf16_t* p, float (&f)[4]) {
-        const uint2 v = *reinterpret_cast<const uint2*>(p);
-        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-    }
-};
-
 template <typename T, int D, int HEADS>
 struct BShape {
-    static constexpr int LPR = D / 4, EPI = WAVE / LPR, HW = D / HEADS, LPH = HW / 4;
-    static constexpr int HSHIFT = D * sizeof(T) == 128 ? 7 : D * sizeof(T) == 256 ? 8 : 9;   // H row bytes
-    static constexpr int GSHIFT = D == 64 ? 8 : 9;                                            // fp32 row bytes
+    static constexpr int VEC = Slice<T>::VEC;
+    static constexpr int LPR = D / VEC, EPI = WAVE / LPR, HW = D / HEADS;
+    static constexpr int LPH = HW >= VEC ? HW / VEC : 1;
+    static constexpr int SHIFT = D * sizeof(T) == 128 ? 7 : D * sizeof(T) == 256 ? 8 : 9;   // row bytes of H and Gn
     static_assert(LPR >= 8, "column-index broadcast uses lanes 0..7 of a slot");
 };
 
 template <typename T, int D, int HEADS>
-__device__ __forceinline__ void load_h(const void* base, int c, int q, float (&f)[4]) {
-    const uint32_t off = (static_cast<uint32_t>(c) << BShape<T, D, HEADS>::HSHIFT) | (static_cast<uint32_t>(q) * (4u * sizeof(T)));
-    Quad<T>::load(reinterpret_cast<const T*>(static_cast<const char*>(base) + off), f);
+__device__ __forceinline__ void load_row(const void* base, int c, int q, float (&f)[Slice<T>::VEC]) {
+    const uint32_t off = (static_cast<uint32_t>(c) << BShape<T, D, HEADS>::SHIFT) | (static_cast<uint32_t>(q) << 4);
+    Slice<T>::load(reinterpret_cast<const T*>(static_cast<const char*>(base) + off), f);
 }
-template <typename T, int D, int HEADS>
-__device__ __forceinline__ void load_g(const float* base, int c, int q, float (&f)[4]) {
-    const uint32_t off = (static_cast<uint32_t>(c) << BShape<T, D, HEADS>::GSHIFT) | (static_cast<uint32_t>(q) << 4);
-    Slice<float>::load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off), f);
+
+template <int VEC>
+__device__ __forceinline__ void load_f32(const float* p, float (&f)[VEC]) {
+#pragma unroll
+    for (int j = 0; j < VEC; j += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + j);
+        f[j] = v.x; f[j + 1] = v.y; f[j + 2] = v.z; f[j + 3] = v.w;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void store_f32(float* p, const float (&f)[VEC]) {
+#pragma unroll
+    for (int j = 0; j < VEC; j += 4) *reinterpret_cast<float4*>(p + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
 }
 
 template <int LPR, int J>
@@ -85,58 +83,60 @@ __device__ __forceinline__ int slot_bcast_b(int v) {
     return __builtin_amdgcn_ds_swizzle(v, (J << 5) | and_mask);
 }
 
-// Step 1, per node.  One lane per 4 columns.
+// Step 1, per node.  One lane per 16-byte slice of the row.
 template <typename T, int D, int HEADS>
 __global__ __launch_bounds__(256) void prop_bwd_node_kernel(const PropBwdArgs a) {
     using SH = BShape<T, D, HEADS>;
-    constexpr int LPR = SH::LPR, HW = SH::HW;
+    constexpr int LPR = SH::LPR, HW = SH::HW, VEC = SH::VEC;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t n = gid / LPR;
     const int q = (int)(gid % LPR);
     const bool ok = n < (size_t)a.N;
     const size_t nn = ok ? n : 0;
-    const int head = (q * 4) / HW;
-    float g[4], o[4], ag[4];
-    Slice<float>::load(a.gout + nn * D + q * 4, g);
-    Slice<float>::load(a.agg + nn * D + q * 4, ag);
+    const int head = (q * VEC) / HW;
+    float g[VEC], o[VEC], ag[VEC];
+    load_f32<VEC>(a.gout + nn * D + q * VEC, g);
+    load_f32<VEC>(a.agg + nn * D + q * VEC, ag);
     if (a.flags & NGACF_ELU) {
-        Quad<T>::load(static_cast<const T*>(a.out) + nn * D + q * 4, o);
+        Slice<T>::load(static_cast<const T*>(a.out) + nn * D + q * VEC, o);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] *= o[j] > 0.f ? 1.f : o[j] + 1.f;   // ELU' = exp(pre) = out + 1 on the negative side
+        for (int j = 0; j < VEC; ++j) g[j] *= o[j] > 0.f ? 1.f : o[j] + 1.f;   // ELU' = exp(pre) = out + 1 on the negative side
     }
     const float r = a.R[nn * HEADS + head];
     const float inv = r > 0.f ? 1.f / r : 0.f;                // isolated node: the aggregate is a constant 0
-    float gn[4], p = 0.f;
+    float gn[VEC], p = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        gn[j] = g[j] * inv;
+    for (int j = 0; j < VEC; ++j) {
+        gn[j] = Slice<T>::round(g[j] * inv);                  // t from the stored (rounded) Gn: both directions agree
         p = fmaf(gn[j], ag[j], p);
     }
     p = lanes_sum<SH::LPH>(p);
     if (!ok) return;
-    Slice<float>::store(a.G + n * D + q * 4, g);
-    Slice<float>::store(a.Gn + n * D + q * 4, gn);
-    if ((q * 4) % HW == 0) a.ST[n * HEADS + head] = make_float2(a.S_src[n * HEADS + head], p);
+    store_f32<VEC>(a.G + n * D + q * VEC, g);
+    Slice<T>::store(static_cast<T*>(a.Gn) + n * D + q * VEC, gn);
+    if ((q * VEC) % HW == 0) a.ST[n * HEADS + head] = make_float2(a.S_src[n * HEADS + head], p);
 }
 
+template <int VEC>
 struct RowCtx {
-    float h_own[4], gn_own[4], av[4];
+    float h_own[VEC], gn_own[VEC], av[VEC];
     float s_dst, t_own;
     uint32_t row_key, salt_h;
     bool dst_is_user;
 };
 
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
-__device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, int head, RowCtx& x) {
+__device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, int head, RowCtx<Slice<T>::VEC>& x) {
+    constexpr int VEC = Slice<T>::VEC;
     x.dst_is_user = row < a.U;
-    load_h<T, D, HEADS>(a.H, row, q, x.h_own);
-    load_g<T, D, HEADS>(a.Gn, row, q, x.gn_own);
+    load_row<T, D, HEADS>(a.H, row, q, x.h_own);
+    load_row<T, D, HEADS>(a.Gn, row, q, x.gn_own);
     x.s_dst = a.S_dst[(size_t)row * HEADS + head];
     x.t_own = a.ST[(size_t)row * HEADS + head].y;
     if (FROM_ROW) {
-        const float* ap = a.avec + (x.dst_is_user ? D : 0) + q * 4;
+        const float* ap = a.avec + (x.dst_is_user ? D : 0) + q * VEC;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x.av[j] = ap[j];
+        for (int j = 0; j < VEC; ++j) x.av[j] = ap[j];
     }
     x.salt_h = x.row_key = 0;
     if (DROP) {
@@ -146,12 +146,13 @@ __device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, i
 }
 
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
-__device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx& x, const float (&hv)[4], const float (&gv)[4],
-                                            float2 st, bool ok, int c, float (&acc)[4], float& dsum) {
-    constexpr int LPH = BShape<T, D, HEADS>::LPH;
+__device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<Slice<T>::VEC>& x, const float (&hv)[Slice<T>::VEC],
+                                            const float (&gv)[Slice<T>::VEC], float2 st, bool ok, int c,
+                                            float (&acc)[Slice<T>::VEC], float& dsum) {
+    constexpr int LPH = BShape<T, D, HEADS>::LPH, VEC = Slice<T>::VEC;
     float dot = 0.f, s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < VEC; ++j) {
         dot = fmaf(x.gn_own[j], hv[j], dot);
         dot = fmaf(gv[j], x.h_own[j], dot);
         if (FROM_ROW) s = fmaf(hv[j], x.av[j], s);
@@ -170,32 +171,37 @@ __device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx& 
     dsum -= ev * de * (s > 0.f ? 1.f : a.alpha);
     const float wgt = m * ev;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = fmaf(wgt, gv[j], acc[j]);
+    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(wgt, gv[j], acc[j]);
 }
 
-template <int D, int HEADS>
-__device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[4], float dsum) {
+template <int D, int HEADS, int VEC>
+__device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum) {
     constexpr int HW = D / HEADS;
-    float g[4], o[4];
-    if (a.flags & NGACF_RESIDUAL) Slice<float>::load(a.G + (size_t)row * D + q * 4, g);
-    else g[0] = g[1] = g[2] = g[3] = 0.f;
-    const float* ao = a.avec + (row < a.U ? 0 : D) + q * 4;        // the node's own type
+    float g[VEC], o[VEC];
+    if (a.flags & NGACF_RESIDUAL) load_f32<VEC>(a.G + (size_t)row * D + q * VEC, g);
+    else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = g[j] + acc[j] + dsum * ao[j];
-    Slice<float>::store(a.dH + (size_t)row * D + q * 4, o);
-    if ((q * 4) % HW == 0) a.dS[(size_t)row * HEADS + head] = dsum;
+        for (int j = 0; j < VEC; ++j) g[j] = 0.f;
+    }
+    const float* ao = a.avec + (row < a.U ? 0 : D) + q * VEC;      // the node's own type
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = g[j] + acc[j] + dsum * ao[j];
+    store_f32<VEC>(a.dH + (size_t)row * D + q * VEC, o);
+    if ((q * VEC) % HW == 0) a.dS[(size_t)row * HEADS + head] = dsum;
 }
 
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
 __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
     using SH = BShape<T, D, HEADS>;
-    constexpr int LPR = SH::LPR, EPI = SH::EPI, HW = SH::HW;
+    constexpr int LPR = SH::LPR, EPI = SH::EPI, HW = SH::HW, VEC = SH::VEC;
     const int lane = threadIdx.x & 63;
     const int slot = lane / LPR, q = lane % LPR;
-    const int head = (q * 4) / HW;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int head = (q * VEC) / HW;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     float dsum = 0.f;
-    RowCtx x;
+    RowCtx<VEC> x;
 
     if ((int)blockIdx.x >= a.nb_long) {
         // ------------------------------------------------------------------ short rows: slot per row
@@ -220,12 +226,12 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
 #pragma unroll
             for (int h0 = 0; h0 < 8; h0 += UNROLL) {
                 if (h0 > 0 && k0 + h0 >= maxdeg) break;
-                float hv[UNROLL][4], gv[UNROLL][4];
+                float hv[UNROLL][VEC], gv[UNROLL][VEC];
                 float2 st[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    load_h<T, D, HEADS>(a.H, c[h0 + u], q, hv[u]);
-                    load_g<T, D, HEADS>(a.Gn, c[h0 + u], q, gv[u]);
+                    load_row<T, D, HEADS>(a.H, c[h0 + u], q, hv[u]);
+                    load_row<T, D, HEADS>(a.Gn, c[h0 + u], q, gv[u]);
                     st[u] = a.ST[(size_t)c[h0 + u] * HEADS + head];
                 }
 #pragma unroll
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
             }
             colv = coln;
         }
-        if (live) finish_row_b<D, HEADS>(a, row, q, head, acc, dsum);
+        if (live) finish_row_b<D, HEADS, VEC>(a, row, q, head, acc, dsum);
         return;
     }
 
@@ -253,12 +259,12 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
             ok[u] = e < end;
             c[u] = a.col[ok[u] ? e : end - 1];
         }
-        float hv[UNROLL][4], gv[UNROLL][4];
+        float hv[UNROLL][VEC], gv[UNROLL][VEC];
         float2 st[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            load_h<T, D, HEADS>(a.H, c[u], q, hv[u]);
-            load_g<T, D, HEADS>(a.Gn, c[u], q, gv[u]);
+            load_row<T, D, HEADS>(a.H, c[u], q, hv[u]);
+            load_row<T, D, HEADS>(a.Gn, c[u], q, gv[u]);
             st[u] = a.ST[(size_t)c[u] * HEADS + head];
         }
 #pragma unroll
@@ -266,46 +272,49 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
             edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], st[u], ok[u], c[u], acc, dsum);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
+    for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     dsum = group_sum<LPR, WAVE>(dsum);
     if (slot != 0) return;
     if (part >= 0) {
-        Slice<float>::store(a.part_acc + (size_t)part * D + q * 4, acc);
-        if ((q * 4) % HW == 0) a.part_r[(size_t)part * HEADS + head] = dsum;
+        store_f32<VEC>(a.part_acc + (size_t)part * D + q * VEC, acc);
+        if ((q * VEC) % HW == 0) a.part_r[(size_t)part * HEADS + head] = dsum;
         return;
     }
-    finish_row_b<D, HEADS>(a, row, q, head, acc, dsum);
+    finish_row_b<D, HEADS, VEC>(a, row, q, head, acc, dsum);
 }
 
-template <int D, int HEADS>
+template <typename T, int D, int HEADS>
 __global__ __launch_bounds__(256) void prop_bwd_split_kernel(const PropBwdArgs a, const int* __restrict__ split, int nsplit) {
-    constexpr int LPR = D / 4, EPI = WAVE / LPR, HW = D / HEADS;
+    using SH = BShape<T, D, HEADS>;
+    constexpr int LPR = SH::LPR, EPI = SH::EPI, HW = SH::HW, VEC = SH::VEC;
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= nsplit) return;
     const int row = split[3 * w], p0 = split[3 * w + 1], np = split[3 * w + 2];
-    const int slot = lane / LPR, q = lane % LPR, head = (q * 4) / HW;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f}, dsum = 0.f;
+    const int slot = lane / LPR, q = lane % LPR, head = (q * VEC) / HW;
+    float acc[VEC], dsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
 #pragma unroll 4
     for (int p = p0 + slot; p < p0 + np; p += EPI) {
-        float v[4];
-        Slice<float>::load(a.part_acc + (size_t)p * D + q * 4, v);
+        float v[VEC];
+        load_f32<VEC>(a.part_acc + (size_t)p * D + q * VEC, v);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += v[j];
+        for (int j = 0; j < VEC; ++j) acc[j] += v[j];
         dsum += a.part_r[(size_t)p * HEADS + head];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
+    for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     dsum = group_sum<LPR, WAVE>(dsum);
     if (slot != 0) return;
-    finish_row_b<D, HEADS>(a, row, q, head, acc, dsum);
+    finish_row_b<D, HEADS, VEC>(a, row, q, head, acc, dsum);
 }
 
 template <typename T, int D, int HEADS>
 static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st) {
     constexpr int EPI = BShape<T, D, HEADS>::EPI;
     {
-        const size_t threads = (size_t)a.N * (D / 4);
+        const size_t threads = (size_t)a.N * BShape<T, D, HEADS>::LPR;
         hipLaunchKernelGGL((prop_bwd_node_kernel<T, D, HEADS>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
         NGACF_CHECK_LAUNCH();
     }
@@ -324,7 +333,7 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
         NGACF_CHECK_LAUNCH();
     }
     if (nsplit > 0) {
-        hipLaunchKernelGGL((prop_bwd_split_kernel<D, HEADS>), dim3((nsplit + 3) / 4), dim3(256), 0, st, a, split, nsplit);
+        hipLaunchKernelGGL((prop_bwd_split_kernel<T, D, HEADS>), dim3((nsplit + 3) / 4), dim3(256), 0, st, a, split, nsplit);
         NGACF_CHECK_LAUNCH();
     }
     return 0;
@@ -339,7 +348,7 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
                               const int32_t* col, const void* H, int dtype,
                               const float* S_dst, const float* S_src, const float* avec,
                               const void* out, const float* agg, const float* R, const float* gout,
-                              float* G, float* Gn, float* ST, float* dH, float* dS,
+                              float* G, void* Gn, float* ST, float* dH, float* dS,
                               float* part_acc, float* part_r,
                               int U, int N, int d, int heads, float alpha,
                               float drop_p, uint64_t seed, int flags, void* stream) {
@@ -350,7 +359,7 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
     if ((nseg > 0 && !segs) || (nshort > 0 && !srow)) return NGACF_E_ARG;
     if (nsplit > 0 && (!split || !part_acc || !part_r)) return NGACF_E_ARG;
     if (!(drop_p >= 0.f && drop_p < 1.f) || !(alpha > 0.f && alpha < 1.f)) return NGACF_E_ARG;
-    if ((uint64_t)N * (uint64_t)d * 4ull >= (1ull << 32)) return NGACF_E_SHAPE;   // 32-bit row offsets (fp32 gradient rows)
+    if ((uint64_t)N * (uint64_t)d * (dtype == NGACF_BF16 ? 2ull : 4ull) >= (1ull << 32)) return NGACF_E_SHAPE;   // 32-bit row offsets
     const bool from_row = (flags & NGACF_SCORE_ROW) != 0;
     PropBwdArgs a;
     a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;

@@ -1,15 +1,16 @@
 // Row transform  H = dropout(X) @ W[type]  with the per-node attention scores
-// S[n,h] = sum_{c in head h} H[n,c] * avec[type][c]  fused into the epilogue, and its
-// backward.  Replaces graphattention/SPUIGACF.py:356-357 (+ the node halves of :361,
-// the F.dropout of :208/:213) for all heads of a stage at once.
+// S[n,h] = sum_{c in head h} H[n,c] * avec[type][c]  fused into the epilogue.
+// Replaces graphattention/SPUIGACF.py:356-357 (+ the node halves of :361, the F.dropout of
+// :208/:213) for all heads of a stage at once.
 //
-// fp32 FMA with the 64..128-wide weight panel resident in LDS: the op is
-// [N,64]x[64,64] -- 16 flop per byte of X/H traffic, bound by HBM, not by MFMA.
+// [N,64]x[64,64] fp32: 16 flop per byte of X/H traffic -- HBM/issue balanced, not MFMA shaped
+// (the fp32 MFMA runs at the vector rate on gfx950).  One workgroup per tile of 16*RPT rows with
+// the 16-32 KB weight panel in LDS; RPT is picked per launch so that the grid fits one residency
+// round (4 workgroups per CU) whenever the graph allows: a persistent 2-per-CU variant measured
+// slower (too few loads in flight per CU), see DESIGN.md.
 #include "ngacf_common.hpp"
 
 namespace ngacf {
-
-constexpr int TM = 64;     // rows per workgroup tile
 
 struct TransArgs {
     const void* X;
@@ -23,9 +24,10 @@ struct TransArgs {
     uint32_t salt;
 };
 
-// thread (ty, tx): rows 4*ty..4*ty+3 of the tile, columns 4*tx..+3 (and 64+4*tx..+3 when DOUT = 128)
-template <typename TX, typename TH, int DIN, int DOUT, int HEADS, bool DROP>
+// thread (ty, tx): rows RPT*ty..RPT*ty+RPT-1 of the tile, columns 4*tx..+3 (and 64+4*tx..+3 when DOUT = 128)
+template <typename TX, typename TH, int DIN, int DOUT, int HEADS, bool DROP, int RPT>
 __global__ __launch_bounds__(256) void transform_fwd_kernel(const TransArgs a) {
+    constexpr int TM = 16 * RPT;                   // rows per workgroup tile
     constexpr int XS = DIN + 4;                    // LDS row stride of the X tile (floats), keeps 16-B alignment
     constexpr int CG = DOUT / 64;                  // column groups per thread
     constexpr int HW = DOUT / HEADS;
@@ -73,24 +75,24 @@ __global__ __launch_bounds__(256) void transform_fwd_kernel(const TransArgs a) {
     __syncthreads();
 
     const int ty = tid >> 4, tx = tid & 15;
-    float acc[4][4 * CG];
+    float acc[RPT][4 * CG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RPT; ++i)
 #pragma unroll
         for (int j = 0; j < 4 * CG; ++j) acc[i][j] = 0.f;
 
-#pragma unroll 4
+#pragma unroll 4                   // full unrolling measured 2x slower (registers / instruction cache)
     for (int k4 = 0; k4 < DIN / 4; ++k4) {
-        float4 xa[4];
+        float4 xa[RPT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const float4*>(Xs + (4 * ty + i) * XS + 4 * k4);
+        for (int i = 0; i < RPT; ++i) xa[i] = *reinterpret_cast<const float4*>(Xs + (RPT * ty + i) * XS + 4 * k4);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int g = 0; g < CG; ++g) {
                 const float4 wb = *reinterpret_cast<const float4*>(Ws + (4 * k4 + kk) * DOUT + 64 * g + 4 * tx);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < RPT; ++i) {
                     const float x = kk == 0 ? xa[i].x : kk == 1 ? xa[i].y : kk == 2 ? xa[i].z : xa[i].w;
                     acc[i][4 * g + 0] = fmaf(x, wb.x, acc[i][4 * g + 0]);
                     acc[i][4 * g + 1] = fmaf(x, wb.y, acc[i][4 * g + 1]);
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(256) void transform_fwd_kernel(const TransArgs a) {
 
     TH* Hg = static_cast<TH*>(a.H);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + 4 * ty + i;
+    for (int i = 0; i < RPT; ++i) {
+        const int row = row0 + RPT * ty + i;
         float part[CG];
 #pragma unroll
         for (int g = 0; g < CG; ++g) {
@@ -126,13 +128,13 @@ __global__ __launch_bounds__(256) void transform_fwd_kernel(const TransArgs a) {
             float p = part[0];
 #pragma unroll
             for (int g = 1; g < CG; ++g) p += part[g];
-            p = group_sum<1, 16>(p);
+            p = lanes_sum<16>(p);
             if (tx == 0 && row < row_end) a.S[row] = p;
         } else {
             static_assert(HEADS == 1 || HW == 8, "multi-head stages use 8-wide heads");
 #pragma unroll
             for (int g = 0; g < CG; ++g) {
-                const float p = group_sum<1, 2>(part[g]);
+                const float p = lanes_sum<2>(part[g]);
                 if ((tx & 1) == 0 && row < row_end) a.S[(size_t)row * HEADS + 8 * g + (tx >> 1)] = p;
             }
         }
@@ -152,22 +154,33 @@ __global__ __launch_bounds__(256) void transform_fwd_kernel(const TransArgs a) {
     }
 }
 
-template <typename TX, typename TH, int DIN, int DOUT, int HEADS>
-static int launch_transform(const TransArgs& a, bool drop, hipStream_t st) {
+template <typename TX, typename TH, int DIN, int DOUT, int HEADS, int RPT>
+static int launch_transform_rpt(const TransArgs& a, bool drop, hipStream_t st) {
+    constexpr int TM = 16 * RPT;
     const int nb = (a.U + TM - 1) / TM + (a.I + TM - 1) / TM;
     if (nb == 0) return 0;
     constexpr size_t lds = (size_t)(TM * (DIN + 4) + DIN * DOUT) * sizeof(float);
     if (drop) {
-        auto k = transform_fwd_kernel<TX, TH, DIN, DOUT, HEADS, true>;
+        auto k = transform_fwd_kernel<TX, TH, DIN, DOUT, HEADS, true, RPT>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(nb), dim3(256), lds, st, a);
     } else {
-        auto k = transform_fwd_kernel<TX, TH, DIN, DOUT, HEADS, false>;
+        auto k = transform_fwd_kernel<TX, TH, DIN, DOUT, HEADS, false, RPT>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(nb), dim3(256), lds, st, a);
     }
     NGACF_CHECK_LAUNCH();
     return 0;
+}
+
+// rows per thread: the smallest tile whose grid fits one residency round (1024 workgroups); 64-row
+// tiles when the graph needs many rounds anyway
+template <typename TX, typename TH, int DIN, int DOUT, int HEADS>
+static int launch_transform(const TransArgs& a, bool drop, hipStream_t st) {
+    auto blocks = [&](int tm) { return (a.U + tm - 1) / tm + (a.I + tm - 1) / tm; };
+    if (blocks(64) <= 1024 || blocks(96) > 1024) return launch_transform_rpt<TX, TH, DIN, DOUT, HEADS, 4>(a, drop, st);
+    if (blocks(80) <= 1024) return launch_transform_rpt<TX, TH, DIN, DOUT, HEADS, 5>(a, drop, st);
+    return launch_transform_rpt<TX, TH, DIN, DOUT, HEADS, 6>(a, drop, st);
 }
 
 template <typename TX, typename TH>
@@ -184,294 +197,6 @@ static int dispatch_transform(const TransArgs& a, int din, int dout, int heads, 
 }
 
 
-// ===========================================================================
-// backward
-// ===========================================================================
-struct TransBwdArgs {
-    const void* X;
-    const float* W;
-    const void* H;
-    const float* dH;
-    const float* dS;
-    float* dX;
-    float* work;
-    int U, I;
-    uint32_t drop_thr;
-    float drop_scale;
-    uint32_t salt;
-    int nbu, nbi;          // workgroups of the dW kernel given to user rows / item rows
-};
-
-// dX = mask * (dH @ W[type]^T): the forward tile kernel with the panel transposed on its way into LDS.
-template <int DIN, int DOUT, bool DROP>
-__global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArgs a) {
-    constexpr int GS = DOUT + 4;                   // LDS row stride of the dH tile
-    constexpr int WS = DIN + 4;                    // LDS row stride of W^T  [DOUT][DIN]
-    constexpr int CG = DIN / 64;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Gs = lds;                               // [TM][GS]
-    float* Wt = lds + TM * GS;                     // [DOUT][WS]
-    const int tid = threadIdx.x;
-    const int nbu = (a.U + TM - 1) / TM;
-    const bool users = (int)blockIdx.x < nbu;
-    const int type = users ? 0 : 1;
-    const int row0 = users ? blockIdx.x * TM : a.U + (blockIdx.x - nbu) * TM;
-    const int row_end = users ? a.U : a.U + a.I;
-    {
-        const float* Wg = a.W + (size_t)type * DIN * DOUT;
-        for (int i = tid; i < DIN * DOUT / 4; i += 256) {
-            const int k = i % DIN, c4 = i / DIN;   // consecutive lanes -> consecutive k: conflict-free LDS stores
-            const float4 v = *reinterpret_cast<const float4*>(Wg + (size_t)k * DOUT + 4 * c4);
-            Wt[(4 * c4 + 0) * WS + k] = v.x;
-            Wt[(4 * c4 + 1) * WS + k] = v.y;
-            Wt[(4 * c4 + 2) * WS + k] = v.z;
-            Wt[(4 * c4 + 3) * WS + k] = v.w;
-        }
-        constexpr int PER_ROW = DOUT / 4;
-        for (int i = tid; i < TM * PER_ROW; i += 256) {
-            const int r = i / PER_ROW, cv = i % PER_ROW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + r < row_end) v = *reinterpret_cast<const float4*>(a.dH + (size_t)(row0 + r) * DOUT + 4 * cv);
-            *reinterpret_cast<float4*>(Gs + r * GS + 4 * cv) = v;
-        }
-    }
-    __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
-    float acc[4][4 * CG];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4 * CG; ++j) acc[i][j] = 0.f;
-#pragma unroll 4
-    for (int c4 = 0; c4 < DOUT / 4; ++c4) {
-        float4 ga[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ga[i] = *reinterpret_cast<const float4*>(Gs + (4 * ty + i) * GS + 4 * c4);
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-#pragma unroll
-            for (int g = 0; g < CG; ++g) {
-                const float4 wb = *reinterpret_cast<const float4*>(Wt + (4 * c4 + cc) * WS + 64 * g + 4 * tx);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float x = cc == 0 ? ga[i].x : cc == 1 ? ga[i].y : cc == 2 ? ga[i].z : ga[i].w;
-                    acc[i][4 * g + 0] = fmaf(x, wb.x, acc[i][4 * g + 0]);
-                    acc[i][4 * g + 1] = fmaf(x, wb.y, acc[i][4 * g + 1]);
-                    acc[i][4 * g + 2] = fmaf(x, wb.z, acc[i][4 * g + 2]);
-                    acc[i][4 * g + 3] = fmaf(x, wb.w, acc[i][4 * g + 3]);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + 4 * ty + i;
-        if (row >= row_end) continue;
-#pragma unroll
-        for (int g = 0; g < CG; ++g) {
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = acc[i][4 * g + j];
-                if (DROP) o[j] = feat_bits(a.salt, row, 64 * g + 4 * tx + j) >= a.drop_thr ? o[j] * a.drop_scale : 0.f;
-            }
-            *reinterpret_cast<float4*>(a.dX + (size_t)row * DIN + 64 * g + 4 * tx) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-}
-
-// Partial dW = Xmasked^T @ dH and davec = sum_n dS[n,head(c)] H[n,c] over a strided set of 64-row tiles;
-// workgroup b leaves its partial in work[b][DIN*DOUT + DOUT].
-template <typename TX, typename TH, int DIN, int DOUT, int HEADS, bool DROP>
-__global__ __launch_bounds__(256) void transform_bwd_dw_kernel(const TransBwdArgs a) {
-    constexpr int XS = DIN + 4, GS = DOUT + 4;
-    constexpr int RI = DIN / 16, RJ = DOUT / 16;   // per-thread tile of dW
-    constexpr int HW = DOUT / HEADS;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Xs = lds;                               // [TM][XS]
-    float* Gs = lds + TM * XS;                     // [TM][GS]
-    const int tid = threadIdx.x;
-    const bool users = (int)blockIdx.x < a.nbu;
-    const int nb = users ? a.nbu : a.nbi;
-    const int bl = users ? blockIdx.x : blockIdx.x - a.nbu;
-    const int rbeg = users ? 0 : a.U, rend = users ? a.U : a.U + a.I;
-    const int ntiles = (rend - rbeg + TM - 1) / TM;
-    const int ty = tid >> 4, tx = tid & 15;
-    float acc[RI][RJ];
-#pragma unroll
-    for (int i = 0; i < RI; ++i)
-#pragma unroll
-        for (int j = 0; j < RJ; ++j) acc[i][j] = 0.f;
-    float da = 0.f;
-    const TX* Xg = static_cast<const TX*>(a.X);
-    const TH* Hg = static_cast<const TH*>(a.H);
-
-    for (int tile = bl; tile < ntiles; tile += nb) {
-        const int row0 = rbeg + tile * TM;
-        __syncthreads();
-        {
-            constexpr int XV = Slice<TX>::VEC, PER_ROW = DIN / XV;
-            for (int i = tid; i < TM * PER_ROW; i += 256) {
-                const int r = i / PER_ROW, cv = i % PER_ROW;
-                float f[XV];
-                if (row0 + r < rend) {
-                    Slice<TX>::load(Xg + (size_t)(row0 + r) * DIN + cv * XV, f);
-                    if (DROP) {
-#pragma unroll
-                        for (int j = 0; j < XV; ++j)
-                            f[j] = feat_bits(a.salt, row0 + r, cv * XV + j) >= a.drop_thr ? f[j] * a.drop_scale : 0.f;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < XV; ++j) f[j] = 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < XV; j += 4)
-                    *reinterpret_cast<float4*>(Xs + r * XS + cv * XV + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
-            }
-            constexpr int GPR = DOUT / 4;
-            for (int i = tid; i < TM * GPR; i += 256) {
-                const int r = i / GPR, cv = i % GPR;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row0 + r < rend) v = *reinterpret_cast<const float4*>(a.dH + (size_t)(row0 + r) * DOUT + 4 * cv);
-                *reinterpret_cast<float4*>(Gs + r * GS + 4 * cv) = v;
-            }
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (int r = 0; r < TM; ++r) {
-            float xa[RI], gb[RJ];
-#pragma unroll
-            for (int i = 0; i < RI; i += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(Xs + r * XS + RI * ty + i);
-                xa[i] = v.x; xa[i + 1] = v.y; xa[i + 2] = v.z; xa[i + 3] = v.w;
-            }
-#pragma unroll
-            for (int j = 0; j < RJ; j += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(Gs + r * GS + RJ * tx + j);
-                gb[j] = v.x; gb[j + 1] = v.y; gb[j + 2] = v.z; gb[j + 3] = v.w;
-            }
-#pragma unroll
-            for (int i = 0; i < RI; ++i)
-#pragma unroll
-                for (int j = 0; j < RJ; ++j) acc[i][j] = fmaf(xa[i], gb[j], acc[i][j]);
-        }
-        {   // davec: thread (rg, c) walks rows rg, rg+RG, ... of the tile; loads are independent
-            constexpr int RG = 256 / DOUT;
-            const int c = tid % DOUT, rg = tid / DOUT;
-#pragma unroll 8
-            for (int r = rg; r < TM; r += RG) {
-                const int row = row0 + r;
-                const bool ok = row < rend;
-                const size_t n = (size_t)(ok ? row : rend - 1);
-                float h;
-                if constexpr (sizeof(TH) == 4) h = reinterpret_cast<const float*>(Hg)[n * DOUT + c];
-                else h = bf16_to_f32(reinterpret_cast<const uint16_t*>(Hg)[n * DOUT + c]);
-                const float s = a.dS[n * HEADS + c / HW];
-                da = fmaf(ok ? s : 0.f, h, da);
-            }
-        }
-    }
-    {   // fold the row groups of davec through LDS
-        constexpr int RG = 256 / DOUT;
-        __syncthreads();
-        lds[tid] = da;
-        __syncthreads();
-        if (tid < DOUT) {
-            da = 0.f;
-#pragma unroll
-            for (int g = 0; g < RG; ++g) da += lds[g * DOUT + tid];
-        }
-    }
-    float* wk = a.work + (size_t)blockIdx.x * (DIN * DOUT + DOUT);
-#pragma unroll
-    for (int i = 0; i < RI; ++i)
-#pragma unroll
-        for (int j = 0; j < RJ; j += 4)
-            *reinterpret_cast<float4*>(wk + (size_t)(RI * ty + i) * DOUT + RJ * tx + j) =
-                make_float4(acc[i][j], acc[i][j + 1], acc[i][j + 2], acc[i][j + 3]);
-    if (tid < DOUT) wk[DIN * DOUT + tid] = da;
-}
-
-// dW[type], davec[type] = sum of the partials of that type's workgroups, in workgroup order
-__global__ __launch_bounds__(256) void transform_bwd_reduce_kernel(const float* __restrict__ work, float* __restrict__ dW,
-                                                                   float* __restrict__ davec, int nbu, int nbi, int wsz, int dwsz) {
-    // 64 outputs per workgroup; the 4 waves take interleaved quarters of the partials, then fold in LDS
-    __shared__ float red[256];
-    const int o = threadIdx.x & 63, pg = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o;                  // over [2][wsz]
-    const bool ok = idx < 2 * wsz;
-    const int type = ok ? idx / wsz : 0, k = ok ? idx % wsz : 0;
-    const int b0 = type == 0 ? 0 : nbu, b1 = type == 0 ? nbu : nbu + nbi;
-    float s = 0.f;
-#pragma unroll 8
-    for (int b = b0 + pg; b < b1; b += 4) s += work[(size_t)b * wsz + k];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (pg != 0 || !ok) return;
-    s = (red[o] + red[64 + o]) + (red[128 + o] + red[192 + o]);
-    if (k < dwsz) dW[(size_t)type * dwsz + k] = s;
-    else davec[(size_t)type * (wsz - dwsz) + (k - dwsz)] = s;
-}
-
-template <typename TX, typename TH, int DIN, int DOUT, int HEADS>
-static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool drop, hipStream_t st) {
-    const int tu = (a.U + TM - 1) / TM, ti = (a.I + TM - 1) / TM;
-    if (tu + ti == 0) return 0;
-    {   // dX
-        constexpr size_t lds = (size_t)(TM * (DOUT + 4) + DOUT * (DIN + 4)) * sizeof(float);
-        if (drop) {
-            auto k = transform_bwd_dx_kernel<DIN, DOUT, true>;
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3(tu + ti), dim3(256), lds, st, a);
-        } else {
-            auto k = transform_bwd_dx_kernel<DIN, DOUT, false>;
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3(tu + ti), dim3(256), lds, st, a);
-        }
-        NGACF_CHECK_LAUNCH();
-    }
-    {   // dW, davec
-        int nb = NGACF_TBWD_BLOCKS;
-        if (tu + ti < nb) { a.nbu = tu; a.nbi = ti; }
-        else {
-            a.nbu = (int)((long long)nb * tu / (tu + ti));
-            if (tu > 0 && a.nbu == 0) a.nbu = 1;
-            if (ti > 0 && a.nbu == nb) a.nbu = nb - 1;
-            a.nbi = ti > 0 ? nb - a.nbu : 0;
-            if (tu == 0) a.nbu = 0;
-        }
-        constexpr size_t lds = (size_t)(TM * (DIN + 4) + TM * (DOUT + 4)) * sizeof(float);
-        if (drop) {
-            auto k = transform_bwd_dw_kernel<TX, TH, DIN, DOUT, HEADS, true>;
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3(a.nbu + a.nbi), dim3(256), lds, st, a);
-        } else {
-            auto k = transform_bwd_dw_kernel<TX, TH, DIN, DOUT, HEADS, false>;
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3(a.nbu + a.nbi), dim3(256), lds, st, a);
-        }
-        NGACF_CHECK_LAUNCH();
-        constexpr int wsz = DIN * DOUT + DOUT;
-        hipLaunchKernelGGL(transform_bwd_reduce_kernel, dim3((2 * wsz + 63) / 64), dim3(256), 0, st,
-                           a.work, dW, davec, a.nbu, a.nbi, wsz, DIN * DOUT);
-        NGACF_CHECK_LAUNCH();
-    }
-    return 0;
-}
-
-template <typename TX, typename TH>
-static int dispatch_transform_bwd(const TransBwdArgs& a, float* dW, float* davec, int din, int dout, int heads, bool drop, hipStream_t st) {
-    if (din == 64 && dout == 64 && heads == 8) return launch_transform_bwd<TX, TH, 64, 64, 8>(a, dW, davec, drop, st);
-    if (din == 64 && dout == 64 && heads == 1) return launch_transform_bwd<TX, TH, 64, 64, 1>(a, dW, davec, drop, st);
-    if (din == 128 && dout == 64 && heads == 8) return launch_transform_bwd<TX, TH, 128, 64, 8>(a, dW, davec, drop, st);
-    if (din == 128 && dout == 64 && heads == 1) return launch_transform_bwd<TX, TH, 128, 64, 1>(a, dW, davec, drop, st);
-    if (din == 64 && dout == 128 && heads == 1) return launch_transform_bwd<TX, TH, 64, 128, 1>(a, dW, davec, drop, st);
-    if (din == 64 && dout == 128 && heads == 16) return launch_transform_bwd<TX, TH, 64, 128, 16>(a, dW, davec, drop, st);
-    if (din == 128 && dout == 128 && heads == 1) return launch_transform_bwd<TX, TH, 128, 128, 1>(a, dW, davec, drop, st);
-    if (din == 128 && dout == 128 && heads == 16) return launch_transform_bwd<TX, TH, 128, 128, 16>(a, dW, davec, drop, st);
-    return NGACF_E_SHAPE;
-}
 
 }  // namespace ngacf
 
@@ -498,24 +223,3 @@ extern "C" int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, c
     return NGACF_E_SHAPE;
 }
 
-extern "C" int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
-                                   const float* dH, const float* dS,
-                                   float* dX, float* dW, float* davec, float* work,
-                                   int U, int I, int din, int dout, int heads,
-                                   float feat_drop_p, uint64_t seed, void* stream) {
-    if (U < 0 || I < 0) return NGACF_E_ARG;
-    if (U + I == 0) return 0;
-    if (!X || !W || !H || !dH || !dS || !dX || !dW || !davec || !work) return NGACF_E_ARG;
-    if (!(feat_drop_p >= 0.f && feat_drop_p < 1.f)) return NGACF_E_ARG;
-    TransBwdArgs a;
-    a.X = X; a.W = W; a.H = H; a.dH = dH; a.dS = dS; a.dX = dX; a.work = work; a.U = U; a.I = I;
-    a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p);
-    a.salt = salt_of(seed, 0u); a.nbu = a.nbi = 0;
-    const bool drop = feat_drop_p > 0.f;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (x_dtype == NGACF_F32 && h_dtype == NGACF_F32) return dispatch_transform_bwd<float, float>(a, dW, davec, din, dout, heads, drop, st);
-    if (x_dtype == NGACF_F32 && h_dtype == NGACF_BF16) return dispatch_transform_bwd<float, bf16_t>(a, dW, davec, din, dout, heads, drop, st);
-    if (x_dtype == NGACF_BF16 && h_dtype == NGACF_BF16) return dispatch_transform_bwd<bf16_t, bf16_t>(a, dW, davec, din, dout, heads, drop, st);
-    if (x_dtype == NGACF_BF16 && h_dtype == NGACF_F32) return dispatch_transform_bwd<bf16_t, float>(a, dW, davec, din, dout, heads, drop, st);
-    return NGACF_E_SHAPE;
-}

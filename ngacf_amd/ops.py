@@ -106,7 +106,7 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
     if score_from_row is None:
-        score_from_row = heads > 1
+        score_from_row = True      # recomputing a.h from the gathered row beats a second gather (profiles/)
     hp = _chk(H, "H", None, N * d, dev)
     if H.dtype not in _DT:
         raise ValueError("H dtype %s" % H.dtype)
@@ -135,7 +135,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
     if score_from_row is None:
-        score_from_row = heads > 1
+        score_from_row = True      # recomputing a.h from the gathered row beats a second gather (profiles/)
     hp = _chk(H, "H", None, N * d, dev)
     sd = _chk(S_dst, "S_dst", torch.float32, N * heads, dev)
     ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
@@ -146,7 +146,8 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     go = _chk(gout, "gout", torch.float32, N * d, dev)
     pp = _plan_ptrs(plan, dev)
     f32 = dict(dtype=torch.float32, device=dev)
-    G, Gn, dH = torch.empty(N, d, **f32), torch.empty(N, d, **f32), torch.empty(N, d, **f32)
+    G, dH = torch.empty(N, d, **f32), torch.empty(N, d, **f32)
+    Gn = torch.empty(N, d, dtype=H.dtype, device=dev)
     t, dS = torch.empty(N, heads, 2, **f32), torch.empty(N, heads, **f32)
     pa = torch.empty(max(plan.nparts, 1), d, **f32)
     pr = torch.empty(max(plan.nparts, 1), heads, **f32)
