@@ -1,0 +1,172 @@
+"""Counterparts of the reference's callers of the hot path:
+
+  train_bpr     train_eval_Gowalla.py:90-144   sequential un-shuffled batches; per row the positive
+                                               AND the negative are re-sampled from the user's sets
+                                               (data/loadGowalla.py:69-77); 2 forwards per step;
+                                               returns total_loss / len(train rows)
+  eval_neg_all  train_eval_Gowalla.py:274-354  all-item ranking; candidates = item pool minus the
+                                               user's *train* positives (loadGowalla.py:63-67), hits =
+                                               test positives, top-20 (heapq.nlargest :370-385), metrics
+                                               of graphattention/metrics.py incl. the NDCG quirk
+                                               (:63-73), sums divided by the number of *train* users (:283)
+
+What changes is where the work happens: the per-user negative `set`s (the 60-100 GB of README.md:19,25)
+become a sorted key array + rejection sampling on the device, and the evaluation computes the propagated
+embeddings once (the reference recomputes a bit-identical propagation for every 64 x 2048 score block).
+"""
+import numpy as np
+import torch
+
+KS = (1, 5, 10, 20)
+
+
+class Interactions:
+    """Train/test interactions as device tensors.
+
+    train_u/train_i: rows of train_df in file order (the batch order of train_bpr);
+    item pool: the distinct items of train ∪ test (`rt`, run_Gowalla.py:46,85)."""
+
+    def __init__(self, train_u, train_i, test_u, test_i, U, I, device):
+        dev = torch.device(device)
+        t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.long, device=dev)
+        self.U, self.I, self.device = U, I, dev
+        self.train_u, self.train_i = t(train_u), t(train_i)
+        self.test_u, self.test_i = t(test_u), t(test_i)
+        self.train_keys = torch.unique(self.train_u * I + self.train_i)            # sorted (user, item) keys
+        self.test_keys = torch.unique(self.test_u * I + self.test_i)
+        ku = self.train_keys // I
+        self.train_ptr = torch.zeros(U + 1, dtype=torch.long, device=dev)
+        self.train_ptr[1:] = torch.cumsum(torch.bincount(ku, minlength=U), 0)     # CSR of the train positives
+        self.train_items = self.train_keys % I
+        pool = torch.zeros(I, dtype=torch.bool, device=dev)
+        pool[self.train_i] = True
+        pool[self.test_i] = True
+        self.pool_mask = pool
+        self.pool_items = torch.nonzero(pool).squeeze(1)
+        self.train_users = torch.unique(self.train_u)                              # len(train_pos_neg), :283
+        tu = self.test_keys // I
+        self.test_ptr = torch.zeros(U + 1, dtype=torch.long, device=dev)
+        self.test_ptr[1:] = torch.cumsum(torch.bincount(tu, minlength=U), 0)
+        self.test_items = self.test_keys % I
+
+    def adjacency(self):
+        """`ui_mat` indices over train ∪ test, coalesced (data/loadGowalla.py:184-253, run_Gowalla.py:82,94)."""
+        key = torch.unique(torch.cat([self.train_keys, self.test_keys]))
+        return torch.stack([key // self.I, key % self.I])
+
+
+def sample_pairs(data, users, generator=None, max_rounds=64):
+    """For every user of the batch: one positive uniformly from the user's train positives and one negative
+    uniformly from (item pool − train positives)  (data/loadGowalla.py:69-77).  Device-side rejection
+    sampling against the sorted key array replaces the per-user Python sets."""
+    dev, I = data.device, data.I
+    g = generator
+    beg, end = data.train_ptr[users], data.train_ptr[users + 1]
+    r = torch.rand(users.numel(), device=dev, generator=g)
+    pos = data.train_items[beg + torch.clamp((r * (end - beg)).long(), max=(end - beg - 1).clamp_min(0))]
+    neg = torch.empty_like(pos)
+    todo = torch.arange(users.numel(), device=dev)
+    for _ in range(max_rounds):
+        cand = data.pool_items[torch.randint(0, data.pool_items.numel(), (todo.numel(),), device=dev, generator=g)]
+        key = users[todo] * I + cand
+        j = torch.searchsorted(data.train_keys, key).clamp_(max=data.train_keys.numel() - 1)
+        ok = data.train_keys[j] != key
+        neg[todo[ok]] = cand[ok]
+        todo = todo[~ok]
+        if todo.numel() == 0:
+            break
+    else:
+        raise RuntimeError("negative sampling did not converge (a user is positive on the whole item pool)")
+    return pos, neg
+
+
+def train_bpr(model, batch_size, data, adj, optim, lossfn, generator=None, log_every=0):
+    model.train()
+    n = data.train_u.numel()
+    total = torch.zeros((), device=data.device)
+    n_batches = n // batch_size + 1                                  # train_eval_Gowalla.py:108
+    for b in range(n_batches):
+        users = data.train_u[b * batch_size:(b + 1) * batch_size]     # sequential slices, no shuffling (:111-115)
+        if users.numel() == 0:
+            continue
+        pos, neg = sample_pairs(data, users, generator)
+        optim.zero_grad(set_to_none=True)
+        pos_scores = model(users, pos, adj)                           # two full propagations with independent
+        neg_scores = model(users, neg, adj)                           # dropout masks (:131-132)
+        loss = lossfn(pos_scores, neg_scores)
+        loss.backward()
+        optim.step()
+        total += loss.detach()
+        if log_every and b % log_every == 0:
+            print("  batch %d/%d loss %.5f" % (b, n_batches, float(loss.detach())), flush=True)
+    return float(total) / n                                           # :144 (sum of batch means / rows)
+
+
+def metrics_from_hits(r, npos, n_norm):
+    """r: [B,20] 0/1 hit lists (rank order), npos: [B] number of test positives.  Returns the four
+    metric vectors @KS summed over the batch and divided by n_norm (graphattention/metrics.py)."""
+    r = r.double()
+    disc = 1.0 / torch.log2(torch.arange(2, 22, device=r.device, dtype=torch.double))
+    ideal = torch.sort(r, dim=1, descending=True).values              # the reference's quirk: ideal DCG from r itself
+    out = {k: [] for k in ("precision", "recall", "ndcg", "hit_ratio")}
+    for K in KS:
+        rk = r[:, :K]
+        hits = rk.sum(1)
+        dcg = (rk * disc[:K]).sum(1)
+        idcg = (ideal[:, :K] * disc[:K]).sum(1)
+        out["precision"].append((hits / K).sum() / n_norm)
+        out["recall"].append((hits / npos.double()).sum() / n_norm)
+        out["ndcg"].append(torch.where(idcg > 0, dcg / idcg.clamp_min(1e-300), torch.zeros_like(dcg)).sum() / n_norm)
+        out["hit_ratio"].append((hits > 0).double().sum() / n_norm)
+    return {k: torch.stack(v) for k, v in out.items()}
+
+
+@torch.no_grad()
+def eval_neg_all(model, batch_size, data, adj, user_batch=4096, return_scores=False):
+    """All-item evaluation.  Users = those with test positives that also appear in train (the merge at
+    train_eval_Gowalla.py:307); normaliser = number of train users (:283)."""
+    model.eval()
+    F = model.propagate(adj).float()                                  # once: eval mode is deterministic
+    U, I = data.U, data.I
+    has_test = (data.test_ptr[1:] - data.test_ptr[:-1]) > 0
+    has_train = (data.train_ptr[1:] - data.train_ptr[:-1]) > 0
+    users = torch.nonzero(has_test & has_train).squeeze(1)
+    n_norm = float(data.train_users.numel())
+    res = {k: torch.zeros(len(KS), dtype=torch.double, device=data.device) for k in ("precision", "recall", "ndcg", "hit_ratio")}
+    Fi = F[U:]
+    neg_inf = torch.finfo(torch.float32).min
+    kept = []
+    for s in range(0, users.numel(), user_batch):
+        ub = users[s:s + user_batch]
+        scores = F[ub] @ Fi.t()                                       # dense [B, I] GEMM (rocBLAS via torch)
+        if return_scores:
+            kept.append(scores.clone())
+        scores[:, ~data.pool_mask] = neg_inf                          # candidates: pool − train positives
+        rows = torch.repeat_interleave(torch.arange(ub.numel(), device=data.device),
+                                       data.train_ptr[ub + 1] - data.train_ptr[ub])
+        cols = _gather_rows(data.train_ptr, data.train_items, ub)
+        scores[rows, cols] = neg_inf
+        top = torch.sort(scores, dim=1, descending=True, stable=True).indices[:, :20]   # ties: lower item id first
+        key = ub[:, None] * I + top
+        j = torch.searchsorted(data.test_keys, key.reshape(-1)).clamp_(max=data.test_keys.numel() - 1)
+        r = (data.test_keys[j] == key.reshape(-1)).reshape(top.shape)
+        valid = torch.gather(scores, 1, top) > neg_inf                # fewer than 20 candidates
+        r = r & valid
+        npos = data.test_ptr[ub + 1] - data.test_ptr[ub]
+        m = metrics_from_hits(r, npos, n_norm)
+        for k in res:
+            res[k] += m[k]
+    out = {k: v.cpu().numpy() for k, v in res.items()}
+    out["auc"] = 0.0                                                  # the reference reports 0 (:385)
+    if return_scores:
+        return out, users, torch.cat(kept)
+    return out
+
+
+def _gather_rows(ptr, items, rows):
+    """Concatenate CSR rows `rows` without a Python loop."""
+    beg, cnt = ptr[rows], ptr[rows + 1] - ptr[rows]
+    total = int(cnt.sum())
+    start = torch.cumsum(cnt, 0) - cnt
+    idx = torch.arange(total, device=ptr.device) - torch.repeat_interleave(start, cnt) + torch.repeat_interleave(beg, cnt)
+    return items[idx]

@@ -1,0 +1,170 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports exactly what
+include/ngacf.h declares (no compute calls), the graph plan, the dropout hash, the module
+surface / state_dict keys."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, params_of
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "ngacf.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(ngacf_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
+        args = [a for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
+        out[m.group(1)] = len(args)
+    return out
+
+
+def test_library_exports_every_declared_symbol_with_matching_arity():
+    from ngacf_amd import _lib
+    decl = _header_functions()
+    assert len(decl) >= 11 and "ngacf_version" in decl
+    for name, nargs in decl.items():
+        assert hasattr(_lib.lib, name), name
+        if name != "ngacf_version":
+            assert len(_lib.SIGNATURES[name]) == nargs, (name, nargs)
+    assert set(_lib.SIGNATURES) | {"ngacf_version"} == set(decl)
+    assert "gfx950" in _lib.version()
+
+
+def test_plan_matches_scipy_csr_and_covers_every_row():
+    import scipy.sparse as sp
+    from ngacf_amd.plan import build_plan
+    g = load_golden("g1_layer_k8_concat")
+    U, I = int(g["U"]), int(g["I"])
+    edge = g["edge"]
+    for seg, short in ((256, 64), (8, 4), (4, -1), (1 << 20, 1 << 20)):
+        p = build_plan(torch.from_numpy(edge), U, I, seg_len=seg, short_max=short)
+        A = sp.csr_matrix((np.ones(edge.shape[1]), (edge[0], edge[1])), shape=(U, I))
+        At = A.T.tocsr()
+        rowptr = np.concatenate([A.indptr, A.indptr[-1] + At.indptr[1:]])
+        col = np.concatenate([A.indices + U, At.indices])
+        assert np.array_equal(p.rowptr.numpy(), rowptr) and np.array_equal(p.col.numpy(), col)
+        # every (row, edge) is covered exactly once by short rows + segments
+        seen = np.zeros(2 * edge.shape[1], dtype=np.int64)
+        rows_done = np.zeros(U + I, dtype=np.int64)
+        for r in p.srow.numpy():
+            seen[rowptr[r]:rowptr[r + 1]] += 1
+            rows_done[r] += 1
+        for r, b, e, part in p.segs.numpy():
+            seen[b:e] += 1
+            assert rowptr[r] <= b <= e <= rowptr[r + 1]
+        rows_done[np.unique(p.segs.numpy()[:, 0])] += 1 if p.nseg else 0
+        assert (seen == 1).all() and (rows_done == 1).all()
+        for r, p0, n in p.split.numpy():
+            parts = sorted(s[3] for s in p.segs.numpy() if s[0] == r)
+            assert parts == list(range(p0, p0 + n))
+    # duplicates merge like coalesce(); unsorted input is fine
+    perm = np.random.RandomState(0).permutation(edge.shape[1])
+    dup = np.concatenate([edge[:, perm], edge[:, :17]], 1)
+    p2 = build_plan(torch.from_numpy(dup), U, I)
+    assert p2.E == edge.shape[1] and np.array_equal(p2.col.numpy(), col)
+
+
+def test_plan_rejects_bad_graphs():
+    from ngacf_amd.plan import build_plan
+    e = torch.tensor([[0, 1, 1], [0, 1, 2]])
+    with pytest.raises(ValueError):
+        build_plan(e, 3, 3)                       # user 2 has no edge (reference asserts, SPUIGACF.py:368)
+    with pytest.raises(ValueError):
+        build_plan(torch.tensor([[0, 5], [0, 1]]), 2, 3)
+    with pytest.raises(ValueError):
+        build_plan(torch.zeros(3, 4, dtype=torch.long), 2, 3)
+    p = build_plan(e[None], 2, 3)                 # [1,2,E] as under DataParallel (SPUIGACF.py:42)
+    assert p.E == 3 and p.N == 5
+    # row-range plans (node partition) cover only their rows
+    q = build_plan(e, 2, 3, row_range=(1, 4))
+    rows = set(q.srow.tolist()) | set(q.segs[:, 0].tolist())
+    assert rows == {1, 2, 3}
+
+
+def test_dropout_hash_properties():
+    from ngacf_amd import rng
+    n = np.arange(200000, dtype=np.uint32)
+    for p in (0.1, 0.25, 0.5):
+        keep = rng.feat_bits(2019, n // 64, n % 64) >= rng.threshold(p)
+        assert abs(keep.mean() - (1 - p)) < 4e-3
+    a = rng.edge_bits(1, 0, n, n[::-1].copy())
+    b = rng.edge_bits(1, 1, n, n[::-1].copy())
+    c = rng.edge_bits(2, 0, n, n[::-1].copy())
+    assert (a != b).mean() > 0.99 and (a != c).mean() > 0.99           # heads / seeds decorrelate
+    assert rng.threshold(0.0) == 0 and rng.keep_scale(a, 0.0).min() == 1.0
+    assert rng.lowbias32(np.uint32(0)) == 0
+
+
+def test_module_surface_and_state_dict_keys():
+    import ngacf_amd
+    for tag, cls in (("spuigacf", ngacf_amd.SPUIGACF), ("spuimultigacf", ngacf_amd.SPUIMultiGACF)):
+        g = load_golden("g234_" + tag)
+        U, I = int(g["U"]), int(g["I"])
+        m = cls(U, I, 64, [64, 64], 0.1, useCuda=False)
+        ref = params_of(g)
+        sd = m.state_dict()
+        assert set(sd) == set(ref)
+        for k, v in ref.items():
+            assert tuple(sd[k].shape) == v.shape, k
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()})
+        assert sum(p.numel() for p in m.parameters()) == sum(v.size for v in ref.values())
+    # init statistics follow the reference (N(0, 0.01^2) embeddings, xavier_normal gain 1.414)
+    torch.manual_seed(0)
+    m = ngacf_amd.SPUIGACF(2000, 3000, 64, [64, 64], 0.1)
+    assert abs(float(m.uEmbd.weight.std()) - 0.01) < 5e-4
+    w = m.gat.attention_0.W_u
+    assert abs(float(w.std()) - 1.414 * (2.0 / (64 + 8)) ** 0.5) < 0.03
+    assert m.gat.out_att.a.shape == (1, 128) and m.gat.attention_3.a.shape == (1, 16)
+
+
+def test_ops_refuse_cpu_tensors():
+    from ngacf_amd import ops
+    with pytest.raises(ValueError):
+        ops.transform_fwd(torch.zeros(4, 64), torch.zeros(2, 64, 64), torch.zeros(2, 64), 2, 2, 8)
+
+
+def test_metrics_from_hits_match_oracle_definitions():
+    from oracle import ngacf_oracle as O
+    from ngacf_amd.train_eval import KS, metrics_from_hits
+    rs = np.random.RandomState(5)
+    r = (rs.rand(40, 20) < 0.25).astype(np.int64)
+    r[0] = 0
+    r[1] = 1
+    r[2] = 0
+    r[2, 19] = 1
+    npos = rs.randint(1, 30, 40)
+    got = metrics_from_hits(torch.from_numpy(r), torch.from_numpy(npos), 50.0)
+    want = {k: np.zeros(4) for k in ("precision", "recall", "ndcg", "hit_ratio")}
+    for row, n in zip(r, npos):
+        p = O.performance(list(range(int(n))), list(row), KS)
+        for k in want:
+            want[k] += p[k] / 50.0
+    for k in want:
+        assert np.allclose(got[k].numpy(), want[k], atol=1e-12), k
+
+
+def test_pair_sampler_semantics():
+    """positives from the user's train set, negatives from pool - train positives (test positives allowed),
+    as data/loadGowalla.py:63-77."""
+    from ngacf_amd.train_eval import Interactions, sample_pairs
+    rs = np.random.RandomState(1)
+    U, I = 30, 50
+    tu = np.repeat(np.arange(U), 6)
+    ti = rs.randint(0, 40, tu.size)                       # items 40..49 never in train
+    te_u = np.arange(U)
+    te_i = rs.randint(40, 48, U)                          # items 48, 49 are outside the pool
+    d = Interactions(tu, ti, te_u, te_i, U, I, "cpu")
+    assert d.pool_items.max() <= 47 and int(d.train_users.numel()) == U
+    g = torch.Generator().manual_seed(0)
+    users = torch.from_numpy(np.tile(np.arange(U), 200))
+    pos, neg = sample_pairs(d, users, g)
+    train = set(zip(tu.tolist(), ti.tolist()))
+    pairs_p = set(zip(users.tolist(), pos.tolist()))
+    assert pairs_p <= train and len(pairs_p) == len(train)          # every train positive is reachable
+    assert not (set(zip(users.tolist(), neg.tolist())) & train)
+    assert int(neg.max()) <= 47 and int((neg >= 40).sum()) > 0      # test items can be drawn as negatives
+    adj = d.adjacency()
+    assert adj.shape[1] == len(train | set(zip(te_u.tolist(), te_i.tolist())))
