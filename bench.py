@@ -67,7 +67,8 @@ def main():
                          % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("NGACF_BENCH_FORCE_DIST") == "1"      # rehearse the N>1 code path on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -79,7 +80,7 @@ def main():
     U, I, E_target = D.SHAPES[wl]
     elem = 2 if args.dtype == "bf16" else 4
 
-    if world > 1:
+    if world > 1 or force_dist:
         from ngacf_amd import dist as ND
         return ND.bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, HBM_PEAK_GBS)
 

@@ -43,6 +43,7 @@ extern "C" {
 /* flags of ngacf_prop_* */
 #define NGACF_ELU        1   /* apply ELU to h + agg (SPUIGACF.py:395-397 and the outer F.elu :214) */
 #define NGACF_RESIDUAL   2   /* out = h_dst + agg (SPUIGACF.py:383,390); clear for SPGA.py:405-409 */
+#define NGACF_SKIP_NODE  8   /* ngacf_prop_bwd: step 1 was already run by ngacf_prop_bwd_node */
 #define NGACF_SCORE_ROW  4   /* recompute the source score a_src . h_src from the gathered row
                                 instead of reading S_src (saves 4*heads bytes per edge) */
 
@@ -65,6 +66,15 @@ int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, const float*
                         void* H, int h_dtype, float* S,
                         int U, int I, int din, int dout, int heads,
                         float feat_drop_p, uint64_t seed, void* stream);
+
+/* The same over row windows (node-partitioned runs, ngacf_amd/dist.py): users [u_lo, u_lo+u_n) and items
+ * [i_lo, i_lo+i_n) (global row = U + i).  H and S are indexed by global row; with x_local != 0, X holds only
+ * the window rows (the u_n user rows first, then the i_n item rows). */
+int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float* W, const float* avec,
+                             void* H, int h_dtype, float* S,
+                             int U, int I, int din, int dout, int heads,
+                             int u_lo, int u_n, int i_lo, int i_n, int x_local,
+                             float feat_drop_p, uint64_t seed, void* stream);
 
 /* Attention propagation, forward, both directions in one launch.
  * Replaces SPUIGACF.py:359-393 (edge gather, exp(-leakyrelu), e_rowsum/e_colsum, edge dropout,
@@ -113,6 +123,22 @@ int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* 
                         float* dX, float* dW, float* davec, float* work,
                         int U, int I, int din, int dout, int heads,
                         float feat_drop_p, uint64_t seed, void* stream);
+
+/* Row-window form (see ngacf_transform_fwd_rows): X and dX local when x_local != 0; dW and davec are the
+ * sums over the window rows only (all-reduce them across ranks). */
+int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
+                             const float* dH, const float* dS,
+                             float* dX, float* dW, float* davec, float* work,
+                             int U, int I, int din, int dout, int heads,
+                             int u_lo, int u_n, int i_lo, int i_n, int x_local,
+                             float feat_drop_p, uint64_t seed, void* stream);
+
+/* Step 1 of ngacf_prop_bwd alone, over row windows; gout holds only the window rows when gout_local != 0.
+ * Lets a node-partitioned run all-gather Gn/ST between the two steps (then ngacf_prop_bwd with NGACF_SKIP_NODE). */
+int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg, const float* R, const float* gout,
+                        const float* S_src, float* G, void* Gn, float* ST,
+                        int U, int N, int d, int heads, int flags,
+                        int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream);
 
 /* Pair scoring: score[b] = sum_c F[u[b],c] * F[U + i[b],c]   (SPUIGACF.py:49-52). */
 int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const int64_t* i,

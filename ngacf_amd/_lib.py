@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libngacf_hip.so")
 
 F32, BF16 = 0, 1
-FLAG_ELU, FLAG_RESIDUAL, FLAG_SCORE_ROW = 1, 2, 4
+FLAG_ELU, FLAG_RESIDUAL, FLAG_SCORE_ROW, FLAG_SKIP_NODE = 1, 2, 4, 8
 TBWD_BLOCKS = 256
 
 _p = ctypes.c_void_p
@@ -29,6 +29,10 @@ SIGNATURES = {
     "ngacf_prop_bwd": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
                        _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u64, _i, _p],
     "ngacf_transform_bwd": [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p],
+    "ngacf_transform_fwd_rows": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _p],
+    "ngacf_transform_bwd_rows": [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                 _f, _u64, _p],
+    "ngacf_prop_bwd_node": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "ngacf_score_fwd": [_p, _i, _p, _p, _p, _i, _i, _i, _p],
     "ngacf_score_bwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "ngacf_bpr_fwd": [_p, _p, _p, _i, _p],

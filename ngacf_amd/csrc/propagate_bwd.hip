@@ -40,6 +40,8 @@ struct PropBwdArgs {
     float* part_acc;
     float* part_r;
     int U, N;
+    int nu_lo, nu_n, ni_lo, ni_n;  // step-1 row windows: users [nu_lo, +nu_n), items [ni_lo, +ni_n) (global row = U + i)
+    int gout_local;                // gout holds only the window rows, users first (node-partitioned runs)
     int nb_long;
     float alpha;
     uint32_t drop_thr;
@@ -89,13 +91,15 @@ __global__ __launch_bounds__(256) void prop_bwd_node_kernel(const PropBwdArgs a)
     using SH = BShape<T, D, HEADS>;
     constexpr int LPR = SH::LPR, HW = SH::HW, VEC = SH::VEC;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t n = gid / LPR;
+    const size_t li = gid / LPR;                              // index inside the row windows
     const int q = (int)(gid % LPR);
-    const bool ok = n < (size_t)a.N;
-    const size_t nn = ok ? n : 0;
+    const bool ok = li < (size_t)(a.nu_n + a.ni_n);
+    const size_t lj = ok ? li : 0;
+    const size_t n = lj < (size_t)a.nu_n ? a.nu_lo + lj : (size_t)a.U + a.ni_lo + (lj - a.nu_n);
+    const size_t nn = n;
     const int head = (q * VEC) / HW;
     float g[VEC], o[VEC], ag[VEC];
-    load_f32<VEC>(a.gout + nn * D + q * VEC, g);
+    load_f32<VEC>(a.gout + (a.gout_local ? lj : nn) * D + q * VEC, g);
     load_f32<VEC>(a.agg + nn * D + q * VEC, ag);
     if (a.flags & NGACF_ELU) {
         Slice<T>::load(static_cast<const T*>(a.out) + nn * D + q * VEC, o);
@@ -311,13 +315,15 @@ __global__ __launch_bounds__(256) void prop_bwd_split_kernel(const PropBwdArgs a
 }
 
 template <typename T, int D, int HEADS>
-static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st) {
+static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st,
+                      bool do_node, bool do_edges) {
     constexpr int EPI = BShape<T, D, HEADS>::EPI;
-    {
-        const size_t threads = (size_t)a.N * BShape<T, D, HEADS>::LPR;
+    if (do_node && a.nu_n + a.ni_n > 0) {
+        const size_t threads = (size_t)(a.nu_n + a.ni_n) * BShape<T, D, HEADS>::LPR;
         hipLaunchKernelGGL((prop_bwd_node_kernel<T, D, HEADS>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
         NGACF_CHECK_LAUNCH();
     }
+    if (!do_edges) return 0;
     a.nb_long = (a.nseg + 3) / 4;
     const int nw_short = (a.nshort + EPI - 1) / EPI;
     const int nb = a.nb_long + (nw_short + 3) / 4;
@@ -343,21 +349,26 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
 
 using namespace ngacf;
 
-extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                              const int32_t* srow, int nshort, const int32_t* rowptr,
-                              const int32_t* col, const void* H, int dtype,
-                              const float* S_dst, const float* S_src, const float* avec,
-                              const void* out, const float* agg, const float* R, const float* gout,
-                              float* G, void* Gn, float* ST, float* dH, float* dS,
-                              float* part_acc, float* part_r,
-                              int U, int N, int d, int heads, float alpha,
-                              float drop_p, uint64_t seed, int flags, void* stream) {
+static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                         const int32_t* srow, int nshort, const int32_t* rowptr,
+                         const int32_t* col, const void* H, int dtype,
+                         const float* S_dst, const float* S_src, const float* avec,
+                         const void* out, const float* agg, const float* R, const float* gout,
+                         float* G, void* Gn, float* ST, float* dH, float* dS,
+                         float* part_acc, float* part_r,
+                         int U, int N, int d, int heads, float alpha,
+                         float drop_p, uint64_t seed, int flags,
+                         int nu_lo, int nu_n, int ni_lo, int ni_n, int gout_local, bool do_node, bool do_edges, void* stream) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
+    if (nu_lo < 0 || nu_n < 0 || ni_lo < 0 || ni_n < 0 || nu_lo + nu_n > U || ni_lo + ni_n > N - U) return NGACF_E_ARG;
     if (N == 0) return 0;
-    if (!col || !rowptr || !H || !S_dst || !S_src || !avec || !out || !agg || !R || !gout || !G || !Gn || !ST || !dH || !dS)
-        return NGACF_E_ARG;
-    if ((nseg > 0 && !segs) || (nshort > 0 && !srow)) return NGACF_E_ARG;
-    if (nsplit > 0 && (!split || !part_acc || !part_r)) return NGACF_E_ARG;
+    if (!S_src || !G || !Gn || !ST) return NGACF_E_ARG;
+    if (do_node && (!out || !agg || !R || !gout)) return NGACF_E_ARG;
+    if (do_edges) {
+        if (!col || !rowptr || !H || !S_dst || !avec || !dH || !dS) return NGACF_E_ARG;
+        if ((nseg > 0 && !segs) || (nshort > 0 && !srow)) return NGACF_E_ARG;
+        if (nsplit > 0 && (!split || !part_acc || !part_r)) return NGACF_E_ARG;
+    }
     if (!(drop_p >= 0.f && drop_p < 1.f) || !(alpha > 0.f && alpha < 1.f)) return NGACF_E_ARG;
     if ((uint64_t)N * (uint64_t)d * (dtype == NGACF_BF16 ? 2ull : 4ull) >= (1ull << 32)) return NGACF_E_SHAPE;   // 32-bit row offsets
     const bool from_row = (flags & NGACF_SCORE_ROW) != 0;
@@ -365,11 +376,12 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
     a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R; a.gout = gout;
     a.G = G; a.Gn = Gn; a.ST = reinterpret_cast<float2*>(ST); a.dH = dH; a.dS = dS; a.part_acc = part_acc; a.part_r = part_r;
-    a.U = U; a.N = N; a.nb_long = 0; a.alpha = alpha;
+    a.U = U; a.N = N; a.nu_lo = nu_lo; a.nu_n = nu_n; a.ni_lo = ni_lo; a.ni_n = ni_n; a.gout_local = gout_local;
+    a.nb_long = 0; a.alpha = alpha;
     a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.flags = flags;
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define NGACF_CASE(T, D, HD) return launch_bwd<T, D, HD>(a, split, nsplit, from_row, drop, st)
+#define NGACF_CASE(T, D, HD) return launch_bwd<T, D, HD>(a, split, nsplit, from_row, drop, st, do_node, do_edges)
     if (dtype == NGACF_F32) {
         if (d == 64 && heads == 8) NGACF_CASE(float, 64, 8);
         if (d == 64 && heads == 1) NGACF_CASE(float, 64, 1);
@@ -383,4 +395,28 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
     }
 #undef NGACF_CASE
     return NGACF_E_SHAPE;
+}
+
+extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                              const int32_t* srow, int nshort, const int32_t* rowptr,
+                              const int32_t* col, const void* H, int dtype,
+                              const float* S_dst, const float* S_src, const float* avec,
+                              const void* out, const float* agg, const float* R, const float* gout,
+                              float* G, void* Gn, float* ST, float* dH, float* dS,
+                              float* part_acc, float* part_r,
+                              int U, int N, int d, int heads, float alpha,
+                              float drop_p, uint64_t seed, int flags, void* stream) {
+    const bool skip_node = (flags & NGACF_SKIP_NODE) != 0;
+    return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
+                         G, Gn, ST, dH, dS, part_acc, part_r, U, N, d, heads, alpha, drop_p, seed, flags,
+                         0, U, 0, N - U, 0, !skip_node, true, stream);
+}
+
+extern "C" int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg, const float* R, const float* gout,
+                                   const float* S_src, float* G, void* Gn, float* ST,
+                                   int U, int N, int d, int heads, int flags,
+                                   int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream) {
+    return prop_bwd_impl(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, dtype, nullptr, S_src, nullptr,
+                         out, agg, R, gout, G, Gn, ST, nullptr, nullptr, nullptr, nullptr, U, N, d, heads, 0.2f, 0.f, 0, flags,
+                         u_lo, u_n, i_lo, i_n, gout_local, true, false, stream);
 }

@@ -19,6 +19,8 @@ struct TransArgs {
     void* H;
     float* S;
     int U, I;
+    int u_lo, u_n, i_lo, i_n;      // row windows: users [u_lo, u_lo+u_n), items [i_lo, i_lo+i_n) (global row = U + i)
+    int x_local;                   // X holds only the window rows, users first (node-partitioned runs)
     uint32_t drop_thr;
     float drop_scale;
     uint32_t salt;
@@ -36,11 +38,12 @@ __global__ __launch_bounds__(256) void transform_fwd_kernel(const TransArgs a) {
     float* Ws = lds + TM * XS;                     // [DIN][DOUT]
 
     const int tid = threadIdx.x;
-    const int nbu = (a.U + TM - 1) / TM;
+    const int nbu = (a.u_n + TM - 1) / TM;
     const bool users = (int)blockIdx.x < nbu;
     const int type = users ? 0 : 1;
-    const int row0 = users ? blockIdx.x * TM : a.U + (blockIdx.x - nbu) * TM;
-    const int row_end = users ? a.U : a.U + a.I;
+    const int row0 = users ? a.u_lo + blockIdx.x * TM : a.U + a.i_lo + (blockIdx.x - nbu) * TM;
+    const int row_end = users ? a.u_lo + a.u_n : a.U + a.i_lo + a.i_n;
+    const int xoff = a.x_local ? (users ? a.u_lo : a.U + a.i_lo - a.u_n) : 0;     // X row = global row - xoff
 
     // weight panel -> LDS (coalesced float4)
     {
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(256) void transform_fwd_kernel(const TransArgs a) {
             const int r = i / PER_ROW, cv = i % PER_ROW;
             float f[XV];
             if (row0 + r < row_end) {
-                Slice<TX>::load(Xg + (size_t)(row0 + r) * DIN + cv * XV, f);
+                Slice<TX>::load(Xg + (size_t)(row0 + r - xoff) * DIN + cv * XV, f);
                 if (DROP) {
 #pragma unroll
                     for (int j = 0; j < XV; ++j)
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void transform_fwd_kernel(const TransArgs a) {
 template <typename TX, typename TH, int DIN, int DOUT, int HEADS, int RPT>
 static int launch_transform_rpt(const TransArgs& a, bool drop, hipStream_t st) {
     constexpr int TM = 16 * RPT;
-    const int nb = (a.U + TM - 1) / TM + (a.I + TM - 1) / TM;
+    const int nb = (a.u_n + TM - 1) / TM + (a.i_n + TM - 1) / TM;
     if (nb == 0) return 0;
     constexpr size_t lds = (size_t)(TM * (DIN + 4) + DIN * DOUT) * sizeof(float);
     if (drop) {
@@ -177,7 +180,7 @@ static int launch_transform_rpt(const TransArgs& a, bool drop, hipStream_t st) {
 // tiles when the graph needs many rounds anyway
 template <typename TX, typename TH, int DIN, int DOUT, int HEADS>
 static int launch_transform(const TransArgs& a, bool drop, hipStream_t st) {
-    auto blocks = [&](int tm) { return (a.U + tm - 1) / tm + (a.I + tm - 1) / tm; };
+    auto blocks = [&](int tm) { return (a.u_n + tm - 1) / tm + (a.i_n + tm - 1) / tm; };
     if (blocks(64) <= 1024 || blocks(96) > 1024) return launch_transform_rpt<TX, TH, DIN, DOUT, HEADS, 4>(a, drop, st);
     if (blocks(80) <= 1024) return launch_transform_rpt<TX, TH, DIN, DOUT, HEADS, 5>(a, drop, st);
     return launch_transform_rpt<TX, TH, DIN, DOUT, HEADS, 6>(a, drop, st);
@@ -202,16 +205,18 @@ static int dispatch_transform(const TransArgs& a, int din, int dout, int heads, 
 
 using namespace ngacf;
 
-extern "C" int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, const float* avec,
-                                   void* H, int h_dtype, float* S,
-                                   int U, int I, int din, int dout, int heads,
-                                   float feat_drop_p, uint64_t seed, void* stream) {
-    if (U < 0 || I < 0) return NGACF_E_ARG;
-    if (U + I == 0) return 0;
+extern "C" int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float* W, const float* avec,
+                                        void* H, int h_dtype, float* S,
+                                        int U, int I, int din, int dout, int heads,
+                                        int u_lo, int u_n, int i_lo, int i_n, int x_local,
+                                        float feat_drop_p, uint64_t seed, void* stream) {
+    if (U < 0 || I < 0 || u_lo < 0 || u_n < 0 || i_lo < 0 || i_n < 0 || u_lo + u_n > U || i_lo + i_n > I) return NGACF_E_ARG;
+    if (u_n + i_n == 0) return 0;
     if (!X || !W || !avec || !H || !S) return NGACF_E_ARG;
     if (!(feat_drop_p >= 0.f && feat_drop_p < 1.f)) return NGACF_E_ARG;
     TransArgs a;
     a.X = X; a.W = W; a.avec = avec; a.H = H; a.S = S; a.U = U; a.I = I;
+    a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.x_local = x_local;
     a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p);
     a.salt = salt_of(seed, 0u);
     const bool drop = feat_drop_p > 0.f;
@@ -223,3 +228,10 @@ extern "C" int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, c
     return NGACF_E_SHAPE;
 }
 
+extern "C" int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, const float* avec,
+                                   void* H, int h_dtype, float* S,
+                                   int U, int I, int din, int dout, int heads,
+                                   float feat_drop_p, uint64_t seed, void* stream) {
+    return ngacf_transform_fwd_rows(X, x_dtype, W, avec, H, h_dtype, S, U, I, din, dout, heads, 0, U, 0, I, 0,
+                                    feat_drop_p, seed, stream);
+}

@@ -18,6 +18,8 @@ struct TransBwdArgs {
     float* dX;
     float* work;
     int U, I;
+    int u_lo, u_n, i_lo, i_n;      // row windows (see transform.hip)
+    int x_local;                   // X and dX hold only the window rows, users first
     uint32_t drop_thr;
     float drop_scale;
     uint32_t salt;
@@ -34,11 +36,12 @@ __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArg
     float* Gs = lds;                               // [TM][GS]
     float* Wt = lds + TM * GS;                     // [DOUT][WS]
     const int tid = threadIdx.x;
-    const int nbu = (a.U + TM - 1) / TM;
+    const int nbu = (a.u_n + TM - 1) / TM;
     const bool users = (int)blockIdx.x < nbu;
     const int type = users ? 0 : 1;
-    const int row0 = users ? blockIdx.x * TM : a.U + (blockIdx.x - nbu) * TM;
-    const int row_end = users ? a.U : a.U + a.I;
+    const int row0 = users ? a.u_lo + blockIdx.x * TM : a.U + a.i_lo + (blockIdx.x - nbu) * TM;
+    const int row_end = users ? a.u_lo + a.u_n : a.U + a.i_lo + a.i_n;
+    const int xoff = a.x_local ? (users ? a.u_lo : a.U + a.i_lo - a.u_n) : 0;
     {
         const float* Wg = a.W + (size_t)type * DIN * DOUT;
         for (int i = tid; i < DIN * DOUT / 4; i += 256) {
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArg
                 o[j] = acc[i][4 * g + j];
                 if (DROP) o[j] = feat_bits(a.salt, row, 64 * g + 4 * tx + j) >= a.drop_thr ? o[j] * a.drop_scale : 0.f;
             }
-            *reinterpret_cast<float4*>(a.dX + (size_t)row * DIN + 64 * g + 4 * tx) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(a.dX + (size_t)(row - xoff) * DIN + 64 * g + 4 * tx) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
 }
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(256) void transform_bwd_dw_kernel(const TransBwdArg
     const bool users = (int)blockIdx.x < a.nbu;
     const int nb = users ? a.nbu : a.nbi;
     const int bl = users ? blockIdx.x : blockIdx.x - a.nbu;
-    const int rbeg = users ? 0 : a.U, rend = users ? a.U : a.U + a.I;
+    const int rbeg = users ? a.u_lo : a.U + a.i_lo, rend = rbeg + (users ? a.u_n : a.i_n);
+    const int xoff = a.x_local ? (users ? a.u_lo : a.U + a.i_lo - a.u_n) : 0;
     const int ntiles = (rend - rbeg + TM - 1) / TM;
     const int ty = tid >> 4, tx = tid & 15;
     float acc[RI][RJ];
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void transform_bwd_dw_kernel(const TransBwdArg
                 const int r = i / PER_ROW, cv = i % PER_ROW;
                 float f[XV];
                 if (row0 + r < rend) {
-                    Slice<TX>::load(Xg + (size_t)(row0 + r) * DIN + cv * XV, f);
+                    Slice<TX>::load(Xg + (size_t)(row0 + r - xoff) * DIN + cv * XV, f);
                     if (DROP) {
 #pragma unroll
                         for (int j = 0; j < XV; ++j)
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void transform_bwd_reduce_kernel(const float* 
 
 template <typename TX, typename TH, int DIN, int DOUT, int HEADS>
 static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool drop, hipStream_t st) {
-    const int tu = (a.U + TM - 1) / TM, ti = (a.I + TM - 1) / TM;
+    const int tu = (a.u_n + TM - 1) / TM, ti = (a.i_n + TM - 1) / TM;
     if (tu + ti == 0) return 0;
     {   // dX
         constexpr size_t lds = (size_t)(TM * (DOUT + 4) + DOUT * (DIN + 4)) * sizeof(float);
@@ -299,24 +303,39 @@ static int dispatch_transform_bwd(const TransBwdArgs& a, float* dW, float* davec
 
 using namespace ngacf;
 
-extern "C" int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
-                                   const float* dH, const float* dS,
-                                   float* dX, float* dW, float* davec, float* work,
-                                   int U, int I, int din, int dout, int heads,
-                                   float feat_drop_p, uint64_t seed, void* stream) {
-    if (U < 0 || I < 0) return NGACF_E_ARG;
-    if (U + I == 0) return 0;
+extern "C" int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
+                                        const float* dH, const float* dS,
+                                        float* dX, float* dW, float* davec, float* work,
+                                        int U, int I, int din, int dout, int heads,
+                                        int u_lo, int u_n, int i_lo, int i_n, int x_local,
+                                        float feat_drop_p, uint64_t seed, void* stream) {
+    if (U < 0 || I < 0 || u_lo < 0 || u_n < 0 || i_lo < 0 || i_n < 0 || u_lo + u_n > U || i_lo + i_n > I) return NGACF_E_ARG;
     if (!X || !W || !H || !dH || !dS || !dX || !dW || !davec || !work) return NGACF_E_ARG;
     if (!(feat_drop_p >= 0.f && feat_drop_p < 1.f)) return NGACF_E_ARG;
     TransBwdArgs a;
     a.X = X; a.W = W; a.H = H; a.dH = dH; a.dS = dS; a.dX = dX; a.work = work; a.U = U; a.I = I;
+    a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.x_local = x_local;
     a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p);
     a.salt = salt_of(seed, 0u); a.nbu = a.nbi = 0;
     const bool drop = feat_drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (u_n + i_n == 0) {                         // nothing owned: the sums are zero
+        hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * 2 * din * dout, st);
+        if (e == hipSuccess) e = hipMemsetAsync(davec, 0, sizeof(float) * 2 * dout, st);
+        return static_cast<int>(e);
+    }
     if (x_dtype == NGACF_F32 && h_dtype == NGACF_F32) return dispatch_transform_bwd<float, float>(a, dW, davec, din, dout, heads, drop, st);
     if (x_dtype == NGACF_F32 && h_dtype == NGACF_BF16) return dispatch_transform_bwd<float, bf16_t>(a, dW, davec, din, dout, heads, drop, st);
     if (x_dtype == NGACF_BF16 && h_dtype == NGACF_BF16) return dispatch_transform_bwd<bf16_t, bf16_t>(a, dW, davec, din, dout, heads, drop, st);
     if (x_dtype == NGACF_BF16 && h_dtype == NGACF_F32) return dispatch_transform_bwd<bf16_t, float>(a, dW, davec, din, dout, heads, drop, st);
     return NGACF_E_SHAPE;
+}
+
+extern "C" int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
+                                   const float* dH, const float* dS,
+                                   float* dX, float* dW, float* davec, float* work,
+                                   int U, int I, int din, int dout, int heads,
+                                   float feat_drop_p, uint64_t seed, void* stream) {
+    return ngacf_transform_bwd_rows(X, x_dtype, W, H, h_dtype, dH, dS, dX, dW, davec, work, U, I, din, dout, heads,
+                                    0, U, 0, I, 0, feat_drop_p, seed, stream);
 }

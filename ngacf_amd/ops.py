@@ -151,7 +151,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     t, dS = torch.empty(N, heads, 2, **f32), torch.empty(N, heads, **f32)
     pa = torch.empty(max(plan.nparts, 1), d, **f32)
     pr = torch.empty(max(plan.nparts, 1), heads, **f32)
-    if plan.row_lo != 0 or plan.row_hi != N:
+    if plan.n_rows != N:
         dH.zero_()
         dS.zero_()
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
@@ -253,3 +253,88 @@ def dropout_bits(kind, seed, a, b, c=None):
                                       _chk(c, "c", torch.int32, n, dev) if c is not None else 0,
                                       bits.data_ptr(), n, _stream()), "ngacf_dropout_bits")
     return bits
+
+
+# ---------------------------------------------------------------------------
+# row-window forms used by the node-partitioned (multi-GPU) path, ngacf_amd/dist.py
+# ---------------------------------------------------------------------------
+def transform_fwd_rows(X, W, avec, H, S, U, I, heads, win, x_local, feat_drop_p=0.0, seed=0):
+    """Transform the rows of `win` = (u_lo, u_n, i_lo, i_n) into the global-row tables H [N,dout], S [N,heads].
+    X is [u_n+i_n, din] when x_local else [N, din]."""
+    dev, N = H.device, U + I
+    din, dout = W.shape[1], W.shape[2]
+    _heads_ok(dout, heads)
+    u_lo, u_n, i_lo, i_n = win
+    xp = _chk(X, "X", None, ((u_n + i_n) if x_local else N) * din, dev)
+    wp = _chk(W, "W", torch.float32, 2 * din * dout, dev)
+    ap = _chk(avec, "avec", torch.float32, 2 * dout, dev)
+    hp = _chk(H, "H", None, N * dout, dev)
+    sp = _chk(S, "S", torch.float32, N * heads, dev)
+    _lib.check(lib.ngacf_transform_fwd_rows(xp, _DT[X.dtype], wp, ap, hp, _DT[H.dtype], sp, U, I, din, dout, heads,
+                                            u_lo, u_n, i_lo, i_n, int(bool(x_local)), float(feat_drop_p), int(seed),
+                                            _stream()), "ngacf_transform_fwd_rows")
+
+
+def transform_bwd_rows(X, W, H, dH, dS, U, I, heads, win, x_local, feat_drop_p=0.0, seed=0):
+    """dX ([u_n+i_n, din] when x_local), and the window's partial dW [2,din,dout], davec [2,dout]."""
+    dev, N = H.device, U + I
+    din, dout = W.shape[1], W.shape[2]
+    _heads_ok(dout, heads)
+    u_lo, u_n, i_lo, i_n = win
+    nx = (u_n + i_n) if x_local else N
+    xp = _chk(X, "X", None, nx * din, dev)
+    wp = _chk(W, "W", torch.float32, 2 * din * dout, dev)
+    hp = _chk(H, "H", None, N * dout, dev)
+    gp = _chk(dH, "dH", torch.float32, N * dout, dev)
+    sp = _chk(dS, "dS", torch.float32, N * heads, dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    dX = torch.empty(nx, din, **f32)
+    dW = torch.empty(2, din, dout, **f32)
+    da = torch.empty(2, dout, **f32)
+    work = torch.empty(_lib.TBWD_BLOCKS, din * dout + dout, **f32)
+    _lib.check(lib.ngacf_transform_bwd_rows(xp, _DT[X.dtype], wp, hp, _DT[H.dtype], gp, sp, dX.data_ptr(), dW.data_ptr(),
+                                            da.data_ptr(), work.data_ptr(), U, I, din, dout, heads,
+                                            u_lo, u_n, i_lo, i_n, int(bool(x_local)), float(feat_drop_p), int(seed),
+                                            _stream()), "ngacf_transform_bwd_rows")
+    return dX, dW, da
+
+
+def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local, elu=True):
+    """Step 1 of the propagation backward over the rows of `win`; writes G, Gn, ST at global rows."""
+    dev, N, d = out.device, out.shape[0], out.shape[1]
+    _heads_ok(d, heads)
+    u_lo, u_n, i_lo, i_n = win
+    op = _chk(out, "out", None, N * d, dev)
+    ap = _chk(agg, "agg", torch.float32, N * d, dev)
+    rp = _chk(R, "R", torch.float32, N * heads, dev)
+    go = _chk(gout, "gout", torch.float32, ((u_n + i_n) if gout_local else N) * d, dev)
+    ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
+    gp = _chk(G, "G", torch.float32, N * d, dev)
+    gn = _chk(Gn, "Gn", out.dtype, N * d, dev)
+    st = _chk(ST, "ST", torch.float32, N * heads * 2, dev)
+    _lib.check(lib.ngacf_prop_bwd_node(op, _DT[out.dtype], ap, rp, go, ss, gp, gn, st, U, N, d, heads,
+                                       FLAG_ELU if elu else 0, u_lo, u_n, i_lo, i_n, int(bool(gout_local)), _stream()),
+               "ngacf_prop_bwd_node")
+
+
+def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=True, score_from_row=True,
+                   drop_p=0.0, seed=0):
+    """Step 2 alone (G, Gn, ST ready for every source row).  Returns dH, dS (rows of the plan valid)."""
+    dev, N, d = H.device, plan.N, H.shape[1]
+    _heads_ok(d, heads)
+    hp = _chk(H, "H", None, N * d, dev)
+    sd = _chk(S_dst, "S_dst", torch.float32, N * heads, dev)
+    ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
+    gp = _chk(G, "G", torch.float32, N * d, dev)
+    gn = _chk(Gn, "Gn", H.dtype, N * d, dev)
+    st = _chk(ST, "ST", torch.float32, N * heads * 2, dev)
+    pp = _plan_ptrs(plan, dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    dH, dS = torch.zeros(N, d, **f32), torch.zeros(N, heads, **f32)
+    pa = torch.empty(max(plan.nparts, 1), d, **f32)
+    pr = torch.empty(max(plan.nparts, 1), heads, **f32)
+    flags = (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) | _lib.FLAG_SKIP_NODE
+    _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, sd, ap, hp, gp, sd, gp, gp, gn, st, dH.data_ptr(),
+                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
+                                  float(drop_p), int(seed), flags, _stream()), "ngacf_prop_bwd")
+    return dH, dS

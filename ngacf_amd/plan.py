@@ -17,12 +17,16 @@ import torch
 
 class GraphPlan:
     def __init__(self, U, I, E, rowptr, col, segs, split, nparts, seg_len, row_lo=0, row_hi=None,
-                 srow=None, short_max=0):
+                 srow=None, short_max=0, row_ranges=None):
         self.U, self.I, self.N, self.E = U, I, U + I, E
         self.rowptr, self.col, self.segs, self.split = rowptr, col, segs, split
         self.nseg, self.nsplit, self.nparts = int(segs.shape[0]), int(split.shape[0]), int(nparts)
         self.seg_len = seg_len
         self.row_lo, self.row_hi = row_lo, (U + I if row_hi is None else row_hi)
+        # dst rows this plan covers: a list of [lo, hi) ranges (one range = everything; two = a rank's
+        # user block and item block in node-partitioned runs)
+        self.row_ranges = list(row_ranges) if row_ranges is not None else [(self.row_lo, self.row_hi)]
+        self.n_rows = sum(hi - lo for lo, hi in self.row_ranges)
         self.device = col.device
         self.n_edges_directed = int(col.shape[0])
         # short rows (degree <= short_max), sorted by degree descending: one lane group per row
@@ -38,14 +42,14 @@ class GraphPlan:
         """(segs, split, nparts) covering EVERY dst row of the range as wave-per-segment work
         items (used by the static-weight SpMM path)."""
         if getattr(self, "_all", None) is None:
-            rows = torch.arange(self.row_lo, self.row_hi, device=self.device)
+            rows = torch.cat([torch.arange(lo, hi, device=self.device) for lo, hi in self.row_ranges])
             self._all = _segments(self.rowptr, rows, self.seg_len)
         return self._all
 
     def to(self, device):
         return GraphPlan(self.U, self.I, self.E, self.rowptr.to(device), self.col.to(device),
                          self.segs.to(device), self.split.to(device), self.nparts, self.seg_len,
-                         self.row_lo, self.row_hi, self.srow.to(device), self.short_max)
+                         self.row_lo, self.row_hi, self.srow.to(device), self.short_max, self.row_ranges)
 
 
 def _segments(rowptr, rows, seg_len):
@@ -73,8 +77,8 @@ def _segments(rowptr, rows, seg_len):
 
 def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None, short_max=64):
     """indices: [2,E] (or [1,2,E], run under DataParallel: SPUIGACF.py:42 squeezes it) integer
-    tensor.  Duplicate pairs are merged like `.coalesce()`.  `row_range=(lo,hi)` keeps only
-    the dst rows lo..hi-1 (node partition of ngacf_amd/dist.py); sources stay global."""
+    tensor.  Duplicate pairs are merged like `.coalesce()`.  `row_range=(lo,hi)` -- or a list of such
+    ranges -- keeps only those dst rows (node partition of ngacf_amd/dist.py); sources stay global."""
     indices = indices.squeeze()
     if indices.dim() != 2 or indices.shape[0] != 2:
         raise ValueError("indices must be [2,E], got %s" % (tuple(indices.shape),))
@@ -99,14 +103,23 @@ def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True,
     rowptr[1:] = torch.cumsum(torch.cat([deg_u, deg_i]), 0)
     by_item = torch.sort(ei * U + eu).values                 # CSC order: item-major, users ascending
     col = torch.cat([ei + U, by_item % U]).to(torch.int32).contiguous()
-    lo, hi = (0, N) if row_range is None else row_range
-    rows = torch.arange(lo, hi, device=dev)
+    if row_range is None:
+        ranges = [(0, N)]
+    elif isinstance(row_range[0], (tuple, list)):
+        ranges = [tuple(r) for r in row_range]
+    else:
+        ranges = [tuple(row_range)]
+    for lo, hi in ranges:
+        if not 0 <= lo <= hi <= N:
+            raise ValueError("row range %s outside [0, %d]" % ((lo, hi), N))
+    lo, hi = ranges[0][0], ranges[-1][1]
+    rows = torch.cat([torch.arange(a, b, device=dev) for a, b in ranges])
     deg = rowptr[rows + 1] - rowptr[rows]
     is_short = deg <= short_max
     order = torch.sort(deg[is_short], descending=True, stable=True).indices
     srow = rows[is_short][order].to(torch.int32).contiguous()
     segs, split, nparts = _segments(rowptr, rows[~is_short], seg_len)
-    plan = GraphPlan(U, I, E, rowptr, col, segs, split, nparts, seg_len, lo, hi, srow, short_max)
+    plan = GraphPlan(U, I, E, rowptr, col, segs, split, nparts, seg_len, lo, hi, srow, short_max, ranges)
     validate_plan(plan)
     return plan
 
@@ -139,4 +152,4 @@ def validate_plan(p):
         assert int(d.max()) <= p.short_max and bool((d[1:] <= d[:-1]).all()), "short rows must be sorted by degree, descending"
     assert int(p.rowptr[-1]) == n2e and int(p.rowptr[-1]) < 2 ** 31
     covered = p.nshort + (int(torch.unique(p.segs[:, 0]).numel()) if p.nseg else 0)
-    assert covered == p.row_hi - p.row_lo, "every dst row of the range must be covered exactly once"
+    assert covered == p.n_rows, "every dst row of the plan's ranges must be covered exactly once"

@@ -1,0 +1,119 @@
+"""TEST-ONLY stand-in for ngacf_amd.ops on CPU tensors (plain torch), used to run the node-partitioned
+choreography of ngacf_amd/dist.py under gloo where no GPU exists.  It mirrors the semantics of the C-ABI
+entry points (row windows, global-row tables, two-step backward), not their speed.  The product never
+imports this file."""
+import torch
+import torch.nn.functional as F
+
+
+def _types(U, N, dev):
+    return (torch.arange(N, device=dev) >= U).long()
+
+
+def _win_rows(U, win, dev):
+    u_lo, u_n, i_lo, i_n = win
+    return torch.cat([torch.arange(u_lo, u_lo + u_n, device=dev), torch.arange(U + i_lo, U + i_lo + i_n, device=dev)])
+
+
+def transform_fwd_rows(X, W, avec, H, S, U, I, heads, win, x_local, feat_drop_p=0.0, seed=0):
+    assert feat_drop_p == 0.0
+    rows = _win_rows(U, win, H.device)
+    Xw = X if x_local else X[rows]
+    t = (rows >= U).long()
+    Hw = torch.einsum("nk,nkd->nd", Xw.float(), W[t])
+    H[rows] = Hw.to(H.dtype)
+    hw = H.shape[1] // heads
+    S[rows] = (H[rows].float() * avec[t]).view(-1, heads, hw).sum(2)
+
+
+def _edges(plan):
+    dst, src = [], []
+    for lo, hi in plan.row_ranges:
+        e0, e1 = int(plan.rowptr[lo]), int(plan.rowptr[hi])
+        deg = plan.rowptr[lo + 1:hi + 1] - plan.rowptr[lo:hi]
+        dst.append(torch.repeat_interleave(torch.arange(lo, hi), deg))
+        src.append(plan.col[e0:e1].long())
+    return torch.cat(dst), torch.cat(src)
+
+
+def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
+             drop_p=0.0, seed=0, save=False, out=None):
+    assert drop_p == 0.0
+    N, d = H.shape
+    hw = d // heads
+    dst, src = _edges(plan)
+    e = torch.exp(-F.leaky_relu(S_dst[dst] + S_src[src], alpha))                       # [E', heads]
+    R = torch.zeros(N, heads).index_add_(0, dst, e)
+    num = torch.zeros(N, d).index_add_(0, dst, e.repeat_interleave(hw, 1) * H[src].float())
+    Rw = R.repeat_interleave(hw, 1)
+    agg = torch.where(Rw > 0, num / Rw.clamp_min(1e-38), torch.zeros_like(num))
+    pre = (H.float() + agg) if residual else agg
+    o = F.elu(pre) if elu else pre
+    res = torch.zeros(N, d, dtype=H.dtype) if out is None else out
+    rows = torch.cat([torch.arange(lo, hi) for lo, hi in plan.row_ranges])
+    res[rows] = o[rows].to(H.dtype)
+    return (res, agg, R) if save else res
+
+
+def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local, elu=True):
+    rows = _win_rows(U, win, out.device)
+    d = out.shape[1]
+    hw = d // heads
+    g = (gout if gout_local else gout[rows]).float().clone()
+    if elu:
+        o = out[rows].float()
+        g = g * torch.where(o > 0, torch.ones_like(o), o + 1.0)
+    r = R[rows]
+    inv = torch.where(r > 0, 1.0 / r.clamp_min(1e-38), torch.zeros_like(r)).repeat_interleave(hw, 1)
+    gn = (g * inv).to(Gn.dtype)
+    G[rows] = g
+    Gn[rows] = gn
+    ST[rows, :, 0] = S_src[rows]
+    ST[rows, :, 1] = (gn.float() * agg[rows]).view(-1, heads, hw).sum(2)
+
+
+def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=True, score_from_row=True,
+                   drop_p=0.0, seed=0):
+    assert drop_p == 0.0
+    N, d = H.shape
+    hw = d // heads
+    dst, src = _edges(plan)
+    Hf, Gf = H.float(), Gn.float()
+    s = S_dst[dst] + ST[src, :, 0]
+    e = torch.exp(-F.leaky_relu(s, alpha))
+    dot = (Gf[dst] * Hf[src] + Gf[src] * Hf[dst]).view(-1, heads, hw).sum(2)
+    de = dot - ST[dst, :, 1] - ST[src, :, 1]
+    ds = -e * de * torch.where(s > 0, torch.ones_like(s), torch.full_like(s, alpha))
+    dS = torch.zeros(N, heads).index_add_(0, dst, ds)
+    acc = torch.zeros(N, d).index_add_(0, dst, e.repeat_interleave(hw, 1) * Gf[src])
+    t = _types(plan.U, N, H.device)
+    dH = (G if residual else torch.zeros_like(G)) + acc + dS.repeat_interleave(hw, 1) * avec[t]
+    keep = torch.zeros(N, dtype=torch.bool)
+    for lo, hi in plan.row_ranges:
+        keep[lo:hi] = True
+    return dH * keep[:, None], dS * keep[:, None]
+
+
+def transform_bwd_rows(X, W, H, dH, dS, U, I, heads, win, x_local, feat_drop_p=0.0, seed=0):
+    assert feat_drop_p == 0.0
+    rows = _win_rows(U, win, H.device)
+    Xw = (X if x_local else X[rows]).float()
+    t = (rows >= U).long()
+    g = dH[rows]
+    dX = torch.einsum("nd,nkd->nk", g, W[t])
+    hw = H.shape[1] // heads
+    dW = torch.zeros_like(W)
+    da = torch.zeros(2, H.shape[1])
+    for ty in (0, 1):
+        m = t == ty
+        dW[ty] = Xw[m].t() @ g[m]
+        da[ty] = (dS[rows][m].repeat_interleave(hw, 1) * H[rows][m].float()).sum(0)
+    if not x_local:
+        full = torch.zeros(U + I, X.shape[1])
+        full[rows] = dX
+        dX = full
+    return dX, dW, da
+
+
+def score(Fm, u, i, U):
+    return (Fm[u] * Fm[i + U]).sum(1)

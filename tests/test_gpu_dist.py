@@ -1,0 +1,93 @@
+"""GPU tests of the row-window entry points the node-partitioned path (ngacf_amd/dist.py) uses: every rank's
+window/plan, run one after the other into shared global-row tables (what the in-place all-gather produces),
+must reproduce the single-GPU result; and the sharded model with world size 1 equals the plain model."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(U, I, E, seed):
+    rs = np.random.RandomState(seed)
+    u = np.concatenate([np.arange(U), rs.randint(0, U, E - U)])
+    i = np.concatenate([rs.randint(0, I, U), rs.randint(0, I, E - U)])
+    key = np.unique(u.astype(np.int64) * I + i)
+    return torch.from_numpy(np.stack([key // I, key % I]))
+
+
+@pytest.mark.parametrize("P,dt", [(2, torch.float32), (3, torch.float32), (4, torch.bfloat16)])
+def test_partitioned_stage_equals_single_gpu(P, dt):
+    from ngacf_amd import ops
+    from ngacf_amd.dist import Partition
+    from ngacf_amd.plan import build_plan
+    dev = torch.device("cuda:0")
+    U, I, heads = 333, 251, 8
+    edge = _graph(U, I, 7000, 3).to(dev)
+    parts = [Partition(U, I, P, r) for r in range(P)]
+    Up, Ip, N = parts[0].Up, parts[0].Ip, parts[0].N
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    X = torch.zeros(N, 64, device=dev)
+    X[:U] = torch.randn(U, 64, device=dev, generator=g)
+    X[Up:Up + I] = torch.randn(I, 64, device=dev, generator=g)
+    W = torch.randn(2, 64, 64, device=dev, generator=g) * 0.2
+    avec = torch.randn(2, 64, device=dev, generator=g) * 0.2
+    gout = torch.randn(N, 64, device=dev, generator=g)
+    # single-GPU reference on the padded graph
+    full = build_plan(edge, Up, Ip, require_user_edges=False, seg_len=32, short_max=8)
+    Xt = X.to(dt) if dt != torch.float32 else X
+    H0, S0 = ops.transform_fwd(Xt, W, avec, Up, Ip, heads, dt, 0.1, 5)
+    out0, agg0, R0 = ops.prop_fwd(full, H0, S0, S0, avec, heads, drop_p=0.1, seed=5, save=True)
+    dH0, dS0 = ops.prop_bwd(full, H0, S0, S0, avec, out0, agg0, R0, gout, heads, drop_p=0.1, seed=5)
+    dX0, dW0, da0 = ops.transform_bwd(Xt, W, H0, dH0, dS0, Up, Ip, heads, 0.1, 5)
+    # the same, rank by rank, into shared tables
+    H = torch.empty_like(H0); S = torch.empty_like(S0)
+    for p in parts:
+        ops.transform_fwd_rows(p.local_rows(Xt).contiguous(), W, avec, H, S, Up, Ip, heads, p.win, True, 0.1, 5)
+    assert torch.equal(H, H0) and torch.equal(S, S0)
+    out = torch.zeros_like(out0); agg = torch.zeros_like(agg0); R = torch.zeros_like(R0)
+    plans = [build_plan(edge, Up, Ip, require_user_edges=False, seg_len=32, short_max=8, row_range=p.row_ranges) for p in parts]
+    for p, pl in zip(parts, plans):
+        o, a_, r_ = ops.prop_fwd(pl, H, S, S, avec, heads, drop_p=0.1, seed=5, save=True)
+        for lo, hi in p.row_ranges:
+            out[lo:hi], agg[lo:hi], R[lo:hi] = o[lo:hi], a_[lo:hi], r_[lo:hi]
+    tol = 1e-6 if dt == torch.float32 else 1e-2
+    assert float((out.float() - out0.float()).abs().max()) <= tol and float((R - R0).abs().max() / R0.abs().max()) < 1e-5
+    G = torch.empty(N, 64, device=dev); Gn = torch.empty(N, 64, device=dev, dtype=dt); ST = torch.empty(N, heads, 2, device=dev)
+    for p in parts:
+        ops.prop_bwd_node(out0, agg0, R0, p.local_rows(gout).contiguous(), S, G, Gn, ST, Up, heads, p.win, True)
+    dH = torch.zeros_like(dH0); dS = torch.zeros_like(dS0)
+    dX = torch.zeros_like(dX0); dW = torch.zeros_like(dW0); da = torch.zeros_like(da0)
+    for p, pl in zip(parts, plans):
+        h_, s_ = ops.prop_bwd_edges(pl, H, S, avec, G, Gn, ST, heads, drop_p=0.1, seed=5)
+        dH += h_; dS += s_
+        x_, w_, a_ = ops.transform_bwd_rows(p.local_rows(Xt).contiguous(), W, H, h_, s_, Up, Ip, heads, p.win, True, 0.1, 5)
+        dW += w_; da += a_
+        dX[p.u_lo:p.u_lo + p.cu] = x_[:p.cu]
+        dX[Up + p.i_lo:Up + p.i_lo + p.ci] = x_[p.cu:]
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    assert rel(dH, dH0) < 1e-5 and rel(dS, dS0) < 1e-4
+    assert rel(dX, dX0) < 1e-5 and rel(dW, dW0) < 1e-4 and rel(da, da0) < 1e-4
+
+
+def test_sharded_model_world1_equals_plain_model():
+    import ngacf_amd
+    from ngacf_amd.dist import ShardedSPUIGACF
+    dev = torch.device("cuda:0")
+    U, I = 333, 251
+    edge = _graph(U, I, 7000, 3).to(dev)
+    torch.manual_seed(1)
+    ref = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev).train()
+    with torch.no_grad():
+        ref.uEmbd.weight.mul_(30); ref.iEmbd.weight.mul_(30)
+    m = ShardedSPUIGACF(U, I, 64, [64, 64], 0.0, world=1, rank=0, stages=3).to(dev).train()
+    m.load_full_state_dict(ref.state_dict())
+    u = torch.randint(0, U, (128,), device=dev); it = torch.randint(0, I, (128,), device=dev)
+    a, b = ref(u, it, edge), m(u, it, edge)
+    assert float((a - b).abs().max() / a.abs().max()) < 1e-6
+    a.sum().backward(); b.sum().backward()
+    assert float((ref.uEmbd.weight.grad - m.uEmbd.weight.grad).abs().max() / ref.uEmbd.weight.grad.abs().max()) < 1e-5
+    for (k, p), (_, q) in zip(ref.gat.named_parameters(), m.gat.named_parameters()):
+        assert float((p.grad - q.grad).abs().max() / p.grad.abs().max().clamp_min(1e-12)) < 1e-4, k
+    sd = m.full_state_dict()
+    assert all(torch.equal(sd[k], v) for k, v in ref.state_dict().items())
