@@ -183,7 +183,7 @@ def main():
 
     out = {"metric": "propagation edges/sec (directed edge traversals, forward, all stages)", "value": round(value, 1),
            "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "%s-scale bipartite graph U=%d I=%d E=%d, d=%d, L=%d stages (%s), 8 heads x 8 + 1 x %d"
                                   % (wl, U, I, E, d, L, type(model).__name__, d),
                       "edges_directed_per_step": trav_per_step, "seg_len": args.seg_len, "parallelism": "1 GPU"},

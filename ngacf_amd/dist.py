@@ -7,7 +7,8 @@ rows with isolated zero nodes), so rank p's rows are contiguous in the global or
 lands IN PLACE in the global table -- no re-layout copy, kernels unchanged.  Rank p owns: its embedding rows
 (+ their Adam state), the CSR rows of its user block and the CSC rows of its item block.
 
-Per stage, forward:   local transform (window) -> all-gather H, S -> local pull traversal
+Per stage, forward:   local transform (window) -> all-gather H -> local pull traversal (source scores are
+                      recomputed from the gathered rows, so the score table never travels)
            backward:  local node step -> all-gather Gn, ST -> local edge step -> local transform backward
                       -> all-reduce of the 16 K small-weight gradients.  No reduce-scatter, no atomics.
 
@@ -89,8 +90,7 @@ class _ShardedStage(torch.autograd.Function):
         H = torch.empty(N, dout, dtype=h_dtype, device=dev)
         S = torch.empty(N, heads, dtype=torch.float32, device=dev)
         be.transform_fwd_rows(X, W, avec, H, S, part.Up, part.Ip, heads, part.win, True, feat_drop_p, seed)
-        comm.all_gather_rows(H)
-        comm.all_gather_rows(S)
+        comm.all_gather_rows(H)            # S stays local: source scores are recomputed from the gathered rows
         need = any(ctx.needs_input_grad[:3])
         res = be.prop_fwd(plan, H, S, S, avec, heads, alpha, True, True, True, drop_p, seed, save=need)
         out = res[0] if need else res

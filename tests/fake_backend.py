@@ -42,7 +42,10 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     N, d = H.shape
     hw = d // heads
     dst, src = _edges(plan)
-    e = torch.exp(-F.leaky_relu(S_dst[dst] + S_src[src], alpha))                       # [E', heads]
+    assert score_from_row, "dist.py never gathers S: source scores come from the gathered rows"
+    t = _types(plan.U, N, H.device)
+    s_src = (H[src].float() * avec[t[src]]).view(-1, heads, hw).sum(2)
+    e = torch.exp(-F.leaky_relu(S_dst[dst] + s_src, alpha))                            # [E', heads]
     R = torch.zeros(N, heads).index_add_(0, dst, e)
     num = torch.zeros(N, d).index_add_(0, dst, e.repeat_interleave(hw, 1) * H[src].float())
     Rw = R.repeat_interleave(hw, 1)
@@ -79,7 +82,9 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     hw = d // heads
     dst, src = _edges(plan)
     Hf, Gf = H.float(), Gn.float()
-    s = S_dst[dst] + ST[src, :, 0]
+    assert score_from_row
+    tt = _types(plan.U, N, H.device)
+    s = S_dst[dst] + (Hf[src] * avec[tt[src]]).view(-1, heads, hw).sum(2)
     e = torch.exp(-F.leaky_relu(s, alpha))
     dot = (Gf[dst] * Hf[src] + Gf[src] * Hf[dst]).view(-1, heads, hw).sum(2)
     de = dot - ST[dst, :, 1] - ST[src, :, 1]
