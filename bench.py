@@ -131,6 +131,11 @@ def main():
                 "traffic": None, "bytes_per_launch": int(avg_bytes), "avg_launch_us": round(avg_ms * 1e3, 2),
                 "per_stage_us": [round(x * 1e3, 2) for x in per_stage_ms],
                 "edges_per_s_in_kernel": round(2 * E / (avg_ms * 1e-3), 1)}
+    # HBM-side bytes per launch from the committed PMC passes of this same command (profiles/): separate
+    # --pmc FETCH_SIZE / WRITE_SIZE runs with the gfx950 correction of MI355X_MICROARCH.md §HBM
+    tf = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % wl)
+    if os.path.exists(tf) and args.stages == 3 and d == 64:
+        roofline["traffic"] = json.load(open(tf))["by_dtype"].get(args.dtype, {}).get("traffic_bytes")
     fwd_bytes = sum(sum(D.algorithmic_bytes_stage(U, I, E, din, dout, elem)) for din, dout, _ in dims)
 
     # ---------------- BPR train steps (reference semantics: 2 propagations per step) ----------------

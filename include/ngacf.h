@@ -12,7 +12,9 @@
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it;
  *   - return value: 0 on success, a negative NGACF_E_* code for a rejected
  *     argument (nothing was launched), or a positive hipError_t from the launch;
- *   - no global mutable state: safe from several host threads on different devices.
+ *   - no global mutable state: safe from several host threads on different devices;
+ *   - dropout seeds: effective seed = `seed` + (*seed_dev if seed_dev != NULL); the device-side addend lets a
+ *     captured hipGraph draw fresh masks on every replay (the host advances it with a captured add).
  *
  * Node numbering: users are 0..U-1, items are U..U+I-1 (N = U+I), exactly the
  * `features = cat([userEmbd, itemEmbd])` order of graphattention/SPUIGACF.py:38-39.
@@ -65,7 +67,7 @@ const char* ngacf_version(void);
 int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, const float* avec,
                         void* H, int h_dtype, float* S,
                         int U, int I, int din, int dout, int heads,
-                        float feat_drop_p, uint64_t seed, void* stream);
+                        float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* The same over row windows (node-partitioned runs, ngacf_amd/dist.py): users [u_lo, u_lo+u_n) and items
  * [i_lo, i_lo+i_n) (global row = U + i).  H and S are indexed by global row; with x_local != 0, X holds only
@@ -74,7 +76,7 @@ int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float* W, const f
                              void* H, int h_dtype, float* S,
                              int U, int I, int din, int dout, int heads,
                              int u_lo, int u_n, int i_lo, int i_n, int x_local,
-                             float feat_drop_p, uint64_t seed, void* stream);
+                             float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* Attention propagation, forward, both directions in one launch.
  * Replaces SPUIGACF.py:359-393 (edge gather, exp(-leakyrelu), e_rowsum/e_colsum, edge dropout,
@@ -92,7 +94,7 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    const float* S_dst, const float* S_src, const float* avec,
                    void* out, float* agg, float* R, float* part_acc, float* part_r,
                    int U, int N, int d, int heads, float alpha,
-                   float drop_p, uint64_t seed, int flags, void* stream);
+                   float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
 
 /* Backward of ngacf_prop_fwd (autograd of SPUIGACF.py:359-397; formulas SURVEY.md §8(a) A4b).
  * Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  ST[n,h] = { S_src[n,h], (g . agg)_h / R }
@@ -109,7 +111,7 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    float* G, void* Gn, float* ST, float* dH, float* dS,
                    float* part_acc, float* part_r,
                    int U, int N, int d, int heads, float alpha,
-                   float drop_p, uint64_t seed, int flags, void* stream);
+                   float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
 
 /* Backward of ngacf_transform_fwd (autograd of SPUIGACF.py:356-357 and the a.mm of :361).
  *   dX   float[N][din]          = mask * (dH @ W[type]^T)
@@ -122,7 +124,7 @@ int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* 
                         const float* dH, const float* dS,
                         float* dX, float* dW, float* davec, float* work,
                         int U, int I, int din, int dout, int heads,
-                        float feat_drop_p, uint64_t seed, void* stream);
+                        float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* Row-window form (see ngacf_transform_fwd_rows): X and dX local when x_local != 0; dW and davec are the
  * sums over the window rows only (all-reduce them across ranks). */
@@ -131,7 +133,7 @@ int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float* W, const v
                              float* dX, float* dW, float* davec, float* work,
                              int U, int I, int din, int dout, int heads,
                              int u_lo, int u_n, int i_lo, int i_n, int x_local,
-                             float feat_drop_p, uint64_t seed, void* stream);
+                             float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* Step 1 of ngacf_prop_bwd alone, over row windows; gout holds only the window rows when gout_local != 0.
  * Lets a node-partitioned run all-gather Gn/ST between the two steps (then ngacf_prop_bwd with NGACF_SKIP_NODE). */

@@ -23,6 +23,7 @@ from . import functional as NF
 from .plan import build_plan
 
 _PLAN_CACHE_MAX = 4
+_SEED_STRIDE = 0x1E3779B97F4A7C15
 
 
 class _PlanCache:
@@ -144,7 +145,15 @@ class _GATBase(nn.Module):
         U, I = int(uidx.numel()), int(iidx.numel())
         plan = self._plans.get(adj.squeeze(), U, I, self.seg_len)
         p = self.dropout if self.training else 0.0
-        base = _fresh_seed() if p > 0 else 0
+        seed_dev = None
+        if p > 0 and getattr(self, "_seed_ctr", None) is not None:
+            # graph-capturable seeding: a device counter advanced by a (captured) add; every forward keeps
+            # its own snapshot so that its backward regenerates the same masks
+            self._seed_ctr.add_(_SEED_STRIDE)
+            seed_dev = self._seed_ctr.clone()
+            base = self._seed_base
+        else:
+            base = _fresh_seed() if p > 0 else 0
         x = features
         if not hasattr(self, "_fused"):
             self._fused = _FusedCache()
@@ -153,8 +162,17 @@ class _GATBase(nn.Module):
             # feature dropout in front of every stage (:208,:213) and the ELU behind it (:397 inside
             # the concat layers, :214 around out_att) are fused into the stage
             x = NF.stage(x, W, avec, plan, len(layers), layers[0].alpha, True, p, p,
-                         NF.stage_seed(base, s), self.compute_dtype)
+                         NF.stage_seed(base, s), self.compute_dtype, seed_dev)
         return x
+
+    def use_device_seed(self, device, on=True):
+        """Dropout seeds from a device-side counter (needed under hipGraph capture: a host-drawn seed
+        would be frozen into the graph)."""
+        if on:
+            self._seed_base = _fresh_seed()
+            self._seed_ctr = torch.zeros(1, dtype=torch.int64, device=device)
+        else:
+            self._seed_ctr = None
 
 
 class SpUIGAT(_GATBase):

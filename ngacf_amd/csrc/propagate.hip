@@ -38,6 +38,7 @@ struct PropArgs {
     uint32_t drop_thr;
     float drop_scale;
     uint64_t seed;
+    const uint64_t* seed_dev;   // optional device-side addend (hipGraph replays advance it)
     int flags;
 };
 
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
         }
         uint32_t salt_h = 0, row_key = 0;
         if (DROP) {
-            salt_h = salt_of(a.seed, 1u + head);
+            salt_h = salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + head);
             row_key = dst_is_user ? (uint32_t)row * RNG_K1 : (uint32_t)row * RNG_K2 + salt_h;
         }
         const int last = deg > 0 ? beg + deg - 1 : 0;     // any valid index for the masked tail
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
     }
     uint32_t salt_h = 0, row_key = 0;
     if (DROP) {
-        salt_h = salt_of(a.seed, 1u + head);
+        salt_h = salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + head);
         row_key = dst_is_user ? (uint32_t)row * RNG_K1 : (uint32_t)row * RNG_K2 + salt_h;
     }
     for (int base = beg; base < end; base += EPI * UNROLL) {
@@ -306,7 +307,7 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
                               const float* S_dst, const float* S_src, const float* avec,
                               void* out, float* agg, float* R, float* part_acc, float* part_r,
                               int U, int N, int d, int heads, float alpha,
-                              float drop_p, uint64_t seed, int flags, void* stream) {
+                              float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
     if (nseg + nshort == 0) return 0;
     if (!col || !H || !S_dst || !out || !rowptr) return NGACF_E_ARG;
@@ -321,7 +322,7 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
     a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R;
     a.part_acc = part_acc; a.part_r = part_r; a.U = U; a.N = N; a.nb_long = 0; a.alpha = alpha;
-    a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.flags = flags;
+    a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.seed_dev = seed_dev; a.flags = flags;
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define NGACF_CASE(T, D, HD) return launch_fwd<T, D, HD>(a, split, nsplit, from_row, drop, st)

@@ -47,6 +47,7 @@ struct PropBwdArgs {
     uint32_t drop_thr;
     float drop_scale;
     uint64_t seed;
+    const uint64_t* seed_dev;
     int flags;
 };
 
@@ -144,7 +145,7 @@ __device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, i
     }
     x.salt_h = x.row_key = 0;
     if (DROP) {
-        x.salt_h = salt_of(a.seed, 1u + head);
+        x.salt_h = salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + head);
         x.row_key = x.dst_is_user ? (uint32_t)row * RNG_K1 : (uint32_t)row * RNG_K2 + x.salt_h;
     }
 }
@@ -357,7 +358,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
                          float* G, void* Gn, float* ST, float* dH, float* dS,
                          float* part_acc, float* part_r,
                          int U, int N, int d, int heads, float alpha,
-                         float drop_p, uint64_t seed, int flags,
+                         float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
                          int nu_lo, int nu_n, int ni_lo, int ni_n, int gout_local, bool do_node, bool do_edges, void* stream) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
     if (nu_lo < 0 || nu_n < 0 || ni_lo < 0 || ni_n < 0 || nu_lo + nu_n > U || ni_lo + ni_n > N - U) return NGACF_E_ARG;
@@ -378,7 +379,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     a.G = G; a.Gn = Gn; a.ST = reinterpret_cast<float2*>(ST); a.dH = dH; a.dS = dS; a.part_acc = part_acc; a.part_r = part_r;
     a.U = U; a.N = N; a.nu_lo = nu_lo; a.nu_n = nu_n; a.ni_lo = ni_lo; a.ni_n = ni_n; a.gout_local = gout_local;
     a.nb_long = 0; a.alpha = alpha;
-    a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.flags = flags;
+    a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.seed_dev = seed_dev; a.flags = flags;
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define NGACF_CASE(T, D, HD) return launch_bwd<T, D, HD>(a, split, nsplit, from_row, drop, st, do_node, do_edges)
@@ -405,10 +406,10 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
                               float* G, void* Gn, float* ST, float* dH, float* dS,
                               float* part_acc, float* part_r,
                               int U, int N, int d, int heads, float alpha,
-                              float drop_p, uint64_t seed, int flags, void* stream) {
+                              float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
     const bool skip_node = (flags & NGACF_SKIP_NODE) != 0;
     return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
-                         G, Gn, ST, dH, dS, part_acc, part_r, U, N, d, heads, alpha, drop_p, seed, flags,
+                         G, Gn, ST, dH, dS, part_acc, part_r, U, N, d, heads, alpha, drop_p, seed, seed_dev, flags,
                          0, U, 0, N - U, 0, !skip_node, true, stream);
 }
 
@@ -417,6 +418,6 @@ extern "C" int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg,
                                    int U, int N, int d, int heads, int flags,
                                    int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream) {
     return prop_bwd_impl(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, dtype, nullptr, S_src, nullptr,
-                         out, agg, R, gout, G, Gn, ST, nullptr, nullptr, nullptr, nullptr, U, N, d, heads, 0.2f, 0.f, 0, flags,
+                         out, agg, R, gout, G, Gn, ST, nullptr, nullptr, nullptr, nullptr, U, N, d, heads, 0.2f, 0.f, 0, nullptr, flags,
                          u_lo, u_n, i_lo, i_n, gout_local, true, false, stream);
 }

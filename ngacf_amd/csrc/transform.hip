@@ -23,7 +23,8 @@ struct TransArgs {
     int x_local;                   // X holds only the window rows, users first (node-partitioned runs)
     uint32_t drop_thr;
     float drop_scale;
-    uint32_t salt;
+    uint64_t seed;
+    const uint64_t* seed_dev;      // optional device-side addend (hipGraph replays advance it)
 };
 
 // thread (ty, tx): rows RPT*ty..RPT*ty+RPT-1 of the tile, columns 4*tx..+3 (and 64+4*tx..+3 when DOUT = 128)
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void transform_fwd_kernel(const TransArgs a) {
     float* Ws = lds + TM * XS;                     // [DIN][DOUT]
 
     const int tid = threadIdx.x;
+    const uint32_t salt = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
     const int nbu = (a.u_n + TM - 1) / TM;
     const bool users = (int)blockIdx.x < nbu;
     const int type = users ? 0 : 1;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void transform_fwd_kernel(const TransArgs a) {
                 if (DROP) {
 #pragma unroll
                     for (int j = 0; j < XV; ++j)
-                        f[j] = feat_bits(a.salt, row0 + r, cv * XV + j) >= a.drop_thr ? f[j] * a.drop_scale : 0.f;
+                        f[j] = feat_bits(salt, row0 + r, cv * XV + j) >= a.drop_thr ? f[j] * a.drop_scale : 0.f;
                 }
             } else {
 #pragma unroll
@@ -209,7 +211,7 @@ extern "C" int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float*
                                         void* H, int h_dtype, float* S,
                                         int U, int I, int din, int dout, int heads,
                                         int u_lo, int u_n, int i_lo, int i_n, int x_local,
-                                        float feat_drop_p, uint64_t seed, void* stream) {
+                                        float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     if (U < 0 || I < 0 || u_lo < 0 || u_n < 0 || i_lo < 0 || i_n < 0 || u_lo + u_n > U || i_lo + i_n > I) return NGACF_E_ARG;
     if (u_n + i_n == 0) return 0;
     if (!X || !W || !avec || !H || !S) return NGACF_E_ARG;
@@ -218,7 +220,7 @@ extern "C" int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float*
     a.X = X; a.W = W; a.avec = avec; a.H = H; a.S = S; a.U = U; a.I = I;
     a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.x_local = x_local;
     a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p);
-    a.salt = salt_of(seed, 0u);
+    a.seed = seed; a.seed_dev = seed_dev;
     const bool drop = feat_drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (x_dtype == NGACF_F32 && h_dtype == NGACF_F32) return dispatch_transform<float, float>(a, din, dout, heads, drop, st);
@@ -231,7 +233,7 @@ extern "C" int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float*
 extern "C" int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, const float* avec,
                                    void* H, int h_dtype, float* S,
                                    int U, int I, int din, int dout, int heads,
-                                   float feat_drop_p, uint64_t seed, void* stream) {
+                                   float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     return ngacf_transform_fwd_rows(X, x_dtype, W, avec, H, h_dtype, S, U, I, din, dout, heads, 0, U, 0, I, 0,
-                                    feat_drop_p, seed, stream);
+                                    feat_drop_p, seed, seed_dev, stream);
 }

@@ -22,7 +22,8 @@ struct TransBwdArgs {
     int x_local;                   // X and dX hold only the window rows, users first
     uint32_t drop_thr;
     float drop_scale;
-    uint32_t salt;
+    uint64_t seed;
+    const uint64_t* seed_dev;
     int nbu, nbi;          // workgroups of the dW kernel given to user rows / item rows
 };
 
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArg
     float* Gs = lds;                               // [TM][GS]
     float* Wt = lds + TM * GS;                     // [DOUT][WS]
     const int tid = threadIdx.x;
+    const uint32_t salt = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
     const int nbu = (a.u_n + TM - 1) / TM;
     const bool users = (int)blockIdx.x < nbu;
     const int type = users ? 0 : 1;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArg
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 o[j] = acc[i][4 * g + j];
-                if (DROP) o[j] = feat_bits(a.salt, row, 64 * g + 4 * tx + j) >= a.drop_thr ? o[j] * a.drop_scale : 0.f;
+                if (DROP) o[j] = feat_bits(salt, row, 64 * g + 4 * tx + j) >= a.drop_thr ? o[j] * a.drop_scale : 0.f;
             }
             *reinterpret_cast<float4*>(a.dX + (size_t)(row - xoff) * DIN + 64 * g + 4 * tx) = make_float4(o[0], o[1], o[2], o[3]);
         }
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(256) void transform_bwd_dw_kernel(const TransBwdArg
     float* Xs = lds;                               // [TM][XS]
     float* Gs = lds + TM * XS;                     // [TM][GS]
     const int tid = threadIdx.x;
+    const uint32_t salt = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
     const bool users = (int)blockIdx.x < a.nbu;
     const int nb = users ? a.nbu : a.nbi;
     const int bl = users ? blockIdx.x : blockIdx.x - a.nbu;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void transform_bwd_dw_kernel(const TransBwdArg
                     if (DROP) {
 #pragma unroll
                         for (int j = 0; j < XV; ++j)
-                            f[j] = feat_bits(a.salt, row0 + r, cv * XV + j) >= a.drop_thr ? f[j] * a.drop_scale : 0.f;
+                            f[j] = feat_bits(salt, row0 + r, cv * XV + j) >= a.drop_thr ? f[j] * a.drop_scale : 0.f;
                     }
                 } else {
 #pragma unroll
@@ -308,7 +311,7 @@ extern "C" int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float*
                                         float* dX, float* dW, float* davec, float* work,
                                         int U, int I, int din, int dout, int heads,
                                         int u_lo, int u_n, int i_lo, int i_n, int x_local,
-                                        float feat_drop_p, uint64_t seed, void* stream) {
+                                        float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     if (U < 0 || I < 0 || u_lo < 0 || u_n < 0 || i_lo < 0 || i_n < 0 || u_lo + u_n > U || i_lo + i_n > I) return NGACF_E_ARG;
     if (!X || !W || !H || !dH || !dS || !dX || !dW || !davec || !work) return NGACF_E_ARG;
     if (!(feat_drop_p >= 0.f && feat_drop_p < 1.f)) return NGACF_E_ARG;
@@ -316,7 +319,7 @@ extern "C" int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float*
     a.X = X; a.W = W; a.H = H; a.dH = dH; a.dS = dS; a.dX = dX; a.work = work; a.U = U; a.I = I;
     a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.x_local = x_local;
     a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p);
-    a.salt = salt_of(seed, 0u); a.nbu = a.nbi = 0;
+    a.seed = seed; a.seed_dev = seed_dev; a.nbu = a.nbi = 0;
     const bool drop = feat_drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (u_n + i_n == 0) {                         // nothing owned: the sums are zero
@@ -335,7 +338,7 @@ extern "C" int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, c
                                    const float* dH, const float* dS,
                                    float* dX, float* dW, float* davec, float* work,
                                    int U, int I, int din, int dout, int heads,
-                                   float feat_drop_p, uint64_t seed, void* stream) {
+                                   float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     return ngacf_transform_bwd_rows(X, x_dtype, W, H, h_dtype, dH, dS, dX, dW, davec, work, U, I, din, dout, heads,
-                                    0, U, 0, I, 0, feat_drop_p, seed, stream);
+                                    0, U, 0, I, 0, feat_drop_p, seed, seed_dev, stream);
 }

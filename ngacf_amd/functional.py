@@ -13,33 +13,34 @@ class _Stage(torch.autograd.Function):
     SpUIGraphAttentionLayer heads computes in SPUIGACF.py:212 (or the out_att call :214)."""
 
     @staticmethod
-    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype):
+    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev=None):
         X = X.contiguous()
         W = W.contiguous().float()
         avec = avec.contiguous().float()
-        H, S = ops.transform_fwd(X, W, avec, plan.U, plan.I, heads, h_dtype, feat_drop_p, seed)
+        H, S = ops.transform_fwd(X, W, avec, plan.U, plan.I, heads, h_dtype, feat_drop_p, seed, seed_dev)
         need = any(ctx.needs_input_grad[:3])
         if need:
-            out, agg, R = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, True, None, drop_p, seed, save=True)
+            out, agg, R = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, True, None, drop_p, seed, save=True,
+                                       seed_dev=seed_dev)
             ctx.save_for_backward(X, W, avec, H, S, out, agg, R)
-            ctx.cfg = (plan, heads, alpha, elu, drop_p, feat_drop_p, seed)
+            ctx.cfg = (plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev)
         else:
-            out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, True, None, drop_p, seed)
+            out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, True, None, drop_p, seed, seed_dev=seed_dev)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         X, W, avec, H, S, out, agg, R = ctx.saved_tensors
-        plan, heads, alpha, elu, drop_p, feat_drop_p, seed = ctx.cfg
+        plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev = ctx.cfg
         gout = gout.contiguous().float()
-        dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, alpha, elu, True, None, drop_p, seed)
-        dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed)
-        return dX.to(X.dtype), dW, da, None, None, None, None, None, None, None, None
+        dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, alpha, elu, True, None, drop_p, seed, seed_dev)
+        dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
+        return dX.to(X.dtype), dW, da, None, None, None, None, None, None, None, None, None
 
 
-def stage(X, W, avec, plan, heads, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=0.0, seed=0, h_dtype=None):
+def stage(X, W, avec, plan, heads, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=0.0, seed=0, h_dtype=None, seed_dev=None):
     return _Stage.apply(X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed,
-                        X.dtype if h_dtype is None else h_dtype)
+                        X.dtype if h_dtype is None else h_dtype, seed_dev)
 
 
 def stage_seed(base, s):

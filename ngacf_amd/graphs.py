@@ -1,0 +1,77 @@
+"""hipGraph capture of the launch-bound loops (MI355X-first: HIP graphs instead of a tracing compiler).
+
+A reference-semantics BPR step is ~180 small launches (2 propagations x 3 stages x {transform, traversal,
+hub-row pass} forward and backward, scoring, loss, per-head gradient plumbing, Adam); eager mode is bound by the
+host's launch rate, not by the GPU.  `GraphedBPRStep` captures one whole step -- forward x2, loss, backward,
+optimizer -- into one graph and replays it; dropout seeds come from a device-side counter that a captured add
+advances, so every replay draws fresh masks.  `GraphedPropagate` does the same for the eval-mode propagation.
+"""
+import torch
+
+from .SPUIGACF import _GATBase
+
+
+def _gats(model):
+    return [m for m in model.modules() if isinstance(m, _GATBase)]
+
+
+class GraphedBPRStep:
+    """step(users, pos, neg) -> loss (a device scalar, valid until the next call).
+
+    optim must be capturable (torch.optim.Adam(..., capturable=True)); batch size is fixed at capture."""
+
+    def __init__(self, model, lossfn, optim, adj, batch_size, warmup=3):
+        dev = next(model.parameters()).device
+        self.model, self.optim = model, optim
+        for g in _gats(model):
+            g.use_device_seed(dev, True)
+        self.u = torch.zeros(batch_size, dtype=torch.long, device=dev)
+        self.p = torch.zeros_like(self.u)
+        self.n = torch.zeros_like(self.u)
+        model.train()
+
+        def step():
+            optim.zero_grad(set_to_none=True)
+            loss = lossfn(model(self.u, self.p, adj), model(self.u, self.n, adj))
+            loss.backward()
+            optim.step()
+            return loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up off the capture: plans, caches, allocator
+            for _ in range(warmup):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        optim.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = step()
+
+    def __call__(self, users, pos, neg):
+        self.u.copy_(users)
+        self.p.copy_(pos)
+        self.n.copy_(neg)
+        self.graph.replay()
+        return self.loss
+
+
+class GraphedPropagate:
+    """propagate() -> the [N, d] propagated embeddings of the model in eval mode (static output buffer)."""
+
+    def __init__(self, model, adj, warmup=2):
+        self.model = model
+        model.eval()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                model.propagate(adj)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = model.propagate(adj)
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out

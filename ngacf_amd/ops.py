@@ -69,7 +69,14 @@ def _heads_ok(d, heads):
         raise ValueError("unsupported row width / heads: d=%d heads=%d (d in %s, heads in {1, d/8})" % (d, heads, SUPPORTED_D))
 
 
-def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.0, seed=0):
+def _sd(seed_dev, dev):
+    """optional device-side seed addend: int64[1] on `dev`"""
+    if seed_dev is None:
+        return 0
+    return _chk(seed_dev, "seed_dev", torch.int64, 1, dev)
+
+
+def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.0, seed=0, seed_dev=None):
     """H[N,dout], S[N,heads] = ngacf_transform_fwd(X[N,din], W[2,din,dout], avec[2,dout])."""
     dev, N = X.device, U + I
     din, dout = W.shape[1], W.shape[2]
@@ -84,8 +91,8 @@ def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.
     H = torch.empty(N, dout, dtype=h_dtype, device=dev)
     S = torch.empty(N, heads, dtype=torch.float32, device=dev)
     _lib.check(lib.ngacf_transform_fwd(xp, _DT[X.dtype], wp, ap, H.data_ptr(), _DT[h_dtype], S.data_ptr(),
-                                       U, I, din, dout, heads, float(feat_drop_p), int(seed), _stream()),
-               "ngacf_transform_fwd")
+                                       U, I, din, dout, heads, float(feat_drop_p), int(seed), _sd(seed_dev, dev),
+                                       _stream()), "ngacf_transform_fwd")
     return H, S
 
 
@@ -101,7 +108,7 @@ def _plan_ptrs(plan, dev):
 
 
 def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
-             drop_p=0.0, seed=0, save=False, out=None):
+             drop_p=0.0, seed=0, save=False, out=None, seed_dev=None):
     """One propagation stage over plan's dst rows.  Returns out (and agg, R when save=True)."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
@@ -125,12 +132,12 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, *pp, hp,
                       _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
                       pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
-                      float(drop_p), int(seed), flags, _stream()), "ngacf_prop_fwd")
+                      float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_fwd")
     return (out, agg, R) if save else out
 
 
 def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, elu=True, residual=True,
-             score_from_row=None, drop_p=0.0, seed=0):
+             score_from_row=None, drop_p=0.0, seed=0, seed_dev=None):
     """Returns dH [N,d] fp32 (with the dS*avec term) and dS [N,heads]."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
@@ -158,11 +165,11 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, ss, ap,
                                   op, gp, rp, go, G.data_ptr(), Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
                                   dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
-                                  float(drop_p), int(seed), flags, _stream()), "ngacf_prop_bwd")
+                                  float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_bwd")
     return dH, dS
 
 
-def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0):
+def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0, seed_dev=None):
     """Returns dX [N,din], dW [2,din,dout], davec [2,dout] (all fp32)."""
     dev, N = X.device, U + I
     din, dout = W.shape[1], W.shape[2]
@@ -179,7 +186,7 @@ def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0):
     work = torch.empty(_lib.TBWD_BLOCKS, din * dout + dout, **f32)
     _lib.check(lib.ngacf_transform_bwd(xp, _DT[X.dtype], wp, hp, _DT[H.dtype], gp, sp, dX.data_ptr(), dW.data_ptr(),
                                        da.data_ptr(), work.data_ptr(), U, I, din, dout, heads,
-                                       float(feat_drop_p), int(seed), _stream()), "ngacf_transform_bwd")
+                                       float(feat_drop_p), int(seed), _sd(seed_dev, dev), _stream()), "ngacf_transform_bwd")
     return dX, dW, da
 
 
@@ -271,7 +278,7 @@ def transform_fwd_rows(X, W, avec, H, S, U, I, heads, win, x_local, feat_drop_p=
     hp = _chk(H, "H", None, N * dout, dev)
     sp = _chk(S, "S", torch.float32, N * heads, dev)
     _lib.check(lib.ngacf_transform_fwd_rows(xp, _DT[X.dtype], wp, ap, hp, _DT[H.dtype], sp, U, I, din, dout, heads,
-                                            u_lo, u_n, i_lo, i_n, int(bool(x_local)), float(feat_drop_p), int(seed),
+                                            u_lo, u_n, i_lo, i_n, int(bool(x_local)), float(feat_drop_p), int(seed), 0,
                                             _stream()), "ngacf_transform_fwd_rows")
 
 
@@ -294,7 +301,7 @@ def transform_bwd_rows(X, W, H, dH, dS, U, I, heads, win, x_local, feat_drop_p=0
     work = torch.empty(_lib.TBWD_BLOCKS, din * dout + dout, **f32)
     _lib.check(lib.ngacf_transform_bwd_rows(xp, _DT[X.dtype], wp, hp, _DT[H.dtype], gp, sp, dX.data_ptr(), dW.data_ptr(),
                                             da.data_ptr(), work.data_ptr(), U, I, din, dout, heads,
-                                            u_lo, u_n, i_lo, i_n, int(bool(x_local)), float(feat_drop_p), int(seed),
+                                            u_lo, u_n, i_lo, i_n, int(bool(x_local)), float(feat_drop_p), int(seed), 0,
                                             _stream()), "ngacf_transform_bwd_rows")
     return dX, dW, da
 
@@ -336,5 +343,5 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     flags = (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) | _lib.FLAG_SKIP_NODE
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, sd, ap, hp, gp, sd, gp, gp, gn, st, dH.data_ptr(),
                                   dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
-                                  float(drop_p), int(seed), flags, _stream()), "ngacf_prop_bwd")
+                                  float(drop_p), int(seed), 0, flags, _stream()), "ngacf_prop_bwd")
     return dH, dS

@@ -75,3 +75,57 @@ def test_ml100k_two_epochs_reach_reference_metrics():
     assert 0.18 < m["recall"][3] < 0.32, m["recall"]
     assert 0.15 < m["precision"][3] < 0.27, m["precision"]
     assert 0.80 < m["hit_ratio"][3] <= 1.0 and 0.45 < m["ndcg"][3] < 0.70
+
+
+def test_graphed_step_equals_eager_and_redraws_dropout():
+    """hipGraph capture of the whole BPR step: same numbers as eager without dropout; with dropout every replay
+    draws new masks (device-side seed counter) and the backward sees the masks of its own forward."""
+    import ngacf_amd
+    from ngacf_amd.graphs import GraphedBPRStep, GraphedPropagate
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(0)
+    U, I, B = 400, 300, 256
+    uu = np.concatenate([np.arange(U), rs.randint(0, U, 8000)]); ii = np.concatenate([rs.randint(0, I, U), rs.randint(0, I, 8000)])
+    key = np.unique(uu.astype(np.int64) * I + ii)
+    adj = torch.from_numpy(np.stack([key // I, key % I])).to(dev)
+    u = torch.from_numpy(rs.randint(0, U, B)).to(dev); p = torch.from_numpy(rs.randint(0, I, B)).to(dev)
+    n = torch.from_numpy(rs.randint(0, I, B)).to(dev)
+
+    def make(drop):
+        torch.manual_seed(4)
+        m = ngacf_amd.SPUIGACF(U, I, 64, [64, 64], drop).to(dev)
+        with torch.no_grad():
+            m.uEmbd.weight.mul_(30); m.iEmbd.weight.mul_(30)
+        return m, torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True)
+
+    # no dropout: graph replay == eager, step by step (warm-up steps included on both sides)
+    me, oe = make(0.0)
+    mg, og = make(0.0)
+    lossfn = ngacf_amd.BPRLoss()
+    gs = GraphedBPRStep(mg, lossfn, og, adj, B, warmup=3)
+    gs.u.copy_(u); gs.p.copy_(p); gs.n.copy_(n)
+    me.train()
+    eager = []
+    for k in range(3 + 3):                                   # the graphed model took 3 warm-up steps on the zero batch
+        uu_, pp_, nn_ = (torch.zeros_like(u),) * 3 if k < 3 else (u, p, n)   # (capture itself executes nothing)
+        oe.zero_grad(set_to_none=True)
+        l = lossfn(me(uu_, pp_, adj), me(uu_, nn_, adj)); l.backward(); oe.step()
+        eager.append(float(l.detach()))
+    graphed = [float(gs(u, p, n)) for _ in range(3)]
+    assert np.allclose(graphed, eager[3:], rtol=2e-5, atol=1e-7), (graphed, eager)
+    assert float((me.uEmbd.weight - mg.uEmbd.weight).abs().max()) < 1e-5
+    # dropout: replays differ from one another although the batch is the same, and training still descends
+    md, od = make(0.3)
+    gd = GraphedBPRStep(md, lossfn, od, adj, B)
+    w0 = md.uEmbd.weight.detach().clone()
+    l1 = float(gd(u, p, n)); w1 = md.uEmbd.weight.detach().clone()
+    md.uEmbd.weight.data.copy_(w0)                           # same weights again -> only the masks can differ
+    l2 = float(gd(u, p, n))
+    assert l1 != l2
+    losses = [float(gd(u, p, n)) for _ in range(30)]
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
+    # eval-mode propagation graph
+    gp = GraphedPropagate(md, adj)
+    with torch.no_grad():
+        ref = md.propagate(adj)
+    assert torch.equal(gp(), ref)
