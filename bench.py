@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--seg-len", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     return ap.parse_args()
 
@@ -105,15 +106,25 @@ def main():
     # ---------------- headline: forward propagation, eval mode ----------------
     model.eval()
     with torch.no_grad():
+        if args.eager:
+            run = lambda: model.propagate(edge)
+        else:                                   # the same launches, captured once into a hipGraph and replayed
+            from ngacf_amd.graphs import GraphedPropagate
+            run = GraphedPropagate(model, edge)
         for _ in range(args.warmup):
-            model.propagate(edge)
+            run()
         sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        sync()
+        t_fwd = time.perf_counter() - t0
+        # per-launch duration of the dominant kernel: events on the launch stream around every ngacf_prop_fwd
+        # call of K eager steps (events cannot be placed inside a replayed graph; same kernels, same data)
         with ops.KernelTimer("ngacf_prop_fwd") as kt:
-            t0 = time.perf_counter()
             for _ in range(args.steps):
                 model.propagate(edge)
             sync()
-            t_fwd = time.perf_counter() - t0
         durs = kt.durations_ms()
     trav_per_step = L * 2 * E
     value = trav_per_step * args.steps / t_fwd
@@ -143,7 +154,8 @@ def main():
     if not args.no_train:
         model.train()
         lossfn = ng.BPRLoss()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=not args.eager,
+                               fused=not args.eager)    # one multi-tensor kernel instead of ~100 per step
         g = torch.Generator(device=dev)
         g.manual_seed(7)
         B = args.batch
@@ -158,6 +170,10 @@ def main():
             opt.step()
             return loss
         ksteps = max(2, min(args.steps, 20))
+        if not args.eager:                      # whole step (2 fwd, loss, bwd, Adam) as one replayed hipGraph
+            from ngacf_amd.graphs import GraphedBPRStep
+            gstep = GraphedBPRStep(model, lossfn, opt, edge, B)
+            step = lambda: gstep(ub, pb, nb)
         for _ in range(min(args.warmup, 3)):
             step()
         sync()
@@ -191,7 +207,8 @@ def main():
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "%s-scale bipartite graph U=%d I=%d E=%d, d=%d, L=%d stages (%s), 8 heads x 8 + 1 x %d"
                                   % (wl, U, I, E, d, L, type(model).__name__, d),
-                      "edges_directed_per_step": trav_per_step, "seg_len": args.seg_len, "parallelism": "1 GPU"},
+                      "edges_directed_per_step": trav_per_step, "seg_len": args.seg_len, "parallelism": "1 GPU",
+                      "launch": "eager" if args.eager else "hipGraph replay"},
            "fwd_algorithmic_GBps": round(fwd_bytes / (ms_per_step * 1e-3) / 1e9, 1),
            "roofline": roofline, "cpu_baseline": cpu}
     if train:

@@ -247,10 +247,12 @@ class _CFBase(nn.Module):
     def getFeatureMat(self):
         """SPUIGACF.py:30-39 without the per-call Python index lists."""
         dev = self.uEmbd.weight.device
-        uidx = torch.arange(self.userNum, device=dev)
-        iidx = torch.arange(self.itemNum, device=dev)
+        idx = getattr(self, "_idx", None)
+        if idx is None or idx[0].device != dev:                       # built once, not per call
+            idx = (torch.arange(self.userNum, device=dev), torch.arange(self.itemNum, device=dev) + self.userNum)
+            self._idx = idx
         features = torch.cat([self.uEmbd.weight, self.iEmbd.weight], dim=0)
-        return uidx, iidx + self.userNum, features
+        return idx[0], idx[1], features
 
     def propagate(self, mask):
         uidx, iidx, features = self.getFeatureMat()

@@ -10,6 +10,12 @@ import torch
 
 from .SPUIGACF import _GATBase
 
+# the warm-up runs on a side stream by design; autograd's stream-mismatch warning is expected there
+try:
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+except AttributeError:      # older torch
+    pass
+
 
 def _gats(model):
     return [m for m in model.modules() if isinstance(m, _GATBase)]
