@@ -49,7 +49,7 @@ extern "C" {
 #define NGACF_SCORE_ROW  4   /* recompute the source score a_src . h_src from the gathered row
                                 instead of reading S_src (saves 4*heads bytes per edge) */
 
-#define NGACF_TBWD_BLOCKS 256 /* workgroups of the dW reduction in ngacf_transform_bwd */
+#define NGACF_TBWD_BLOCKS 1024 /* workgroups of the dW reduction in ngacf_transform_bwd */
 
 #define NGACF_E_ARG     (-1)  /* null pointer / negative size */
 #define NGACF_E_SHAPE   (-2)  /* unsupported (d, heads, dtype) combination */

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libngacf_hip.so")
 
 F32, BF16 = 0, 1
 FLAG_ELU, FLAG_RESIDUAL, FLAG_SCORE_ROW, FLAG_SKIP_NODE = 1, 2, 4, 8
-TBWD_BLOCKS = 256
+TBWD_BLOCKS = 1024
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

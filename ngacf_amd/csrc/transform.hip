@@ -203,6 +203,11 @@ static int dispatch_transform(const TransArgs& a, int din, int dout, int heads, 
 
 
 
+// transform_mfma.hip: the bf16-storage path on the matrix cores
+int transform_fwd_mfma(const void* X, int x_dtype, const float* W, const float* avec, void* H, float* S,
+                       int U, int I, int din, int dout, int heads, int u_lo, int u_n, int i_lo, int i_n, int x_local,
+                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st);
+
 }  // namespace ngacf
 
 using namespace ngacf;
@@ -223,11 +228,12 @@ extern "C" int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float*
     a.seed = seed; a.seed_dev = seed_dev;
     const bool drop = feat_drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (x_dtype == NGACF_F32 && h_dtype == NGACF_F32) return dispatch_transform<float, float>(a, din, dout, heads, drop, st);
-    if (x_dtype == NGACF_F32 && h_dtype == NGACF_BF16) return dispatch_transform<float, bf16_t>(a, din, dout, heads, drop, st);
-    if (x_dtype == NGACF_BF16 && h_dtype == NGACF_BF16) return dispatch_transform<bf16_t, bf16_t>(a, din, dout, heads, drop, st);
-    if (x_dtype == NGACF_BF16 && h_dtype == NGACF_F32) return dispatch_transform<bf16_t, float>(a, din, dout, heads, drop, st);
-    return NGACF_E_SHAPE;
+    if ((x_dtype != NGACF_F32 && x_dtype != NGACF_BF16) || (h_dtype != NGACF_F32 && h_dtype != NGACF_BF16)) return NGACF_E_SHAPE;
+    if (h_dtype == NGACF_BF16)                     // bf16 storage: bf16 MFMA, fp32 accumulate
+        return transform_fwd_mfma(X, x_dtype, W, avec, H, S, U, I, din, dout, heads, u_lo, u_n, i_lo, i_n, x_local,
+                                  feat_drop_p, seed, seed_dev, st);
+    if (x_dtype == NGACF_F32) return dispatch_transform<float, float>(a, din, dout, heads, drop, st);
+    return dispatch_transform<bf16_t, float>(a, din, dout, heads, drop, st);
 }
 
 extern "C" int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, const float* avec,

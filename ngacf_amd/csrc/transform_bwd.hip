@@ -22,6 +22,7 @@ struct TransBwdArgs {
     int x_local;                   // X and dX hold only the window rows, users first
     uint32_t drop_thr;
     float drop_scale;
+    float drop_p;
     uint64_t seed;
     const uint64_t* seed_dev;
     int nbu, nbi;          // workgroups of the dW kernel given to user rows / item rows
@@ -243,11 +244,19 @@ __global__ __launch_bounds__(256) void transform_bwd_reduce_kernel(const float* 
     else davec[(size_t)type * (wsz - dwsz) + (k - dwsz)] = s;
 }
 
+int transform_dx_mfma(const float* dH, const float* W, float* dX, int U, int I, int din, int dout, int heads,
+                      int u_lo, int u_n, int i_lo, int i_n, int x_local,
+                      float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st);   // transform_mfma.hip
+
 template <typename TX, typename TH, int DIN, int DOUT, int HEADS>
 static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool drop, hipStream_t st) {
     const int tu = (a.u_n + TM - 1) / TM, ti = (a.i_n + TM - 1) / TM;
     if (tu + ti == 0) return 0;
-    {   // dX
+    if constexpr (sizeof(TH) == 2) {   // bf16 storage: dX on the matrix cores
+        const int rc = transform_dx_mfma(a.dH, a.W, a.dX, a.U, a.I, DIN, DOUT, HEADS, a.u_lo, a.u_n, a.i_lo, a.i_n, a.x_local,
+                                         a.drop_p, a.seed, a.seed_dev, st);
+        if (rc != 0) return rc;
+    } else {   // dX
         constexpr size_t lds = (size_t)(TM * (DOUT + 4) + DOUT * (DIN + 4)) * sizeof(float);
         if (drop) {
             auto k = transform_bwd_dx_kernel<DIN, DOUT, true>;
@@ -318,7 +327,7 @@ extern "C" int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float*
     TransBwdArgs a;
     a.X = X; a.W = W; a.H = H; a.dH = dH; a.dS = dS; a.dX = dX; a.work = work; a.U = U; a.I = I;
     a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.x_local = x_local;
-    a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p);
+    a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p); a.drop_p = feat_drop_p;
     a.seed = seed; a.seed_dev = seed_dev; a.nbu = a.nbi = 0;
     const bool drop = feat_drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);

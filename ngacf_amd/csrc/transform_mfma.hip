@@ -1,0 +1,232 @@
+// bf16-storage form of the row transform and of its dX backward on the matrix cores.
+//
+//   forward  H[n, :] = X[n, :] @ W[type]          (contraction over din)      + scores S = H . a
+//   dX       dX[n, :] = dH[n, :] @ W[type]^T      (contraction over dout)
+//
+// Both are D^T = A . B^T with A taken from the 64..128-wide weight panel and B from node rows, so one
+// kernel serves both: v_mfma_f32_32x32x16_bf16 with the NODE on the lane (B operand) and the output
+// column on the accumulator registers.  A lane then owns 4 consecutive output columns of its node per
+// register group -> 8-byte (bf16) / 16-byte (fp32) row-contiguous stores, and the B fragment of a node is
+// 16 contiguous bytes of its row: no LDS transpose anywhere.  The weight panel is converted to bf16
+// A-fragments once per workgroup (LDS, 8..32 KB).  fp32 accumulate; operands rounded to bf16 (this path
+// runs only when H is stored as bf16 -- the fp32 path keeps the exact FMA kernels of transform.hip).
+#include "ngacf_common.hpp"
+
+namespace ngacf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int MF_TPW = 1;          // 32-row tiles per wave
+
+struct MfmaArgs {
+    const void* B;                 // node rows: X (forward) or dH (dX)
+    const float* M;                // W [2][DIN][DOUT]
+    const float* avec;             // [2][DOUT]  (forward)
+    void* out;                     // H (forward, global rows) or dX
+    float* S;                      // [N][heads] (forward)
+    int U, I;
+    int u_lo, u_n, i_lo, i_n;      // row windows
+    int b_local;                   // B holds only the window rows (forward: X local)
+    int out_local;                 // out holds only the window rows (dX local)
+    uint32_t drop_thr;
+    float drop_scale;
+    uint64_t seed;
+    const uint64_t* seed_dev;
+};
+
+__device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = static_cast<__bf16>(f[j]);
+    return r;
+}
+
+// TB: type of the node-row operand (bf16_t or float); TO: output element type; FWD: forward (else dX)
+template <typename TB, typename TO, int DIN, int DOUT, bool FWD, int HEADS, bool DROP>
+__global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
+    constexpr int KD = FWD ? DIN : DOUT;           // contraction width
+    constexpr int OD = FWD ? DOUT : DIN;           // output width
+    constexpr int KS = KD / 16, OT = OD / 32;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    bf16x8* Af = reinterpret_cast<bf16x8*>(lds_raw);           // [KS][OT][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_u = (a.u_n + 31) / 32, tiles_i = (a.i_n + 31) / 32;
+    const int nbu = (tiles_u + 4 * MF_TPW - 1) / (4 * MF_TPW);
+    const bool users = (int)blockIdx.x < nbu;
+    const int type = users ? 0 : 1;
+    const int bl = users ? blockIdx.x : blockIdx.x - nbu;
+    const int win_lo = users ? a.u_lo : a.U + a.i_lo;
+    const int win_end = win_lo + (users ? a.u_n : a.i_n);
+    const int ntiles = users ? tiles_u : tiles_i;
+    const int loc_off = users ? a.u_lo : a.U + a.i_lo - a.u_n;  // global row - loc_off = local row
+    const uint32_t salt = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
+
+    {   // weight panel -> bf16 A fragments: A[i][k] = W[k][i] (forward) or W[i][k] (dX)
+        const float* M = a.M + (size_t)type * DIN * DOUT;
+        for (int slot = tid; slot < KS * OT * 64; slot += 256) {
+            const int l = slot & 63, t = (slot >> 6) % OT, s = (slot >> 6) / OT;
+            const int i = 32 * t + (l & 31), k0 = 16 * s + 8 * (l >> 5);
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = FWD ? M[(size_t)(k0 + j) * DOUT + i] : M[(size_t)i * DOUT + k0 + j];
+            Af[slot] = pack8(f);
+        }
+    }
+    __syncthreads();
+
+    const int r = lane & 31, h = lane >> 5;
+    const TB* Bg = static_cast<const TB*>(a.B);
+#pragma unroll 1
+    for (int it = 0; it < MF_TPW; ++it) {
+        const int tile = (bl * 4 + wave) * MF_TPW + it;
+        if (tile >= ntiles) break;
+        const int node = win_lo + tile * 32 + r;
+        const bool ok = node < win_end;
+        const int nd = ok ? node : win_end - 1;
+        const size_t brow = (size_t)(a.b_local ? nd - loc_off : nd);
+
+        bf16x8 bf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c0 = 16 * s + 8 * h;
+            if constexpr (sizeof(TB) == 2 && !(FWD && DROP)) {
+                bf[s] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const uint16_t*>(Bg) + brow * KD + c0);
+            } else {
+                float f[8];
+                if constexpr (sizeof(TB) == 2) {
+                    Slice<bf16_t>::load(reinterpret_cast<const bf16_t*>(Bg) + brow * KD + c0, f);
+                } else {
+                    const float4 v0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Bg) + brow * KD + c0);
+                    const float4 v1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Bg) + brow * KD + c0 + 4);
+                    f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+                }
+                if (FWD && DROP) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = feat_bits(salt, nd, c0 + j) >= a.drop_thr ? f[j] * a.drop_scale : 0.f;
+                }
+                bf[s] = pack8(f);
+            }
+        }
+        f32x16 acc[OT];
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int t = 0; t < OT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[(s * OT + t) * 64 + lane], bf[s], acc[t], 0, 0, 0);
+
+        // lane: node r (+ half h); acc[t][4g + j] = output column 32t + 8g + 4h + j
+        if constexpr (FWD) {
+            const float* av = a.avec + type * DOUT;
+            float head_part[OT * 4];
+            float total = 0.f;
+            uint16_t* Hg = reinterpret_cast<uint16_t*>(a.out);
+#pragma unroll
+            for (int t = 0; t < OT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = 32 * t + 8 * g + 4 * h;
+                    const float4 a4 = *reinterpret_cast<const float4*>(av + c);
+                    uint32_t b[4];
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        b[j] = f32_to_bf16(acc[t][4 * g + j]);
+                        v[j] = bf16_to_f32(b[j]);
+                    }
+                    float p = v[0] * a4.x;
+                    p = fmaf(v[1], a4.y, p); p = fmaf(v[2], a4.z, p); p = fmaf(v[3], a4.w, p);
+                    head_part[t * 4 + g] = p;
+                    total += p;
+                    if (ok) *reinterpret_cast<uint2*>(Hg + (size_t)nd * DOUT + c) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+                }
+            if (HEADS == 1) {
+                total += __shfl_xor(total, 32, 64);
+                if (ok && h == 0) a.S[nd] = total;
+            } else {                                   // 8-wide heads: head 4t+g = this lane's 4 columns + the other half's
+#pragma unroll
+                for (int q = 0; q < OT * 4; ++q) {
+                    const float p = head_part[q] + __shfl_xor(head_part[q], 32, 64);
+                    if (ok && h == 0) a.S[(size_t)nd * HEADS + q] = p;
+                }
+            }
+        } else {
+            const size_t orow = (size_t)(a.out_local ? nd - loc_off : nd);
+#pragma unroll
+            for (int t = 0; t < OT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = 32 * t + 8 * g + 4 * h;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[t][4 * g + j];
+                        if (DROP) v[j] = feat_bits(salt, nd, c + j) >= a.drop_thr ? v[j] * a.drop_scale : 0.f;
+                    }
+                    if (!ok) continue;
+                    if constexpr (sizeof(TO) == 4) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow * DIN + c) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        const uint32_t lo = f32_to_bf16(v[0]) | (f32_to_bf16(v[1]) << 16), hi = f32_to_bf16(v[2]) | (f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + orow * DIN + c) = make_uint2(lo, hi);
+                    }
+                }
+        }
+    }
+}
+
+template <typename TB, typename TO, int DIN, int DOUT, bool FWD, int HEADS>
+static int launch_mfma(const MfmaArgs& a, bool drop, hipStream_t st) {
+    constexpr int KD = FWD ? DIN : DOUT, OD = FWD ? DOUT : DIN;
+    const int tiles_u = (a.u_n + 31) / 32, tiles_i = (a.i_n + 31) / 32;
+    const int nb = (tiles_u + 4 * MF_TPW - 1) / (4 * MF_TPW) + (tiles_i + 4 * MF_TPW - 1) / (4 * MF_TPW);
+    if (nb == 0) return 0;
+    constexpr size_t lds = (size_t)(KD / 16) * (OD / 32) * 64 * 16;
+    if (drop) hipLaunchKernelGGL((transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, true>), dim3(nb), dim3(256), lds, st, a);
+    else      hipLaunchKernelGGL((transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, false>), dim3(nb), dim3(256), lds, st, a);
+    NGACF_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename TB, typename TO, bool FWD>
+static int dispatch_mfma(const MfmaArgs& a, int din, int dout, int heads, bool drop, hipStream_t st) {
+    if (din == 64 && dout == 64 && heads == 8) return launch_mfma<TB, TO, 64, 64, FWD, 8>(a, drop, st);
+    if (din == 64 && dout == 64 && heads == 1) return launch_mfma<TB, TO, 64, 64, FWD, 1>(a, drop, st);
+    if (din == 128 && dout == 64 && heads == 8) return launch_mfma<TB, TO, 128, 64, FWD, 8>(a, drop, st);
+    if (din == 128 && dout == 64 && heads == 1) return launch_mfma<TB, TO, 128, 64, FWD, 1>(a, drop, st);
+    if (din == 64 && dout == 128 && heads == 1) return launch_mfma<TB, TO, 64, 128, FWD, 1>(a, drop, st);
+    if (din == 64 && dout == 128 && heads == 16) return launch_mfma<TB, TO, 64, 128, FWD, 16>(a, drop, st);
+    if (din == 128 && dout == 128 && heads == 1) return launch_mfma<TB, TO, 128, 128, FWD, 1>(a, drop, st);
+    if (din == 128 && dout == 128 && heads == 16) return launch_mfma<TB, TO, 128, 128, FWD, 16>(a, drop, st);
+    return NGACF_E_SHAPE;
+}
+
+// entry points used by transform.hip / transform_bwd.hip when H is stored as bf16
+int transform_fwd_mfma(const void* X, int x_dtype, const float* W, const float* avec, void* H, float* S,
+                       int U, int I, int din, int dout, int heads, int u_lo, int u_n, int i_lo, int i_n, int x_local,
+                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st) {
+    MfmaArgs a;
+    a.B = X; a.M = W; a.avec = avec; a.out = H; a.S = S; a.U = U; a.I = I;
+    a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.b_local = x_local; a.out_local = 0;
+    a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p); a.seed = seed; a.seed_dev = seed_dev;
+    const bool drop = feat_drop_p > 0.f;
+    if (x_dtype == NGACF_BF16) return dispatch_mfma<bf16_t, bf16_t, true>(a, din, dout, heads, drop, st);
+    return dispatch_mfma<float, bf16_t, true>(a, din, dout, heads, drop, st);
+}
+
+int transform_dx_mfma(const float* dH, const float* W, float* dX, int U, int I, int din, int dout, int heads,
+                      int u_lo, int u_n, int i_lo, int i_n, int x_local,
+                      float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st) {
+    MfmaArgs a;
+    a.B = dH; a.M = W; a.avec = nullptr; a.out = dX; a.S = nullptr; a.U = U; a.I = I;
+    a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.b_local = 0; a.out_local = x_local;
+    a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p); a.seed = seed; a.seed_dev = seed_dev;
+    return dispatch_mfma<float, float, false>(a, din, dout, heads, feat_drop_p > 0.f, st);
+}
+
+}  // namespace ngacf
