@@ -23,8 +23,12 @@
  *   col   int32[2E]      source node (global id) of every directed edge; the 2E entries
  *                        are the CSR of the user rows followed by the CSC of the item rows
  *   rowptr int32[N+1]    edge range of every dst row in `col`
- *   srow  int32[nshort]  the short dst rows (degree <= plan.short_max), sorted by degree,
- *                        descending: traversed one lane group per row
+ *   srow  int32[nshort]  the short dst rows (degree <= plan.short_max): traversed one lane group per row.
+ *                        First the user rows (sorted by degree, descending, padded with -1 to a multiple of
+ *                        16 = nshort_user entries), then the item rows (sorted likewise)
+ *   nseg_user            number of leading entries of `segs` that are user rows; a launch works through
+ *                        [user segs][user short rows][item segs][item short rows], so each half re-reads only
+ *                        ONE of the two node tables and that table stays L2 resident
  *   segs  int32[nseg][4] work items of the long rows {dst row, first edge, one-past-last edge, part}:
  *                        part < 0  -> the segment is the whole row, finished in place;
  *                        part >= 0 -> slice of a hub row, partial sums go to slot `part`
@@ -89,7 +93,7 @@ int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float* W, const f
  * drop_p > 0 applies the edge dropout of :375 (numerators only), mask keyed by
  * (seed, head, user, item) so both directions see the same mask. */
 int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                   const int32_t* srow, int nshort, const int32_t* rowptr,
+                   const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
                    void* out, float* agg, float* R, float* part_acc, float* part_r,
@@ -104,7 +108,7 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  *   G float[N][d], Gn [N][d] dtype, ST float[N][heads][2]: workspace    dH float[N][d], dS float[N][heads]: results
  *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows */
 int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                   const int32_t* srow, int nshort, const int32_t* rowptr,
+                   const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
                    const void* out, const float* agg, const float* R, const float* gout,

@@ -33,7 +33,7 @@ struct PropArgs {
     float* part_acc;
     float* part_r;
     int U, N;
-    int nb_long;           // workgroups [0, nb_long) run the long mode
+    WorkOrder order;
     float alpha;
     uint32_t drop_thr;
     float drop_scale;
@@ -140,13 +140,16 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
     float rsum = 0.f;
     float av[VEC];
 
-    if ((int)blockIdx.x >= a.nb_long) {
+    bool is_short;
+    int widx, wend;
+    locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, is_short, widx, wend);
+    if (widx >= wend) return;
+    if (is_short) {
         // ------------------------------------------------------------------ short rows: slot per row
-        const int w = (blockIdx.x - a.nb_long) * 4 + (threadIdx.x >> 6);
-        const int ridx = w * EPI + slot;
-        const bool live = ridx < a.nshort;
-        if (w * EPI >= a.nshort) return;
-        const int row = a.srow[live ? ridx : a.nshort - 1];
+        const int ridx = widx + slot;
+        const int rraw = a.srow[ridx < wend ? ridx : wend - 1];
+        const bool live = ridx < wend && rraw >= 0;          // -1 = padding between the user and item lists
+        const int row = live ? rraw : 0;
         const int beg = a.rowptr[row];
         const int deg = live ? a.rowptr[row + 1] - beg : 0;
         const int maxdeg = uniform(deg);                  // rows are sorted: slot 0 holds the longest
@@ -193,8 +196,7 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
     }
 
     // ---------------------------------------------------------------------- long rows: wave per segment
-    const int w = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (w >= a.nseg) return;
+    const int w = uniform(widx);
     const int4 sg = a.segs[w];
     const int row = uniform(sg.x), beg = uniform(sg.y), end = uniform(sg.z), part = uniform(sg.w);
     const bool dst_is_user = row < a.U;
@@ -276,9 +278,8 @@ __global__ __launch_bounds__(256) void prop_fwd_split_kernel(const PropArgs a, c
 template <typename T, int D, int HEADS>
 static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st) {
     constexpr int EPI = Shape<T, D, HEADS>::EPI;
-    a.nb_long = (a.nseg + 3) / 4;
-    const int nw_short = (a.nshort + EPI - 1) / EPI;
-    const int nb = a.nb_long + (nw_short + 3) / 4;
+    int nb = 0;
+    a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, EPI, &nb);
     if (nb > 0) {
         const dim3 grid(nb), block(256);
         if (from_row) {
@@ -302,13 +303,15 @@ static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, b
 using namespace ngacf;
 
 extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                              const int32_t* srow, int nshort, const int32_t* rowptr,
+                              const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,
                               const int32_t* col, const void* H, int dtype,
                               const float* S_dst, const float* S_src, const float* avec,
                               void* out, float* agg, float* R, float* part_acc, float* part_r,
                               int U, int N, int d, int heads, float alpha,
                               float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
+    if (nseg_user < 0 || nseg_user > nseg || nshort_user < 0 || nshort_user > nshort || (nshort_user % 16 != 0 && nshort_user != nshort))
+        return NGACF_E_ARG;
     if (nseg + nshort == 0) return 0;
     if (!col || !H || !S_dst || !out || !rowptr) return NGACF_E_ARG;
     if ((nseg > 0 && !segs) || (nshort > 0 && !srow)) return NGACF_E_ARG;
@@ -321,7 +324,7 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
     PropArgs a;
     a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R;
-    a.part_acc = part_acc; a.part_r = part_r; a.U = U; a.N = N; a.nb_long = 0; a.alpha = alpha;
+    a.part_acc = part_acc; a.part_r = part_r; a.U = U; a.N = N; a.order.nseg_u = nseg_user; a.order.nshort_u = nshort_user; a.alpha = alpha;
     a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.seed_dev = seed_dev; a.flags = flags;
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -42,7 +42,7 @@ struct PropBwdArgs {
     int U, N;
     int nu_lo, nu_n, ni_lo, ni_n;  // step-1 row windows: users [nu_lo, +nu_n), items [ni_lo, +ni_n) (global row = U + i)
     int gout_local;                // gout holds only the window rows, users first (node-partitioned runs)
-    int nb_long;
+    WorkOrder order;
     float alpha;
     uint32_t drop_thr;
     float drop_scale;
@@ -208,13 +208,16 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
     float dsum = 0.f;
     RowCtx<VEC> x;
 
-    if ((int)blockIdx.x >= a.nb_long) {
+    bool is_short;
+    int widx, wend;
+    locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, is_short, widx, wend);
+    if (widx >= wend) return;
+    if (is_short) {
         // ------------------------------------------------------------------ short rows: slot per row
-        const int w = (blockIdx.x - a.nb_long) * 4 + (threadIdx.x >> 6);
-        if (w * EPI >= a.nshort) return;
-        const int ridx = w * EPI + slot;
-        const bool live = ridx < a.nshort;
-        const int row = a.srow[live ? ridx : a.nshort - 1];
+        const int ridx = widx + slot;
+        const int rraw = a.srow[ridx < wend ? ridx : wend - 1];
+        const bool live = ridx < wend && rraw >= 0;          // -1 = padding between the user and item lists
+        const int row = live ? rraw : 0;
         const int beg = a.rowptr[row];
         const int deg = live ? a.rowptr[row + 1] - beg : 0;
         const int maxdeg = uniform(deg);
@@ -250,8 +253,7 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
     }
 
     // ---------------------------------------------------------------------- long rows: wave per segment
-    const int w = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (w >= a.nseg) return;
+    const int w = uniform(widx);
     const int4 sg = a.segs[w];
     const int row = uniform(sg.x), beg = uniform(sg.y), end = uniform(sg.z), part = uniform(sg.w);
     load_ctx<T, D, HEADS, FROM_ROW, DROP>(a, row, q, head, x);
@@ -325,9 +327,8 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
         NGACF_CHECK_LAUNCH();
     }
     if (!do_edges) return 0;
-    a.nb_long = (a.nseg + 3) / 4;
-    const int nw_short = (a.nshort + EPI - 1) / EPI;
-    const int nb = a.nb_long + (nw_short + 3) / 4;
+    int nb = 0;
+    a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, EPI, &nb);
     if (nb > 0) {
         const dim3 grid(nb), block(256);
         if (from_row) {
@@ -351,7 +352,7 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
 using namespace ngacf;
 
 static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                         const int32_t* srow, int nshort, const int32_t* rowptr,
+                         const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,
                          const int32_t* col, const void* H, int dtype,
                          const float* S_dst, const float* S_src, const float* avec,
                          const void* out, const float* agg, const float* R, const float* gout,
@@ -361,6 +362,8 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
                          float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
                          int nu_lo, int nu_n, int ni_lo, int ni_n, int gout_local, bool do_node, bool do_edges, void* stream) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
+    if (nseg_user < 0 || nseg_user > nseg || nshort_user < 0 || nshort_user > nshort || (nshort_user % 16 != 0 && nshort_user != nshort))
+        return NGACF_E_ARG;
     if (nu_lo < 0 || nu_n < 0 || ni_lo < 0 || ni_n < 0 || nu_lo + nu_n > U || ni_lo + ni_n > N - U) return NGACF_E_ARG;
     if (N == 0) return 0;
     if (!S_src || !G || !Gn || !ST) return NGACF_E_ARG;
@@ -378,7 +381,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R; a.gout = gout;
     a.G = G; a.Gn = Gn; a.ST = reinterpret_cast<float2*>(ST); a.dH = dH; a.dS = dS; a.part_acc = part_acc; a.part_r = part_r;
     a.U = U; a.N = N; a.nu_lo = nu_lo; a.nu_n = nu_n; a.ni_lo = ni_lo; a.ni_n = ni_n; a.gout_local = gout_local;
-    a.nb_long = 0; a.alpha = alpha;
+    a.order.nseg_u = nseg_user; a.order.nshort_u = nshort_user; a.alpha = alpha;
     a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.seed_dev = seed_dev; a.flags = flags;
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -399,7 +402,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
 }
 
 extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                              const int32_t* srow, int nshort, const int32_t* rowptr,
+                              const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,
                               const int32_t* col, const void* H, int dtype,
                               const float* S_dst, const float* S_src, const float* avec,
                               const void* out, const float* agg, const float* R, const float* gout,
@@ -408,7 +411,7 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
                               int U, int N, int d, int heads, float alpha,
                               float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
     const bool skip_node = (flags & NGACF_SKIP_NODE) != 0;
-    return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
+    return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, nseg_user, nshort_user, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
                          G, Gn, ST, dH, dS, part_acc, part_r, U, N, d, heads, alpha, drop_p, seed, seed_dev, flags,
                          0, U, 0, N - U, 0, !skip_node, true, stream);
 }
@@ -417,7 +420,7 @@ extern "C" int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg,
                                    const float* S_src, float* G, void* Gn, float* ST,
                                    int U, int N, int d, int heads, int flags,
                                    int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream) {
-    return prop_bwd_impl(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, dtype, nullptr, S_src, nullptr,
+    return prop_bwd_impl(nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, dtype, nullptr, S_src, nullptr,
                          out, agg, R, gout, G, Gn, ST, nullptr, nullptr, nullptr, nullptr, U, N, d, heads, 0.2f, 0.f, 0, nullptr, flags,
                          u_lo, u_n, i_lo, i_n, gout_local, true, false, stream);
 }

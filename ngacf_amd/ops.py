@@ -104,7 +104,7 @@ def _plan_ptrs(plan, dev):
     col = _chk(plan.col, "plan.col", torch.int32, plan.n_edges_directed, dev) if plan.n_edges_directed else 0
     srow = _chk(plan.srow, "plan.srow", torch.int32, plan.nshort, dev) if plan.nshort else 0
     rowptr = _chk(plan.rowptr32, "plan.rowptr32", torch.int32, plan.N + 1, dev)
-    return (segs, plan.nseg, split, plan.nsplit, srow, plan.nshort, rowptr, col)
+    return (segs, plan.nseg, split, plan.nsplit, srow, plan.nshort, plan.nseg_user, plan.nshort_user, rowptr, col)
 
 
 def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,

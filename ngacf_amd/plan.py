@@ -32,6 +32,7 @@ class GraphPlan:
         # short rows (degree <= short_max), sorted by degree descending: one lane group per row
         self.srow = srow if srow is not None else torch.empty(0, dtype=torch.int32, device=col.device)
         self.nshort, self.short_max = int(self.srow.shape[0]), short_max
+        self.nseg_user, self.nshort_user = self.nseg, self.nshort       # build_plan sets the user/item split
         self.rowptr32 = rowptr.to(torch.int32).contiguous()
 
     @property
@@ -47,9 +48,11 @@ class GraphPlan:
         return self._all
 
     def to(self, device):
-        return GraphPlan(self.U, self.I, self.E, self.rowptr.to(device), self.col.to(device),
-                         self.segs.to(device), self.split.to(device), self.nparts, self.seg_len,
-                         self.row_lo, self.row_hi, self.srow.to(device), self.short_max, self.row_ranges)
+        p = GraphPlan(self.U, self.I, self.E, self.rowptr.to(device), self.col.to(device),
+                      self.segs.to(device), self.split.to(device), self.nparts, self.seg_len,
+                      self.row_lo, self.row_hi, self.srow.to(device), self.short_max, self.row_ranges)
+        p.nseg_user, p.nshort_user = self.nseg_user, self.nshort_user
+        return p
 
 
 def _segments(rowptr, rows, seg_len):
@@ -116,10 +119,24 @@ def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True,
     rows = torch.cat([torch.arange(a, b, device=dev) for a, b in ranges])
     deg = rowptr[rows + 1] - rowptr[rows]
     is_short = deg <= short_max
-    order = torch.sort(deg[is_short], descending=True, stable=True).indices
-    srow = rows[is_short][order].to(torch.int32).contiguous()
-    segs, split, nparts = _segments(rowptr, rows[~is_short], seg_len)
+    is_user = rows < U
+    # work order of a launch: user rows first, then item rows (each half gathers only the other type's table)
+    sr = []
+    for m in (is_short & is_user, is_short & ~is_user):
+        order = torch.sort(deg[m], descending=True, stable=True).indices
+        sr.append(rows[m][order])
+    pad = (-sr[0].numel()) % 16
+    nshort_user = sr[0].numel() + pad
+    srow = torch.cat([sr[0], torch.full((pad,), -1, dtype=torch.long, device=dev), sr[1]]).to(torch.int32).contiguous()
+    seg_u, split_u, np_u = _segments(rowptr, rows[~is_short & is_user], seg_len)
+    seg_i, split_i, np_i = _segments(rowptr, rows[~is_short & ~is_user], seg_len)
+    seg_i[:, 3] = torch.where(seg_i[:, 3] >= 0, seg_i[:, 3] + np_u, seg_i[:, 3])
+    split_i[:, 1] += np_u
+    segs = torch.cat([seg_u, seg_i]).contiguous()
+    split = torch.cat([split_u, split_i]).contiguous()
+    nparts = np_u + np_i
     plan = GraphPlan(U, I, E, rowptr, col, segs, split, nparts, seg_len, lo, hi, srow, short_max, ranges)
+    plan.nseg_user, plan.nshort_user = int(seg_u.shape[0]), int(nshort_user)
     validate_plan(plan)
     return plan
 
@@ -145,11 +162,25 @@ def validate_plan(p):
     if p.nsplit:
         sp = p.split.long()
         assert int((sp[:, 1] + sp[:, 2]).max()) <= p.nparts and int(sp[:, 1].min()) >= 0
+    n_real_short = 0
     if p.nshort:
-        sr = p.srow.long()
-        assert int(sr.min()) >= 0 and int(sr.max()) < p.N, "short row out of range"
-        d = p.rowptr[sr + 1] - p.rowptr[sr]
-        assert int(d.max()) <= p.short_max and bool((d[1:] <= d[:-1]).all()), "short rows must be sorted by degree, descending"
+        assert p.nshort_user % 16 == 0 or p.nshort_user == p.nshort
+        for part, want_user in ((p.srow[:p.nshort_user].long(), True), (p.srow[p.nshort_user:].long(), False)):
+            real = part[part >= 0]
+            n_real_short += int(real.numel())
+            if want_user:
+                assert bool((part[:real.numel()] >= 0).all()), "padding must trail the user list"
+            else:
+                assert real.numel() == part.numel(), "no padding inside the item list"
+            if real.numel():
+                assert int(real.max()) < p.N and bool(((real < p.U) == want_user).all()), "short row in the wrong half"
+                d = p.rowptr[real + 1] - p.rowptr[real]
+                assert int(d.max()) <= p.short_max and bool((d[1:] <= d[:-1]).all()), \
+                    "short rows must be sorted by degree, descending, within each half"
+    if p.nseg:
+        su = p.segs[:p.nseg_user, 0].long()
+        si = p.segs[p.nseg_user:, 0].long()
+        assert (su.numel() == 0 or int(su.max()) < p.U) and (si.numel() == 0 or int(si.min()) >= p.U)
     assert int(p.rowptr[-1]) == n2e and int(p.rowptr[-1]) < 2 ** 31
-    covered = p.nshort + (int(torch.unique(p.segs[:, 0]).numel()) if p.nseg else 0)
+    covered = n_real_short + (int(torch.unique(p.segs[:, 0]).numel()) if p.nseg else 0)
     assert covered == p.n_rows, "every dst row of the plan's ranges must be covered exactly once"

@@ -71,10 +71,10 @@ def test_library_loaded_and_rejects_bad_shapes(dev):
     from ngacf_amd import _lib
     assert "gfx950" in ngacf_amd.version()
     # unsupported row width is refused before any launch
-    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 2, 48, 1, 0.2, 0.0, 0, 0, 3, 0)
+    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 2, 48, 1, 0.2, 0.0, 0, 0, 3, 0)
     assert rc == -2
     # a table of 2^32 bytes or more does not fit the 32-bit row offsets: refused, not wrapped
-    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1 << 24, 64, 8, 0.2, 0.0, 0, 0, 3, 0)
+    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1 << 24, 64, 8, 0.2, 0.0, 0, 0, 3, 0)
     assert rc == -2
     assert _lib.lib.ngacf_score_fwd(0, 0, 0, 0, 0, 5, 1, 64, 0) == -1
 
@@ -166,7 +166,7 @@ def test_split_rows_match_unsplit(dev):
         if (seg, short) == (8, 4):
             assert plan.nsplit > 100 and plan.nshort > 0
         if short == 1 << 20:
-            assert plan.nseg == 0 and plan.nshort == U + I
+            assert plan.nseg == 0 and int((plan.srow >= 0).sum()) == U + I
         out, agg, R = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)
         dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, g, 8)
         if ref is None:
