@@ -55,7 +55,7 @@ def make_model(ng, U, I, d, stages, droprate, dtype, dev):
 
 
 def stage_dims(model):
-    return [(l[0].in_dim, l[0].out_dim * len(l), len(l)) for l in model.gat._stages()]
+    return model.gat.stage_shapes()
 
 
 def main():
@@ -218,8 +218,7 @@ def main():
 
 def stage_layer_names(model):
     """state_dict prefixes of the layers of every stage, in execution order."""
-    name_of = {id(m): "gat." + n for n, m in model.gat.named_modules()}
-    return [[name_of[id(l)] for l in layers] for layers in model.gat._stages()]
+    return [["gat." + n for n in names] for names in model.gat.stage_layer_names()]
 
 
 if __name__ == "__main__":

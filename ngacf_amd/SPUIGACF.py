@@ -113,6 +113,25 @@ class SpUIGraphAttentionLayer(nn.Module):
         self._plans = _PlanCache()
         self.seg_len = 256
 
+    # ---- attached mode: inside a GAT stack the weights of all heads of a stage live in ONE fused parameter
+    # (no per-head concat / gradient-slice kernels per step); the layer then only presents views of it.
+    def _attach(self, owner, stage, head):
+        for n in ("W_u", "W_i", "a"):
+            del self._parameters[n]
+        object.__setattr__(self, "_owner", (owner, stage, head))     # plain attribute: no module cycle
+
+    def __getattr__(self, name):
+        if name in ("W_u", "W_i", "a"):
+            own = self.__dict__.get("_owner")
+            if own is not None:
+                return own[0]._head_view(own[1], own[2], name)
+        return super().__getattr__(name)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        if self.__dict__.get("_owner") is not None:
+            return                                                    # the owning stack consumes this layer's keys
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
     def forward(self, uidx, iidx, features, indices):
         U, I = int(uidx.numel()), int(iidx.numel())
         plan = self._plans.get(indices.squeeze(), U, I, self.seg_len)
@@ -141,6 +160,87 @@ class _GATBase(nn.Module):
     compute_dtype = torch.float32    # storage type of H and of the stage outputs (fp32 | bf16)
     seg_len = 256
 
+    def _finalize_stages(self):
+        """Move the per-head weights the layer constructors drew (reference init, SPUIGACF.py:270-278) into one
+        fused parameter pair per stage: stage{s}_W [2,din,dout] (W_u heads | W_i heads), stage{s}_a [2,dout]."""
+        self._layer_names = {id(m): n for n, m in self.named_modules() if isinstance(m, SpUIGraphAttentionLayer)}
+        for s, layers in enumerate(self._stages()):
+            k = layers[0].out_dim
+            W = torch.stack([torch.cat([l.W_u.data for l in layers], 1), torch.cat([l.W_i.data for l in layers], 1)])
+            a = torch.stack([torch.cat([l.a.data[0, :k] for l in layers]), torch.cat([l.a.data[0, k:] for l in layers])])
+            self.register_parameter("stage%d_W" % s, nn.Parameter(W.contiguous()))
+            self.register_parameter("stage%d_a" % s, nn.Parameter(a.contiguous()))
+            for h, l in enumerate(layers):
+                l._attach(self, s, h)
+
+    def stage_params(self, s):
+        return getattr(self, "stage%d_W" % s), getattr(self, "stage%d_a" % s)
+
+    def stage_shapes(self):
+        """[(din, dout, heads)] per stage"""
+        return [(l[0].in_dim, l[0].out_dim * len(l), len(l)) for l in self._stages()]
+
+    def stage_layer_names(self):
+        """reference state_dict prefixes (relative to this module) of every stage's layers, in order"""
+        return [[self._layer_names[id(l)] for l in layers] for layers in self._stages()]
+
+    def _head_view(self, s, h, name):
+        W, a = self.stage_params(s)
+        k = self._stages()[s][0].out_dim
+        sl = slice(h * k, (h + 1) * k)
+        if name == "W_u":
+            return W[0][:, sl]
+        if name == "W_i":
+            return W[1][:, sl]
+        return torch.cat([a[0][sl], a[1][sl]])[None]
+
+    def reference_named(self, what="data"):
+        """{reference state_dict key (relative): tensor} of the weights (what='data') or gradients ('grad')."""
+        out = {}
+        for s, (layers, names) in enumerate(zip(self._stages(), self.stage_layer_names())):
+            W, a = self.stage_params(s)
+            if what == "grad":
+                W, a = W.grad, a.grad
+            k = layers[0].out_dim
+            for h, n in enumerate(names):
+                sl = slice(h * k, (h + 1) * k)
+                out[n + ".W_u"], out[n + ".W_i"] = W[0][:, sl], W[1][:, sl]
+                out[n + ".a"] = torch.cat([a[0][sl], a[1][sl]])[None]
+        return out
+
+    # state_dict in the reference's per-head layout (checkpoint interchange, run_Gowalla.py:127-130,143)
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        for n, t in self.reference_named().items():
+            destination[prefix + n] = t if keep_vars else t.detach().clone()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        with torch.no_grad():
+            for s, (layers, names) in enumerate(zip(self._stages(), self.stage_layer_names())):
+                W, a = self.stage_params(s)
+                k = layers[0].out_dim
+                for h, n in enumerate(names):
+                    sl = slice(h * k, (h + 1) * k)
+                    for key, dst in ((n + ".W_u", W[0][:, sl]), (n + ".W_i", W[1][:, sl])):
+                        if prefix + key in state_dict:
+                            src = state_dict[prefix + key]
+                            if tuple(src.shape) != tuple(dst.shape):
+                                error_msgs.append("size mismatch for %s: %s vs %s" % (prefix + key, tuple(src.shape), tuple(dst.shape)))
+                            else:
+                                dst.copy_(src)
+                        elif strict:
+                            missing_keys.append(prefix + key)
+                    if prefix + n + ".a" in state_dict:
+                        src = state_dict[prefix + n + ".a"]
+                        if tuple(src.shape) != (1, 2 * k):
+                            error_msgs.append("size mismatch for %s" % (prefix + n + ".a"))
+                        else:
+                            a[0][sl].copy_(src[0, :k])
+                            a[1][sl].copy_(src[0, k:])
+                    elif strict:
+                        missing_keys.append(prefix + n + ".a")
+            for p_ in self.parameters(recurse=False):
+                p_._version                                            # (copy_ above already bumped the versions)
+
     def _run(self, uidx, iidx, features, adj):
         U, I = int(uidx.numel()), int(iidx.numel())
         plan = self._plans.get(adj.squeeze(), U, I, self.seg_len)
@@ -155,10 +255,8 @@ class _GATBase(nn.Module):
         else:
             base = _fresh_seed() if p > 0 else 0
         x = features
-        if not hasattr(self, "_fused"):
-            self._fused = _FusedCache()
         for s, layers in enumerate(self._stages()):
-            W, avec = self._fused.get(s, layers)
+            W, avec = self.stage_params(s)
             # feature dropout in front of every stage (:208,:213) and the ELU behind it (:397 inside
             # the concat layers, :214 around out_att) are fused into the stage
             x = NF.stage(x, W, avec, plan, len(layers), layers[0].alpha, True, p, p,
@@ -185,6 +283,7 @@ class SpUIGAT(_GATBase):
             self.add_module("attention_{}".format(i), attention)
         self.out_att = SpUIGraphAttentionLayer(nhid * nheads, nclass, dropout=dropout, alpha=alpha, concat=False)
         self._plans = _PlanCache()
+        self._finalize_stages()
 
     def _stages(self):
         return [self.attentions, [self.out_att]]
@@ -207,6 +306,7 @@ class SPUIMultiGAT(_GATBase):
             self.add_module("attention2_{}".format(i), attention)
         self.out_att = SpUIGraphAttentionLayer(nhid * nheads, nclass, dropout=dropout, alpha=alpha, concat=False)
         self._plans = _PlanCache()
+        self._finalize_stages()
 
     def _stages(self):
         return [self.attentions1, self.attentions2, [self.out_att]]
@@ -231,6 +331,7 @@ class StackedSpUIGAT(_GATBase):
             self.hidden.append(grp)
         self.out_att = SpUIGraphAttentionLayer(nhid * nheads, nclass, dropout=dropout, alpha=alpha, concat=False)
         self._plans = _PlanCache()
+        self._finalize_stages()
 
     def _stages(self):
         return self.hidden + [[self.out_att]]
@@ -293,6 +394,14 @@ class SPUIStackedGACF(_CFBase):
         self.iEmbd = nn.Embedding(itemNum, embedSize)
         self.gat = StackedSpUIGAT(embedSize, 8, embedSize, droprate, 0.2, 8, stages - 1)
         self._init_weight_()
+
+
+def reference_named_grads(model):
+    """{reference state_dict key: gradient} for a *CF model (embeddings + the per-head slices of the fused stage
+    gradients), e.g. to compare with the reference's named_parameters() gradients."""
+    out = {"uEmbd.weight": model.uEmbd.weight.grad, "iEmbd.weight": model.iEmbd.weight.grad}
+    out.update({"gat." + k: v for k, v in model.gat.reference_named("grad").items()})
+    return out
 
 
 def set_compute_dtype(model, dtype):

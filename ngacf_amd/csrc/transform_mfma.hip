@@ -17,7 +17,8 @@ namespace ngacf {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int MF_TPW = 1;          // 32-row tiles per wave
+constexpr int MF_MAX_BLOCKS = 4096;  // ~16 workgroups per CU: beyond that a wave takes several 32-row tiles, so the
+                                    // per-workgroup weight-panel prologue stays amortised on 10^7-row tables
 
 struct MfmaArgs {
     const void* B;                 // node rows: X (forward) or dH (dX)
@@ -33,6 +34,7 @@ struct MfmaArgs {
     float drop_scale;
     uint64_t seed;
     const uint64_t* seed_dev;
+    int tpw;                       // 32-row tiles per wave
 };
 
 __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_u = (a.u_n + 31) / 32, tiles_i = (a.i_n + 31) / 32;
-    const int nbu = (tiles_u + 4 * MF_TPW - 1) / (4 * MF_TPW);
+    const int nbu = (tiles_u + 4 * a.tpw - 1) / (4 * a.tpw);
     const bool users = (int)blockIdx.x < nbu;
     const int type = users ? 0 : 1;
     const int bl = users ? blockIdx.x : blockIdx.x - nbu;
@@ -79,8 +81,8 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const TB* Bg = static_cast<const TB*>(a.B);
 #pragma unroll 1
-    for (int it = 0; it < MF_TPW; ++it) {
-        const int tile = (bl * 4 + wave) * MF_TPW + it;
+    for (int it = 0; it < a.tpw; ++it) {
+        const int tile = (bl * 4 + wave) * a.tpw + it;
         if (tile >= ntiles) break;
         const int node = win_lo + tile * 32 + r;
         const bool ok = node < win_end;
@@ -181,10 +183,12 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
 }
 
 template <typename TB, typename TO, int DIN, int DOUT, bool FWD, int HEADS>
-static int launch_mfma(const MfmaArgs& a, bool drop, hipStream_t st) {
+static int launch_mfma(MfmaArgs a, bool drop, hipStream_t st) {
     constexpr int KD = FWD ? DIN : DOUT, OD = FWD ? DOUT : DIN;
     const int tiles_u = (a.u_n + 31) / 32, tiles_i = (a.i_n + 31) / 32;
-    const int nb = (tiles_u + 4 * MF_TPW - 1) / (4 * MF_TPW) + (tiles_i + 4 * MF_TPW - 1) / (4 * MF_TPW);
+    a.tpw = (tiles_u + tiles_i + 4 * MF_MAX_BLOCKS - 1) / (4 * MF_MAX_BLOCKS);
+    if (a.tpw < 1) a.tpw = 1;
+    const int nb = (tiles_u + 4 * a.tpw - 1) / (4 * a.tpw) + (tiles_i + 4 * a.tpw - 1) / (4 * a.tpw);
     if (nb == 0) return 0;
     constexpr size_t lds = (size_t)(KD / 16) * (OD / 32) * 64 * 16;
     if (drop) hipLaunchKernelGGL((transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, true>), dim3(nb), dim3(256), lds, st, a);
@@ -213,7 +217,7 @@ int transform_fwd_mfma(const void* X, int x_dtype, const float* W, const float* 
     MfmaArgs a;
     a.B = X; a.M = W; a.avec = avec; a.out = H; a.S = S; a.U = U; a.I = I;
     a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.b_local = x_local; a.out_local = 0;
-    a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p); a.seed = seed; a.seed_dev = seed_dev;
+    a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p); a.seed = seed; a.seed_dev = seed_dev; a.tpw = 1;
     const bool drop = feat_drop_p > 0.f;
     if (x_dtype == NGACF_BF16) return dispatch_mfma<bf16_t, bf16_t, true>(a, din, dout, heads, drop, st);
     return dispatch_mfma<float, bf16_t, true>(a, din, dout, heads, drop, st);
@@ -225,7 +229,7 @@ int transform_dx_mfma(const float* dH, const float* W, float* dX, int U, int I, 
     MfmaArgs a;
     a.B = dH; a.M = W; a.avec = nullptr; a.out = dX; a.S = nullptr; a.U = U; a.I = I;
     a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.b_local = 0; a.out_local = x_local;
-    a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p); a.seed = seed; a.seed_dev = seed_dev;
+    a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p); a.seed = seed; a.seed_dev = seed_dev; a.tpw = 1;
     return dispatch_mfma<float, float, false>(a, din, dout, heads, feat_drop_p > 0.f, st);
 }
 

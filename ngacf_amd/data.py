@@ -16,7 +16,8 @@ SHAPES = {          # (U, I, E) -- SURVEY.md §8
     "gowalla": (29858, 40981, 1027370),
     "yelp": (45919, 45538, 1185065),
     "synthetic1b": (10_000_000, 5_000_000, 1_000_000_000),
-}
+    "synthetic200m": (10_000_000, 5_000_000, 200_000_000),     # same node tables (1.9 GB bf16: far beyond the 256 MB
+}                                                               # Infinity Cache), a fifth of the edges: true-HBM regime
 
 
 def synthetic_bipartite(U, I, E, seed=2019, device="cpu", alpha_pop=0.8, sigma=1.0, chunk=1 << 26):

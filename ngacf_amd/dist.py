@@ -24,7 +24,7 @@ import torch.nn as nn
 from . import functional as NF
 from . import ops as _hip_ops
 from .plan import build_plan
-from .SPUIGACF import SpUIGAT, SPUIMultiGAT, StackedSpUIGAT, _FusedCache, _fresh_seed
+from .SPUIGACF import SpUIGAT, SPUIMultiGAT, StackedSpUIGAT, _fresh_seed
 
 
 class Partition:
@@ -163,7 +163,7 @@ class ShardedSPUIGACF(nn.Module):
         full_u = torch.empty(userNum, embedSize).normal_(std=0.01)       # SPUIGACF.py:26-28
         full_i = torch.empty(itemNum, embedSize).normal_(std=0.01)
         self.load_full_embeddings(full_u, full_i)
-        self._plans, self._fused = {}, _FusedCache()
+        self._plans = {}
         self.compute_dtype = torch.float32
         self.seg_len = 256
 
@@ -211,7 +211,7 @@ class ShardedSPUIGACF(nn.Module):
         base = _fresh_seed() if drop > 0 else 0                          # same CPU generator state on every rank
         x = torch.cat([self.uEmbd.weight, self.iEmbd.weight], 0)
         for s, layers in enumerate(self.gat._stages()):
-            W, avec = self._fused.get(s, layers)
+            W, avec = self.gat.stage_params(s)
             x = _ShardedStage.apply(x, W, avec, self.part, plan, self.comm, self.be, len(layers), layers[0].alpha,
                                     drop, drop, NF.stage_seed(base, s), self.compute_dtype)
         return x

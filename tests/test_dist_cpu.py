@@ -57,9 +57,9 @@ def _worker(rank, world, port, tag, multi, q):
         err["pad"] = max(float(m.uEmbd.weight.grad[nu:].abs().max()) if nu < p.cu else 0.0,
                          float(m.iEmbd.weight.grad[ni:].abs().max()) if ni < p.ci else 0.0)
         worst = 0.0
-        for k, prm in m.gat.named_parameters():
+        for k, gr in m.gat.reference_named("grad").items():
             ref = g["g_f64.gat." + k]
-            worst = max(worst, float(np.abs(prm.grad.numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-12))
+            worst = max(worst, float(np.abs(gr.numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-12))
         err["gat"] = worst
         full = m.full_state_dict()
         err["sd"] = max(float((full[k] - sd[k]).abs().max()) for k in sd)

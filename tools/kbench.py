@@ -42,6 +42,7 @@ def main():
     N = U + I
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     g = torch.Generator(device=dev); g.manual_seed(1)
+    print("graph built", flush=True)
     X = torch.randn(N, 64, device=dev, generator=g) * 0.1
     W = torch.randn(2, 64, 64, device=dev, generator=g) * 0.2
     avec = torch.randn(2, 64, device=dev, generator=g) * 0.2
