@@ -104,21 +104,22 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  * Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  ST[n,h] = { S_src[n,h], (g . agg)_h / R }
  * Step 2 (per edge, pull):  dH[n] = g[n] + sum_src m e Gn[src] + dS[n,h] * avec[type(n)]
  *                           dS[n,h] = sum_src -e * lrelu'(s) * (m (Gn[n].H[src] + Gn[src].H[n])_h - t[n] - t[src])
- *   gout [N,d] float   out [N,d] dtype (forward output)   agg, R: as saved by the forward
+ *   gout [N,d] dtype (the gradient arrives in the storage type of `out`)   out [N,d] dtype (forward output)
+ *   agg, R: as saved by the forward
  *   G float[N][d], Gn [N][d] dtype, ST float[N][heads][2]: workspace    dH float[N][d], dS float[N][heads]: results
  *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows */
 int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                    const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
-                   const void* out, const float* agg, const float* R, const float* gout,
+                   const void* out, const float* agg, const float* R, const void* gout,
                    float* G, void* Gn, float* ST, float* dH, float* dS,
                    float* part_acc, float* part_r,
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
 
 /* Backward of ngacf_transform_fwd (autograd of SPUIGACF.py:356-357 and the a.mm of :361).
- *   dX   float[N][din]          = mask * (dH @ W[type]^T)
+ *   dX   [N][din] x_dtype       = mask * (dH @ W[type]^T)   (stored in X's type: it is the gradient of X)
  *   dW   float[2][din][dout]    = (mask * X)[type rows]^T @ dH[type rows]
  *   davec float[2][dout]        = sum_n dS[n,head(c)] * H[n,c]
  *   work  float[NGACF_TBWD_BLOCKS][din*dout + dout]: per-workgroup partial sums, reduced in
@@ -126,7 +127,7 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  * dH already contains the dS*avec term (ngacf_prop_bwd adds it). */
 int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
                         const float* dH, const float* dS,
-                        float* dX, float* dW, float* davec, float* work,
+                        void* dX, float* dW, float* davec, float* work,
                         int U, int I, int din, int dout, int heads,
                         float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
@@ -134,14 +135,14 @@ int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* 
  * sums over the window rows only (all-reduce them across ranks). */
 int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
                              const float* dH, const float* dS,
-                             float* dX, float* dW, float* davec, float* work,
+                             void* dX, float* dW, float* davec, float* work,
                              int U, int I, int din, int dout, int heads,
                              int u_lo, int u_n, int i_lo, int i_n, int x_local,
                              float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* Step 1 of ngacf_prop_bwd alone, over row windows; gout holds only the window rows when gout_local != 0.
  * Lets a node-partitioned run all-gather Gn/ST between the two steps (then ngacf_prop_bwd with NGACF_SKIP_NODE). */
-int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg, const float* R, const float* gout,
+int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg, const float* R, const void* gout,
                         const float* S_src, float* G, void* Gn, float* ST,
                         int U, int N, int d, int heads, int flags,
                         int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream);

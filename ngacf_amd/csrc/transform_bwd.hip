@@ -15,7 +15,7 @@ struct TransBwdArgs {
     const void* H;
     const float* dH;
     const float* dS;
-    float* dX;
+    void* dX;                      // [rows][din] of X's type
     float* work;
     int U, I;
     int u_lo, u_n, i_lo, i_n;      // row windows (see transform.hip)
@@ -29,7 +29,7 @@ struct TransBwdArgs {
 };
 
 // dX = mask * (dH @ W[type]^T): the forward tile kernel with the panel transposed on its way into LDS.
-template <int DIN, int DOUT, bool DROP>
+template <typename TX, int DIN, int DOUT, bool DROP>
 __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArgs a) {
     constexpr int GS = DOUT + 4;                   // LDS row stride of the dH tile
     constexpr int WS = DIN + 4;                    // LDS row stride of W^T  [DOUT][DIN]
@@ -103,7 +103,12 @@ __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArg
                 o[j] = acc[i][4 * g + j];
                 if (DROP) o[j] = feat_bits(salt, row, 64 * g + 4 * tx + j) >= a.drop_thr ? o[j] * a.drop_scale : 0.f;
             }
-            *reinterpret_cast<float4*>(a.dX + (size_t)(row - xoff) * DIN + 64 * g + 4 * tx) = make_float4(o[0], o[1], o[2], o[3]);
+            if constexpr (sizeof(TX) == 4) {
+                *reinterpret_cast<float4*>(static_cast<float*>(a.dX) + (size_t)(row - xoff) * DIN + 64 * g + 4 * tx) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                const uint32_t lo = f32_to_bf16(o[0]) | (f32_to_bf16(o[1]) << 16), hi = f32_to_bf16(o[2]) | (f32_to_bf16(o[3]) << 16);
+                *reinterpret_cast<uint2*>(static_cast<uint16_t*>(a.dX) + (size_t)(row - xoff) * DIN + 64 * g + 4 * tx) = make_uint2(lo, hi);
+            }
         }
     }
 }
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void transform_bwd_reduce_kernel(const float* 
     else davec[(size_t)type * (wsz - dwsz) + (k - dwsz)] = s;
 }
 
-int transform_dx_mfma(const float* dH, const float* W, float* dX, int U, int I, int din, int dout, int heads,
+int transform_dx_mfma(const float* dH, const float* W, void* dX, int dx_dtype, int U, int I, int din, int dout, int heads,
                       int u_lo, int u_n, int i_lo, int i_n, int x_local,
                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st);   // transform_mfma.hip
 
@@ -253,17 +258,17 @@ static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool dr
     const int tu = (a.u_n + TM - 1) / TM, ti = (a.i_n + TM - 1) / TM;
     if (tu + ti == 0) return 0;
     if constexpr (sizeof(TH) == 2) {   // bf16 storage: dX on the matrix cores
-        const int rc = transform_dx_mfma(a.dH, a.W, a.dX, a.U, a.I, DIN, DOUT, HEADS, a.u_lo, a.u_n, a.i_lo, a.i_n, a.x_local,
+        const int rc = transform_dx_mfma(a.dH, a.W, a.dX, sizeof(TX) == 2 ? NGACF_BF16 : NGACF_F32, a.U, a.I, DIN, DOUT, HEADS, a.u_lo, a.u_n, a.i_lo, a.i_n, a.x_local,
                                          a.drop_p, a.seed, a.seed_dev, st);
         if (rc != 0) return rc;
     } else {   // dX
         constexpr size_t lds = (size_t)(TM * (DOUT + 4) + DOUT * (DIN + 4)) * sizeof(float);
         if (drop) {
-            auto k = transform_bwd_dx_kernel<DIN, DOUT, true>;
+            auto k = transform_bwd_dx_kernel<TX, DIN, DOUT, true>;
             if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k, dim3(tu + ti), dim3(256), lds, st, a);
         } else {
-            auto k = transform_bwd_dx_kernel<DIN, DOUT, false>;
+            auto k = transform_bwd_dx_kernel<TX, DIN, DOUT, false>;
             if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k, dim3(tu + ti), dim3(256), lds, st, a);
         }
@@ -317,7 +322,7 @@ using namespace ngacf;
 
 extern "C" int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
                                         const float* dH, const float* dS,
-                                        float* dX, float* dW, float* davec, float* work,
+                                        void* dX, float* dW, float* davec, float* work,
                                         int U, int I, int din, int dout, int heads,
                                         int u_lo, int u_n, int i_lo, int i_n, int x_local,
                                         float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
@@ -345,7 +350,7 @@ extern "C" int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float*
 
 extern "C" int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
                                    const float* dH, const float* dS,
-                                   float* dX, float* dW, float* davec, float* work,
+                                   void* dX, float* dW, float* davec, float* work,
                                    int U, int I, int din, int dout, int heads,
                                    float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     return ngacf_transform_bwd_rows(X, x_dtype, W, H, h_dtype, dH, dS, dX, dW, davec, work, U, I, din, dout, heads,

@@ -104,7 +104,7 @@ class _ShardedStage(torch.autograd.Function):
         X, W, avec, H, S, out, agg, R = ctx.saved_tensors
         part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed = ctx.cfg
         dev, N, d = H.device, part.N, H.shape[1]
-        g_local = g_local.contiguous().float()
+        g_local = g_local.contiguous().to(H.dtype)
         G = torch.empty(N, d, dtype=torch.float32, device=dev)
         Gn = torch.empty(N, d, dtype=H.dtype, device=dev)
         ST = torch.empty(N, heads, 2, dtype=torch.float32, device=dev)

@@ -32,10 +32,10 @@ class _Stage(torch.autograd.Function):
     def backward(ctx, gout):
         X, W, avec, H, S, out, agg, R = ctx.saved_tensors
         plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev = ctx.cfg
-        gout = gout.contiguous().float()
+        gout = gout.contiguous().to(H.dtype)              # already H's type under autograd: no cast kernel
         dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, alpha, elu, True, None, drop_p, seed, seed_dev)
         dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
-        return dX.to(X.dtype), dW, da, None, None, None, None, None, None, None, None, None
+        return dX, dW, da, None, None, None, None, None, None, None, None, None
 
 
 def stage(X, W, avec, plan, heads, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=0.0, seed=0, h_dtype=None, seed_dev=None):

@@ -150,7 +150,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     op = _chk(out, "out", H.dtype, N * d, dev)
     gp = _chk(agg, "agg", torch.float32, N * d, dev)
     rp = _chk(R, "R", torch.float32, N * heads, dev)
-    go = _chk(gout, "gout", torch.float32, N * d, dev)
+    go = _chk(gout, "gout", H.dtype, N * d, dev)
     pp = _plan_ptrs(plan, dev)
     f32 = dict(dtype=torch.float32, device=dev)
     G, dH = torch.empty(N, d, **f32), torch.empty(N, d, **f32)
@@ -180,7 +180,7 @@ def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0, seed_de
     gp = _chk(dH, "dH", torch.float32, N * dout, dev)
     sp = _chk(dS, "dS", torch.float32, N * heads, dev)
     f32 = dict(dtype=torch.float32, device=dev)
-    dX = torch.empty(N, din, **f32)
+    dX = torch.empty(N, din, dtype=X.dtype, device=dev)
     dW = torch.empty(2, din, dout, **f32)
     da = torch.empty(2, dout, **f32)
     work = torch.empty(_lib.TBWD_BLOCKS, din * dout + dout, **f32)
@@ -295,7 +295,7 @@ def transform_bwd_rows(X, W, H, dH, dS, U, I, heads, win, x_local, feat_drop_p=0
     gp = _chk(dH, "dH", torch.float32, N * dout, dev)
     sp = _chk(dS, "dS", torch.float32, N * heads, dev)
     f32 = dict(dtype=torch.float32, device=dev)
-    dX = torch.empty(nx, din, **f32)
+    dX = torch.empty(nx, din, dtype=X.dtype, device=dev)
     dW = torch.empty(2, din, dout, **f32)
     da = torch.empty(2, dout, **f32)
     work = torch.empty(_lib.TBWD_BLOCKS, din * dout + dout, **f32)
@@ -314,7 +314,7 @@ def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local
     op = _chk(out, "out", None, N * d, dev)
     ap = _chk(agg, "agg", torch.float32, N * d, dev)
     rp = _chk(R, "R", torch.float32, N * heads, dev)
-    go = _chk(gout, "gout", torch.float32, ((u_n + i_n) if gout_local else N) * d, dev)
+    go = _chk(gout, "gout", out.dtype, ((u_n + i_n) if gout_local else N) * d, dev)
     ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
     gp = _chk(G, "G", torch.float32, N * d, dev)
     gn = _chk(Gn, "Gn", out.dtype, N * d, dev)

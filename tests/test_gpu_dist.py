@@ -32,7 +32,7 @@ def test_partitioned_stage_equals_single_gpu(P, dt):
     X[Up:Up + I] = torch.randn(I, 64, device=dev, generator=g)
     W = torch.randn(2, 64, 64, device=dev, generator=g) * 0.2
     avec = torch.randn(2, 64, device=dev, generator=g) * 0.2
-    gout = torch.randn(N, 64, device=dev, generator=g)
+    gout = torch.randn(N, 64, device=dev, generator=g).to(dt)
     # single-GPU reference on the padded graph
     full = build_plan(edge, Up, Ip, require_user_edges=False, seg_len=32, short_max=8)
     Xt = X.to(dt) if dt != torch.float32 else X
@@ -57,17 +57,17 @@ def test_partitioned_stage_equals_single_gpu(P, dt):
     for p in parts:
         ops.prop_bwd_node(out0, agg0, R0, p.local_rows(gout).contiguous(), S, G, Gn, ST, Up, heads, p.win, True)
     dH = torch.zeros_like(dH0); dS = torch.zeros_like(dS0)
-    dX = torch.zeros_like(dX0); dW = torch.zeros_like(dW0); da = torch.zeros_like(da0)
+    dX = torch.zeros_like(dX0).float(); dW = torch.zeros_like(dW0); da = torch.zeros_like(da0)
     for p, pl in zip(parts, plans):
         h_, s_ = ops.prop_bwd_edges(pl, H, S, avec, G, Gn, ST, heads, drop_p=0.1, seed=5)
         dH += h_; dS += s_
         x_, w_, a_ = ops.transform_bwd_rows(p.local_rows(Xt).contiguous(), W, H, h_, s_, Up, Ip, heads, p.win, True, 0.1, 5)
         dW += w_; da += a_
-        dX[p.u_lo:p.u_lo + p.cu] = x_[:p.cu]
-        dX[Up + p.i_lo:Up + p.i_lo + p.ci] = x_[p.cu:]
+        dX[p.u_lo:p.u_lo + p.cu] = x_[:p.cu].float()
+        dX[Up + p.i_lo:Up + p.i_lo + p.ci] = x_[p.cu:].float()
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
     assert rel(dH, dH0) < 1e-5 and rel(dS, dS0) < 1e-4
-    assert rel(dX, dX0) < 1e-5 and rel(dW, dW0) < 1e-4 and rel(da, da0) < 1e-4
+    assert rel(dX, dX0.float()) < 1e-5 and rel(dW, dW0) < 1e-4 and rel(da, da0) < 1e-4
 
 
 def test_sharded_model_world1_equals_plain_model():

@@ -160,7 +160,7 @@ def test_split_rows_match_unsplit(dev):
     W, avec = (_t(x, dev) for x in _fused(p, names))
     X = _t(np.random.RandomState(2).randn(U + I, 64).astype(np.float32), dev)
     H, S = ops.transform_fwd(X, W, avec, U, I, 8)
-    g = torch.randn(U + I, 64, device=dev)
+    g = torch.randn(U + I, 64, device=dev)                 # fp32 H here, so an fp32 gradient
     ref = None
     # (seg_len, short_max): all rows as whole-wave segments / cut into slices / every mix of the
     # slot-per-row mode with the long mode / all rows in the slot-per-row mode

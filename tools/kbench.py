@@ -65,7 +65,7 @@ def main():
                             print("  prop_fwd  %s heads=%d from_row=%d drop=%.1f: med %.1f us min %.1f" % (tag, heads, fr, p, med, mn))
                 if "bwd" in what:
                     out, agg, R = ops.prop_fwd(plan, H, S, S, avec, heads, save=True)
-                    go = torch.randn(N, 64, device=dev, generator=g)
+                    go = torch.randn(N, 64, device=dev, generator=g).to(dt)
                     for fr in (True, False):
                         for p in (0.0, 0.1):
                             med, mn = timeit(lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, go, heads, score_from_row=fr, drop_p=p, seed=3))
