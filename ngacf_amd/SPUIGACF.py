@@ -384,6 +384,57 @@ class SPUIMultiGACF(_CFBase):
         self._init_weight_()
 
 
+class GPLayer(nn.Module):
+    """SPUIGACF.py:174-185: features -> (laplacianMat + selfLoop) @ features (static-weight propagation)."""
+
+    def forward(self, features, propagation, selfLoop=True):
+        return propagation(features, self_loop=bool(selfLoop))
+
+
+class SPUIGAGPCF(_CFBase):
+    """SPUIGACF.py:103-172: SpUIGAT, then len(layers) x [(L + I) @ X -> Linear -> ReLU], all stage outputs
+    concatenated and scored by a dot product.  `adj` is the Laplacian as a torch sparse COO tensor (what
+    data/loadGowalla.py:get_adj_mat returns for adj_type 'mean_adj' / 'norm_adj') or a (rows, cols, vals) triple."""
+
+    def __init__(self, userNum, itemNum, adj, embedSize, layers, droprate, useCuda=True):
+        super().__init__()
+        self.useCuda, self.userNum, self.itemNum, self.droprate = useCuda, userNum, itemNum, droprate
+        self.uEmbd = nn.Embedding(userNum, embedSize)
+        self.iEmbd = nn.Embedding(itemNum, embedSize)
+        self.gat = SpUIGAT(nfeat=embedSize, nhid=8, nclass=embedSize, dropout=droprate, nheads=8, alpha=0.2)
+        self.GPlayers = nn.ModuleList()
+        self.Affinelayers = nn.ModuleList()
+        dims = [embedSize] + list(layers)                                # :127 (without mutating the caller's list)
+        for From, To in zip(dims[:-1], dims[1:]):
+            self.GPlayers.append(GPLayer())
+            self.Affinelayers.append(nn.Linear(From, To))
+        self._adj, self._prop = adj, None
+        self._init_weight_()
+
+    def _propagation(self, dev):
+        if self._prop is None:
+            from .spmm import StaticPropagation
+            if isinstance(self._adj, (tuple, list)):
+                r, c, v = self._adj
+            else:
+                a = self._adj.coalesce()
+                r, c, v = a.indices()[0], a.indices()[1], a.values()
+            self._prop = StaticPropagation(r.to(dev), c.to(dev), v.to(dev).float(), self.userNum + self.itemNum)
+        return self._prop
+
+    def forward(self, userIdx, itemIdx, mask):
+        features = self.propagate(mask).float()
+        prop = self._propagation(features.device)
+        final = [features]
+        for gp, aff in zip(self.GPlayers, self.Affinelayers):
+            if features.shape[1] not in (64, 128):
+                raise ValueError("GPLayer widths must be 64 or 128 on the accelerated path")
+            features = torch.relu(aff(gp(features, prop, True)))          # :164-165
+            final.append(features)
+        final = torch.cat(final, dim=1)                                   # :167
+        return torch.sum(final[userIdx] * final[itemIdx + self.userNum], dim=1)
+
+
 class SPUIStackedGACF(_CFBase):
     """Depth-generalised model for the BASELINE "L=4" config (stages = n_hidden + 1)."""
 

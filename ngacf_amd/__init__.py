@@ -7,5 +7,5 @@ from . import _lib                                             # noqa: F401  (lo
 from ._lib import version                                      # noqa: F401
 from .BPRLoss import BPRLoss                                   # noqa: F401
 from .plan import GraphPlan, build_plan                        # noqa: F401
-from .SPUIGACF import (SPUIGACF, SPUIMultiGACF, SPUIStackedGACF, SpUIGAT, SPUIMultiGAT,   # noqa: F401
+from .SPUIGACF import (SPUIGACF, SPUIGAGPCF, SPUIMultiGACF, SPUIStackedGACF, GPLayer, SpUIGAT, SPUIMultiGAT,   # noqa: F401
                        SpUIGraphAttentionLayer, set_compute_dtype)

@@ -29,3 +29,40 @@ def validate_square(p):
         s = p.segs.long()
         assert int(s[:, 0].max()) < p.N and int(s[:, 2].max()) <= p.col.numel() and bool((s[:, 1] <= s[:, 2]).all())
         assert int(s[:, 3].max()) < max(p.nparts, 1)
+
+
+class _SpMM(torch.autograd.Function):
+    """out = (L + I) @ X through ngacf_spmm_fwd; the backward is the same product with the transposed matrix."""
+
+    @staticmethod
+    def forward(ctx, X, plan, val, plan_t, val_t, self_loop):
+        from . import ops
+        ctx.cfg = (plan_t, val_t, self_loop)
+        return ops.spmm_fwd(plan, val, X.contiguous(), self_loop)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        plan_t, val_t, self_loop = ctx.cfg
+        return ops.spmm_fwd(plan_t, val_t, g.contiguous(), self_loop), None, None, None, None, None
+
+
+class StaticPropagation:
+    """GPLayer.forward (SPUIGACF.py:178-185): features -> (L + I) @ features for a fixed sparse L given as COO."""
+
+    def __init__(self, rows, cols, vals, N, seg_len=256):
+        self.plan, self.val = build_square_plan(rows, cols, vals, N, seg_len)
+        self.plan_t, self.val_t = build_square_plan(cols, rows, vals, N, seg_len)
+
+    def __call__(self, X, self_loop=True):
+        return _SpMM.apply(X, self.plan, self.val, self.plan_t, self.val_t, self_loop)
+
+
+def mean_adj_coo(indices, U, I):
+    """`mean_adj` of data/loadGowalla.py:186-227: D^-1/2 A D^-1/2 over the (U+I)x(U+I) bipartite block matrix,
+    as COO (rows, cols, vals) on the device of `indices` ([2,E], items not offset)."""
+    u, i = indices[0].long(), indices[1].long() + U
+    r, c = torch.cat([u, i]), torch.cat([i, u])
+    deg = torch.bincount(r, minlength=U + I).float()
+    dis = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
+    return r, c, dis[r] * dis[c]

@@ -416,3 +416,35 @@ def test_gowalla_scale_properties(dev):
     o1 = ops.prop_fwd(plan, H, S, S, avec, 1, elu=False, score_from_row=False)
     o2 = ops.prop_fwd(plan, 2 * H, S, S, avec, 1, elu=False, score_from_row=False)
     assert float((o2 - 2 * o1).abs().max()) < 1e-4
+
+
+def test_spuigagpcf_static_propagation_forward_backward(dev):
+    """SPUIGAGPCF (SPUIGACF.py:103-172): GAT + GPLayer (L + I) @ X stack, against the same math in torch."""
+    import ngacf_amd
+    from ngacf_amd.spmm import mean_adj_coo
+    U, I = 120, 90
+    edge = _t(_random_graph(U, I, 1500, 4), dev)
+    r, c, v = mean_adj_coo(edge, U, I)
+    torch.manual_seed(0)
+    m = ngacf_amd.SPUIGAGPCF(U, I, (r, c, v), 64, [64, 64], 0.0).to(dev).train()
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30); m.iEmbd.weight.mul_(30)
+    u = torch.randint(0, U, (64,), device=dev); it = torch.randint(0, I, (64,), device=dev)
+    sc = m(u, it, edge)
+    sc.sum().backward()
+    # torch restatement of the tail on the same propagated features
+    F0 = m.propagate(edge).detach().requires_grad_(True)
+    L = torch.sparse_coo_tensor(torch.stack([r, c]), v, (U + I, U + I)).coalesce()
+    eye = torch.sparse_coo_tensor(torch.arange(U + I, device=dev).repeat(2, 1), torch.ones(U + I, device=dev), (U + I, U + I))
+    x, outs = F0, [F0]
+    for aff in m.Affinelayers:
+        x = torch.relu(aff(torch.sparse.mm((L + eye).coalesce(), x)))
+        outs.append(x)
+    fin = torch.cat(outs, 1)
+    ref = (fin[u] * fin[it + U]).sum(1)
+    assert float((sc - ref).abs().max() / ref.abs().max()) < 1e-5
+    g_ref = torch.autograd.grad(ref.sum(), m.Affinelayers[0].weight, retain_graph=True)[0]
+    assert float((m.Affinelayers[0].weight.grad - g_ref).abs().max() / g_ref.abs().max()) < 1e-4
+    assert m.uEmbd.weight.grad.abs().sum() > 0
+    assert set(k for k in m.state_dict() if not k.startswith("gat.")) == \
+        {"uEmbd.weight", "iEmbd.weight", "Affinelayers.0.weight", "Affinelayers.0.bias", "Affinelayers.1.weight", "Affinelayers.1.bias"}
