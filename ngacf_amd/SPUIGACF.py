@@ -340,10 +340,51 @@ class StackedSpUIGAT(_GATBase):
         return self._run(uidx, iidx, features, adj)
 
 
+class _Table(torch.autograd.Function):
+    """features = cat([uEmbd.weight, iEmbd.weight]) (SPUIGACF.py:36-38) without the copy: both embedding
+    parameters alias one [N,d] table (see _CFBase._link_tables), which is returned as is; the backward hands
+    each parameter its slice of the gradient."""
+
+    @staticmethod
+    def forward(ctx, wu, wi, flat):
+        ctx.U = wu.shape[0]
+        return flat.view(flat.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.U], g[ctx.U:], None
+
+
 class _CFBase(nn.Module):
     def _init_weight_(self):
         nn.init.normal_(self.uEmbd.weight, std=0.01)                 # SPUIGACF.py:26-28
         nn.init.normal_(self.iEmbd.weight, std=0.01)
+        self._link_tables()
+
+    def _link_tables(self):
+        """Make uEmbd.weight and iEmbd.weight views of one contiguous [U+I, d] table (same Parameter objects,
+        same values; state_dict, optimizers and in-place updates are unaffected)."""
+        wu, wi = self.uEmbd.weight, self.iEmbd.weight
+        U = wu.shape[0]
+        flat = torch.empty(U + wi.shape[0], wu.shape[1], device=wu.device, dtype=wu.dtype)
+        flat[:U] = wu.data
+        flat[U:] = wi.data
+        wu.data, wi.data = flat[:U], flat[U:]
+        object.__setattr__(self, "_flat", flat)
+
+    def _apply(self, fn, recurse=True):
+        r = super()._apply(fn, recurse)                               # .to()/.cuda()/.float() move the halves apart
+        if "uEmbd" in self._modules and "iEmbd" in self._modules:
+            self._link_tables()
+        return r
+
+    def _features(self):
+        wu, wi, flat = self.uEmbd.weight, self.iEmbd.weight, self.__dict__.get("_flat")
+        if flat is None or flat.device != wu.device or wu.data_ptr() != flat.data_ptr() \
+                or wi.data_ptr() != flat.data_ptr() + wu.numel() * wu.element_size():
+            self._link_tables()                                       # somebody re-assigned .data: alias again
+            flat = self._flat
+        return _Table.apply(wu, wi, flat)
 
     def getFeatureMat(self):
         """SPUIGACF.py:30-39 without the per-call Python index lists."""
@@ -352,8 +393,7 @@ class _CFBase(nn.Module):
         if idx is None or idx[0].device != dev:                       # built once, not per call
             idx = (torch.arange(self.userNum, device=dev), torch.arange(self.itemNum, device=dev) + self.userNum)
             self._idx = idx
-        features = torch.cat([self.uEmbd.weight, self.iEmbd.weight], dim=0)
-        return idx[0], idx[1], features
+        return idx[0], idx[1], self._features()
 
     def propagate(self, mask):
         uidx, iidx, features = self.getFeatureMat()
