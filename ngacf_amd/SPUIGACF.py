@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as NF
-from .plan import build_plan
+from .plan import build_plan, squeeze_mask
 
 _PLAN_CACHE_MAX = 4
 _SEED_STRIDE = 0x1E3779B97F4A7C15
@@ -134,7 +134,7 @@ class SpUIGraphAttentionLayer(nn.Module):
 
     def forward(self, uidx, iidx, features, indices):
         U, I = int(uidx.numel()), int(iidx.numel())
-        plan = self._plans.get(indices.squeeze(), U, I, self.seg_len)
+        plan = self._plans.get(squeeze_mask(indices), U, I, self.seg_len)
         p = self.droprate if self.training else 0.0
         k = self.out_dim
         if k in (64, 128):
@@ -243,7 +243,7 @@ class _GATBase(nn.Module):
 
     def _run(self, uidx, iidx, features, adj):
         U, I = int(uidx.numel()), int(iidx.numel())
-        plan = self._plans.get(adj.squeeze(), U, I, self.seg_len)
+        plan = self._plans.get(squeeze_mask(adj), U, I, self.seg_len)
         p = self.dropout if self.training else 0.0
         seed_dev = None
         if p > 0 and getattr(self, "_seed_ctr", None) is not None:
@@ -397,7 +397,7 @@ class _CFBase(nn.Module):
 
     def propagate(self, mask):
         uidx, iidx, features = self.getFeatureMat()
-        return self.gat(uidx, iidx, features, mask.squeeze())        # :42-46
+        return self.gat(uidx, iidx, features, squeeze_mask(mask))        # :42-46
 
     def forward(self, userIdx, itemIdx, mask):
         features = self.propagate(mask)

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from . import functional as NF
 from . import ops as _hip_ops
-from .plan import build_plan
+from .plan import build_plan, squeeze_mask
 from .SPUIGACF import SpUIGAT, SPUIMultiGAT, StackedSpUIGAT, _fresh_seed
 
 
@@ -196,7 +196,7 @@ class ShardedSPUIGACF(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------------------
     def _plan(self, mask):
-        mask = mask.squeeze()
+        mask = squeeze_mask(mask)
         key = (mask.data_ptr(), tuple(mask.shape), mask._version, self.seg_len)
         if key not in self._plans:
             p = self.part

@@ -78,11 +78,17 @@ def _segments(rowptr, rows, seg_len):
     return segs, split, int(cut.sum())
 
 
+def squeeze_mask(mask):
+    """The reference's `mask.squeeze()` (SPUIGACF.py:42) for the [1,2,E] DataParallel form -- without collapsing a
+    one-edge graph's [2,1] into [2]."""
+    return mask[0] if mask.dim() == 3 and mask.shape[0] == 1 else mask
+
+
 def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None, short_max=64):
     """indices: [2,E] (or [1,2,E], run under DataParallel: SPUIGACF.py:42 squeezes it) integer
     tensor.  Duplicate pairs are merged like `.coalesce()`.  `row_range=(lo,hi)` -- or a list of such
     ranges -- keeps only those dst rows (node partition of ngacf_amd/dist.py); sources stay global."""
-    indices = indices.squeeze()
+    indices = squeeze_mask(indices)
     if indices.dim() != 2 or indices.shape[0] != 2:
         raise ValueError("indices must be [2,E], got %s" % (tuple(indices.shape),))
     dev = torch.device(device) if device is not None else indices.device

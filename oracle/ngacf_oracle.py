@@ -121,8 +121,11 @@ def layer_backward(g_out, fwd, X, W_u, W_i, a, edge, U, I, alpha=0.2, concat=Tru
 # --------------------------------------------------------------------------
 # SpUIGAT / SPUIMultiGAT stacks  (SPUIGACF.py:207-215, :246-256)
 # --------------------------------------------------------------------------
-def stage_names(multi=False, nheads=8):
-    """Per propagation stage: list of state_dict prefixes of its layers."""
+def stage_names(multi=False, nheads=8, hidden=None):
+    """Per propagation stage: list of state_dict prefixes of its layers.  `hidden` = number of 8-head stages of
+    the depth-generalised stack (ngacf_amd.StackedSpUIGAT, same naming as SPUIMultiGAT: attention{s}_{h})."""
+    if hidden is not None:
+        return [["gat.attention%d_%d" % (s + 1, h) for h in range(nheads)] for s in range(hidden)] + [["gat.out_att"]]
     if multi:
         return [["gat.attention1_%d" % h for h in range(nheads)],
                 ["gat.attention2_%d" % h for h in range(nheads)],
@@ -131,12 +134,12 @@ def stage_names(multi=False, nheads=8):
 
 
 def spuigat_forward(params, X, edge, U, I, multi=False, alpha=0.2, nheads=8,
-                    feat_masks=None, edge_masks=None, keep=False):
+                    feat_masks=None, edge_masks=None, keep=False, hidden=None):
     """Eval-mode stack when the mask arguments are None.  feat_masks[stage] is the
     multiplier of the F.dropout in front of that stage (SPUIGACF.py:208,213);
     edge_masks[stage][head] the per-layer edge dropout multiplier (:375).
     The last stage is the concat=False layer followed by F.elu (:214)."""
-    stages = stage_names(multi, nheads)
+    stages = stage_names(multi, nheads, hidden)
     x = X
     tape = []
     for si, names in enumerate(stages):
@@ -159,9 +162,9 @@ def spuigat_forward(params, X, edge, U, I, multi=False, alpha=0.2, nheads=8,
 
 
 def spuigat_backward(g, tape, params, edge, U, I, multi=False, alpha=0.2, nheads=8,
-                     feat_masks=None, edge_masks=None):
+                     feat_masks=None, edge_masks=None, hidden=None):
     """Gradient of spuigat_forward w.r.t. X and all layer parameters."""
-    stages = stage_names(multi, nheads)
+    stages = stage_names(multi, nheads, hidden)
     grads = {}
     for si in reversed(range(len(stages))):
         names = stages[si]
@@ -204,13 +207,13 @@ def bpr_loss(pos, neg):
     return -np.mean(np.log(1.0 / (1.0 + np.exp(-x))))                              # BPRLoss.py:9
 
 
-def bpr_step_grads(params, userIdx, posIdx, negIdx, edge, multi=False, alpha=0.2, nheads=8):
+def bpr_step_grads(params, userIdx, posIdx, negIdx, edge, multi=False, alpha=0.2, nheads=8, hidden=None):
     """loss and d(loss)/d(every parameter) for one reference train step without
     dropout: two propagations (train_eval_Gowalla.py:131-134) that are identical
     when droprate == 0, so their gradients add on one tape."""
     U, I = params["uEmbd.weight"].shape[0], params["iEmbd.weight"].shape[0]
     X = features_of(params)
-    F, tape = spuigat_forward(params, X, edge, U, I, multi=multi, alpha=alpha, nheads=nheads, keep=True)
+    F, tape = spuigat_forward(params, X, edge, U, I, multi=multi, alpha=alpha, nheads=nheads, keep=True, hidden=hidden)
     fu, fp, fn = F[userIdx], F[posIdx + U], F[negIdx + U]
     pos, neg = np.sum(fu * fp, 1), np.sum(fu * fn, 1)
     loss = bpr_loss(pos, neg)
@@ -220,7 +223,7 @@ def bpr_step_grads(params, userIdx, posIdx, negIdx, edge, multi=False, alpha=0.2
     np.add.at(gF, userIdx, gx[:, None] * (fp - fn))
     np.add.at(gF, posIdx + U, gx[:, None] * fu)
     np.add.at(gF, negIdx + U, -gx[:, None] * fu)
-    dX, grads = spuigat_backward(gF, tape, params, edge, U, I, multi=multi, alpha=alpha, nheads=nheads)
+    dX, grads = spuigat_backward(gF, tape, params, edge, U, I, multi=multi, alpha=alpha, nheads=nheads, hidden=hidden)
     grads["uEmbd.weight"], grads["iEmbd.weight"] = dX[:U], dX[U:]
     return loss, pos, neg, grads
 

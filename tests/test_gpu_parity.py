@@ -448,3 +448,57 @@ def test_spuigagpcf_static_propagation_forward_backward(dev):
     assert m.uEmbd.weight.grad.abs().sum() > 0
     assert set(k for k in m.state_dict() if not k.startswith("gat.")) == \
         {"uEmbd.weight", "iEmbd.weight", "Affinelayers.0.weight", "Affinelayers.0.bias", "Affinelayers.1.weight", "Affinelayers.1.bias"}
+
+
+@pytest.mark.parametrize("U,I,pairs", [(1, 1, [(0, 0)]), (3, 2, [(0, 0), (1, 0), (2, 1)]), (5, 9, [(u, (3 * u) % 9) for u in range(5)] + [(0, 8), (4, 8)])])
+def test_tiny_graphs_vs_oracle(dev, U, I, pairs):
+    """Graphs smaller than one wave / one tile; items without any user; every user of degree 1."""
+    import ngacf_amd
+    from ngacf_amd.SPUIGACF import reference_named_grads
+    edge = np.array(sorted(set(pairs)), dtype=np.int64).T
+    torch.manual_seed(U * 7 + I)
+    m = ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.0).to(dev).train()
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(40); m.iEmbd.weight.mul_(40)
+    p64 = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    u = np.arange(U) % U; pos = np.arange(U) % I; neg = (np.arange(U) + 1) % I
+    loss_o, pos_o, neg_o, grads_o = O.bpr_step_grads(p64, u, pos, neg, edge)
+    e = _t(edge, dev)
+    ps, ns = m(_t(u, dev), _t(pos, dev), e), m(_t(u, dev), _t(neg, dev), e)
+    loss = ngacf_amd.BPRLoss()(ps, ns)
+    loss.backward()
+    smax = max(float(np.abs(pos_o).max()), float(np.abs(neg_o).max()), 1.0)      # scores are O(100) here
+    assert _maxabs(ps, pos_o) < 1e-5 * smax and _maxabs(ns, neg_o) < 1e-5 * smax
+    assert abs(float(loss.detach()) - loss_o) < 1e-5 * max(abs(loss_o), 1.0)
+    for k, gr in reference_named_grads(m).items():
+        assert _maxabs(gr, grads_o[k]) <= 1e-3 * max(float(np.abs(grads_o[k]).max()), 1e-9) + 1e-7, k
+
+
+def test_d128_four_stage_stack_vs_oracle(dev):
+    """BASELINE config 4 shape: embedSize 128, three 8-head stages + the 128-wide out layer (rows of 256/512 B)."""
+    import ngacf_amd
+    from ngacf_amd.SPUIGACF import reference_named_grads
+    U, I = 260, 190
+    edge = _random_graph(U, I, 5000, 31, hub=200)
+    torch.manual_seed(3)
+    m = ngacf_amd.SPUIStackedGACF(U, I, 128, [64, 64], 0.0, stages=4).to(dev).train()
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30); m.iEmbd.weight.mul_(30)
+    assert m.gat.stage_shapes() == [(128, 64, 8), (64, 64, 8), (64, 64, 8), (64, 128, 1)]
+    p64 = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    rs = np.random.RandomState(0)
+    B = 128
+    u, pos, neg = rs.randint(0, U, B), rs.randint(0, I, B), rs.randint(0, I, B)
+    loss_o, pos_o, neg_o, grads_o = O.bpr_step_grads(p64, u, pos, neg, edge, hidden=3)
+    e = _t(edge, dev)
+    ps, ns = m(_t(u, dev), _t(pos, dev), e), m(_t(u, dev), _t(neg, dev), e)
+    loss = ngacf_amd.BPRLoss()(ps, ns)
+    loss.backward()
+    smax = float(np.abs(pos_o).max())
+    assert _maxabs(ps, pos_o) < 1e-5 * max(smax, 1.0) and abs(float(loss.detach()) - loss_o) < 1e-5
+    for k, gr in reference_named_grads(m).items():
+        assert _maxabs(gr, grads_o[k]) / max(float(np.abs(grads_o[k]).max()), 1e-12) < 1e-3, k
+    # bf16 storage on the same shape runs and stays close
+    ngacf_amd.set_compute_dtype(m, torch.bfloat16)
+    ps16 = m(_t(u, dev), _t(pos, dev), e)
+    assert float((ps16 - ps).abs().max() / ps.abs().max()) < 5e-2
