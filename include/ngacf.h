@@ -89,7 +89,10 @@ int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float* W, const f
  *   avec   float[2][d]     (as in ngacf_transform_fwd; used only with NGACF_SCORE_ROW)
  *   out    [N,d] dtype     agg float[N][d] / R float[N][heads]: normalised aggregate and
  *                          denominators, saved for the backward (both may be NULL)
- *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for long rows
+ *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows
+ *   part_split int32[nparts] (hub row of every slot), tickets int32[nsplit] (all zero on entry, left all zero):
+ *       with both given, the last-arriving slice of a hub row finishes it inside the launch (agent-scope
+ *       release/acquire, no waiting); with NULL a small second kernel does (same sums, same order)
  * drop_p > 0 applies the edge dropout of :375 (numerators only), mask keyed by
  * (seed, head, user, item) so both directions see the same mask. */
 int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
@@ -97,6 +100,7 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
                    void* out, float* agg, float* R, float* part_acc, float* part_r,
+                   const int32_t* part_split, int32_t* tickets,
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
 

@@ -32,6 +32,9 @@ struct PropArgs {
     float* R;
     float* part_acc;
     float* part_r;
+    const int* split;      // {row, first part, parts} of the hub rows
+    const int* part_split; // hub row (index into split) of every partial-sum slot
+    int* tickets;          // arrival counter per hub row (all zero between launches); NULL = finish in a 2nd kernel
     int U, N;
     WorkOrder order;
     float alpha;
@@ -233,15 +236,61 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     rsum = group_sum<LPR, WAVE>(rsum);
-    if (slot != 0) return;
-    if (part >= 0) {            // slice of a hub row: leave partial sums for prop_fwd_split_kernel
-        float* pa = a.part_acc + (size_t)part * D + q * VEC;
-#pragma unroll
-        for (int j = 0; j < VEC; j += 4) *reinterpret_cast<float4*>(pa + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
-        if ((q * VEC) % SH::HW == 0) a.part_r[(size_t)part * HEADS + head] = rsum;
+    if (part < 0) {
+        if (slot == 0) finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
         return;
     }
-    finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+    // slice of a hub row: leave the partial sums in slot `part`
+    if (a.tickets == nullptr) {                            // prop_fwd_split_kernel finishes the row
+        if (slot == 0) {
+            float* pa = a.part_acc + (size_t)part * D + q * VEC;
+#pragma unroll
+            for (int j = 0; j < VEC; j += 4) *reinterpret_cast<float4*>(pa + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+            if ((q * VEC) % SH::HW == 0) a.part_r[(size_t)part * HEADS + head] = rsum;
+        }
+        return;
+    }
+    // The slice that arrives LAST finishes the row in this launch (cdna_hip_programming.md Guideline 16, counter form):
+    // write-through (sc1) stores of the partial sums -> drain -> relaxed agent-scope ticket; the last arriver: agent-scope
+    // acquire -> plain loads.  No release fence (a buffer_wbl2 per slice tripled the kernel time), no wave ever waits on
+    // another one.  Partials are added in slot order, so the result does not depend on which slice came last.
+    if (slot == 0) {
+        unsigned long long* pa = reinterpret_cast<unsigned long long*>(a.part_acc + (size_t)part * D + q * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; j += 2) {
+            const unsigned long long bits = (unsigned long long)__float_as_uint(acc[j]) | ((unsigned long long)__float_as_uint(acc[j + 1]) << 32);
+            __hip_atomic_store(pa + j / 2, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if ((q * VEC) % SH::HW == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned*>(a.part_r + (size_t)part * HEADS + head), __float_as_uint(rsum),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int si = uniform(a.part_split[part]);
+    const int p0 = uniform(a.split[3 * si + 1]), np = uniform(a.split[3 * si + 2]);
+    int tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add(a.tickets + si, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (uniform(tk) != np - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(a.tickets + si, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    rsum = 0.f;
+#pragma unroll 4
+    for (int p = p0 + slot; p < p0 + np; p += EPI) {
+        const float* pa = a.part_acc + (size_t)p * D + q * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; j += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(pa + j);
+            acc[j] += v.x; acc[j + 1] += v.y; acc[j + 2] += v.z; acc[j + 3] += v.w;
+        }
+        rsum += a.part_r[(size_t)p * HEADS + head];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
+    rsum = group_sum<LPR, WAVE>(rsum);
+    if (slot == 0) finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
 }
 
 // Hub rows: add the partial sums of the row's slices (slots take interleaved slices, fixed order) and finish.
@@ -291,7 +340,7 @@ static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, b
         }
         NGACF_CHECK_LAUNCH();
     }
-    if (nsplit > 0) {
+    if (nsplit > 0 && a.tickets == nullptr) {
         hipLaunchKernelGGL((prop_fwd_split_kernel<T, D, HEADS>), dim3((nsplit + 3) / 4), dim3(256), 0, st, a, split, nsplit);
         NGACF_CHECK_LAUNCH();
     }
@@ -307,6 +356,7 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
                               const int32_t* col, const void* H, int dtype,
                               const float* S_dst, const float* S_src, const float* avec,
                               void* out, float* agg, float* R, float* part_acc, float* part_r,
+                              const int32_t* part_split, int32_t* tickets,
                               int U, int N, int d, int heads, float alpha,
                               float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
@@ -324,7 +374,8 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
     PropArgs a;
     a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R;
-    a.part_acc = part_acc; a.part_r = part_r; a.U = U; a.N = N; a.order.nseg_u = nseg_user; a.order.nshort_u = nshort_user; a.alpha = alpha;
+    a.part_acc = part_acc; a.part_r = part_r; a.split = split; a.part_split = part_split;
+    a.tickets = (part_split && nsplit > 0) ? tickets : nullptr; a.U = U; a.N = N; a.order.nseg_u = nseg_user; a.order.nshort_u = nshort_user; a.alpha = alpha;
     a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.seed_dev = seed_dev; a.flags = flags;
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -107,6 +107,20 @@ def _plan_ptrs(plan, dev):
     return (segs, plan.nseg, split, plan.nsplit, srow, plan.nshort, plan.nseg_user, plan.nshort_user, rowptr, col)
 
 
+# Hub rows can be finished by their last-arriving slice inside the launch (sc1 stores + agent-scope ticket/acquire,
+# bitwise equal to the two-kernel path: tests/test_gpu_parity.py).  Measured 31.5 us against 27 + 4.9 us for the
+# two kernels (a release-fence form: 75 us) -- a 2 us gain that does not pay for an inter-workgroup protocol on
+# the default path, so the plain second kernel stays the default.
+INKERNEL_HUB_FINISH = False
+
+
+def _hub(plan, dev):
+    if not INKERNEL_HUB_FINISH or plan.nsplit == 0:
+        return 0, 0
+    return (_chk(plan.part_split, "plan.part_split", torch.int32, plan.nparts, dev),
+            _chk(plan.tickets, "plan.tickets", torch.int32, plan.nsplit, dev))
+
+
 def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
              drop_p=0.0, seed=0, save=False, out=None, seed_dev=None):
     """One propagation stage over plan's dst rows.  Returns out (and agg, R when save=True)."""
@@ -131,7 +145,7 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
     _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, *pp, hp,
                       _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
-                      pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
+                      pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev), plan.U, N, d, heads, float(alpha),
                       float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_fwd")
     return (out, agg, R) if save else out
 

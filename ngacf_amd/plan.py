@@ -34,6 +34,12 @@ class GraphPlan:
         self.nshort, self.short_max = int(self.srow.shape[0]), short_max
         self.nseg_user, self.nshort_user = self.nseg, self.nshort       # build_plan sets the user/item split
         self.rowptr32 = rowptr.to(torch.int32).contiguous()
+        # hub rows: slot -> hub row, and one arrival counter per hub row (zero between launches)
+        if self.nsplit:
+            self.part_split = torch.repeat_interleave(torch.arange(self.nsplit, device=col.device), split[:, 2].long()).to(torch.int32)
+        else:
+            self.part_split = torch.empty(0, dtype=torch.int32, device=col.device)
+        self.tickets = torch.zeros(max(self.nsplit, 1), dtype=torch.int32, device=col.device)[:self.nsplit]
 
     @property
     def degrees(self):
@@ -168,6 +174,9 @@ def validate_plan(p):
     if p.nsplit:
         sp = p.split.long()
         assert int((sp[:, 1] + sp[:, 2]).max()) <= p.nparts and int(sp[:, 1].min()) >= 0
+        ps = p.part_split.long()
+        assert ps.numel() == p.nparts and bool((sp[ps, 1] <= torch.arange(p.nparts, device=ps.device)).all()) \
+            and bool((torch.arange(p.nparts, device=ps.device) < sp[ps, 1] + sp[ps, 2]).all()), "slot -> hub row map is inconsistent"
     n_real_short = 0
     if p.nshort:
         assert p.nshort_user % 16 == 0 or p.nshort_user == p.nshort

@@ -71,10 +71,10 @@ def test_library_loaded_and_rejects_bad_shapes(dev):
     from ngacf_amd import _lib
     assert "gfx950" in ngacf_amd.version()
     # unsupported row width is refused before any launch
-    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 2, 48, 1, 0.2, 0.0, 0, 0, 3, 0)
+    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 2, 48, 1, 0.2, 0.0, 0, 0, 3, 0)
     assert rc == -2
     # a table of 2^32 bytes or more does not fit the 32-bit row offsets: refused, not wrapped
-    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1 << 24, 64, 8, 0.2, 0.0, 0, 0, 3, 0)
+    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1 << 24, 64, 8, 0.2, 0.0, 0, 0, 3, 0)
     assert rc == -2
     assert _lib.lib.ngacf_score_fwd(0, 0, 0, 0, 0, 5, 1, 64, 0) == -1
 
@@ -502,3 +502,35 @@ def test_d128_four_stage_stack_vs_oracle(dev):
     ngacf_amd.set_compute_dtype(m, torch.bfloat16)
     ps16 = m(_t(u, dev), _t(pos, dev), e)
     assert float((ps16 - ps).abs().max() / ps.abs().max()) < 5e-2
+
+
+def test_inkernel_hub_finish_is_bitwise_equal_to_two_kernel_path(dev):
+    """Hub rows are finished by their last-arriving slice inside the launch (agent-scope release/acquire ticket).
+    Partials are added in slot order on both paths, so the outputs must be BITWISE equal -- any stale read of
+    another workgroup's partial sums would show.  Repeated under load, caches warmed by the previous launch."""
+    from ngacf_amd import ops
+    from ngacf_amd.data import synthetic_bipartite
+    from ngacf_amd.plan import build_plan
+    U, I, E = 29858, 40981, 1027370
+    edge = synthetic_bipartite(U, I, E, seed=7, device=dev)
+    N = U + I
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    X = torch.randn(N, 64, device=dev, generator=g)
+    W = torch.randn(2, 64, 64, device=dev, generator=g) * 0.2
+    avec = torch.randn(2, 64, device=dev, generator=g) * 0.2
+    for seg, dt in ((256, torch.float32), (32, torch.bfloat16), (64, torch.float32)):
+        plan = build_plan(edge, U, I, seg_len=seg)
+        assert plan.nsplit > 400
+        H, S = ops.transform_fwd(X.to(dt), W, avec, U, I, 8, dt)
+        ref = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)          # default: second kernel finishes the hub rows
+        ops.INKERNEL_HUB_FINISH = True
+        try:
+            for it in range(25):
+                out = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)
+                for a_, b_ in zip(out, ref):
+                    assert torch.equal(a_, b_), (seg, dt, it)
+                assert int(plan.tickets.abs().sum()) == 0              # counters are left clean
+                if it % 5 == 0:                                        # unrelated traffic between launches
+                    torch.randn(4_000_000, device=dev).sum()
+        finally:
+            ops.INKERNEL_HUB_FINISH = False
