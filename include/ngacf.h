@@ -105,12 +105,12 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
 
 /* Backward of ngacf_prop_fwd (autograd of SPUIGACF.py:359-397; formulas SURVEY.md §8(a) A4b).
- * Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  ST[n,h] = { S_src[n,h], (g . agg)_h / R }
+ * Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  t[n,h] = (g . agg)_h / R   (ST below = this t table)
  * Step 2 (per edge, pull):  dH[n] = g[n] + sum_src m e Gn[src] + dS[n,h] * avec[type(n)]
  *                           dS[n,h] = sum_src -e * lrelu'(s) * (m (Gn[n].H[src] + Gn[src].H[n])_h - t[n] - t[src])
  *   gout [N,d] dtype (the gradient arrives in the storage type of `out`)   out [N,d] dtype (forward output)
  *   agg, R: as saved by the forward
- *   G float[N][d], Gn [N][d] dtype, ST float[N][heads][2]: workspace    dH float[N][d], dS float[N][heads]: results
+ *   G float[N][d], Gn [N][d] dtype, ST float[N][heads] (the t table): workspace    dH float[N][d], dS float[N][heads]: results
  *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows */
 int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                    const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,

@@ -1,7 +1,7 @@
 // Attention propagation, backward (pull-only, no atomics): autograd of
 // graphattention/SPUIGACF.py:359-397; formulas SURVEY.md 8(a) row A4b.
 //
-// Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  ST[n,h] = { S_src[n,h], (g . agg)_h / R }
+// Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  t[n,h] = (g . agg)_h / R
 // Step 2 (per directed edge, pulled by the destination row n, source c):
 //     e  = exp(-lrelu(S_dst[n] + S_src[c]))          m = edge dropout multiplier
 //     de = m * (Gn[n].H[c] + Gn[c].H[n])_h - t[n] - t[c]
@@ -34,7 +34,7 @@ struct PropBwdArgs {
     const void* gout;              // [rows][d] of the stage's storage type (the dtype autograd hands back)
     float* G;
     void* Gn;
-    float2* ST;
+    float* Tn;                     // t[N][heads]
     float* dH;
     float* dS;
     float* part_acc;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void prop_bwd_node_kernel(const PropBwdArgs a)
     if (!ok) return;
     store_f32<VEC>(a.G + n * D + q * VEC, g);
     Slice<T>::store(static_cast<T*>(a.Gn) + n * D + q * VEC, gn);
-    if ((q * VEC) % HW == 0) a.ST[n * HEADS + head] = make_float2(a.S_src[n * HEADS + head], p);
+    if ((q * VEC) % HW == 0) a.Tn[n * HEADS + head] = p;
 }
 
 template <int VEC>
@@ -137,7 +137,7 @@ __device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, i
     load_row<T, D, HEADS>(a.H, row, q, x.h_own);
     load_row<T, D, HEADS>(a.Gn, row, q, x.gn_own);
     x.s_dst = a.S_dst[(size_t)row * HEADS + head];
-    x.t_own = a.ST[(size_t)row * HEADS + head].y;
+    x.t_own = a.Tn[(size_t)row * HEADS + head];
     if (FROM_ROW) {
         const float* ap = a.avec + (x.dst_is_user ? D : 0) + q * VEC;
 #pragma unroll
@@ -152,7 +152,7 @@ __device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, i
 
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
 __device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<Slice<T>::VEC>& x, const float (&hv)[Slice<T>::VEC],
-                                            const float (&gv)[Slice<T>::VEC], float2 st, bool ok, int c,
+                                            const float (&gv)[Slice<T>::VEC], float s_src, float t_src, bool ok, int c,
                                             float (&acc)[Slice<T>::VEC], float& dsum) {
     constexpr int LPH = BShape<T, D, HEADS>::LPH, VEC = Slice<T>::VEC;
     float dot = 0.f, s = 0.f;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<S
         if (FROM_ROW) s = fmaf(hv[j], x.av[j], s);
     }
     dot = lanes_sum<LPH>(dot);
-    s = FROM_ROW ? lanes_sum<LPH>(s) : st.x;
+    s = FROM_ROW ? lanes_sum<LPH>(s) : s_src;
     s += x.s_dst;
     const float lr = fmaxf(s, a.alpha * s);
     const float ev = ok ? __expf(-lr) : 0.f;
@@ -172,7 +172,7 @@ __device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<S
         const uint32_t other = x.dst_is_user ? (uint32_t)c * RNG_K2 + x.salt_h : (uint32_t)c * RNG_K1;
         m = lowbias32(x.row_key ^ other) >= a.drop_thr ? a.drop_scale : 0.f;
     }
-    const float de = m * dot - x.t_own - st.y;
+    const float de = m * dot - x.t_own - t_src;
     dsum -= ev * de * (s > 0.f ? 1.f : a.alpha);
     const float wgt = m * ev;
 #pragma unroll
@@ -235,16 +235,17 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
             for (int h0 = 0; h0 < 8; h0 += UNROLL) {
                 if (h0 > 0 && k0 + h0 >= maxdeg) break;
                 float hv[UNROLL][VEC], gv[UNROLL][VEC];
-                float2 st[UNROLL];
+                float ss[UNROLL], tc[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     load_row<T, D, HEADS>(a.H, c[h0 + u], q, hv[u]);
                     load_row<T, D, HEADS>(a.Gn, c[h0 + u], q, gv[u]);
-                    st[u] = a.ST[(size_t)c[h0 + u] * HEADS + head];
+                    tc[u] = a.Tn[(size_t)c[h0 + u] * HEADS + head];
+                    ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[h0 + u] * HEADS + head];
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
-                    edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], st[u], k0 + h0 + u < deg, c[h0 + u], acc, dsum);
+                    edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], k0 + h0 + u < deg, c[h0 + u], acc, dsum);
             }
             colv = coln;
         }
@@ -267,16 +268,17 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
             c[u] = a.col[ok[u] ? e : end - 1];
         }
         float hv[UNROLL][VEC], gv[UNROLL][VEC];
-        float2 st[UNROLL];
+        float ss[UNROLL], tc[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             load_row<T, D, HEADS>(a.H, c[u], q, hv[u]);
             load_row<T, D, HEADS>(a.Gn, c[u], q, gv[u]);
-            st[u] = a.ST[(size_t)c[u] * HEADS + head];
+            tc[u] = a.Tn[(size_t)c[u] * HEADS + head];
+            ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[u] * HEADS + head];
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
-            edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], st[u], ok[u], c[u], acc, dsum);
+            edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], ok[u], c[u], acc, dsum);
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
@@ -379,7 +381,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     PropBwdArgs a;
     a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R; a.gout = gout;
-    a.G = G; a.Gn = Gn; a.ST = reinterpret_cast<float2*>(ST); a.dH = dH; a.dS = dS; a.part_acc = part_acc; a.part_r = part_r;
+    a.G = G; a.Gn = Gn; a.Tn = ST; a.dH = dH; a.dS = dS; a.part_acc = part_acc; a.part_r = part_r;
     a.U = U; a.N = N; a.nu_lo = nu_lo; a.nu_n = nu_n; a.ni_lo = ni_lo; a.ni_n = ni_n; a.gout_local = gout_local;
     a.order.nseg_u = nseg_user; a.order.nshort_u = nshort_user; a.alpha = alpha;
     a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.seed_dev = seed_dev; a.flags = flags;

@@ -107,7 +107,7 @@ class _ShardedStage(torch.autograd.Function):
         g_local = g_local.contiguous().to(H.dtype)
         G = torch.empty(N, d, dtype=torch.float32, device=dev)
         Gn = torch.empty(N, d, dtype=H.dtype, device=dev)
-        ST = torch.empty(N, heads, 2, dtype=torch.float32, device=dev)
+        ST = torch.empty(N, heads, dtype=torch.float32, device=dev)       # t[n,h]
         be.prop_bwd_node(out, agg, R, g_local, S, G, Gn, ST, part.Up, heads, part.win, True, True)
         comm.all_gather_rows(Gn)
         comm.all_gather_rows(ST)

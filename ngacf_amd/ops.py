@@ -169,7 +169,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     f32 = dict(dtype=torch.float32, device=dev)
     G, dH = torch.empty(N, d, **f32), torch.empty(N, d, **f32)
     Gn = torch.empty(N, d, dtype=H.dtype, device=dev)
-    t, dS = torch.empty(N, heads, 2, **f32), torch.empty(N, heads, **f32)
+    t, dS = torch.empty(N, heads, **f32), torch.empty(N, heads, **f32)
     pa = torch.empty(max(plan.nparts, 1), d, **f32)
     pr = torch.empty(max(plan.nparts, 1), heads, **f32)
     if plan.n_rows != N:
@@ -332,7 +332,7 @@ def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local
     ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
     gp = _chk(G, "G", torch.float32, N * d, dev)
     gn = _chk(Gn, "Gn", out.dtype, N * d, dev)
-    st = _chk(ST, "ST", torch.float32, N * heads * 2, dev)
+    st = _chk(ST, "ST", torch.float32, N * heads, dev)
     _lib.check(lib.ngacf_prop_bwd_node(op, _DT[out.dtype], ap, rp, go, ss, gp, gn, st, U, N, d, heads,
                                        FLAG_ELU if elu else 0, u_lo, u_n, i_lo, i_n, int(bool(gout_local)), _stream()),
                "ngacf_prop_bwd_node")
@@ -348,7 +348,7 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
     gp = _chk(G, "G", torch.float32, N * d, dev)
     gn = _chk(Gn, "Gn", H.dtype, N * d, dev)
-    st = _chk(ST, "ST", torch.float32, N * heads * 2, dev)
+    st = _chk(ST, "ST", torch.float32, N * heads, dev)
     pp = _plan_ptrs(plan, dev)
     f32 = dict(dtype=torch.float32, device=dev)
     dH, dS = torch.zeros(N, d, **f32), torch.zeros(N, heads, **f32)

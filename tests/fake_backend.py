@@ -71,8 +71,7 @@ def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local
     gn = (g * inv).to(Gn.dtype)
     G[rows] = g
     Gn[rows] = gn
-    ST[rows, :, 0] = S_src[rows]
-    ST[rows, :, 1] = (gn.float() * agg[rows]).view(-1, heads, hw).sum(2)
+    ST[rows] = (gn.float() * agg[rows]).view(-1, heads, hw).sum(2)
 
 
 def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=True, score_from_row=True,
@@ -87,7 +86,7 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     s = S_dst[dst] + (Hf[src] * avec[tt[src]]).view(-1, heads, hw).sum(2)
     e = torch.exp(-F.leaky_relu(s, alpha))
     dot = (Gf[dst] * Hf[src] + Gf[src] * Hf[dst]).view(-1, heads, hw).sum(2)
-    de = dot - ST[dst, :, 1] - ST[src, :, 1]
+    de = dot - ST[dst] - ST[src]
     ds = -e * de * torch.where(s > 0, torch.ones_like(s), torch.full_like(s, alpha))
     dS = torch.zeros(N, heads).index_add_(0, dst, ds)
     acc = torch.zeros(N, d).index_add_(0, dst, e.repeat_interleave(hw, 1) * Gf[src])

@@ -53,7 +53,7 @@ def test_partitioned_stage_equals_single_gpu(P, dt):
             out[lo:hi], agg[lo:hi], R[lo:hi] = o[lo:hi], a_[lo:hi], r_[lo:hi]
     tol = 1e-6 if dt == torch.float32 else 1e-2
     assert float((out.float() - out0.float()).abs().max()) <= tol and float((R - R0).abs().max() / R0.abs().max()) < 1e-5
-    G = torch.empty(N, 64, device=dev); Gn = torch.empty(N, 64, device=dev, dtype=dt); ST = torch.empty(N, heads, 2, device=dev)
+    G = torch.empty(N, 64, device=dev); Gn = torch.empty(N, 64, device=dev, dtype=dt); ST = torch.empty(N, heads, device=dev)
     for p in parts:
         ops.prop_bwd_node(out0, agg0, R0, p.local_rows(gout).contiguous(), S, G, Gn, ST, Up, heads, p.win, True)
     dH = torch.zeros_like(dH0); dS = torch.zeros_like(dS0)
