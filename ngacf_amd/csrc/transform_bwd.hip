@@ -1,5 +1,6 @@
 // Backward of the row transform (transform.hip): dX = mask * (dH @ W^T), dW = (mask*X)^T @ dH,
 // davec = sum_n dS[n,head(c)] H[n,c].  Autograd of graphattention/SPUIGACF.py:356-357,:361.
+#include <cstdlib>
 #include "ngacf_common.hpp"
 
 namespace ngacf {
@@ -228,6 +229,194 @@ __global__ __launch_bounds__(256) void transform_bwd_dw_kernel(const TransBwdArg
     if (tid < DOUT) wk[DIN * DOUT + tid] = da;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// bf16-storage form of the dW / davec partial on the matrix cores:  dW[k][c] = sum_n Xm[n][k] dH[n][c].
+// The contraction runs over NODES, so both MFMA operands want "8 consecutive nodes of one column" per lane:
+// a 64-node tile of X and of dH (rounded to bf16) is staged row-major in LDS with coalesced 16-byte stores
+// and consumed column-major with ds_read_b64_tr_b16 (the hardware transpose read of gfx950).  The 4 waves
+// own the 4 quadrants of the [DIN][DOUT] result, so there is no cross-wave reduction; the next tile's global
+// loads are in flight while the current one is multiplied.  davec rides along on the VALU.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 dw_bf16x8;
+typedef __attribute__((ext_vector_type(4))) short dw_short4;
+typedef __attribute__((ext_vector_type(8))) short dw_short8;
+typedef __attribute__((ext_vector_type(16))) float dw_f32x16;
+
+__device__ __forceinline__ dw_bf16x8 tr_frag(const char* lds_base, int off_lo, int off_hi) {
+    typedef __attribute__((address_space(3))) dw_short4 lds_short4;
+    const dw_short4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(lds_base + off_lo));
+    const dw_short4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(lds_base + off_hi));
+    const dw_short8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(dw_bf16x8, v);
+}
+
+__device__ __forceinline__ uint4 pack_bf16x8(const float (&f)[8]) {
+    return make_uint4(f32_to_bf16(f[0]) | (f32_to_bf16(f[1]) << 16), f32_to_bf16(f[2]) | (f32_to_bf16(f[3]) << 16),
+                      f32_to_bf16(f[4]) | (f32_to_bf16(f[5]) << 16), f32_to_bf16(f[6]) | (f32_to_bf16(f[7]) << 16));
+}
+
+template <typename TX, int DIN, int DOUT, int HEADS, bool DROP>
+__global__ __launch_bounds__(256) void transform_dw_mfma_kernel(const TransBwdArgs a) {
+    constexpr int TN = 64;                               // nodes per tile
+    constexpr int SX = DIN * 2 + 64, SG = DOUT * 2 + 64;  // LDS row strides (bytes): 4 consecutive rows on disjoint 16-bank windows
+    constexpr int KW = DIN / 64, CW = DOUT / 64;          // 32-blocks of k / of c per wave (2 x 2 wave grid)
+    constexpr int HW = DOUT / HEADS;
+    constexpr int XI = TN * (DIN / 8) / 256, GI = TN * (DOUT / 8) / 256;   // 8-element items per thread per tile
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    char* Xs = lds_raw;                                  // [TN][SX]
+    char* Gs = lds_raw + TN * SX;                        // [TN][SG]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wc = wave & 1;
+    const uint32_t salt = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
+    const bool users = (int)blockIdx.x < a.nbu;
+    const int nb = users ? a.nbu : a.nbi;
+    const int bl = users ? blockIdx.x : blockIdx.x - a.nbu;
+    const int rbeg = users ? a.u_lo : a.U + a.i_lo, rend = rbeg + (users ? a.u_n : a.i_n);
+    const int xoff = a.x_local ? (users ? a.u_lo : a.U + a.i_lo - a.u_n) : 0;
+    const int ntiles = (rend - rbeg + TN - 1) / TN;
+    const TX* Xg = static_cast<const TX*>(a.X);
+    const uint16_t* Hg = static_cast<const uint16_t*>(a.H);
+
+    dw_f32x16 acc[KW][CW];
+#pragma unroll
+    for (int i = 0; i < KW; ++i)
+#pragma unroll
+        for (int j = 0; j < CW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float da[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) da[e] = 0.f;
+
+    // staged registers of one tile
+    uint4 xr[XI], gr[GI];
+    auto fetch = [&](int tile) {
+        const int row0 = rbeg + tile * TN;
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int i = tid + 256 * j, r = i / (DIN / 8), q = i % (DIN / 8);
+            const int row = row0 + r;
+            float f[8];
+            if (row < rend) {
+                if constexpr (sizeof(TX) == 2) {
+                    if constexpr (!DROP) {
+                        xr[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Xg) + (size_t)(row - xoff) * DIN + 8 * q);
+                        continue;
+                    }
+                    Slice<bf16_t>::load(reinterpret_cast<const bf16_t*>(Xg) + (size_t)(row - xoff) * DIN + 8 * q, f);
+                } else {
+                    const float4 v0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Xg) + (size_t)(row - xoff) * DIN + 8 * q);
+                    const float4 v1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Xg) + (size_t)(row - xoff) * DIN + 8 * q + 4);
+                    f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+                }
+                if (DROP) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = feat_bits(salt, row, 8 * q + e) >= a.drop_thr ? f[e] * a.drop_scale : 0.f;
+                }
+                xr[j] = pack_bf16x8(f);
+            } else {
+                xr[j] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GI; ++j) {
+            const int i = tid + 256 * j, r = i / (DOUT / 8), q = i % (DOUT / 8);
+            const int row = row0 + r;
+            if (row < rend) {
+                const float4 v0 = *reinterpret_cast<const float4*>(a.dH + (size_t)row * DOUT + 8 * q);
+                const float4 v1 = *reinterpret_cast<const float4*>(a.dH + (size_t)row * DOUT + 8 * q + 4);
+                const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                gr[j] = pack_bf16x8(f);
+                // davec: this thread's 8 columns of row `row` (the column group q is the same for every item)
+                const uint4 hv = *reinterpret_cast<const uint4*>(Hg + (size_t)row * DOUT + 8 * q);
+                const float s = a.dS[(size_t)row * HEADS + (8 * q) / HW];
+                const uint32_t w[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    da[2 * e] = fmaf(s, bf16_to_f32(w[e] & 0xffffu), da[2 * e]);
+                    da[2 * e + 1] = fmaf(s, bf16_to_f32(w[e] >> 16), da[2 * e + 1]);
+                }
+            } else {
+                gr[j] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int i = tid + 256 * j, r = i / (DIN / 8), q = i % (DIN / 8);
+            *reinterpret_cast<uint4*>(Xs + r * SX + 16 * q) = xr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < GI; ++j) {
+            const int i = tid + 256 * j, r = i / (DOUT / 8), q = i % (DOUT / 8);
+            *reinterpret_cast<uint4*>(Gs + r * SG + 16 * q) = gr[j];
+        }
+    };
+
+    // transposed-read addressing: 16-lane group g = lane>>4 takes nodes 8*(g>>1).. of columns 16*(g&1)..; lane 4q+p of
+    // the group points at node q, columns 4p..4p+3
+    const int g4 = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int node_in_step = 8 * (g4 >> 1) + qq;
+    const int col_in_blk = 16 * (g4 & 1) + 4 * pp;
+
+    int tile = bl;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += nb) {
+        __syncthreads();                                  // everyone done reading the previous tile
+        stage();
+        __syncthreads();
+        if (tile + nb < ntiles) fetch(tile + nb);         // next tile's loads fly under the MFMAs
+#pragma unroll
+        for (int s = 0; s < TN / 16; ++s) {
+            dw_bf16x8 af[KW], bf[CW];
+#pragma unroll
+            for (int i = 0; i < KW; ++i) {
+                const int off = (16 * s + node_in_step) * SX + (32 * (wk * KW + i) + col_in_blk) * 2;
+                af[i] = tr_frag(Xs, off, off + 4 * SX);
+            }
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+                const int off = (16 * s + node_in_step) * SG + (32 * (wc * CW + j) + col_in_blk) * 2;
+                bf[j] = tr_frag(Gs, off, off + 4 * SG);
+            }
+#pragma unroll
+            for (int i = 0; i < KW; ++i)
+#pragma unroll
+                for (int j = 0; j < CW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // partial of this workgroup: acc[i][j][reg] = dW[32(wk KW + i) + (reg&3) + 8(reg>>2) + 4(lane>>5)][32(wc CW + j) + (lane&31)]
+    float* wkp = a.work + (size_t)blockIdx.x * (DIN * DOUT + DOUT);
+#pragma unroll
+    for (int i = 0; i < KW; ++i)
+#pragma unroll
+        for (int j = 0; j < CW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = 32 * (wk * KW + i) + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                wkp[(size_t)k * DOUT + 32 * (wc * CW + j) + (lane & 31)] = acc[i][j][e];
+            }
+    {   // davec: fold the threads that share a column group
+        constexpr int QN = DOUT / 8, TG = 256 / QN;
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds_raw);   // [256][8]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = da[e];
+        __syncthreads();
+        if (tid < DOUT) {
+            const int q = tid >> 3, e = tid & 7;
+            float s = 0.f;
+#pragma unroll 8
+            for (int m = 0; m < TG; ++m) s += red[(q + QN * m) * 8 + e];
+            wkp[DIN * DOUT + tid] = s;
+        }
+    }
+}
+
 // dW[type], davec[type] = sum of the partials of that type's workgroups, in workgroup order
 __global__ __launch_bounds__(256) void transform_bwd_reduce_kernel(const float* __restrict__ work, float* __restrict__ dW,
                                                                    float* __restrict__ davec, int nbu, int nbi, int wsz, int dwsz) {
@@ -276,6 +465,10 @@ static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool dr
     }
     {   // dW, davec
         int nb = NGACF_TBWD_BLOCKS;
+        if constexpr (sizeof(TH) == 2) {
+            static const int tuned = [] { const char* e = getenv("NGACF_DW_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= NGACF_TBWD_BLOCKS ? v : 256; }();
+            nb = tuned;
+        }
         if (tu + ti < nb) { a.nbu = tu; a.nbi = ti; }
         else {
             a.nbu = (int)((long long)nb * tu / (tu + ti));
@@ -285,7 +478,12 @@ static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool dr
             if (tu == 0) a.nbu = 0;
         }
         constexpr size_t lds = (size_t)(TM * (DIN + 4) + TM * (DOUT + 4)) * sizeof(float);
-        if (drop) {
+        if constexpr (sizeof(TH) == 2) {
+            constexpr size_t lm = (size_t)64 * (DIN * 2 + 64) + (size_t)64 * (DOUT * 2 + 64);
+            static_assert(lm >= 256 * 8 * sizeof(float), "davec fold reuses the tile image");
+            if (drop) hipLaunchKernelGGL((transform_dw_mfma_kernel<TX, DIN, DOUT, HEADS, true>), dim3(a.nbu + a.nbi), dim3(256), lm, st, a);
+            else      hipLaunchKernelGGL((transform_dw_mfma_kernel<TX, DIN, DOUT, HEADS, false>), dim3(a.nbu + a.nbi), dim3(256), lm, st, a);
+        } else if (drop) {
             auto k = transform_bwd_dw_kernel<TX, TH, DIN, DOUT, HEADS, true>;
             if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k, dim3(a.nbu + a.nbi), dim3(256), lds, st, a);

@@ -333,6 +333,46 @@ def test_bf16_storage_close_to_fp32(dev):
         assert rel < 5e-2, (k, rel)
 
 
+@pytest.mark.parametrize("din,dout,heads", [(64, 64, 8), (64, 64, 1), (128, 64, 8), (64, 128, 16), (128, 128, 1)])
+@pytest.mark.parametrize("xdt", ["bf16", "fp32"])
+def test_bf16_transform_backward_on_matrix_cores(dev, din, dout, heads, xdt):
+    """bf16 storage runs dX and dW on MFMA (transposed LDS reads for dW): compare with fp32 torch matmuls of the
+    SAME bf16-rounded operands (fp32 accumulate on both sides, so only the summation order differs)."""
+    from ngacf_amd import ops, rng
+    g = torch.Generator(device=dev).manual_seed(din + dout + heads)
+    for U, I, p in ((1, 1, 0.0), (37, 91, 0.0), (1000, 1531, 0.25)):      # ragged tiles, both types, with feature dropout
+        N = U + I
+        X = torch.randn(N, din, device=dev, generator=g)
+        X = X.to(torch.bfloat16) if xdt == "bf16" else X
+        W = torch.randn(2, din, dout, device=dev, generator=g) * 0.2
+        avec = torch.randn(2, dout, device=dev, generator=g)
+        H, _ = ops.transform_fwd(X, W, avec, U, I, heads, torch.bfloat16, feat_drop_p=p, seed=11)
+        dH = torch.randn(N, dout, device=dev, generator=g)
+        dS = torch.randn(N, heads, device=dev, generator=g)
+        dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=p, seed=11)
+        Xm = X.float()
+        if p > 0:
+            n = torch.arange(N, device=dev, dtype=torch.int64)[:, None].expand(N, din)
+            c = torch.arange(din, device=dev, dtype=torch.int64)[None].expand(N, din)
+            bits = rng.feat_bits(11, n.cpu().numpy().astype(np.uint32), c.cpu().numpy().astype(np.uint32))
+            keep = torch.from_numpy((bits >= rng.threshold(p)).astype(np.float32)).to(dev) / (1 - p)
+        else:
+            keep = torch.ones(N, din, device=dev)
+        Xb = (Xm * keep).to(torch.bfloat16).float()
+        gb = dH.to(torch.bfloat16).float()
+        Wb = W.to(torch.bfloat16).float()
+        for t, (lo, hi) in enumerate(((0, U), (U, N))):
+            ref_dw = Xb[lo:hi].T @ gb[lo:hi]
+            assert float((dW[t] - ref_dw).abs().max()) <= 1e-4 * max(1.0, float(ref_dw.abs().max())), (t, U, I)
+            ref_dx = (gb[lo:hi] @ Wb[t].T) * keep[lo:hi]
+            tol = 2e-2 if xdt == "bf16" else 1e-4
+            assert float((dX[lo:hi].float() - ref_dx).abs().max()) <= tol * max(1.0, float(ref_dx.abs().max())), (t, U, I)
+            hw = dout // heads
+            ref_da = (dS[lo:hi].repeat_interleave(hw, 1) * H[lo:hi].float()).sum(0)
+            assert float((da[t] - ref_da).abs().max()) <= 1e-4 * max(1.0, float(ref_da.abs().max())), (t, U, I)
+
+
+
 # ---------------------------------------------------------------------------
 # scoring, BPR, static SpMM
 # ---------------------------------------------------------------------------
