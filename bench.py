@@ -173,7 +173,8 @@ def main():
         if not args.eager:                      # whole step (2 fwd, loss, bwd, Adam) as one replayed hipGraph
             from ngacf_amd.graphs import GraphedBPRStep
             gstep = GraphedBPRStep(model, lossfn, opt, edge, B)
-            step = lambda: gstep(ub, pb, nb)
+            upn = torch.stack([ub, pb, nb])              # the sampler's output, packed: one device copy per step
+            step = lambda: gstep(upn)
         for _ in range(min(args.warmup, 3)):
             step()
         sync()

@@ -24,6 +24,7 @@ from .plan import build_plan, squeeze_mask
 
 _PLAN_CACHE_MAX = 4
 _SEED_STRIDE = 0x1E3779B97F4A7C15
+_CTR_STRIDE = 0x2545F4914F6CDD1D          # device-counter step (odd, unrelated to the per-call stride)
 
 
 class _PlanCache:
@@ -247,11 +248,13 @@ class _GATBase(nn.Module):
         p = self.dropout if self.training else 0.0
         seed_dev = None
         if p > 0 and getattr(self, "_seed_ctr", None) is not None:
-            # graph-capturable seeding: a device counter advanced by a (captured) add; every forward keeps
-            # its own snapshot so that its backward regenerates the same masks
-            self._seed_ctr.add_(_SEED_STRIDE)
-            seed_dev = self._seed_ctr.clone()
-            base = self._seed_base
+            # graph-capturable seeding: seed = host part + device counter.  The host part differs per forward call
+            # (a constant inside a captured graph); the counter is advanced once per step by its owner
+            # (advance_device_seed(), a captured add in GraphedBPRStep) BEFORE the forwards, so a forward and its
+            # backward read the same value and no per-call snapshot kernel is needed.
+            self._seed_call += 1
+            base = (self._seed_base + self._seed_call * _SEED_STRIDE) & 0x3FFFFFFFFFFFFFFF
+            seed_dev = self._seed_ctr
         else:
             base = _fresh_seed() if p > 0 else 0
         x = features
@@ -268,9 +271,15 @@ class _GATBase(nn.Module):
         would be frozen into the graph)."""
         if on:
             self._seed_base = _fresh_seed()
+            self._seed_call = 0
             self._seed_ctr = torch.zeros(1, dtype=torch.int64, device=device)
         else:
             self._seed_ctr = None
+
+    def advance_device_seed(self):
+        """One (capturable) add on the device counter: call once per training step, before the forwards."""
+        if getattr(self, "_seed_ctr", None) is not None:
+            self._seed_ctr.add_(_CTR_STRIDE)
 
 
 class SpUIGAT(_GATBase):

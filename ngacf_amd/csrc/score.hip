@@ -68,7 +68,11 @@ __global__ __launch_bounds__(256) void bpr_fwd_kernel(const float* __restrict__ 
     __shared__ float ws[4];
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (ws[0] + ws[1] + ws[2] + ws[3]) / (float)B);
+    if (threadIdx.x == 0) {
+        const float v = (ws[0] + ws[1] + ws[2] + ws[3]) / (float)B;
+        if (gridDim.x == 1) *loss = v;                      // usual batch sizes: one workgroup, deterministic, no pre-zero
+        else atomicAdd(loss, v);
+    }
 }
 
 __global__ __launch_bounds__(256) void bpr_bwd_kernel(const float* __restrict__ pos, const float* __restrict__ neg,
@@ -142,7 +146,11 @@ extern "C" int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const
 
 extern "C" int ngacf_bpr_fwd(const float* pos, const float* neg, float* loss, int B, void* stream) {
     if (B <= 0 || !pos || !neg || !loss) return NGACF_E_ARG;
-    const int nb = (B + 255) / 256 < 64 ? (B + 255) / 256 : 64;
+    const int nb = B <= (1 << 16) ? 1 : 64;
+    if (nb > 1) {
+        const hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return static_cast<int>(e);
+    }
     hipLaunchKernelGGL(bpr_fwd_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), pos, neg, loss, B);
     NGACF_CHECK_LAUNCH();
     return 0;

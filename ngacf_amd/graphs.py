@@ -31,12 +31,14 @@ class GraphedBPRStep:
         self.model, self.optim = model, optim
         for g in _gats(model):
             g.use_device_seed(dev, True)
-        self.u = torch.zeros(batch_size, dtype=torch.long, device=dev)
-        self.p = torch.zeros_like(self.u)
-        self.n = torch.zeros_like(self.u)
+        self.upn = torch.zeros(3, batch_size, dtype=torch.long, device=dev)     # users / positives / negatives
+        self.u, self.p, self.n = self.upn[0], self.upn[1], self.upn[2]
         model.train()
+        gats = _gats(model)
 
         def step():
+            for g in gats:
+                g.advance_device_seed()                     # one captured add per step: fresh masks every replay
             optim.zero_grad(set_to_none=True)
             loss = lossfn(model(self.u, self.p, adj), model(self.u, self.n, adj))
             loss.backward()
@@ -54,10 +56,14 @@ class GraphedBPRStep:
         with torch.cuda.graph(self.graph):
             self.loss = step()
 
-    def __call__(self, users, pos, neg):
-        self.u.copy_(users)
-        self.p.copy_(pos)
-        self.n.copy_(neg)
+    def __call__(self, users, pos=None, neg=None):
+        """step(users, pos, neg), or step(upn) with the three index rows packed as one [3, B] tensor (one copy)."""
+        if pos is None:
+            self.upn.copy_(users)
+        else:
+            self.u.copy_(users)
+            self.p.copy_(pos)
+            self.n.copy_(neg)
         self.graph.replay()
         return self.loss
 

@@ -234,7 +234,7 @@ def score_bwd(F, u, i, gscore, U):
 
 def bpr_fwd(pos, neg):
     dev, B = pos.device, pos.numel()
-    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
     _lib.check(lib.ngacf_bpr_fwd(_chk(pos, "pos", torch.float32, B, dev), _chk(neg, "neg", torch.float32, B, dev),
                                  loss.data_ptr(), B, _stream()), "ngacf_bpr_fwd")
     return loss
