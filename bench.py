@@ -58,8 +58,21 @@ def stage_dims(model):
     return model.gat.stage_shapes()
 
 
+_RESULT_FD = None
+
+
+def emit(line):
+    """The ONE JSON line, on the real stdout.  Everything else that lands on fd 1 during the run (RCCL prints a
+    version banner there at init) has been pointed at stderr."""
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, (line + "\n").encode())
+
+
 def main():
+    global _RESULT_FD
     args = parse()
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -83,7 +96,7 @@ def main():
 
     if world > 1 or force_dist:
         from ngacf_amd import dist as ND
-        return ND.bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, HBM_PEAK_GBS)
+        return ND.bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, HBM_PEAK_GBS, emit)
 
     torch.manual_seed(2019)
     if wl == "ml100k":
@@ -214,7 +227,7 @@ def main():
            "roofline": roofline, "cpu_baseline": cpu}
     if train:
         out.update(train)
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
 
 
 def stage_layer_names(model):

@@ -10,7 +10,8 @@ lands IN PLACE in the global table -- no re-layout copy, kernels unchanged.  Ran
 Per stage, forward:   local transform (window) -> all-gather H -> local pull traversal (source scores are
                       recomputed from the gathered rows, so the score table never travels)
            backward:  local node step -> all-gather Gn, ST -> local edge step -> local transform backward
-                      -> all-reduce of the 16 K small-weight gradients.  No reduce-scatter, no atomics.
+                      -> all-reduce of the 16 K small-weight gradients (per stage, or once per step with
+                      comm.defer_weight_reduce + reduce_grads()).  No reduce-scatter, no atomics.
 
 `backend` is the module that runs the local compute (default: ngacf_amd.ops = the HIP library).  The CPU
 tests inject a torch stand-in to exercise partition + collectives under gloo; the product never does.
@@ -53,30 +54,49 @@ class Partition:
 
 class Comm:
     """The collectives of the path.  In-place all-gather: rank p's block of `full` is already where the
-    gathered table wants it."""
+    gathered table wants it.  Under RCCL every call is ONE grouped launch (ncclGroupStart/End through c10d's
+    coalescing manager) however many tables and halves it carries: at Gowalla scale a stage is bound by the
+    number of collective launches, not by their bytes."""
 
     def __init__(self, part, group=None):
         self.part, self.group = part, group
         self.world = part.P
         self._base = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._coalesce = self._base and hasattr(dist.distributed_c10d, "_coalescing_manager")
+        self.force = False                    # rehearsal on one rank: issue the collectives even when world == 1
+        self.defer_weight_reduce = False      # True: the caller sums weight gradients once per step (reduce_grads)
+        self.launches = 0                     # grouped collective launches issued (for the tests / the bench line)
 
-    def all_gather_rows(self, full):
+    def _grouped(self, n_ops):
+        import contextlib
+        self.launches += 1 if (self._coalesce or n_ops == 0) else n_ops
+        if self._coalesce and n_ops > 1:
+            return dist.distributed_c10d._coalescing_manager(group=self.group)
+        return contextlib.nullcontext()
+
+    def all_gather_rows(self, *fulls):
+        """Every `full` is a global-row table [Up+Ip, ...] whose local user block and item block are filled."""
         p = self.part
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
-        for lo, n, tot in ((0, p.cu, p.Up), (p.Up, p.ci, p.Ip)):
-            out = full[lo:lo + tot]
-            mine = full[lo + p.rank * n: lo + (p.rank + 1) * n]
-            if self._base:
-                dist.all_gather_into_tensor(out, mine, group=self.group)
-            else:                                                 # gloo: list form
-                chunks = [out[r * n:(r + 1) * n] for r in range(self.world)]
-                dist.all_gather(chunks, mine.clone(), group=self.group)
+        pairs = []
+        for full in fulls:
+            for lo, n, tot in ((0, p.cu, p.Up), (p.Up, p.ci, p.Ip)):
+                pairs.append((full[lo:lo + tot], full[lo + p.rank * n: lo + (p.rank + 1) * n], n))
+        with self._grouped(len(pairs)):
+            for out, mine, n in pairs:
+                if self._base:
+                    dist.all_gather_into_tensor(out, mine, group=self.group)
+                else:                                             # gloo: list form
+                    chunks = [out[r * n:(r + 1) * n] for r in range(self.world)]
+                    dist.all_gather(chunks, mine.clone(), group=self.group)
 
-    def all_reduce_sum(self, t):
-        if self.world > 1:
-            dist.all_reduce(t, group=self.group)
-        return t
+    def all_reduce_sum(self, *ts):
+        if self.world > 1 or self.force:
+            with self._grouped(len(ts)):
+                for t in ts:
+                    dist.all_reduce(t, group=self.group)
+        return ts[0] if len(ts) == 1 else ts
 
 
 class _ShardedStage(torch.autograd.Function):
@@ -109,12 +129,11 @@ class _ShardedStage(torch.autograd.Function):
         Gn = torch.empty(N, d, dtype=H.dtype, device=dev)
         ST = torch.empty(N, heads, dtype=torch.float32, device=dev)       # t[n,h]
         be.prop_bwd_node(out, agg, R, g_local, S, G, Gn, ST, part.Up, heads, part.win, True, True)
-        comm.all_gather_rows(Gn)
-        comm.all_gather_rows(ST)
+        comm.all_gather_rows(Gn, ST)                                       # one grouped launch
         dH, dS = be.prop_bwd_edges(plan, H, S, avec, G, Gn, ST, heads, alpha, True, True, drop_p, seed)
         dX, dW, da = be.transform_bwd_rows(X, W, H, dH, dS, part.Up, part.Ip, heads, part.win, True, feat_drop_p, seed)
-        comm.all_reduce_sum(dW)
-        comm.all_reduce_sum(da)
+        if not comm.defer_weight_reduce:
+            comm.all_reduce_sum(dW, da)
         return (dX.to(X.dtype), dW, da) + (None,) * 10
 
 
@@ -194,6 +213,13 @@ class ShardedSPUIGACF(nn.Module):
         sd.update({"gat." + k: v.detach().clone() for k, v in self.gat.state_dict().items()})
         return sd
 
+    def reduce_grads(self):
+        """With comm.defer_weight_reduce: sum the stage-weight gradients over the ranks in ONE grouped all-reduce,
+        after backward() and before the optimizer step (embedding rows are owned, their gradients are local)."""
+        gs = [p.grad for p in self.gat.parameters() if p.grad is not None]
+        if gs:
+            self.comm.all_reduce_sum(*gs)
+
     # ---- forward ------------------------------------------------------------------------------------------
     def _plan(self, mask):
         mask = squeeze_mask(mask)
@@ -229,8 +255,14 @@ class ShardedSPUIGACF(nn.Module):
 # ---------------------------------------------------------------------------------------------------------
 # bench.py --gpus N (N > 1): strong scaling of the named workload over a node partition
 # ---------------------------------------------------------------------------------------------------------
-def bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, hbm_peak):
+def bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, hbm_peak, emit=print):
+    """Strong scaling of the named workload over a node partition.  Order of events: (1) forward timed with eager
+    launches, (2) train step timed with eager launches, (3) the forward again as ONE replayed hipGraph (kernels +
+    grouped RCCL launches).  (3) replaces (1)'s number only if it completes; a watchdog prints the eager line and
+    exits if the captured path stalls, so a capture problem can never cost the measurement."""
     import json
+    import os
+    import threading
     import time
     from . import data as D
     torch.manual_seed(2019)
@@ -240,32 +272,51 @@ def bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, hbm_peak):
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.seg_len = args.seg_len
     L = len(model.gat._stages())
+    model.comm.force = world == 1                 # one-rank rehearsal (NGACF_BENCH_FORCE_DIST=1): still issue the collectives
+    model.comm.defer_weight_reduce = True
+    trav = L * 2 * E                              # all ranks together traverse every edge once per forward
 
     def sync():
         dist.barrier()
         torch.cuda.synchronize()
 
-    model.eval()
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            model.propagate_local(edge)
+    def timed(fn, warmup, steps):
+        for _ in range(warmup):
+            fn()
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            model.propagate_local(edge)
+        for _ in range(steps):
+            fn()
         sync()
         t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    t_fwd = float(t)
-    trav = L * 2 * E                                                     # all ranks together traverse every edge once
-    out = {"metric": "propagation edges/sec (directed edge traversals, forward, all stages)",
-           "value": round(trav * args.steps / t_fwd, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": round(1e3 * t_fwd / args.steps, 4), "higher_is_better": True,
-           "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": "%s-scale bipartite graph U=%d I=%d E=%d, d=%d, L=%d stages, node-partitioned over %d GPUs"
-                                  % (args.workload, U, I, E, d, L, world),
-                      "edges_directed_per_step": trav, "parallelism": "node partition x%d, 1 all-gather per stage" % world},
-           "roofline": None, "cpu_baseline": None}
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+    def line(t_fwd, launch, launches_fwd, extra):
+        out = {"metric": "propagation edges/sec (directed edge traversals, forward, all stages)",
+               "value": round(trav * args.steps / t_fwd, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(1e3 * t_fwd / args.steps, 4), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "%s-scale bipartite graph U=%d I=%d E=%d, d=%d, L=%d stages, node-partitioned over %d GPUs"
+                                      % (args.workload, U, I, E, d, L, world),
+                          "edges_directed_per_step": trav, "launch": launch,
+                          "parallelism": "node partition x%d, 1 grouped all-gather launch per stage (%d per forward)"
+                                         % (world, launches_fwd)},
+               "roofline": None, "cpu_baseline": None}
+        out.update(extra)
+        return json.dumps(out)
+
+    # ---- (1) forward, eager ------------------------------------------------------------------------------------
+    model.eval()
+    fwd = lambda: model.propagate_local(edge)
+    with torch.no_grad():
+        model.comm.launches = 0
+        fwd()
+        launches_fwd = model.comm.launches
+        t_eager = timed(fwd, args.warmup, args.steps)
+    extra = {"ms_per_step_eager": round(1e3 * t_eager / args.steps, 4)}
+
+    # ---- (2) train step, eager ---------------------------------------------------------------------------------
     if not args.no_train:
         model.train()
         lossfn = ng.BPRLoss()
@@ -281,19 +332,56 @@ def bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, hbm_peak):
             opt.zero_grad(set_to_none=True)
             loss = lossfn(model(ub, pb, edge), model(ub, nb, edge))
             loss.backward()
+            model.reduce_grads()                                          # one grouped all-reduce of the stage weights
             opt.step()
         ksteps = max(2, min(args.steps, 20))
-        for _ in range(min(args.warmup, 3)):
-            step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(ksteps):
-            step()
-        sync()
-        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        out.update({"bpr_pairs_per_s": round(B * ksteps / float(t), 1), "train_ms_per_step": round(1e3 * float(t) / ksteps, 3),
-                    "train_steps": ksteps, "batch": B})
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+        model.comm.launches = 0
+        step()
+        per_step = model.comm.launches
+        t_tr = timed(step, min(args.warmup, 3), ksteps)
+        extra.update({"bpr_pairs_per_s": round(B * ksteps / t_tr, 1), "train_ms_per_step": round(1e3 * t_tr / ksteps, 3),
+                      "train_steps": ksteps, "batch": B, "collective_launches_per_train_step": per_step})
+        model.eval()
+
+    eager_line = line(t_eager, "eager", launches_fwd, extra)
+    if getattr(args, "eager", False) or os.environ.get("NGACF_DIST_GRAPH") == "0":
+        if rank == 0:
+            emit(eager_line)
+        dist.destroy_process_group()
+        return
+
+    # ---- (3) forward as one hipGraph, under a watchdog -----------------------------------------------------------
+    lock, done = threading.Lock(), []
+
+    def finish(text, hard):
+        with lock:
+            if not done:
+                done.append(1)
+                if rank == 0:
+                    emit(text)
+        if hard:                                   # a rank may be stuck inside a collective: leave without teardown
+            os._exit(0)
+
+    dog = threading.Timer(float(os.environ.get("NGACF_DIST_GRAPH_TIMEOUT", "90")), finish, (eager_line, True))
+    dog.daemon = True
+    dog.start()
+    try:
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fwd()
+            torch.cuda.current_stream().wait_stream(side)
+            sync()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fwd()
+            t_graph = timed(graph.replay, args.warmup, args.steps)
+    except Exception as e:                         # capture refused here (maybe not on the peers): the eager numbers stand
+        import sys
+        print("[bench] sharded hipGraph capture not used: %r" % (e,), file=sys.stderr, flush=True)
+        finish(eager_line, True)
+    dog.cancel()
+    better = t_graph < t_eager                     # t_* are already max-over-ranks: every rank decides alike
+    finish(line(t_graph, "hipGraph replay (kernels + grouped RCCL launches)", launches_fwd, extra) if better else eager_line, False)
     dist.destroy_process_group()

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tag, multi, q):
+def _worker(rank, world, port, tag, multi, defer, q):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, HERE)
@@ -37,12 +37,15 @@ def _worker(rank, world, port, tag, multi, q):
         sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
         m = ShardedSPUIGACF(U, I, 64, [64, 64], 0.0, world, rank, stages=3 if multi else 2, backend=fake_backend)
         m.load_full_state_dict(sd)
+        m.comm.defer_weight_reduce = defer
         m.train()
         edge = torch.from_numpy(g["edge"])
         u, pos, neg = (torch.from_numpy(g[k]) for k in ("u", "pos", "neg"))
         ps, ns = m(u, pos, edge), m(u, neg, edge)
         loss = -torch.log(torch.sigmoid(ps - ns)).mean()
         loss.backward()
+        if defer:
+            m.reduce_grads()                  # one all-reduce per step instead of one per stage
         p = m.part
         nu, ni = p.n_real_local()
         err = {}
@@ -71,12 +74,13 @@ def _worker(rank, world, port, tag, multi, q):
         q.put((rank, {"exception": "%s\n%s" % (e, traceback.format_exc())}))
 
 
-@pytest.mark.parametrize("world,tag,multi", [(2, "spuigacf", False), (2, "spuimultigacf", True), (3, "spuigacf", False)])
-def test_sharded_model_matches_reference_under_gloo(world, tag, multi):
+@pytest.mark.parametrize("world,tag,multi,defer", [(2, "spuigacf", False, False), (2, "spuimultigacf", True, True),
+                                                   (3, "spuigacf", False, True)])
+def test_sharded_model_matches_reference_under_gloo(world, tag, multi, defer):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tag, multi, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tag, multi, defer, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
