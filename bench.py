@@ -155,6 +155,19 @@ def main():
                 "traffic": None, "bytes_per_launch": int(avg_bytes), "avg_launch_us": round(avg_ms * 1e3, 2),
                 "per_stage_us": [round(x * 1e3, 2) for x in per_stage_ms],
                 "edges_per_s_in_kernel": round(2 * E / (avg_ms * 1e-3), 1)}
+    # the box's own streaming rate next to the spec peak: device-to-device copy of 1 GiB (read + write counted)
+    cp_a = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    cp_b = torch.empty_like(cp_a)
+    for _ in range(3):
+        cp_b.copy_(cp_a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        cp_b.copy_(cp_a)
+    e1.record()
+    torch.cuda.synchronize()
+    roofline["measured_copy_GBps"] = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    del cp_a, cp_b
     # HBM-side bytes per launch from the committed PMC passes of this same command (profiles/): separate
     # --pmc FETCH_SIZE / WRITE_SIZE runs with the gfx950 correction of MI355X_MICROARCH.md §HBM
     tf = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % wl)
@@ -199,6 +212,21 @@ def main():
         train = {"bpr_pairs_per_s": round(B * ksteps / t_tr, 1), "train_ms_per_step": round(1e3 * t_tr / ksteps, 3),
                  "train_steps": ksteps, "batch": B, "droprate": args.droprate, "final_loss": round(float(loss.detach()), 6),
                  "fwd_bwd_traversals_per_s": round(4 * trav_per_step * ksteps / t_tr, 1)}
+        if not args.eager:
+            # reported SEPARATELY: the opt-in mode that shares one propagation between the
+            # positive and the negative scoring of a step -- not reference semantics, never the headline number
+            opt2 = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True, fused=True)
+            gshared = GraphedBPRStep(model, lossfn, opt2, edge, B, shared_propagation=True)
+            for _ in range(min(args.warmup, 3)):
+                gshared(upn)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(ksteps):
+                gshared(upn)
+            sync()
+            t_sh = time.perf_counter() - t0
+            train["shared_propagation_optin"] = {"bpr_pairs_per_s": round(B * ksteps / t_sh, 1),
+                                                 "train_ms_per_step": round(1e3 * t_sh / ksteps, 3)}
 
     # ---------------- CPU baseline: reference operator order on the host cores (checker code) -------------
     cpu = None

@@ -264,6 +264,10 @@ class _GATBase(nn.Module):
             # the concat layers, :214 around out_att) are fused into the stage
             x = NF.stage(x, W, avec, plan, len(layers), layers[0].alpha, True, p, p,
                          NF.stage_seed(base, s), self.compute_dtype, seed_dev)
+            if getattr(self, "debug_asserts", False):
+                # the reference's per-layer checks (SPUIGACF.py:384,391); a device sync each, so off by default.
+                # (:368, "every user has an edge", is enforced once at plan build.)
+                assert not bool(torch.isnan(x).any()), "NaN after propagation stage %d" % s
         return x
 
     def use_device_seed(self, device, on=True):
@@ -411,6 +415,13 @@ class _CFBase(nn.Module):
     def forward(self, userIdx, itemIdx, mask):
         features = self.propagate(mask)
         return NF.score(features, userIdx, itemIdx, self.userNum)    # :49-52
+
+    def forward_pairs(self, userIdx, posIdx, negIdx, mask):
+        """OPT-IN, not reference semantics: one propagation shared by the positive and the negative scoring of a
+        BPR step (the reference calls forward() twice, train_eval_Gowalla.py:128-129, i.e. two propagations with
+        independent dropout masks).  Identical to two forward() calls when droprate == 0 or in eval mode."""
+        features = self.propagate(mask)
+        return (NF.score(features, userIdx, posIdx, self.userNum), NF.score(features, userIdx, negIdx, self.userNum))
 
 
 class SPUIGACF(_CFBase):

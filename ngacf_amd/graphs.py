@@ -26,7 +26,7 @@ class GraphedBPRStep:
 
     optim must be capturable (torch.optim.Adam(..., capturable=True)); batch size is fixed at capture."""
 
-    def __init__(self, model, lossfn, optim, adj, batch_size, warmup=3):
+    def __init__(self, model, lossfn, optim, adj, batch_size, warmup=3, shared_propagation=False):
         dev = next(model.parameters()).device
         self.model, self.optim = model, optim
         for g in _gats(model):
@@ -40,7 +40,10 @@ class GraphedBPRStep:
             for g in gats:
                 g.advance_device_seed()                     # one captured add per step: fresh masks every replay
             optim.zero_grad(set_to_none=True)
-            loss = lossfn(model(self.u, self.p, adj), model(self.u, self.n, adj))
+            if shared_propagation:                          # opt-in: one propagation per step (model.forward_pairs)
+                loss = lossfn(*model.forward_pairs(self.u, self.p, self.n, adj))
+            else:                                           # reference semantics: two forwards, two propagations
+                loss = lossfn(model(self.u, self.p, adj), model(self.u, self.n, adj))
             loss.backward()
             optim.step()
             return loss

@@ -129,3 +129,35 @@ def test_graphed_step_equals_eager_and_redraws_dropout():
     with torch.no_grad():
         ref = md.propagate(adj)
     assert torch.equal(gp(), ref)
+
+
+@pytest.mark.gpu
+def test_forward_pairs_equals_two_forwards_without_dropout_and_debug_asserts():
+    """The opt-in shared-propagation entry point gives the reference's numbers whenever the two forwards of a step
+    would have seen the same propagation (droprate 0); debug_asserts reproduces the reference's NaN check."""
+    import ngacf_amd
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(3)
+    U, I, B = 300, 200, 128
+    uu = np.concatenate([np.arange(U), rs.randint(0, U, 4000)]); ii = np.concatenate([rs.randint(0, I, U), rs.randint(0, I, 4000)])
+    key = np.unique(uu.astype(np.int64) * I + ii)
+    adj = torch.from_numpy(np.stack([key // I, key % I])).to(dev)
+    u, p, n = (torch.from_numpy(rs.randint(0, hi, B)).to(dev) for hi in (U, I, I))
+    torch.manual_seed(1)
+    m = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev).train()
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30); m.iEmbd.weight.mul_(30)
+    lossfn = ngacf_amd.BPRLoss()
+    l2 = lossfn(m(u, p, adj), m(u, n, adj)); l2.backward()
+    g2 = {k: v.grad.clone() for k, v in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    l1 = lossfn(*m.forward_pairs(u, p, n, adj)); l1.backward()
+    assert abs(float(l1) - float(l2)) < 1e-6
+    for k, v in m.named_parameters():
+        assert float((v.grad - g2[k]).abs().max()) <= 1e-5 * max(1.0, float(g2[k].abs().max())), k
+    m.gat.debug_asserts = True
+    m(u, p, adj)                                                    # clean run passes the checks
+    with torch.no_grad():
+        m.uEmbd.weight[0, 0] = float("nan")
+    with pytest.raises(AssertionError):
+        m(u, p, adj)
