@@ -91,3 +91,36 @@ def algorithmic_bytes_stage(U, I, E, din, dout, elem_bytes):
     trav = 2 * E * (4 + dout * elem_bytes) + N * (2 * dout * elem_bytes + 8)
     trans = N * (din + dout) * elem_bytes
     return trav, trans
+
+
+# ---------------------------------------------------------------------------------------------------------
+# on-disk adjacency caches of the reference (data/loadGowalla.py:229-253: scipy `save_npz` files next to the CSVs)
+# ---------------------------------------------------------------------------------------------------------
+ADJ_FILES = {"ui_mat": "s_ui_adj.npz", "plain_adj": "s_plain_adj.npz", "norm_adj": "s_norm_adj.npz", "mean_adj": "s_mean_adj.npz"}
+
+
+def load_adj_npz(path):
+    """A scipy sparse .npz (any format save_npz wrote) -> (indices [2,nnz] int64, values [nnz] float32, shape),
+    in `.coalesce()` order (row-major sorted, duplicates summed) like get_adj_mat's return (:253)."""
+    import scipy.sparse as sp
+    m = sp.load_npz(path).tocsr()
+    m.sum_duplicates()
+    m.sort_indices()
+    coo = m.tocoo()
+    return (np.stack([coo.row.astype(np.int64), coo.col.astype(np.int64)]), coo.data.astype(np.float32), tuple(m.shape))
+
+
+def save_adj_npz(path, indices, values, shape):
+    import scipy.sparse as sp
+    indices = np.asarray(indices)
+    sp.save_npz(path, sp.coo_matrix((np.asarray(values), (indices[0], indices[1])), shape=shape))
+
+
+def load_ui_mat(root, U=None, I=None):
+    """`s_ui_adj.npz` (the U x I interaction matrix, adj_type 'ui_mat') -> the [2,E] mask SPUIGACF.forward takes.
+    The stored ratings are ignored by the attention path, as in the reference (only `.indices()` is used,
+    train_eval_Gowalla.py:97-104)."""
+    idx, _, shape = load_adj_npz(os.path.join(root, ADJ_FILES["ui_mat"]))
+    if U is not None and (shape[0] > U or shape[1] > I):
+        raise ValueError("s_ui_adj.npz is %s, model is %d x %d" % (shape, U, I))
+    return idx

@@ -66,3 +66,14 @@ def mean_adj_coo(indices, U, I):
     deg = torch.bincount(r, minlength=U + I).float()
     dis = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
     return r, c, dis[r] * dis[c]
+
+
+def norm_adj_coo(indices, U, I):
+    """`norm_adj` of data/loadGowalla.py:196-222: (D+I)^-1/2 (A + I) (D+I)^-1/2 -- the self loop is inside the
+    normalisation.  COO (rows, cols, vals) over the (U+I) x (U+I) block matrix, diagonal entries last."""
+    u, i = indices[0].long(), indices[1].long() + U
+    n = torch.arange(U + I, device=indices.device)
+    r, c = torch.cat([u, i, n]), torch.cat([i, u, n])
+    deg = torch.bincount(r, minlength=U + I).float()           # >= 1 everywhere: the loop counts
+    dis = deg.pow(-0.5)
+    return r, c, dis[r] * dis[c]

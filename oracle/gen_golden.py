@@ -217,6 +217,17 @@ def g7_static_spmm(edge, U, I):
          L_col=Lt.indices()[1].numpy(), L_val=Lt.values().numpy(), out=out.numpy())
 
 
+def g7b_norm_adj(edge, U, I):
+    """adj_type 'norm_adj' and 'plain_adj' straight from the reference's buildLaplacianMat."""
+    import pandas as pd
+    from data.loadGowalla import buildLaplacianMat
+    rt = pd.DataFrame({"userId": edge[0], "itemId": edge[1], "rating": np.ones(edge.shape[1])})
+    L = buildLaplacianMat(rt, U, I, "norm_adj").tocsr()
+    L.sort_indices()
+    L = L.tocoo()
+    save("g7b_norm_adj", edge=edge, U=U, I=I, row=L.row.astype(np.int64), col=L.col.astype(np.int64), val=L.data.astype(np.float64))
+
+
 def g8_metrics():
     import train_eval_Gowalla as TE
     rs = np.random.RandomState(8)
@@ -278,12 +289,15 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     edge = toy_graph()
     U, I = 50, 40
+    if "--only-g7b" in sys.argv:                      # added after the first batch: leaves the other fixtures untouched
+        return g7b_norm_adj(edge[:, edge[1] < 37], U, 37)
     g1_layers(edge, U, I)
     g2_g3_g4_model(edge, U, I, multi=False, tag="spuigacf")
     g2_g3_g4_model(edge, U, I, multi=True, tag="spuimultigacf")
     g4b_fixed_dropout(edge, U, I)
     g6_spga()
     g7_static_spmm(edge[:, edge[1] < 37], U, 37)      # buildLaplacianMat infers shapes from max ids
+    g7b_norm_adj(edge[:, edge[1] < 37], U, 37)
     g8_metrics()
     g9_g10_ml100k()
 

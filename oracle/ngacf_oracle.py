@@ -268,6 +268,19 @@ def mean_adj(edge, U, I, rating=None):
     return L.row, L.col, L.data
 
 
+def norm_adj(edge, U, I):
+    """data/loadGowalla.py:196-222 adj_type == 'norm_adj': normalize_adj(adj + selfLoop)."""
+    N = U + I
+    r = np.ones(edge.shape[1])
+    A = sp.coo_matrix((np.concatenate([r, r]),
+                       (np.concatenate([edge[0], edge[1] + U]), np.concatenate([edge[1] + U, edge[0]]))),
+                      shape=(N, N)).tocsr() + sp.eye(N, format="csr")
+    deg = np.asarray(A.sum(axis=1)).reshape(N)
+    dis = np.power(deg, -0.5)
+    L = (sp.diags(dis) @ A @ sp.diags(dis)).tocoo()
+    return L.row, L.col, L.data
+
+
 # --------------------------------------------------------------------------
 # metrics (graphattention/metrics.py) and eval ranking (train_eval_Gowalla.py)
 # --------------------------------------------------------------------------

@@ -170,3 +170,33 @@ def test_pair_sampler_semantics():
     assert int(neg.max()) <= 47 and int((neg >= 40).sum()) > 0      # test items can be drawn as negatives
     adj = d.adjacency()
     assert adj.shape[1] == len(train | set(zip(te_u.tolist(), te_i.tolist())))
+
+
+def test_adjacency_npz_ingest_and_normalised_variants(tmp_path):
+    """N3: the reference's scipy .npz adjacency caches load into the [2,E] mask in coalesce() order, whatever
+    format/ordering they were saved in; mean_adj / norm_adj match the oracle's scipy restatement."""
+    import scipy.sparse as sp
+    from oracle import ngacf_oracle as O
+    from ngacf_amd import data as D
+    from ngacf_amd.spmm import mean_adj_coo, norm_adj_coo
+    g = load_golden("g1_layer_k8_concat")
+    U, I, edge = int(g["U"]), int(g["I"]), g["edge"]
+    perm = np.random.RandomState(0).permutation(edge.shape[1])
+    e2 = np.concatenate([edge[:, perm], edge[:, :5]], 1)                      # shuffled + duplicates
+    for fmt in ("coo", "csr", "csc"):
+        m = sp.coo_matrix((np.ones(e2.shape[1]), (e2[0], e2[1])), shape=(U, I)).asformat(fmt)
+        sp.save_npz(str(tmp_path / D.ADJ_FILES["ui_mat"]), m)
+        idx = D.load_ui_mat(str(tmp_path), U, I)
+        assert np.array_equal(idx, edge), fmt
+    with pytest.raises(ValueError):
+        D.load_ui_mat(str(tmp_path), U - 1, I)
+    D.save_adj_npz(str(tmp_path / "x.npz"), edge, np.arange(edge.shape[1]) + 1.0, (U, I))
+    idx, val, shape = D.load_adj_npz(str(tmp_path / "x.npz"))
+    assert np.array_equal(idx, edge) and np.array_equal(val, np.arange(edge.shape[1]) + 1.0) and shape == (U, I)
+    N = U + I
+    for ours, ref in ((mean_adj_coo, O.mean_adj), (norm_adj_coo, O.norm_adj)):
+        r, c, v = ours(torch.from_numpy(edge), U, I)
+        a = sp.coo_matrix((v.numpy().astype(np.float64), (r.numpy(), c.numpy())), shape=(N, N)).toarray()
+        rr, cc, vv = ref(edge, U, I)
+        b = sp.coo_matrix((vv, (rr, cc)), shape=(N, N)).toarray()
+        assert np.abs(a - b).max() < 1e-6

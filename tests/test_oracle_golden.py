@@ -139,3 +139,19 @@ def test_cpu_baseline_matches_goldens(tag, multi):
     x = torch.cat([p["uEmbd.weight"], p["iEmbd.weight"]])
     out = CB.forward(p, x, torch.from_numpy(g["edge"]), U, I, O.stage_names(multi))
     assert _maxabs(out.numpy(), g["F_f32"]) < 5e-6
+
+
+def test_g7b_norm_adj_matches_reference_builder():
+    """adj_type 'norm_adj' (data/loadGowalla.py:196-222) as the reference's own buildLaplacianMat produced it:
+    pins the oracle restatement and the host-side builder."""
+    import scipy.sparse as sp
+    import torch
+    from ngacf_amd.spmm import norm_adj_coo
+    g = load_golden("g7b_norm_adj")
+    U, I, edge = int(g["U"]), int(g["I"]), g["edge"]
+    N = U + I
+    ref = sp.coo_matrix((g["val"], (g["row"], g["col"])), shape=(N, N)).toarray()
+    r, c, v = O.norm_adj(edge, U, I)
+    assert np.abs(sp.coo_matrix((v, (r, c)), shape=(N, N)).toarray() - ref).max() < 1e-12
+    r, c, v = norm_adj_coo(torch.from_numpy(edge), U, I)
+    assert np.abs(sp.coo_matrix((v.numpy().astype(np.float64), (r.numpy(), c.numpy())), shape=(N, N)).toarray() - ref).max() < 1e-6
