@@ -65,31 +65,16 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
     const int loc_off = users ? a.u_lo : a.U + a.i_lo - a.u_n;  // global row - loc_off = local row
     const uint32_t salt = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
 
-    {   // weight panel -> bf16 A fragments: A[i][k] = W[k][i] (forward) or W[i][k] (dX)
-        const float* M = a.M + (size_t)type * DIN * DOUT;
-        for (int slot = tid; slot < KS * OT * 64; slot += 256) {
-            const int l = slot & 63, t = (slot >> 6) % OT, s = (slot >> 6) / OT;
-            const int i = 32 * t + (l & 31), k0 = 16 * s + 8 * (l >> 5);
-            float f[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = FWD ? M[(size_t)(k0 + j) * DOUT + i] : M[(size_t)i * DOUT + k0 + j];
-            Af[slot] = pack8(f);
-        }
-    }
-    __syncthreads();
-
     const int r = lane & 31, h = lane >> 5;
     const TB* Bg = static_cast<const TB*>(a.B);
-#pragma unroll 1
-    for (int it = 0; it < a.tpw; ++it) {
+    // node-row operand of one 32-row tile -> bf16 B fragments (16 contiguous bytes of the node's row per k-step)
+    auto load_tile = [&](int it, bf16x8 (&bf)[KS], int& nd_out, bool& ok_out) {
         const int tile = (bl * 4 + wave) * a.tpw + it;
-        if (tile >= ntiles) break;
         const int node = win_lo + tile * 32 + r;
-        const bool ok = node < win_end;
+        const bool ok = tile < ntiles && node < win_end;
         const int nd = ok ? node : win_end - 1;
+        nd_out = nd; ok_out = ok;
         const size_t brow = (size_t)(a.b_local ? nd - loc_off : nd);
-
-        bf16x8 bf[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int c0 = 16 * s + 8 * h;
@@ -111,6 +96,28 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
                 bf[s] = pack8(f);
             }
         }
+    };
+    bf16x8 bf[KS];
+    int nd;
+    bool ok;
+    load_tile(0, bf, nd, ok);            // in flight while the workgroup builds the weight panel
+
+    {   // weight panel -> bf16 A fragments: A[i][k] = W[k][i] (forward) or W[i][k] (dX)
+        const float* M = a.M + (size_t)type * DIN * DOUT;
+        for (int slot = tid; slot < KS * OT * 64; slot += 256) {
+            const int l = slot & 63, t = (slot >> 6) % OT, s = (slot >> 6) / OT;
+            const int i = 32 * t + (l & 31), k0 = 16 * s + 8 * (l >> 5);
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = FWD ? M[(size_t)(k0 + j) * DOUT + i] : M[(size_t)i * DOUT + k0 + j];
+            Af[slot] = pack8(f);
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int it = 0; it < a.tpw; ++it) {
+        if ((bl * 4 + wave) * a.tpw + it >= ntiles) break;
         f32x16 acc[OT];
 #pragma unroll
         for (int t = 0; t < OT; ++t)
@@ -122,6 +129,9 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
             for (int t = 0; t < OT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[(s * OT + t) * 64 + lane], bf[s], acc[t], 0, 0, 0);
 
+        const int nd_cur = nd;
+        const bool ok_cur = ok;
+        if (it + 1 < a.tpw) load_tile(it + 1, bf, nd, ok);     // next tile's rows fly under this tile's epilogue
         // lane: node r (+ half h); acc[t][4g + j] = output column 32t + 8g + 4h + j
         if constexpr (FWD) {
             const float* av = a.avec + type * DOUT;
@@ -145,20 +155,25 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
                     p = fmaf(v[1], a4.y, p); p = fmaf(v[2], a4.z, p); p = fmaf(v[3], a4.w, p);
                     head_part[t * 4 + g] = p;
                     total += p;
-                    if (ok) *reinterpret_cast<uint2*>(Hg + (size_t)nd * DOUT + c) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+                    if (ok_cur) *reinterpret_cast<uint2*>(Hg + (size_t)nd_cur * DOUT + c) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
                 }
             if (HEADS == 1) {
                 total += __shfl_xor(total, 32, 64);
-                if (ok && h == 0) a.S[nd] = total;
+                if (ok_cur && h == 0) a.S[nd_cur] = total;
             } else {                                   // 8-wide heads: head 4t+g = this lane's 4 columns + the other half's
+                float p[OT * 4];
 #pragma unroll
-                for (int q = 0; q < OT * 4; ++q) {
-                    const float p = head_part[q] + __shfl_xor(head_part[q], 32, 64);
-                    if (ok && h == 0) a.S[(size_t)nd * HEADS + q] = p;
+                for (int q = 0; q < OT * 4; ++q) p[q] = head_part[q] + __shfl_xor(head_part[q], 32, 64);
+                // half 0 stores heads 0..3 (+8..11), half 1 heads 4..7 (+12..15): one 16-byte store per lane and group
+#pragma unroll
+                for (int q0 = 0; q0 < OT * 4; q0 += 8) {
+                    const float4 v = h == 0 ? make_float4(p[q0], p[q0 + 1], p[q0 + 2], p[q0 + 3])
+                                            : make_float4(p[q0 + 4], p[q0 + 5], p[q0 + 6], p[q0 + 7]);
+                    if (ok_cur) *reinterpret_cast<float4*>(a.S + (size_t)nd_cur * HEADS + q0 + 4 * h) = v;
                 }
             }
         } else {
-            const size_t orow = (size_t)(a.out_local ? nd - loc_off : nd);
+            const size_t orow = (size_t)(a.out_local ? nd_cur - loc_off : nd_cur);
 #pragma unroll
             for (int t = 0; t < OT; ++t)
 #pragma unroll
@@ -168,9 +183,9 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         v[j] = acc[t][4 * g + j];
-                        if (DROP) v[j] = feat_bits(salt, nd, c + j) >= a.drop_thr ? v[j] * a.drop_scale : 0.f;
+                        if (DROP) v[j] = feat_bits(salt, nd_cur, c + j) >= a.drop_thr ? v[j] * a.drop_scale : 0.f;
                     }
-                    if (!ok) continue;
+                    if (!ok_cur) continue;
                     if constexpr (sizeof(TO) == 4) {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow * DIN + c) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {

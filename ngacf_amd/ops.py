@@ -111,7 +111,7 @@ def _plan_ptrs(plan, dev):
 # bitwise equal to the two-kernel path: tests/test_gpu_parity.py).  Measured 31.5 us against 27 + 4.9 us for the
 # two kernels (a release-fence form: 75 us) -- a 2 us gain that does not pay for an inter-workgroup protocol on
 # the default path, so the plain second kernel stays the default.
-INKERNEL_HUB_FINISH = False
+INKERNEL_HUB_FINISH = __import__("os").environ.get("NGACF_INKERNEL_HUB") == "1"
 
 
 def _hub(plan, dev):
