@@ -159,7 +159,7 @@ int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const int64_t* i
                     const float* gscore, float* gF, int B, int U, int d, void* stream);
 
 /* BPR loss  -mean(log(sigmoid(pos - neg)))  (graphattention/BPRLoss.py:8-9).
- * loss is a single float, accumulated with atomics: zero it first. */
+ * loss is a single float; the function overwrites it (no pre-zeroing needed). */
 int ngacf_bpr_fwd(const float* pos, const float* neg, float* loss, int B, void* stream);
 /* gpos[b] = -gloss * sigmoid(neg-pos) / B ; gneg = -gpos */
 int ngacf_bpr_bwd(const float* pos, const float* neg, const float* gloss,
@@ -170,6 +170,16 @@ int ngacf_bpr_bwd(const float* pos, const float* neg, const float* gloss,
 int ngacf_spmm_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                    const int32_t* col, const float* val, const void* X, int dtype,
                    void* out, float* part_acc, int N, int d, int self_loop, void* stream);
+
+/* All-item ranking of the evaluation: for each of the B users the K (<= 32) best-scoring candidate items,
+ * score(u, i) = F[u] . F[U + i], candidates = items with pool_mask[i] != 0 minus the user's train positives
+ * (train_ptr/train_items: CSR over users, items ascending inside a row), best first, ties to the lower item id.
+ * Replaces the host-side ranking of train_eval_Gowalla.py:274-354 (per-block score transfer) and :370-385
+ * (heapq.nlargest(K, ...) per user in a process pool); the [B][I] score matrix is never materialised.
+ * top_items[b][r] = -1 (top_scores = -FLT_MAX) when user b has fewer than r+1 candidates.  d in {64, 128}. */
+int ngacf_eval_topk(const void* F, int dtype, const int64_t* users, int B, int U, int I, int d,
+                    const uint8_t* pool_mask, const int64_t* train_ptr, const int32_t* train_items,
+                    int K, int32_t* top_items, float* top_scores, void* stream);
 
 /* Counter-hash dropout mask bits, exposed so tests can pin the device RNG against the
  * host restatement: bits[k] = the 32-bit hash the kernels compare against drop_p * 2^32.

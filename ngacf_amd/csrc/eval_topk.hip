@@ -1,0 +1,302 @@
+// All-item ranking of the evaluation: for every evaluated user the K best-scoring
+// candidate items, candidates = item pool minus the user's train positives, ties broken by the lower item id.
+// Replaces train_eval_Gowalla.py:274-354 (score blocks shipped to the host) + :370-385 (heapq.nlargest per user
+// in a process pool).  The [users x items] score matrix is a dense contraction -> matrix cores; it is never
+// written to memory: a wave keeps the running top-K of its 32 users and only scores that beat a user's current
+// K-th best leave the accumulator registers.
+//
+//   workgroup = 32 users x all items, 4 waves; wave w takes the 32-item tiles t = w (mod 4)
+//   tile      = S[32 users][32 items] by v_mfma_f32_32x32x2_f32 (fp32 table: exact products, fp32 accumulate)
+//               or v_mfma_f32_32x32x16_bf16 (bf16 table: products of bf16 values are exact in fp32 too)
+//   select    = per accumulator register (one user per 32-lane half): score > tau_user; the rare survivors
+//               append THEMSELVES to the user's LDS buffer (K live entries + slack; slot by LDS atomic, no
+//               wave-serial work); when a buffer overflows the wave compacts it: train positives of the user out (first 64 cached in LDS), every entry
+//               ranked against the others in registers, the K best rewritten in order, tau_user raised
+//   finish    = the 4 waves' lists of a user are merged by rank ((score desc, item asc) is a total order)
+//
+// Items stream in ascending id order inside a wave, so "score > tau" (strict) is exactly the stable descending
+// sort's tie rule; the cross-wave merge compares ids explicitly.
+#include "ngacf_common.hpp"
+
+namespace ngacf {
+
+typedef __attribute__((ext_vector_type(16))) float tk_f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 tk_bf16x8;
+
+constexpr int TK_MAXK = 32;          // largest K
+constexpr int TK_CAP = 48;           // buffer entries per (wave, user): K live + slack between compactions
+constexpr int TK_CACHE = 64;          // train items of a user kept in LDS
+constexpr float TK_NEG = -3.402823466e38f;
+
+// largest float below x (finite x): "score > below(t)" is "score >= t"
+__device__ __forceinline__ float tk_below(float x) {
+    const int b = __float_as_int(x);
+    return x > 0.f ? __int_as_float(b - 1) : (x < 0.f ? __int_as_float(b + 1) : -1.401298464e-45f);
+}
+
+struct TopkArgs {
+    const void* F;                 // [U+I][d] propagated embeddings
+    const int64_t* users;          // [B] user ids
+    const uint8_t* pool;           // [I] 1 = item is a candidate at all
+    const int64_t* train_ptr;      // [U+1] CSR of the train positives
+    const int32_t* train_items;    // sorted inside a row
+    int32_t* top_items;            // [B][K], -1 when a user has fewer than K candidates
+    float* top_scores;             // [B][K]
+    int B, U, I, K;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int NA = BF ? D / 16 : D / 2;        // operand registers (bf16x8 fragments / floats) per row
+    // plain (not volatile) LDS arrays: volatile accesses are emitted as system-coherent flat_load/flat_store, an order
+    // of magnitude slower than ds_read/ds_write.  In-wave ordering needs nothing more: LDS executes a wave's
+    // operations in order and the compiler keeps may-aliasing accesses to one array in program order.
+    __shared__ float l_score[4][32][TK_CAP];
+    __shared__ int l_item[4][32][TK_CAP];
+    __shared__ int l_cnt[4][32];
+    __shared__ int c_item[32][TK_CACHE];
+    __shared__ int c_deg[32];
+    // best K-th-best any of the 4 waves holds for a user, stored one ulp lower: another wave's candidate with exactly
+    // that score may carry a lower item id and must still get through (ties go to the lower id)
+    __shared__ float g_tau[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    const int u0 = blockIdx.x * 32;
+    const int K = a.K;
+
+    // ---- per-user state: empty lists, the first TK_CACHE train items ---------------------------------------
+    if (lane < 32) l_cnt[wave][lane] = 0;
+    if (tid < 32) g_tau[tid] = TK_NEG;
+    for (int i = wave; i < 32; i += 4) {
+        const int ub = u0 + i;
+        int deg = 0;
+        if (ub < a.B) {
+            const int64_t u = a.users[ub];
+            const int64_t p0 = a.train_ptr[u];
+            deg = (int)(a.train_ptr[u + 1] - p0);
+            if (lane < deg && lane < TK_CACHE) c_item[i][lane] = a.train_items[p0 + lane];
+        }
+        if (lane == 0) c_deg[i] = deg;
+    }
+
+    // ---- A operand: this lane's user row (users past the batch end take the last one and never select) ------
+    const int my_u = u0 + col < a.B ? u0 + col : a.B - 1;
+    const T* urow = static_cast<const T*>(a.F) + (size_t)a.users[my_u] * D;
+    float af[BF ? 1 : NA];
+    tk_bf16x8 ab[BF ? NA : 1];
+    if constexpr (BF) {
+#pragma unroll
+        for (int s = 0; s < NA; ++s) ab[s] = *reinterpret_cast<const tk_bf16x8*>(reinterpret_cast<const uint16_t*>(urow) + 16 * s + 8 * kh);
+    } else {
+#pragma unroll
+        for (int s = 0; s < NA; s += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(urow) + kh * (D / 2) + s);
+            af[s] = v.x; af[s + 1] = v.y; af[s + 2] = v.z; af[s + 3] = v.w;
+        }
+    }
+    // threshold of the user behind accumulator register e in this lane's half: user (e&3) + 8(e>>2) + 4 kh
+    float tau[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tau[e] = (u0 + (e & 3) + 8 * (e >> 2) + 4 * kh) < a.B ? TK_NEG : 3.402823466e38f;
+    __syncthreads();
+
+    const T* items = static_cast<const T*>(a.F) + (size_t)a.U * D;
+    const int ntiles = (a.I + 31) / 32;
+
+    // The wave compacts user ui's buffer of n entries: train positives out, the K best kept in rank order
+    // ((score desc, item asc) is a total order, so ranks are distinct).  Returns the new entry count; `own` = the
+    // K-th best when K entries remain.  All arguments are wave-uniform.
+    auto compact = [&](int ui, int n, float& own) -> int {
+        own = TK_NEG;
+        if (n == 0) return 0;
+        const bool live = lane < n;
+        const float s_t = live ? l_score[wave][ui][lane] : TK_NEG;
+        const int i_t = live ? l_item[wave][ui][lane] : 0x7fffffff;
+        const int deg = c_deg[ui];
+        const int nc = deg < TK_CACHE ? deg : TK_CACHE;
+        bool member = false;
+        for (int c = 0; c < nc; ++c) member |= i_t == c_item[ui][c];          // broadcast reads
+        if (deg > TK_CACHE && live && !member && i_t > c_item[ui][TK_CACHE - 1]) {
+            const int64_t p0 = a.train_ptr[a.users[u0 + ui]];
+            int lo = TK_CACHE, hi = deg;                                       // per-lane binary search over the uncached tail
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (a.train_items[p0 + mid] < i_t) lo = mid + 1; else hi = mid;
+            }
+            member = lo < deg && a.train_items[p0 + lo] == i_t;
+        }
+        const bool valid = live && !member;
+        const unsigned long long vm = __ballot(valid);
+        int rank = 0;
+        for (int t = 0; t < n; ++t) {
+            if (!((vm >> t) & 1ull)) continue;
+            const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s_t), t));
+            const int i2 = __builtin_amdgcn_readlane(i_t, t);
+            rank += (s2 > s_t || (s2 == s_t && i2 < i_t)) ? 1 : 0;
+        }
+        const int nvalid = __popcll(vm);
+        const int ncnt = nvalid < K ? nvalid : K;
+        if (valid && rank < K) {
+            l_score[wave][ui][rank] = s_t;
+            l_item[wave][ui][rank] = i_t;
+        }
+        if (ncnt == K) {
+            const unsigned long long last = __ballot(valid && rank == K - 1);
+            own = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s_t), __builtin_ctzll(last)));
+        }
+        return ncnt;
+    };
+
+#pragma unroll 1
+    for (int tile = wave; tile < ntiles; tile += 4) {
+        const int j = tile * 32 + col;
+        const bool jv = j < a.I;
+        const int jj = jv ? j : a.I - 1;
+        const T* irow = items + (size_t)jj * D;
+        const bool cand = jv && a.pool[jj] != 0;
+        tk_f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        if constexpr (BF) {
+            tk_bf16x8 bb[NA];
+#pragma unroll
+            for (int s = 0; s < NA; ++s) bb[s] = *reinterpret_cast<const tk_bf16x8*>(reinterpret_cast<const uint16_t*>(irow) + 16 * s + 8 * kh);
+#pragma unroll
+            for (int s = 0; s < NA; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[s], bb[s], acc, 0, 0, 0);
+        } else {
+            float bfv[NA];
+#pragma unroll
+            for (int s = 0; s < NA; s += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(irow) + kh * (D / 2) + s);
+                bfv[s] = v.x; bfv[s + 1] = v.y; bfv[s + 2] = v.z; bfv[s + 3] = v.w;
+            }
+#pragma unroll
+            for (int s = 0; s < NA; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bfv[s], acc, 0, 0, 0);
+        }
+
+        // acc[e] in lane (col, kh) = score(user (e&3) + 8(e>>2) + 4kh, item tile*32 + col)
+        if (((tile - wave) & 28) == 0) {                   // every 8th tile of this wave: what the other waves found
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tau[e] = fmaxf(tau[e], g_tau[(e & 3) + 8 * (e >> 2) + 4 * kh]);
+        }
+        // survivors append themselves to their user's buffer: one LDS atomic for the slot, no wave-serial work
+        unsigned int pend = 0u;                            // bit e: this lane's score of register e found the buffer full
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = cand ? acc[e] : TK_NEG;
+            const bool pass = v > tau[e];
+            if (__ballot(pass) == 0ull) continue;
+            if (pass) {
+                const int ui = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                const int pos = atomicAdd(&l_cnt[wave][ui], 1);
+                if (pos < TK_CAP) {
+                    l_score[wave][ui][pos] = v;
+                    l_item[wave][ui][pos] = j;
+                } else {
+                    pend |= 1u << e;
+                }
+            }
+        }
+        while (__ballot(pend != 0u) != 0ull) {             // rare: some buffer overflowed -> compact it, raise tau, retry
+            const int c = lane < 32 ? l_cnt[wave][lane] : 0;
+            unsigned int over = (unsigned int)__ballot(lane < 32 && c >= TK_CAP);
+            while (over) {
+                const int ui = __builtin_ctz(over);
+                over &= over - 1u;
+                float own;
+                const int n = compact(ui, TK_CAP, own);
+                if (lane == 0) l_cnt[wave][ui] = n;
+                if (n == K) {
+                    if (lane == 0 && tk_below(own) > g_tau[ui]) g_tau[ui] = tk_below(own);   // racy on purpose (see g_tau)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if ((e & 3) + 8 * (e >> 2) + 4 * kh == ui) tau[e] = fmaxf(tau[e], own);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (!(pend & (1u << e))) continue;
+                const float v = cand ? acc[e] : TK_NEG;
+                pend &= ~(1u << e);
+                if (v > tau[e]) {
+                    const int ui = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    const int pos = atomicAdd(&l_cnt[wave][ui], 1);
+                    if (pos < TK_CAP) {
+                        l_score[wave][ui][pos] = v;
+                        l_item[wave][ui][pos] = j;
+                    } else {
+                        pend |= 1u << e;
+                    }
+                }
+            }
+        }
+    }
+    // leave every list compacted: valid entries only, best first, at most K
+    for (int ui = 0; ui < 32; ++ui) {
+        float own;
+        const int have = l_cnt[wave][ui];
+        const int cnt = compact(ui, have < TK_CAP ? have : TK_CAP, own);
+        if (lane == 0) l_cnt[wave][ui] = cnt;
+    }
+    __syncthreads();
+
+    // ---- merge the 4 waves' lists of each user by rank ----------------------------------------------------------
+    for (int ui = wave; ui < 32; ui += 4) {
+        const int ub = u0 + ui;
+        if (ub >= a.B) continue;
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) total += l_cnt[w][ui];
+#pragma unroll 1
+        for (int c = lane; c < 4 * TK_MAXK; c += 64) {
+            const int w = c / TK_MAXK, p = c % TK_MAXK;     // compacted lists hold at most K <= TK_MAXK entries
+            if (p >= l_cnt[w][ui]) continue;
+            const float s = l_score[w][ui][p];
+            const int it = l_item[w][ui][p];
+            int rank = 0;
+            for (int w2 = 0; w2 < 4; ++w2) {
+                const int n2 = l_cnt[w2][ui];
+                for (int p2 = 0; p2 < n2; ++p2) {
+                    const float s2 = l_score[w2][ui][p2];
+                    const int it2 = l_item[w2][ui][p2];
+                    rank += (s2 > s || (s2 == s && it2 < it)) ? 1 : 0;
+                }
+            }
+            if (rank < K) {
+                a.top_items[(size_t)ub * K + rank] = it;
+                a.top_scores[(size_t)ub * K + rank] = s;
+            }
+        }
+        const int filled = total < K ? total : K;
+        if (lane >= filled && lane < K) {
+            a.top_items[(size_t)ub * K + lane] = -1;
+            a.top_scores[(size_t)ub * K + lane] = TK_NEG;
+        }
+    }
+}
+
+}  // namespace ngacf
+
+using namespace ngacf;
+
+extern "C" int ngacf_eval_topk(const void* F, int dtype, const int64_t* users, int B, int U, int I, int d,
+                               const uint8_t* pool_mask, const int64_t* train_ptr, const int32_t* train_items,
+                               int K, int32_t* top_items, float* top_scores, void* stream) {
+    if (B < 0 || U <= 0 || I <= 0 || K <= 0 || K > TK_MAXK) return NGACF_E_ARG;
+    if (B == 0) return 0;
+    if (!F || !users || !pool_mask || !train_ptr || !train_items || !top_items || !top_scores) return NGACF_E_ARG;
+    TopkArgs a;
+    a.F = F; a.users = users; a.pool = pool_mask; a.train_ptr = train_ptr; a.train_items = train_items;
+    a.top_items = top_items; a.top_scores = top_scores; a.B = B; a.U = U; a.I = I; a.K = K;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((B + 31) / 32), block(256);
+    if (dtype == NGACF_F32 && d == 64) hipLaunchKernelGGL((eval_topk_kernel<float, 64>), grid, block, 0, st, a);
+    else if (dtype == NGACF_F32 && d == 128) hipLaunchKernelGGL((eval_topk_kernel<float, 128>), grid, block, 0, st, a);
+    else if (dtype == NGACF_BF16 && d == 64) hipLaunchKernelGGL((eval_topk_kernel<bf16_t, 64>), grid, block, 0, st, a);
+    else if (dtype == NGACF_BF16 && d == 128) hipLaunchKernelGGL((eval_topk_kernel<bf16_t, 128>), grid, block, 0, st, a);
+    else return NGACF_E_SHAPE;
+    NGACF_CHECK_LAUNCH();
+    return 0;
+}

@@ -359,3 +359,23 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
                                   dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
                                   float(drop_p), int(seed), 0, flags, _stream()), "ngacf_prop_bwd")
     return dH, dS
+
+
+def eval_topk(F, users, U, I, pool_mask, train_ptr, train_items, K=20):
+    """top_items [B,K] int32 (-1 = no candidate left), top_scores [B,K] fp32: the K best candidate items of every
+    user, candidates = pool minus the user's train positives, ties to the lower item id (ngacf_eval_topk)."""
+    dev, d, B = F.device, F.shape[1], users.numel()
+    if d not in SUPPORTED_D or F.dtype not in _DT:
+        raise ValueError("unsupported F: d=%d dtype=%s" % (d, F.dtype))
+    if not 0 < K <= 32:
+        raise ValueError("K must be in 1..32")
+    fp = _chk(F, "F", None, (U + I) * d, dev)
+    top_i = torch.empty(B, K, dtype=torch.int32, device=dev)
+    top_s = torch.empty(B, K, dtype=torch.float32, device=dev)
+    if B:
+        _lib.check(lib.ngacf_eval_topk(fp, _DT[F.dtype], _chk(users, "users", torch.int64, B, dev), B, U, I, d,
+                                       _chk(pool_mask, "pool_mask", torch.uint8, I, dev),
+                                       _chk(train_ptr, "train_ptr", torch.int64, U + 1, dev),
+                                       _chk(train_items, "train_items", torch.int32, train_items.numel(), dev),
+                                       K, top_i.data_ptr(), top_s.data_ptr(), _stream()), "ngacf_eval_topk")
+    return top_i, top_s

@@ -17,6 +17,8 @@ embeddings once (the reference recomputes a bit-identical propagation for every 
 import numpy as np
 import torch
 
+from . import ops
+
 KS = (1, 5, 10, 20)
 
 
@@ -38,10 +40,12 @@ class Interactions:
         self.train_ptr = torch.zeros(U + 1, dtype=torch.long, device=dev)
         self.train_ptr[1:] = torch.cumsum(torch.bincount(ku, minlength=U), 0)     # CSR of the train positives
         self.train_items = self.train_keys % I
+        self.train_items32 = self.train_items.to(torch.int32)
         pool = torch.zeros(I, dtype=torch.bool, device=dev)
         pool[self.train_i] = True
         pool[self.test_i] = True
         self.pool_mask = pool
+        self.pool_mask_u8 = pool.to(torch.uint8)
         self.pool_items = torch.nonzero(pool).squeeze(1)
         self.train_users = torch.unique(self.train_u)                              # len(train_pos_neg), :283
         tu = self.test_keys // I
@@ -122,36 +126,29 @@ def metrics_from_hits(r, npos, n_norm):
 
 
 @torch.no_grad()
-def eval_neg_all(model, batch_size, data, adj, user_batch=4096, return_scores=False):
+def eval_neg_all(model, batch_size, data, adj, user_batch=1 << 20, return_scores=False):
     """All-item evaluation.  Users = those with test positives that also appear in train (the merge at
     train_eval_Gowalla.py:307); normaliser = number of train users (:283)."""
     model.eval()
-    F = model.propagate(adj).float()                                  # once: eval mode is deterministic
+    F = model.propagate(adj).contiguous()                             # once: eval mode is deterministic
     U, I = data.U, data.I
     has_test = (data.test_ptr[1:] - data.test_ptr[:-1]) > 0
     has_train = (data.train_ptr[1:] - data.train_ptr[:-1]) > 0
     users = torch.nonzero(has_test & has_train).squeeze(1)
     n_norm = float(data.train_users.numel())
     res = {k: torch.zeros(len(KS), dtype=torch.double, device=data.device) for k in ("precision", "recall", "ndcg", "hit_ratio")}
-    Fi = F[U:]
-    neg_inf = torch.finfo(torch.float32).min
     kept = []
     for s in range(0, users.numel(), user_batch):
-        ub = users[s:s + user_batch]
-        scores = F[ub] @ Fi.t()                                       # dense [B, I] GEMM (rocBLAS via torch)
+        ub = users[s:s + user_batch].contiguous()
+        # scoring F_u . F_i^T on the matrix cores fused with the top-20 selection (ngacf_eval_topk): candidates =
+        # pool - train positives, best first, ties to the lower item id (= the stable sort of heapq.nlargest's input)
+        top, top_s = ops.eval_topk(F, ub, U, I, data.pool_mask_u8, data.train_ptr, data.train_items32, 20)
         if return_scores:
-            kept.append(scores.clone())
-        scores[:, ~data.pool_mask] = neg_inf                          # candidates: pool − train positives
-        rows = torch.repeat_interleave(torch.arange(ub.numel(), device=data.device),
-                                       data.train_ptr[ub + 1] - data.train_ptr[ub])
-        cols = _gather_rows(data.train_ptr, data.train_items, ub)
-        scores[rows, cols] = neg_inf
-        top = torch.sort(scores, dim=1, descending=True, stable=True).indices[:, :20]   # ties: lower item id first
-        key = ub[:, None] * I + top
+            kept.append(F[ub].float() @ F[U:].float().t())
+        valid = top >= 0                                              # fewer than 20 candidates
+        key = ub[:, None] * I + top.long().clamp_(min=0)
         j = torch.searchsorted(data.test_keys, key.reshape(-1)).clamp_(max=data.test_keys.numel() - 1)
-        r = (data.test_keys[j] == key.reshape(-1)).reshape(top.shape)
-        valid = torch.gather(scores, 1, top) > neg_inf                # fewer than 20 candidates
-        r = r & valid
+        r = (data.test_keys[j] == key.reshape(-1)).reshape(top.shape) & valid
         npos = data.test_ptr[ub + 1] - data.test_ptr[ub]
         m = metrics_from_hits(r, npos, n_norm)
         for k in res:

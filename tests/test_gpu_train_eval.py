@@ -161,3 +161,58 @@ def test_forward_pairs_equals_two_forwards_without_dropout_and_debug_asserts():
         m.uEmbd.weight[0, 0] = float("nan")
     with pytest.raises(AssertionError):
         m(u, p, adj)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,dt", [(64, "fp32"), (64, "bf16"), (128, "fp32"), (128, "bf16")])
+def test_eval_topk_kernel_matches_stable_sort_exactly(d, dt):
+    """ngacf_eval_topk (MFMA scoring fused with top-K selection) against masked scores + stable descending sort.
+    Integer-valued embeddings make every dot product exact in fp32 whatever the summation order, and produce
+    thousands of exact score ties, so the comparison is bit-for-bit including the tie rule (lower item id first)."""
+    from ngacf_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(d)
+    U, I, K = 333, 1777, 20
+    F = torch.randint(-2, 3, (U + I, d), device=dev, generator=g).float()
+    Fq = F.to(torch.bfloat16) if dt == "bf16" else F
+    pool = torch.rand(I, device=dev, generator=g) < 0.9
+    pool[:40] = True
+    # train positives: user 0 is a hub with 300 items (beyond the 64 cached in LDS), user 1 leaves < K candidates
+    deg = torch.randint(1, 30, (U,), device=dev, generator=g)
+    deg[0] = 300
+    rows = torch.repeat_interleave(torch.arange(U, device=dev), deg)
+    cols = torch.randint(0, I, (rows.numel(),), device=dev, generator=g)
+    hub_cols = torch.randperm(I, device=dev, generator=g)[:300]
+    cols[:300] = hub_cols
+    all_items = torch.arange(I, device=dev)
+    keep1 = all_items[pool][:7]                                            # user 1: everything but 7 pool items is "train"
+    m1 = torch.ones(I, dtype=torch.bool, device=dev); m1[keep1] = False
+    rows = torch.cat([rows, torch.full((int(m1.sum()),), 1, device=dev)])
+    cols = torch.cat([cols, all_items[m1]])
+    key = torch.unique(rows * I + cols)
+    ku, ki = key // I, key % I
+    ptr = torch.zeros(U + 1, dtype=torch.long, device=dev)
+    ptr[1:] = torch.cumsum(torch.bincount(ku, minlength=U), 0)
+    users = torch.cat([torch.arange(0, 150, device=dev), torch.arange(200, U, device=dev)])   # 283: not a multiple of 32
+    top, top_s = ops.eval_topk(Fq, users, U, I, pool.to(torch.uint8), ptr, ki.to(torch.int32), K)
+    sc = F[users] @ F[U:].t()
+    neg = torch.finfo(torch.float32).min
+    sc[:, ~pool] = neg
+    mask = torch.zeros(U, I, dtype=torch.bool, device=dev); mask[ku, ki] = True
+    sc[mask[users]] = neg
+    order = torch.sort(sc, dim=1, descending=True, stable=True)
+    want_i, want_s = order.indices[:, :K], order.values[:, :K]
+    valid = want_s > neg
+    assert int((~valid).sum()) > 0                                          # the short-candidate-list case is exercised
+    assert torch.equal(top.long()[valid], want_i[valid]) and bool((top[~valid] == -1).all())
+    assert torch.equal(top_s[valid], want_s[valid])
+    # random real-valued table: same sets up to fp32 summation order (scores agree to 1e-5)
+    Fr = torch.randn(U + I, d, device=dev, generator=g)
+    Fr = Fr.to(torch.bfloat16) if dt == "bf16" else Fr
+    top, top_s = ops.eval_topk(Fr, users, U, I, pool.to(torch.uint8), ptr, ki.to(torch.int32), K)
+    sc = Fr[users].float() @ Fr[U:].float().t()
+    sc[:, ~pool] = neg; sc[mask[users]] = neg
+    want_s = torch.sort(sc, dim=1, descending=True, stable=True).values[:, :K]
+    ok = want_s > neg
+    assert float((top_s[ok] - want_s[ok]).abs().max()) < 1e-3 * float(want_s[ok].abs().max())
+    assert ops.eval_topk(Fq, users[:0], U, I, pool.to(torch.uint8), ptr, ki.to(torch.int32), K)[0].shape == (0, K)

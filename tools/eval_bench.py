@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--workload", default="gowalla")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--user-batch", type=int, default=4096)
+    ap.add_argument("--user-batch", type=int, default=1 << 20)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     U, I, E = D.SHAPES[a.workload]
