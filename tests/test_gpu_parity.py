@@ -2,6 +2,8 @@
 CPU oracle on the same inputs, against the reference-generated golden fixtures, and -- at
 Gowalla scale -- through size-independent properties.  fp32 bar: max-abs 1e-4 (north_star);
 tighter where the arithmetic allows.  Run with:  pytest -m gpu"""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -574,3 +576,28 @@ def test_inkernel_hub_finish_is_bitwise_equal_to_two_kernel_path(dev):
                     torch.randn(4_000_000, device=dev).sum()
         finally:
             ops.INKERNEL_HUB_FINISH = False
+
+
+def test_integration_md_stub_runs(dev):
+    """The ctypes binding shown in INTEGRATION.md is executed verbatim (library path redirected to the in-tree .so)
+    and must reproduce the packaged stage."""
+    import re
+    from conftest import ROOT
+    from ngacf_amd import functional as NF
+    from ngacf_amd.plan import build_plan
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\nimport ctypes, torch\n(.*?)```", md, flags=re.S).group(0)[len("```python\n"):-3]
+    code = code.replace('"libngacf_hip.so"', repr(os.path.join(ROOT, "ngacf_amd", "lib", "libngacf_hip.so")))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    g = load_golden("g1_layer_k8_concat")
+    U, I = int(g["U"]), int(g["I"])
+    plan = build_plan(_t(g["edge"], dev), U, I)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn(U + I, 64, device=dev, generator=gen)
+    W = torch.randn(2, 64, 64, device=dev, generator=gen) * 0.2
+    avec = torch.randn(2, 64, device=dev, generator=gen) * 0.2
+    for heads in (8, 1):
+        got = ns["stage"](plan, X, W, avec, heads)
+        want = NF.stage(X, W, avec, plan, heads)
+        assert torch.equal(got, want)
