@@ -181,6 +181,16 @@ int ngacf_eval_topk(const void* F, int dtype, const int64_t* users, int B, int U
                     const uint8_t* pool_mask, const int64_t* train_ptr, const int32_t* train_items,
                     int K, int32_t* top_items, float* top_scores, void* stream);
 
+/* BPR pair sampler: for batch row r, u = users[offset + (offset_dev ? *offset_dev : 0) + r]; pos = a uniform draw from
+ * the user's train positives (CSR train_ptr/train_items, items ascending); neg = a uniform draw from
+ * pool_items[0..P) that is not a train positive of u (rejection, at most 64 rounds; rows that fail bump *unresolved).
+ * Replaces data/loadGowalla.py:63-77 (per-user Python sets + random.choice per row).  Randomness: counter hash of
+ * (seed + *seed_dev, row, round) -- host restatement: ngacf_amd/rng.py:sample_pairs_host. */
+int ngacf_sample_pairs(const int64_t* users, long long offset, const int64_t* offset_dev,
+                       const int64_t* train_ptr, const int32_t* train_items,
+                       const int32_t* pool_items, int P, uint64_t seed, const uint64_t* seed_dev,
+                       int64_t* u_out, int64_t* pos_out, int64_t* neg_out, int* unresolved, int B, void* stream);
+
 /* Counter-hash dropout mask bits, exposed so tests can pin the device RNG against the
  * host restatement: bits[k] = the 32-bit hash the kernels compare against drop_p * 2^32.
  * kind 0: feature mask, a = node, b = column.  kind 1: edge mask, a = user, b = item (global id), c = head. */

@@ -26,11 +26,28 @@ class GraphedBPRStep:
 
     optim must be capturable (torch.optim.Adam(..., capturable=True)); batch size is fixed at capture."""
 
-    def __init__(self, model, lossfn, optim, adj, batch_size, warmup=3, shared_propagation=False):
+    def __init__(self, model, lossfn, optim, adj, batch_size, warmup=3, shared_propagation=False, data=None,
+                 preserve_state=False):
+        """data: a train_eval.Interactions -> the graph also SAMPLES its batch (ngacf_sample_pairs over the rows
+        train_u[offset : offset+B], offset and sampler seed advanced by captured adds): use begin_epoch()/replay().
+        preserve_state: put parameters and optimizer state back after the warm-up steps (a training loop must not
+        see them)."""
         dev = next(model.parameters()).device
         self.model, self.optim = model, optim
         for g in _gats(model):
             g.use_device_seed(dev, True)
+        self.data = data
+        if data is not None:
+            from . import ops
+            from .train_eval import SAMPLE_STRIDE
+            self.offset = torch.zeros(1, dtype=torch.int64, device=dev)       # first row of the batch in train_u
+            self.sample_seed = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.unresolved = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.total = torch.zeros((), device=dev)                          # sum of the batch losses of the epoch
+        saved = None
+        if preserve_state:
+            saved = ([p.detach().clone() for p in model.parameters()],
+                     {id(t): t.detach().clone() for st in optim.state.values() for t in st.values() if torch.is_tensor(t)})
         self.upn = torch.zeros(3, batch_size, dtype=torch.long, device=dev)     # users / positives / negatives
         self.u, self.p, self.n = self.upn[0], self.upn[1], self.upn[2]
         model.train()
@@ -39,6 +56,12 @@ class GraphedBPRStep:
         def step():
             for g in gats:
                 g.advance_device_seed()                     # one captured add per step: fresh masks every replay
+            if data is not None:                            # the batch itself: rows offset .. offset+B of train_u
+                ops.sample_pairs(data.train_u, 0, batch_size, data.train_ptr, data.train_items32, data.pool_items32,
+                                 0, out=self.upn, unresolved=self.unresolved, offset_dev=self.offset,
+                                 seed_dev=self.sample_seed)
+                self.offset.add_(batch_size)
+                self.sample_seed.add_(SAMPLE_STRIDE)
             optim.zero_grad(set_to_none=True)
             if shared_propagation:                          # opt-in: one propagation per step (model.forward_pairs)
                 loss = lossfn(*model.forward_pairs(self.u, self.p, self.n, adj))
@@ -46,6 +69,8 @@ class GraphedBPRStep:
                 loss = lossfn(model(self.u, self.p, adj), model(self.u, self.n, adj))
             loss.backward()
             optim.step()
+            if data is not None:
+                self.total.add_(loss.detach())
             return loss
 
         side = torch.cuda.Stream()
@@ -58,6 +83,25 @@ class GraphedBPRStep:
         optim.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.loss = step()
+        if saved is not None:                               # undo the warm-up updates, in place (the graph holds these tensors)
+            with torch.no_grad():
+                for p, v in zip(model.parameters(), saved[0]):
+                    p.copy_(v)
+                for st in optim.state.values():
+                    for t in st.values():
+                        if torch.is_tensor(t):
+                            t.copy_(saved[1][id(t)]) if id(t) in saved[1] else t.zero_()
+
+    def begin_epoch(self, seed):
+        """Sampling mode: start at row 0 of train_u with sampler seed `seed`."""
+        self.offset.zero_()
+        self.sample_seed.fill_(int(seed))
+        self.total.zero_()
+        self.unresolved.zero_()
+
+    def replay(self):
+        self.graph.replay()
+        return self.loss
 
     def __call__(self, users, pos=None, neg=None):
         """step(users, pos, neg), or step(upn) with the three index rows packed as one [3, B] tensor (one copy)."""
@@ -90,3 +134,14 @@ class GraphedPropagate:
     def __call__(self):
         self.graph.replay()
         return self.out
+
+
+def graphed_epoch_step(model, lossfn, optim, adj, batch_size, data):
+    """The sampling GraphedBPRStep of (model, optimizer, adjacency, batch size, data), captured once and kept on the
+    model (train_bpr(graph=True) asks for it every epoch)."""
+    key = (id(optim), adj.data_ptr(), tuple(adj.shape), batch_size, id(data))
+    cache = model.__dict__.setdefault("_graphed_steps", {})
+    if key not in cache:
+        cache.clear()
+        cache[key] = GraphedBPRStep(model, lossfn, optim, adj, batch_size, data=data, preserve_state=True)
+    return cache[key]

@@ -379,3 +379,25 @@ def eval_topk(F, users, U, I, pool_mask, train_ptr, train_items, K=20):
                                        _chk(train_items, "train_items", torch.int32, train_items.numel(), dev),
                                        K, top_i.data_ptr(), top_s.data_ptr(), _stream()), "ngacf_eval_topk")
     return top_i, top_s
+
+
+def sample_pairs(train_u, offset, B, train_ptr, train_items32, pool_items32, seed, out=None, unresolved=None,
+                 offset_dev=None, seed_dev=None):
+    """(users, pos, neg) of the batch rows train_u[offset : offset+B] (ngacf_sample_pairs).  `out` = an int64 [3,B]
+    buffer to fill (GraphedBPRStep's static input); `offset_dev`/`seed_dev` = optional int64[1] device addends."""
+    dev = train_u.device
+    if out is None:
+        out = torch.empty(3, B, dtype=torch.int64, device=dev)
+    if unresolved is None:
+        unresolved = torch.zeros(1, dtype=torch.int32, device=dev)
+    if B:
+        U = train_ptr.numel() - 1
+        _chk(out, "out", torch.int64, 3 * B, dev)
+        _lib.check(lib.ngacf_sample_pairs(_chk(train_u, "train_u", torch.int64, train_u.numel(), dev), int(offset), _sd(offset_dev, dev),
+                                          _chk(train_ptr, "train_ptr", torch.int64, U + 1, dev),
+                                          _chk(train_items32, "train_items", torch.int32, train_items32.numel(), dev),
+                                          _chk(pool_items32, "pool_items", torch.int32, pool_items32.numel(), dev),
+                                          pool_items32.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, _sd(seed_dev, dev),
+                                          out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                          _chk(unresolved, "unresolved", torch.int32, 1, dev), B, _stream()), "ngacf_sample_pairs")
+    return out, unresolved

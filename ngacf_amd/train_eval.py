@@ -47,6 +47,7 @@ class Interactions:
         self.pool_mask = pool
         self.pool_mask_u8 = pool.to(torch.uint8)
         self.pool_items = torch.nonzero(pool).squeeze(1)
+        self.pool_items32 = self.pool_items.to(torch.int32)
         self.train_users = torch.unique(self.train_u)                              # len(train_pos_neg), :283
         tu = self.test_keys // I
         self.test_ptr = torch.zeros(U + 1, dtype=torch.long, device=dev)
@@ -84,26 +85,75 @@ def sample_pairs(data, users, generator=None, max_rounds=64):
     return pos, neg
 
 
-def train_bpr(model, batch_size, data, adj, optim, lossfn, generator=None, log_every=0):
+SAMPLE_STRIDE = 0x2545F4914F6CDD1D                    # sampler seed step from one batch to the next
+
+
+def _epoch_seed(generator, dev):
+    if generator is None:
+        return int(torch.randint(0, 2 ** 62, (1,)).item())                # torch's CPU generator (torch.manual_seed)
+    return int(torch.randint(0, 2 ** 62, (1,), device=generator.device, generator=generator).item())
+
+
+def train_bpr(model, batch_size, data, adj, optim, lossfn, generator=None, log_every=0, graph=False):
+    """One epoch (train_eval_Gowalla.py:90-144).  On the GPU the pairs come from ngacf_sample_pairs (one launch per
+    batch, no host synchronisation); with graph=True every full batch is ONE hipGraph replay (sampler, 2 forwards,
+    loss, backward, optimizer: ngacf_amd.graphs.GraphedBPRStep; the optimizer must be capturable) and only a ragged
+    last batch runs eagerly.  Both modes draw the same pairs for the same seed."""
     model.train()
     n = data.train_u.numel()
+    B = batch_size
+    if data.device.type != "cuda":
+        return _train_bpr_host_sampler(model, B, data, adj, optim, lossfn, generator, log_every)
+    seed0 = _epoch_seed(generator, data.device)
     total = torch.zeros((), device=data.device)
-    n_batches = n // batch_size + 1                                  # train_eval_Gowalla.py:108
-    for b in range(n_batches):
-        users = data.train_u[b * batch_size:(b + 1) * batch_size]     # sequential slices, no shuffling (:111-115)
-        if users.numel() == 0:
+    unres = torch.zeros(1, dtype=torch.int32, device=data.device)
+    first_eager = 0
+    if graph and n >= B:
+        from .graphs import graphed_epoch_step
+        gs = graphed_epoch_step(model, lossfn, optim, adj, B, data)
+        gs.begin_epoch(seed0)
+        for _ in range(n // B):
+            gs.replay()
+        total += gs.total
+        unres += gs.unresolved
+        first_eager = n // B
+    n_batches = n // B + 1                                            # train_eval_Gowalla.py:108
+    for b in range(first_eager, n_batches):
+        rows = min(B, n - b * B)                                      # sequential slices, no shuffling (:111-115)
+        if rows <= 0:
             continue
-        pos, neg = sample_pairs(data, users, generator)
+        upn, _ = ops.sample_pairs(data.train_u, b * B, rows, data.train_ptr, data.train_items32, data.pool_items32,
+                                  seed0 + b * SAMPLE_STRIDE, unresolved=unres)
         optim.zero_grad(set_to_none=True)
-        pos_scores = model(users, pos, adj)                           # two full propagations with independent
-        neg_scores = model(users, neg, adj)                           # dropout masks (:131-132)
+        pos_scores = model(upn[0], upn[1], adj)                       # two full propagations with independent
+        neg_scores = model(upn[0], upn[2], adj)                       # dropout masks (:131-132)
         loss = lossfn(pos_scores, neg_scores)
         loss.backward()
         optim.step()
         total += loss.detach()
         if log_every and b % log_every == 0:
             print("  batch %d/%d loss %.5f" % (b, n_batches, float(loss.detach())), flush=True)
+    if int(unres) != 0:
+        raise RuntimeError("negative sampling did not converge (a user is positive on the whole item pool)")
     return float(total) / n                                           # :144 (sum of batch means / rows)
+
+
+def _train_bpr_host_sampler(model, batch_size, data, adj, optim, lossfn, generator=None, log_every=0):
+    """The same loop with the torch statement of the sampler (CPU tensors: host-logic tests)."""
+    n = data.train_u.numel()
+    total = torch.zeros((), device=data.device)
+    n_batches = n // batch_size + 1
+    for b in range(n_batches):
+        users = data.train_u[b * batch_size:(b + 1) * batch_size]
+        if users.numel() == 0:
+            continue
+        pos, neg = sample_pairs(data, users, generator)
+        optim.zero_grad(set_to_none=True)
+        loss = lossfn(model(users, pos, adj), model(users, neg, adj))
+        loss.backward()
+        optim.step()
+        total += loss.detach()
+    return float(total) / n
 
 
 def metrics_from_hits(r, npos, n_norm):

@@ -77,7 +77,9 @@ def main(args):
     print("adj.shape", tuple(adj.shape))
     model = create_model(args, data.U, data.I, dev)
     lossfn = ngacf_amd.BPRLoss()
-    optim = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    # capturable + fused: the optimizer step is part of the replayed hipGraph of a batch (train_bpr(graph=True))
+    optim = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay,
+                             capturable=not args.eager, fused=not args.eager)
     os.makedirs("ckpts", exist_ok=True)
     if args.resume_from:
         ck = torch.load("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, args.resume_from), map_location=dev)
@@ -88,7 +90,7 @@ def main(args):
     history = []
     for epoch in range(args.resume_from, args.epochs):
         t0 = time.time()
-        loss = train_bpr(model, args.batch_size, data, adj, optim, lossfn, gen)
+        loss = train_bpr(model, args.batch_size, data, adj, optim, lossfn, gen, graph=not args.eager)
         torch.cuda.synchronize()
         print("------epoch:{}, train_loss:{:5f}, time consuming:{:.2f}s".format(epoch, loss, time.time() - t0), flush=True)
         if (epoch + 1) % args.save_every == 0:
@@ -126,6 +128,7 @@ def parse(argv=None):
     p.add_argument("--gpu_id", type=str, default="0")
     p.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"])
     p.add_argument("--stages", type=int, default=0, help="0 = the model's own depth; L>0 = SPUIStackedGACF with L stages")
+    p.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of one hipGraph replay per batch")
     p.add_argument("--data_root", type=str, default="")
     p.add_argument("--synthetic", type=str, default="", choices=["", "ml100k", "gowalla", "yelp"])
     a = p.parse_args(argv)

@@ -216,3 +216,73 @@ def test_eval_topk_kernel_matches_stable_sort_exactly(d, dt):
     ok = want_s > neg
     assert float((top_s[ok] - want_s[ok]).abs().max()) < 1e-3 * float(want_s[ok].abs().max())
     assert ops.eval_topk(Fq, users[:0], U, I, pool.to(torch.uint8), ptr, ki.to(torch.int32), K)[0].shape == (0, K)
+
+
+@pytest.mark.gpu
+def test_pair_sampler_kernel_matches_host_statement_and_semantics():
+    """ngacf_sample_pairs: bit-exact against the numpy statement (ngacf_amd/rng.py), positives from the user's train
+    set, negatives from pool - train positives, both roughly uniform; offsets/seeds may come from device counters."""
+    from ngacf_amd import ops, rng
+    from ngacf_amd.train_eval import Interactions
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(1)
+    U, I = 40, 60
+    tu = np.repeat(np.arange(U), 8); ti = rs.randint(0, 50, tu.size)          # items 50..59 never in train
+    tu = np.concatenate([tu, np.zeros(45, dtype=np.int64)]); ti = np.concatenate([ti, np.arange(45)])   # user 0: 45 of the 58 pool items
+    te_u = np.arange(U); te_i = rs.randint(50, 58, U)                          # items 58, 59 outside the pool
+    d = Interactions(tu, ti, te_u, te_i, U, I, dev)
+    B = 4096
+    users = torch.from_numpy(np.tile(np.arange(U), B // U + 1)[:B]).to(dev)
+    upn, unres = ops.sample_pairs(users, 0, B, d.train_ptr, d.train_items32, d.pool_items32, 12345)
+    pos, neg, un = rng.sample_pairs_host(users.cpu().numpy(), d.train_ptr.cpu().numpy(), d.train_items32.cpu().numpy(),
+                                         d.pool_items32.cpu().numpy(), 12345)
+    assert int(unres) == un == 0
+    assert np.array_equal(upn[0].cpu().numpy(), users.cpu().numpy())
+    assert np.array_equal(upn[1].cpu().numpy(), pos) and np.array_equal(upn[2].cpu().numpy(), neg)
+    train = set(zip(tu.tolist(), ti.tolist()))
+    got_p = set(zip(users.tolist(), upn[1].tolist())); got_n = set(zip(users.tolist(), upn[2].tolist()))
+    assert got_p <= train and not (got_n & train)
+    assert int(upn[2].max()) <= 57 and int((upn[2] >= 50).sum()) > 0            # test items are legal negatives
+    assert len(got_p) > 0.9 * len(train)                                        # every positive is reachable
+    neg0 = upn[2][users == 0].cpu().numpy()                                      # the hub user: 13 legal negatives, ~uniform
+    cnt = np.bincount(neg0, minlength=I)
+    legal = np.nonzero(cnt)[0]
+    assert len(legal) == 13 and cnt[legal].min() > 0.3 * cnt[legal].mean()
+    # device-side offset and seed addends give the same rows as host values
+    off = torch.tensor([100], dtype=torch.int64, device=dev); sd = torch.tensor([345], dtype=torch.int64, device=dev)
+    a, _ = ops.sample_pairs(users, 0, 512, d.train_ptr, d.train_items32, d.pool_items32, 12000, offset_dev=off, seed_dev=sd)
+    b, _ = ops.sample_pairs(users, 100, 512, d.train_ptr, d.train_items32, d.pool_items32, 12345)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_graphed_epoch_equals_eager_epoch_without_dropout():
+    """train_bpr(graph=True): every full batch is one hipGraph replay that samples its own pairs; the ragged last
+    batch runs eagerly; warm-up steps of the capture leave no trace.  Same seeds -> same pairs -> same epoch."""
+    import ngacf_amd
+    from ngacf_amd.train_eval import Interactions, train_bpr
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(2)
+    U, I, B = 300, 200, 256
+    tu = np.concatenate([np.arange(U), rs.randint(0, U, 2500)]); ti = np.concatenate([rs.randint(0, I, U), rs.randint(0, I, 2500)])
+    te_u = rs.randint(0, U, 400); te_i = rs.randint(0, I, 400)
+    data = Interactions(tu, ti, te_u, te_i, U, I, dev)
+    adj = data.adjacency()
+    n = data.train_u.numel()
+    assert n % B != 0 and n // B >= 5
+
+    def run(graph):
+        torch.manual_seed(5)
+        m = ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.0).to(dev)
+        with torch.no_grad():
+            m.uEmbd.weight.mul_(30); m.iEmbd.weight.mul_(30)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True)
+        gen = torch.Generator(device=dev); gen.manual_seed(77)                  # epoch seeds (capturing draws from the CPU generator)
+        losses = [train_bpr(m, B, data, adj, opt, ngacf_amd.BPRLoss(), gen, graph=graph) for _ in range(2)]
+        return losses, m.uEmbd.weight.detach().clone(), m.gat.out_att.W_u.detach().clone()
+
+    le, we, ae = run(False)
+    lg, wg, ag = run(True)
+    assert np.allclose(le, lg, rtol=2e-5, atol=1e-9), (le, lg)
+    assert float((we - wg).abs().max()) < 2e-5 * float(we.abs().max()) + 1e-6
+    assert float((ae - ag).abs().max()) < 1e-4 * float(ae.abs().max()) + 1e-6
