@@ -1,0 +1,54 @@
+"""HBM-side traffic of the dominant kernel from PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
+WRITE_SIZE in SEPARATE rocprofv3 --pmc passes of the same bench command (kernel-trace only), units of KB, FETCH_SIZE
+doubled on gfx950.  Writes profiles/r01_traffic_<workload>.json (bench.py puts traffic_bytes into roofline.traffic).
+Run on the GPU box:  python tools/traffic.py gowalla   (this process never touches the GPU itself)."""
+import collections
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one_pass(counter, workload, dtype, tag):
+    out = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s_%s" % (tag, dtype, counter))
+    subprocess.run(["rm", "-rf", out])
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-train",
+           "--workload", workload, "--dtype", dtype]
+    subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    tot, n = collections.defaultdict(float), collections.defaultdict(int)
+    for root, _, files in os.walk(out):
+        for f in files:
+            if f.endswith("counter_collection.csv"):
+                for r in csv.DictReader(open(os.path.join(root, f))):
+                    if "prop_fwd_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        tot[counter] += float(r["Counter_Value"])
+                        n[counter] += 1
+    return tot[counter] / max(n[counter], 1), n[counter]
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "gowalla"
+    res = {"workload": wl, "stages": 3,
+           "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --steps 10 --warmup 2 "
+                      "--no-cpu-baseline --no-train --workload %s [--dtype fp32]  (tools/traffic.py)" % wl,
+           "by_dtype": {}}
+    for dt in ("bf16", "fp32"):
+        fetch, nf = one_pass("FETCH_SIZE", wl, dt, wl)
+        write, nw = one_pass("WRITE_SIZE", wl, dt, wl)
+        res["by_dtype"][dt] = {"kernel": "prop_fwd_kernel", "launches": [nf, nw], "fetch_size_kb": round(fetch, 1),
+                               "write_size_kb": round(write, 1),
+                               "traffic_bytes": int(round((2.0 * fetch + write) * 1024)),
+                               "note": "bytes crossing the L2<->fabric boundary per launch (Infinity-Cache hits included), "
+                                       "avg over the launches of all stages; FETCH_SIZE x2 = gfx950 correction"}
+        print(wl, dt, res["by_dtype"][dt], flush=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r01_traffic_%s.json" % wl), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
