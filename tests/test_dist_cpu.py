@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tag, multi, defer, q):
+def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, HERE)
@@ -32,10 +32,10 @@ def _worker(rank, world, port, tag, multi, defer, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import fake_backend
         from ngacf_amd.dist import ShardedSPUIGACF
-        g = dict(np.load(os.path.join(HERE, "golden", "g234_%s.npz" % tag)))
+        g = dict(np.load(tag if os.path.isabs(tag) else os.path.join(HERE, "golden", "g234_%s.npz" % tag)))
         U, I = int(g["U"]), int(g["I"])
         sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
-        m = ShardedSPUIGACF(U, I, 64, [64, 64], 0.0, world, rank, stages=3 if multi else 2, backend=fake_backend)
+        m = ShardedSPUIGACF(U, I, d, [64, 64], 0.0, world, rank, stages=stages or (3 if multi else 2), backend=fake_backend)
         m.load_full_state_dict(sd)
         m.comm.defer_weight_reduce = defer
         m.train()
@@ -102,3 +102,40 @@ def test_partition_covers_every_node_once():
         rows = np.concatenate([np.concatenate([np.arange(lo, hi) for lo, hi in p.row_ranges]) for p in parts])
         assert np.array_equal(np.sort(rows), np.arange(parts[0].N))
         assert sum(sum(p.n_real_local()) for p in parts) == U + I
+
+
+def test_sharded_d128_four_stages_matches_oracle_under_gloo(tmp_path):
+    """BASELINE config 3 (embedSize 128, L = 4, table sharded with one all-gather per stage) at world size 2: the
+    expected values come from the float64 oracle on the unsharded model."""
+    import torch
+    from oracle import ngacf_oracle as O
+    import ngacf_amd
+    rs = np.random.RandomState(4)
+    U, I, B = 70, 55, 48
+    uu = np.concatenate([np.arange(U), rs.randint(0, U, 900)]); ii = np.concatenate([rs.randint(0, I - 3, U), rs.randint(0, I - 3, 900)])
+    key = np.unique(uu.astype(np.int64) * I + ii)
+    edge = np.stack([key // I, key % I])
+    torch.manual_seed(9)
+    ref = ngacf_amd.SPUIStackedGACF(U, I, 128, [64, 64], 0.0, useCuda=False, stages=4)
+    sd = {k: v.detach().numpy().astype(np.float64) for k, v in ref.state_dict().items()}
+    sd["uEmbd.weight"] *= 8; sd["iEmbd.weight"] *= 8      # scores O(1): the worker's plain fp32 -log(sigmoid) stays finite
+    u, pos, neg = rs.randint(0, U, B), rs.randint(0, I, B), rs.randint(0, I, B)
+    loss, ps, ns, grads = O.bpr_step_grads(sd, u, pos, neg, edge, hidden=3)
+    path = str(tmp_path / "d128.npz")
+    np.savez(path, U=U, I=I, edge=edge, u=u, pos=pos, neg=neg, pos_f64=ps, neg_f64=ns, loss_f64=loss,
+             **{"p." + k: v.astype(np.float32) for k, v in sd.items()}, **{"g_f64." + k: v for k, v in grads.items()})
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, path, False, True, q, 128, 4)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err in res:
+        assert "exception" not in err, err.get("exception")
+        assert err["scores"] < 1e-5 and err["loss"] < 1e-5, (rank, err)
+        assert err["emb"] < 5e-4 and err["gat"] < 5e-4, (rank, err)
+        assert err["pad"] == 0.0 and err["sd"] == 0.0 and err["keys"], (rank, err)
