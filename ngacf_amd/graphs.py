@@ -27,7 +27,7 @@ class GraphedBPRStep:
     optim must be capturable (torch.optim.Adam(..., capturable=True)); batch size is fixed at capture."""
 
     def __init__(self, model, lossfn, optim, adj, batch_size, warmup=3, shared_propagation=False, data=None,
-                 preserve_state=False):
+                 preserve_state=False, concurrent_forwards=True):
         """data: a train_eval.Interactions -> the graph also SAMPLES its batch (ngacf_sample_pairs over the rows
         train_u[offset : offset+B], offset and sampler seed advanced by captured adds): use begin_epoch()/replay().
         preserve_state: put parameters and optimizer state back after the warm-up steps (a training loop must not
@@ -52,6 +52,7 @@ class GraphedBPRStep:
         self.u, self.p, self.n = self.upn[0], self.upn[1], self.upn[2]
         model.train()
         gats = _gats(model)
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 
         def step():
             for g in gats:
@@ -65,6 +66,20 @@ class GraphedBPRStep:
             optim.zero_grad(set_to_none=True)
             if shared_propagation:                          # opt-in: one propagation per step (model.forward_pairs)
                 loss = lossfn(*model.forward_pairs(self.u, self.p, self.n, adj))
+            elif concurrent_forwards:
+                # reference semantics (two forwards, two propagations) as two parallel branches of the graph: the
+                # chains are independent until the loss, and autograd replays each branch's backward on the stream
+                # of its forward, so the many small launch-bound kernels of one chain fill the gaps of the other
+                cur = torch.cuda.current_stream()
+                sa.wait_stream(cur)
+                sb.wait_stream(cur)
+                with torch.cuda.stream(sa):
+                    ps = model(self.u, self.p, adj)
+                with torch.cuda.stream(sb):
+                    ns = model(self.u, self.n, adj)
+                cur.wait_stream(sa)
+                cur.wait_stream(sb)
+                loss = lossfn(ps, ns)
             else:                                           # reference semantics: two forwards, two propagations
                 loss = lossfn(model(self.u, self.p, adj), model(self.u, self.n, adj))
             loss.backward()
