@@ -86,3 +86,30 @@ class _BPR(torch.autograd.Function):
 
 def bpr_loss(pos, neg):
     return _BPR.apply(pos, neg)
+
+
+class _ScorePairBPR(torch.autograd.Function):
+    """loss = BPR(score(Fa, u, pos), score(Fb, u, neg)) as ONE autograd node (SPUIGACF.py:49-52 twice + BPRLoss.py:8-9).
+    Used by the graphed step whose two propagations run as parallel branches: one node means both table gradients
+    leave the loss at the same point of the stream order, so both backward branches start together."""
+
+    @staticmethod
+    def forward(ctx, Fa, Fb, u, pos, neg, U):
+        Fa, Fb = Fa.contiguous(), Fb.contiguous()
+        u, pos, neg = u.contiguous().long(), pos.contiguous().long(), neg.contiguous().long()
+        ps, ns = ops.score_fwd(Fa, u, pos, U), ops.score_fwd(Fb, u, neg, U)
+        ctx.save_for_backward(Fa, Fb, u, pos, neg, ps, ns)
+        ctx.U = U
+        return ops.bpr_fwd(ps, ns)
+
+    @staticmethod
+    def backward(ctx, g):
+        Fa, Fb, u, pos, neg, ps, ns = ctx.saved_tensors
+        gp, gn = ops.bpr_bwd(ps, ns, g)
+        gFa = ops.score_bwd(Fa, u, pos, gp, ctx.U).to(Fa.dtype)
+        gFb = ops.score_bwd(Fb, u, neg, gn, ctx.U).to(Fb.dtype)
+        return gFa, gFb, None, None, None, None
+
+
+def score_pair_bpr(Fa, Fb, u, pos, neg, U):
+    return _ScorePairBPR.apply(Fa, Fb, u, pos, neg, U)
