@@ -128,7 +128,9 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  *   davec float[2][dout]        = sum_n dS[n,head(c)] * H[n,c]
  *   work  float[NGACF_TBWD_BLOCKS][din*dout + dout]: per-workgroup partial sums, reduced in
  *         workgroup order (no atomics: results are bitwise reproducible)
- * dH already contains the dS*avec term (ngacf_prop_bwd adds it). */
+ * dH already contains the dS*avec term (ngacf_prop_bwd adds it).
+ * Either half may be skipped: dX == NULL computes only dW/davec, dW == NULL (davec, work ignored) only dX, so a caller
+ * can put the two independent halves on different streams. */
 int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
                         const float* dH, const float* dS,
                         void* dX, float* dW, float* davec, float* work,

@@ -446,7 +446,9 @@ template <typename TX, typename TH, int DIN, int DOUT, int HEADS>
 static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool drop, hipStream_t st) {
     const int tu = (a.u_n + TM - 1) / TM, ti = (a.i_n + TM - 1) / TM;
     if (tu + ti == 0) return 0;
-    if constexpr (sizeof(TH) == 2) {   // bf16 storage: dX on the matrix cores
+    if (a.dX == nullptr) {
+        // caller asked for the weight gradients only (the dX half runs in another call, possibly on another stream)
+    } else if constexpr (sizeof(TH) == 2) {   // bf16 storage: dX on the matrix cores
         const int rc = transform_dx_mfma(a.dH, a.W, a.dX, sizeof(TX) == 2 ? NGACF_BF16 : NGACF_F32, a.U, a.I, DIN, DOUT, HEADS, a.u_lo, a.u_n, a.i_lo, a.i_n, a.x_local,
                                          a.drop_p, a.seed, a.seed_dev, st);
         if (rc != 0) return rc;
@@ -463,7 +465,7 @@ static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool dr
         }
         NGACF_CHECK_LAUNCH();
     }
-    {   // dW, davec
+    if (dW != nullptr) {   // dW, davec
         int nb = NGACF_TBWD_BLOCKS;
         if constexpr (sizeof(TH) == 2) {
             static const int tuned = [] { const char* e = getenv("NGACF_DW_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= NGACF_TBWD_BLOCKS ? v : 256; }();
@@ -525,7 +527,9 @@ extern "C" int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float*
                                         int u_lo, int u_n, int i_lo, int i_n, int x_local,
                                         float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     if (U < 0 || I < 0 || u_lo < 0 || u_n < 0 || i_lo < 0 || i_n < 0 || u_lo + u_n > U || i_lo + i_n > I) return NGACF_E_ARG;
-    if (!X || !W || !H || !dH || !dS || !dX || !dW || !davec || !work) return NGACF_E_ARG;
+    if (!X || !W || !H || !dH || !dS) return NGACF_E_ARG;
+    if (!dX && !dW) return NGACF_E_ARG;                          // one half may be left out (NULL), not both
+    if (dW && (!davec || !work)) return NGACF_E_ARG;
     if (!(feat_drop_p >= 0.f && feat_drop_p < 1.f)) return NGACF_E_ARG;
     TransBwdArgs a;
     a.X = X; a.W = W; a.H = H; a.dH = dH; a.dS = dS; a.dX = dX; a.work = work; a.U = U; a.I = I;
@@ -535,6 +539,7 @@ extern "C" int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float*
     const bool drop = feat_drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (u_n + i_n == 0) {                         // nothing owned: the sums are zero
+        if (!dW) return 0;
         hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * 2 * din * dout, st);
         if (e == hipSuccess) e = hipMemsetAsync(davec, 0, sizeof(float) * 2 * dout, st);
         return static_cast<int>(e);

@@ -183,8 +183,9 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     return dH, dS
 
 
-def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0, seed_dev=None):
-    """Returns dX [N,din], dW [2,din,dout], davec [2,dout] (all fp32)."""
+def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0, seed_dev=None, part="both"):
+    """Returns dX [N,din] (X's dtype), dW [2,din,dout], davec [2,dout] (fp32).  part = "dx" / "dw": only that half
+    (the other results are None) -- the halves are independent and may run on different streams."""
     dev, N = X.device, U + I
     din, dout = W.shape[1], W.shape[2]
     _heads_ok(dout, heads)
@@ -194,12 +195,17 @@ def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0, seed_de
     gp = _chk(dH, "dH", torch.float32, N * dout, dev)
     sp = _chk(dS, "dS", torch.float32, N * heads, dev)
     f32 = dict(dtype=torch.float32, device=dev)
-    dX = torch.empty(N, din, dtype=X.dtype, device=dev)
-    dW = torch.empty(2, din, dout, **f32)
-    da = torch.empty(2, dout, **f32)
-    work = torch.empty(_lib.TBWD_BLOCKS, din * dout + dout, **f32)
-    _lib.check(lib.ngacf_transform_bwd(xp, _DT[X.dtype], wp, hp, _DT[H.dtype], gp, sp, dX.data_ptr(), dW.data_ptr(),
-                                       da.data_ptr(), work.data_ptr(), U, I, din, dout, heads,
+    dX = dW = da = None
+    ptr = lambda t: t.data_ptr() if t is not None else 0
+    if part != "dw":
+        dX = torch.empty(N, din, dtype=X.dtype, device=dev)
+    work = None
+    if part != "dx":
+        dW = torch.empty(2, din, dout, **f32)
+        da = torch.empty(2, dout, **f32)
+        work = torch.empty(_lib.TBWD_BLOCKS, din * dout + dout, **f32)
+    _lib.check(lib.ngacf_transform_bwd(xp, _DT[X.dtype], wp, hp, _DT[H.dtype], gp, sp, ptr(dX), ptr(dW),
+                                       ptr(da), ptr(work), U, I, din, dout, heads,
                                        float(feat_drop_p), int(seed), _sd(seed_dev, dev), _stream()), "ngacf_transform_bwd")
     return dX, dW, da
 

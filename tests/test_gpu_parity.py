@@ -363,6 +363,11 @@ def test_bf16_transform_backward_on_matrix_cores(dev, din, dout, heads, xdt):
         Xb = (Xm * keep).to(torch.bfloat16).float()
         gb = dH.to(torch.bfloat16).float()
         Wb = W.to(torch.bfloat16).float()
+        # either half alone (NULL for the other) gives the same bits
+        only_dx = ops.transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=p, seed=11, part="dx")
+        only_dw = ops.transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=p, seed=11, part="dw")
+        assert only_dx[1] is None and only_dw[0] is None
+        assert torch.equal(only_dx[0], dX) and torch.equal(only_dw[1], dW) and torch.equal(only_dw[2], da)
         for t, (lo, hi) in enumerate(((0, U), (U, N))):
             ref_dw = Xb[lo:hi].T @ gb[lo:hi]
             assert float((dW[t] - ref_dw).abs().max()) <= 1e-4 * max(1.0, float(ref_dw.abs().max())), (t, U, I)
