@@ -240,7 +240,16 @@ def main():
         p_cpu = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
         x_cpu = torch.cat([p_cpu["uEmbd.weight"], p_cpu["iEmbd.weight"]])
         sec, iters = CB.time_forward(p_cpu, x_cpu, edge.cpu(), U, I, names, budget_s=args.cpu_budget)
+        model_name = "unknown"
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("model name"):
+                    model_name = ln.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
         cpu = {"value": round(trav_per_step / sec, 1), "unit": "edges/s", "cores": ncores, "kind": "port",
+               "cpu_model": model_name, "host_cpus": os.cpu_count(),
                "sample": "%d eval forward(s) of the same %s graph and weights (L=%d, fp32), %.2f s each, torch CPU ops in "
                          "the reference's operator order (oracle/cpu_baseline.py)" % (iters, wl, L, sec)}
 
