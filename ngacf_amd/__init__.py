@@ -9,3 +9,4 @@ from .BPRLoss import BPRLoss                                   # noqa: F401
 from .plan import GraphPlan, build_plan                        # noqa: F401
 from .SPUIGACF import (SPUIGACF, SPUIGAGPCF, SPUIMultiGACF, SPUIStackedGACF, GPLayer, SpUIGAT, SPUIMultiGAT,   # noqa: F401
                        SpUIGraphAttentionLayer, set_compute_dtype)
+from . import SPGA                                             # noqa: F401,E402  (SPGA.SpGraphAttentionLayer, SPGA.SpGAT)

@@ -606,3 +606,47 @@ def test_integration_md_stub_runs(dev):
         got = ns["stage"](plan, X, W, avec, heads)
         want = NF.stage(X, W, avec, plan, heads)
         assert torch.equal(got, want)
+
+
+def test_g6_spga_layer_and_spgat_forward_backward(dev):
+    """SPGA family (SPGA.py:330-421) on the bipartite double cover: the layer against the reference's own outputs
+    (G6, k=8/concat and k=64/no-concat), SpGAT forward + every gradient against a float64 torch statement."""
+    from ngacf_amd.SPGA import SpGAT, SpGraphAttentionLayer
+    g = load_golden("g6_spga_layer")
+    N = int(g["N"])
+    X = _t(g["X"], dev)
+    edge = _t(g["edge"], dev)
+    adj = torch.zeros(N, N, device=dev)
+    adj[edge[0], edge[1]] = 1.0
+    for tag, k, concat in (("k8", 8, True), ("k64", 64, False)):
+        l = SpGraphAttentionLayer(64, k, dropout=0.0, alpha=0.2, concat=concat).to(dev).eval()
+        with torch.no_grad():
+            l.W.copy_(_t(g["W_" + tag], dev)); l.a.copy_(_t(g["a_" + tag], dev))
+        for a in (adj, edge):                                    # dense adjacency (reference call) or the edge list
+            assert _maxabs(l(X, a), g["out_" + tag]) < 1e-5, tag
+    # SpGAT, train mode without dropout, all gradients
+    torch.manual_seed(2)
+    m = SpGAT(64, 8, 64, 0.0, 0.2, 8).to(dev).train()
+    Xr = X.clone().requires_grad_(True)
+    out = m(Xr, adj)
+    wgt = torch.randn(N, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    (out * wgt).sum().backward()
+
+    def ref_layer(x, W, a, concat):
+        k = W.shape[1]
+        h = x @ W
+        s = h[edge[0]] @ a[0, :k] + h[edge[1]] @ a[0, k:]
+        e = torch.exp(-torch.nn.functional.leaky_relu(s, 0.2))
+        R = torch.zeros(N, dtype=x.dtype, device=dev).index_add_(0, edge[0], e)
+        hp = torch.zeros(N, k, dtype=x.dtype, device=dev).index_add_(0, edge[0], e[:, None] * h[edge[1]]) / R[:, None]
+        return torch.nn.functional.elu(hp) if concat else hp
+
+    P = {n: p.detach().double().requires_grad_(True) for n, p in m.named_parameters()}
+    X64 = X.double().requires_grad_(True)
+    x1 = torch.cat([ref_layer(X64, P["attention_%d.W" % h], P["attention_%d.a" % h], True) for h in range(8)], 1)
+    ref = torch.nn.functional.elu(ref_layer(x1, P["out_att.W"], P["out_att.a"], False))
+    (ref * wgt.double()).sum().backward()
+    assert _maxabs(out, ref.detach().cpu().numpy()) < 1e-4
+    assert _maxabs(Xr.grad, X64.grad.cpu().numpy()) < 2e-4 * float(X64.grad.abs().max())
+    for n, p in m.named_parameters():
+        assert _maxabs(p.grad, P[n].grad.cpu().numpy()) < 5e-4 * max(float(P[n].grad.abs().max()), 1e-9), n
