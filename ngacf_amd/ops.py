@@ -12,7 +12,15 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16}
 SUPPORTED_D = (64, 128)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (the C-level getters cost ~0.3 us; the
+    torch.cuda.current_stream() object path ~5 us, which matters when a forward is ~20 launches)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -1,6 +1,8 @@
 """GPU tests of the callers of the hot path: evaluation against the oracle's
 restatement of eval_neg_all on the same score matrix, and a short ml100k training run whose metrics
 must land where the reference's own run lands (Recall@20 0.245 after 2 epochs)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -286,3 +288,26 @@ def test_graphed_epoch_equals_eager_epoch_without_dropout():
     assert np.allclose(le, lg, rtol=2e-5, atol=1e-9), (le, lg)
     assert float((we - wg).abs().max()) < 2e-5 * float(we.abs().max()) + 1e-6
     assert float((ae - ag).abs().max()) < 1e-4 * float(ae.abs().max()) + 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    """bench.py: exactly one line on stdout, a JSON object with the contract's keys, the roofline and the CPU baseline."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-budget", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "edges/s" and d["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    assert "workload" in d["config"] and d["value"] > 1e9 and d["bpr_pairs_per_s"] > 1e5
