@@ -25,7 +25,7 @@ import torch.nn as nn
 from . import functional as NF
 from . import ops as _hip_ops
 from .plan import build_plan, squeeze_mask
-from .SPUIGACF import SpUIGAT, SPUIMultiGAT, StackedSpUIGAT, _fresh_seed
+from .SPUIGACF import SpUIGAT, SPUIMultiGAT, StackedSpUIGAT, _fresh_seed, _SEED_STRIDE, _CTR_STRIDE
 
 
 class Partition:
@@ -103,26 +103,27 @@ class _ShardedStage(torch.autograd.Function):
     """One propagation stage on this rank's rows.  Input/output are LOCAL ([n_local, d], users first)."""
 
     @staticmethod
-    def forward(ctx, X, W, avec, part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed, h_dtype):
+    def forward(ctx, X, W, avec, part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed, h_dtype, seed_dev=None):
         X = X.contiguous()
         W, avec = W.contiguous().float(), avec.contiguous().float()
         dev, N, dout = X.device, part.N, W.shape[2]
         H = torch.empty(N, dout, dtype=h_dtype, device=dev)
         S = torch.empty(N, heads, dtype=torch.float32, device=dev)
-        be.transform_fwd_rows(X, W, avec, H, S, part.Up, part.Ip, heads, part.win, True, feat_drop_p, seed)
+        sd = {} if seed_dev is None else {"seed_dev": seed_dev}        # (the CPU test stand-in has no device seeds)
+        be.transform_fwd_rows(X, W, avec, H, S, part.Up, part.Ip, heads, part.win, True, feat_drop_p, seed, **sd)
         comm.all_gather_rows(H)            # S stays local: source scores are recomputed from the gathered rows
         need = any(ctx.needs_input_grad[:3])
-        res = be.prop_fwd(plan, H, S, S, avec, heads, alpha, True, True, True, drop_p, seed, save=need)
+        res = be.prop_fwd(plan, H, S, S, avec, heads, alpha, True, True, True, drop_p, seed, save=need, **sd)
         out = res[0] if need else res
         if need:
             ctx.save_for_backward(X, W, avec, H, S, out, res[1], res[2])
-            ctx.cfg = (part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed)
+            ctx.cfg = (part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed, sd)
         return part.local_rows(out)
 
     @staticmethod
     def backward(ctx, g_local):
         X, W, avec, H, S, out, agg, R = ctx.saved_tensors
-        part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed = ctx.cfg
+        part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed, sd = ctx.cfg
         dev, N, d = H.device, part.N, H.shape[1]
         g_local = g_local.contiguous().to(H.dtype)
         G = torch.empty(N, d, dtype=torch.float32, device=dev)
@@ -130,11 +131,11 @@ class _ShardedStage(torch.autograd.Function):
         ST = torch.empty(N, heads, dtype=torch.float32, device=dev)       # t[n,h]
         be.prop_bwd_node(out, agg, R, g_local, S, G, Gn, ST, part.Up, heads, part.win, True, True)
         comm.all_gather_rows(Gn, ST)                                       # one grouped launch
-        dH, dS = be.prop_bwd_edges(plan, H, S, avec, G, Gn, ST, heads, alpha, True, True, drop_p, seed)
-        dX, dW, da = be.transform_bwd_rows(X, W, H, dH, dS, part.Up, part.Ip, heads, part.win, True, feat_drop_p, seed)
+        dH, dS = be.prop_bwd_edges(plan, H, S, avec, G, Gn, ST, heads, alpha, True, True, drop_p, seed, **sd)
+        dX, dW, da = be.transform_bwd_rows(X, W, H, dH, dS, part.Up, part.Ip, heads, part.win, True, feat_drop_p, seed, **sd)
         if not comm.defer_weight_reduce:
             comm.all_reduce_sum(dW, da)
-        return (dX.to(X.dtype), dW, da) + (None,) * 10
+        return (dX.to(X.dtype), dW, da) + (None,) * 11
 
 
 class _GatherRows(torch.autograd.Function):
@@ -231,15 +232,34 @@ class ShardedSPUIGACF(nn.Module):
                                           row_range=p.row_ranges)
         return self._plans[key]
 
+    def use_device_seed(self, device, on=True):
+        """Dropout seeds = per-call host constant + a device counter (advance_device_seed): what a captured hipGraph needs
+        to draw fresh masks on every replay (same scheme as SPUIGACF._GATBase)."""
+        if on:
+            self._seed_base, self._seed_call = _fresh_seed(), 0
+            self._seed_ctr = torch.zeros(1, dtype=torch.int64, device=device)
+        else:
+            self._seed_ctr = None
+
+    def advance_device_seed(self):
+        if getattr(self, "_seed_ctr", None) is not None:
+            self._seed_ctr.add_(_CTR_STRIDE)
+
     def propagate_local(self, mask):
         plan = self._plan(mask)
         drop = self.droprate if self.training else 0.0
-        base = _fresh_seed() if drop > 0 else 0                          # same CPU generator state on every rank
+        seed_dev = None
+        if drop > 0 and getattr(self, "_seed_ctr", None) is not None:
+            self._seed_call += 1
+            base = (self._seed_base + self._seed_call * _SEED_STRIDE) & 0x3FFFFFFFFFFFFFFF
+            seed_dev = self._seed_ctr
+        else:
+            base = _fresh_seed() if drop > 0 else 0                      # same CPU generator state on every rank
         x = torch.cat([self.uEmbd.weight, self.iEmbd.weight], 0)
         for s, layers in enumerate(self.gat._stages()):
             W, avec = self.gat.stage_params(s)
             x = _ShardedStage.apply(x, W, avec, self.part, plan, self.comm, self.be, len(layers), layers[0].alpha,
-                                    drop, drop, NF.stage_seed(base, s), self.compute_dtype)
+                                    drop, drop, NF.stage_seed(base, s), self.compute_dtype, seed_dev)
         return x
 
     def propagate(self, mask):
@@ -381,7 +401,31 @@ def bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, hbm_peak, em
         import sys
         print("[bench] sharded hipGraph capture not used: %r" % (e,), file=sys.stderr, flush=True)
         finish(eager_line, True)
-    dog.cancel()
     better = t_graph < t_eager                     # t_* are already max-over-ranks: every rank decides alike
-    finish(line(t_graph, "hipGraph replay (kernels + grouped RCCL launches)", launches_fwd, extra) if better else eager_line, False)
+    best = line(t_graph, "hipGraph replay (kernels + grouped RCCL launches)", launches_fwd, extra) if better else eager_line
+    # ---- (4) the train step as one hipGraph (sampler-free: fixed batch, as in (2)), same watchdog ------------------
+    if not args.no_train:
+        dog.cancel()
+        dog = threading.Timer(float(os.environ.get("NGACF_DIST_GRAPH_TIMEOUT", "90")), finish, (best, True))
+        dog.daemon = True
+        dog.start()
+        try:
+            from .graphs import GraphedBPRStep
+            model.train()
+            opt_g = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True, fused=True)
+            gs = GraphedBPRStep(model, lossfn, opt_g, edge, B, concurrent_forwards=False, after_backward=model.reduce_grads)
+            upn = torch.stack([ub, pb, nb])
+            t_trg = timed(lambda: gs(upn), min(args.warmup, 3), ksteps)
+            if t_trg < t_tr:
+                extra = dict(extra, bpr_pairs_per_s=round(B * ksteps / t_trg, 1), train_ms_per_step=round(1e3 * t_trg / ksteps, 3),
+                             train_launch="hipGraph replay (kernels + grouped RCCL launches + fused Adam)",
+                             train_ms_per_step_eager=round(1e3 * t_tr / ksteps, 3))
+                best = line(t_graph, "hipGraph replay (kernels + grouped RCCL launches)", launches_fwd, extra) if better \
+                    else line(t_eager, "eager", launches_fwd, extra)
+        except Exception as e:
+            import sys
+            print("[bench] sharded hipGraph train step not used: %r" % (e,), file=sys.stderr, flush=True)
+            finish(best, True)
+    dog.cancel()
+    finish(best, False)
     dist.destroy_process_group()

@@ -8,7 +8,6 @@ advances, so every replay draws fresh masks.  `GraphedPropagate` does the same f
 """
 import torch
 
-from .SPUIGACF import _GATBase
 
 # the warm-up runs on a side stream by design; autograd's stream-mismatch warning is expected there
 try:
@@ -18,7 +17,8 @@ except AttributeError:      # older torch
 
 
 def _gats(model):
-    return [m for m in model.modules() if isinstance(m, _GATBase)]
+    """Everything in the model that draws dropout seeds (the GAT stacks; the sharded model of ngacf_amd/dist.py)."""
+    return [m for m in model.modules() if hasattr(m, "advance_device_seed") and hasattr(m, "use_device_seed")]
 
 
 class GraphedBPRStep:
@@ -27,7 +27,7 @@ class GraphedBPRStep:
     optim must be capturable (torch.optim.Adam(..., capturable=True)); batch size is fixed at capture."""
 
     def __init__(self, model, lossfn, optim, adj, batch_size, warmup=3, shared_propagation=False, data=None,
-                 preserve_state=False, concurrent_forwards=True, fuse_loss_node=False):
+                 preserve_state=False, concurrent_forwards=True, fuse_loss_node=False, after_backward=None):
         """data: a train_eval.Interactions -> the graph also SAMPLES its batch (ngacf_sample_pairs over the rows
         train_u[offset : offset+B], offset and sampler seed advanced by captured adds): use begin_epoch()/replay().
         preserve_state: put parameters and optimizer state back after the warm-up steps (a training loop must not
@@ -101,6 +101,8 @@ class GraphedBPRStep:
             else:                                           # reference semantics: two forwards, two propagations
                 loss = lossfn(model(self.u, self.p, adj), model(self.u, self.n, adj))
             loss.backward()
+            if after_backward is not None:                  # e.g. the sharded model's grouped weight-gradient all-reduce
+                after_backward()
             optim.step()
             if data is not None:
                 self.total.add_(loss.detach())

@@ -293,7 +293,7 @@ def dropout_bits(kind, seed, a, b, c=None):
 # ---------------------------------------------------------------------------
 # row-window forms used by the node-partitioned (multi-GPU) path, ngacf_amd/dist.py
 # ---------------------------------------------------------------------------
-def transform_fwd_rows(X, W, avec, H, S, U, I, heads, win, x_local, feat_drop_p=0.0, seed=0):
+def transform_fwd_rows(X, W, avec, H, S, U, I, heads, win, x_local, feat_drop_p=0.0, seed=0, seed_dev=None):
     """Transform the rows of `win` = (u_lo, u_n, i_lo, i_n) into the global-row tables H [N,dout], S [N,heads].
     X is [u_n+i_n, din] when x_local else [N, din]."""
     dev, N = H.device, U + I
@@ -306,11 +306,11 @@ def transform_fwd_rows(X, W, avec, H, S, U, I, heads, win, x_local, feat_drop_p=
     hp = _chk(H, "H", None, N * dout, dev)
     sp = _chk(S, "S", torch.float32, N * heads, dev)
     _lib.check(lib.ngacf_transform_fwd_rows(xp, _DT[X.dtype], wp, ap, hp, _DT[H.dtype], sp, U, I, din, dout, heads,
-                                            u_lo, u_n, i_lo, i_n, int(bool(x_local)), float(feat_drop_p), int(seed), 0,
+                                            u_lo, u_n, i_lo, i_n, int(bool(x_local)), float(feat_drop_p), int(seed), _sd(seed_dev, dev),
                                             _stream()), "ngacf_transform_fwd_rows")
 
 
-def transform_bwd_rows(X, W, H, dH, dS, U, I, heads, win, x_local, feat_drop_p=0.0, seed=0):
+def transform_bwd_rows(X, W, H, dH, dS, U, I, heads, win, x_local, feat_drop_p=0.0, seed=0, seed_dev=None):
     """dX ([u_n+i_n, din] when x_local), and the window's partial dW [2,din,dout], davec [2,dout]."""
     dev, N = H.device, U + I
     din, dout = W.shape[1], W.shape[2]
@@ -329,7 +329,7 @@ def transform_bwd_rows(X, W, H, dH, dS, U, I, heads, win, x_local, feat_drop_p=0
     work = torch.empty(_lib.TBWD_BLOCKS, din * dout + dout, **f32)
     _lib.check(lib.ngacf_transform_bwd_rows(xp, _DT[X.dtype], wp, hp, _DT[H.dtype], gp, sp, dX.data_ptr(), dW.data_ptr(),
                                             da.data_ptr(), work.data_ptr(), U, I, din, dout, heads,
-                                            u_lo, u_n, i_lo, i_n, int(bool(x_local)), float(feat_drop_p), int(seed), 0,
+                                            u_lo, u_n, i_lo, i_n, int(bool(x_local)), float(feat_drop_p), int(seed), _sd(seed_dev, dev),
                                             _stream()), "ngacf_transform_bwd_rows")
     return dX, dW, da
 
@@ -353,7 +353,7 @@ def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local
 
 
 def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=True, score_from_row=True,
-                   drop_p=0.0, seed=0):
+                   drop_p=0.0, seed=0, seed_dev=None):
     """Step 2 alone (G, Gn, ST ready for every source row).  Returns dH, dS (rows of the plan valid)."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
@@ -371,7 +371,7 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     flags = (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) | _lib.FLAG_SKIP_NODE
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, sd, ap, hp, gp, sd, gp, gp, gn, st, dH.data_ptr(),
                                   dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
-                                  float(drop_p), int(seed), 0, flags, _stream()), "ngacf_prop_bwd")
+                                  float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_bwd")
     return dH, dS
 
 

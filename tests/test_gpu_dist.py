@@ -91,3 +91,27 @@ def test_sharded_model_world1_equals_plain_model():
         assert float((p.grad - q.grad).abs().max() / p.grad.abs().max().clamp_min(1e-12)) < 1e-4, k
     sd = m.full_state_dict()
     assert all(torch.equal(sd[k], v) for k, v in ref.state_dict().items())
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_rehearsal_on_one_rank():
+    """bench.py's N>1 code path on a one-rank RCCL group (NGACF_BENCH_FORCE_DIST=1, collectives forced): eager timing,
+    then the hipGraph-captured forward and train step with the grouped RCCL launches inside; exactly one JSON line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, NGACF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 1e9
+    assert "3 per forward" in d["config"]["parallelism"] and d["collective_launches_per_train_step"] == 15
+    assert d["ms_per_step_eager"] > 0 and d["bpr_pairs_per_s"] > 1e5
