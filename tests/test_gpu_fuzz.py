@@ -44,7 +44,18 @@ def test_random_stage_forward_backward_vs_oracle(seed):
     Wl = [(rs.randn(d, k) * 0.3, rs.randn(d, k) * 0.3, rs.randn(1, 2 * k) * 0.4) for _ in range(heads)]
     wgt = rs.randn(N, d)
     # oracle: heads side by side (SPUIGACF.py:212), ELU inside; gradient of sum(out * wgt)
-    cache = [O.layer_forward(X, Wu, Wi, a, edge, U, I, concat=True) for Wu, Wi, a in Wl]
+    # half of the cases in train mode: edge dropout on the numerators (SPUIGACF.py:375) and feature dropout in front of
+    # the stage (:208), both from the host statement of the counter hash (bit-exact with the device, ngacf_amd/rng.py)
+    p_drop = float(rs.choice([0.0, 0.0, 0.1, 0.5]))
+    dseed = int(rs.randint(1, 2 ** 31))
+    em = [None] * heads
+    if p_drop > 0:
+        from ngacf_amd import rng
+        nn_, cc_ = np.meshgrid(np.arange(N), np.arange(d), indexing="ij")
+        X_in = X
+        X = X * rng.keep_scale(rng.feat_bits(dseed, nn_, cc_), p_drop).astype(np.float64)      # what the stage sees
+        em = [rng.keep_scale(rng.edge_bits(dseed, h, edge[0], edge[1] + U), p_drop).astype(np.float64) for h in range(heads)]
+    cache = [O.layer_forward(X, Wu, Wi, a, edge, U, I, concat=True, edge_mask=em[h]) for h, (Wu, Wi, a) in enumerate(Wl)]
     out_o = np.concatenate([c["out"] for c in cache], 1)
     if min(float(np.abs(c["s"]).min()) for c in cache if c["s"].size) < 1e-5:
         # an edge score within fp32 rounding of LeakyReLU's kink: float64 and fp32 may take different slopes there
@@ -53,16 +64,19 @@ def test_random_stage_forward_backward_vs_oracle(seed):
     gX_o = np.zeros_like(X)
     gW_o = []
     for h, ((Wu, Wi, a), c) in enumerate(zip(Wl, cache)):
-        gx, gwu, gwi, ga = O.layer_backward(wgt[:, h * k:(h + 1) * k], c, X, Wu, Wi, a, edge, U, I, concat=True)
+        gx, gwu, gwi, ga = O.layer_backward(wgt[:, h * k:(h + 1) * k], c, X, Wu, Wi, a, edge, U, I, concat=True, edge_mask=em[h])
         gX_o += gx
         gW_o.append((gwu, gwi, ga))
+    if p_drop > 0:                                                          # chain rule through the feature mask
+        gX_o = gX_o * rng.keep_scale(rng.feat_bits(dseed, nn_, cc_), p_drop).astype(np.float64)
+        X = X_in
     plan = build_plan(torch.from_numpy(edge).to(dev), U, I, seg_len=seg_len, short_max=short_max)
     Xt = torch.from_numpy(X).float().to(dev).requires_grad_(True)
     W = torch.from_numpy(np.stack([np.concatenate([w[0] for w in Wl], 1), np.concatenate([w[1] for w in Wl], 1)])).float().to(dev).requires_grad_(True)
     av = torch.from_numpy(np.stack([np.concatenate([w[2][0, :k] for w in Wl]), np.concatenate([w[2][0, k:] for w in Wl])])).float().to(dev).requires_grad_(True)
-    out = NF.stage(Xt, W, av, plan, heads, 0.2, True)
+    out = NF.stage(Xt, W, av, plan, heads, 0.2, True, p_drop, p_drop, dseed)
     (out * torch.from_numpy(wgt).float().to(dev)).sum().backward()
-    tag = (seed, U, I, edge.shape[1], heads, short_max, seg_len)
+    tag = (seed, U, I, edge.shape[1], heads, short_max, seg_len, p_drop)
     assert float(np.abs(out.detach().cpu().numpy() - out_o).max()) < 1e-4 * max(1.0, float(np.abs(out_o).max())), tag
     assert float(np.abs(Xt.grad.cpu().numpy() - gX_o).max()) < 2e-4 * max(1.0, float(np.abs(gX_o).max())), tag
     gWu = np.concatenate([g[0] for g in gW_o], 1); gWi = np.concatenate([g[1] for g in gW_o], 1)
@@ -71,3 +85,53 @@ def test_random_stage_forward_backward_vs_oracle(seed):
     ga_u = np.concatenate([g[2][0, :k] for g in gW_o]); ga_i = np.concatenate([g[2][0, k:] for g in gW_o])
     assert float(np.abs(av.grad[0].cpu().numpy() - ga_u).max()) < 2e-4 * max(1.0, float(np.abs(ga_u).max())), tag
     assert float(np.abs(av.grad[1].cpu().numpy() - ga_i).max()) < 2e-4 * max(1.0, float(np.abs(ga_i).max())), tag
+
+
+@pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("NGACF_FUZZ_ITERS", "12")) // 3)))
+def test_random_eval_topk_and_sampler_vs_host(seed):
+    """ngacf_eval_topk against masked scores + stable sort (integer tables: exact, with ties), ngacf_sample_pairs against
+    its numpy statement, on random sizes: ragged user blocks, tiny pools, K from 1 to 32, users with few candidates."""
+    from ngacf_amd import ops, rng
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(5000 + seed)
+    U, I = int(rs.randint(1, 300)), int(rs.randint(1, 900))
+    d = int(rs.choice([64, 128]))
+    K = int(rs.randint(1, 33))
+    dt = torch.bfloat16 if rs.rand() < 0.5 else torch.float32
+    g = torch.Generator(device=dev).manual_seed(seed)
+    F = torch.randint(-2, 3, (U + I, d), device=dev, generator=g).float()
+    pool = torch.rand(I, device=dev, generator=g) < float(rs.choice([0.05, 0.5, 1.0]))
+    pool[int(rs.randint(0, I))] = True
+    deg = rs.randint(0, min(I, 90) + 1, U)
+    deg[rs.randint(0, U)] = min(I, int(rs.randint(0, 400)))                     # one row beyond the 64-entry LDS cache
+    rows = np.repeat(np.arange(U), deg)
+    cols = np.concatenate([rs.permutation(I)[:n] for n in deg]) if rows.size else np.zeros(0, dtype=np.int64)
+    key = np.unique(rows.astype(np.int64) * I + cols)
+    ku, ki = torch.from_numpy(key // I).to(dev), torch.from_numpy(key % I).to(dev)
+    ptr = torch.zeros(U + 1, dtype=torch.long, device=dev)
+    ptr[1:] = torch.cumsum(torch.bincount(ku, minlength=U), 0)
+    users = torch.from_numpy(rs.permutation(U)[:int(rs.randint(1, U + 1))]).to(dev)
+    top, top_s = ops.eval_topk(F.to(dt), users, U, I, pool.to(torch.uint8), ptr, ki.to(torch.int32), K)
+    sc = F[users] @ F[U:].t()
+    neg = torch.finfo(torch.float32).min
+    sc[:, ~pool] = neg
+    mask = torch.zeros(U, I, dtype=torch.bool, device=dev); mask[ku, ki] = True
+    sc[mask[users]] = neg
+    order = torch.sort(sc, dim=1, descending=True, stable=True)
+    kk = min(K, I)
+    want_i, want_s = order.indices[:, :kk], order.values[:, :kk]
+    valid = want_s > neg
+    tag = (seed, U, I, d, K, str(dt))
+    assert torch.equal(top[:, :kk].long()[valid], want_i[valid]) and bool((top[:, :kk][~valid] == -1).all()), tag
+    assert bool((top[:, kk:] == -1).all()) and torch.equal(top_s[:, :kk][valid], want_s[valid]), tag
+    # sampler: only users with a train positive and a legal negative can be sampled
+    ok_users = [u for u in range(U) if deg[u] > 0 and int((pool.cpu().numpy() & ~mask[u].cpu().numpy()).sum()) > 0]
+    if ok_users:
+        B = int(rs.randint(1, 700))
+        bu = torch.from_numpy(rs.choice(ok_users, B)).to(dev)
+        pool_items = torch.nonzero(pool).squeeze(1).to(torch.int32)
+        sd = int(rs.randint(0, 2 ** 40))
+        upn, unres = ops.sample_pairs(bu, 0, B, ptr, ki.to(torch.int32), pool_items, sd)
+        pos, ng, un = rng.sample_pairs_host(bu.cpu().numpy(), ptr.cpu().numpy(), ki.to(torch.int32).cpu().numpy(), pool_items.cpu().numpy(), sd)
+        assert int(unres) == un, tag
+        assert np.array_equal(upn[1].cpu().numpy(), pos) and np.array_equal(upn[2].cpu().numpy(), ng), tag
