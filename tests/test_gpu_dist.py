@@ -16,7 +16,7 @@ def _graph(U, I, E, seed):
     return torch.from_numpy(np.stack([key // I, key % I]))
 
 
-@pytest.mark.parametrize("P,dt", [(2, torch.float32), (3, torch.float32), (4, torch.bfloat16)])
+@pytest.mark.parametrize("P,dt", [(2, torch.float32), (3, torch.float32), (4, torch.bfloat16), (8, torch.float32), (8, torch.bfloat16)])
 def test_partitioned_stage_equals_single_gpu(P, dt):
     from ngacf_amd import ops
     from ngacf_amd.dist import Partition
