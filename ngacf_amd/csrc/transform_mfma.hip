@@ -137,33 +137,48 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
             const float* av = a.avec + type * DOUT;
             float head_part[OT * 4];
             float total = 0.f;
-            uint16_t* Hg = reinterpret_cast<uint16_t*>(a.out);
+            char* Hrow = reinterpret_cast<char*>(a.out) + (size_t)nd_cur * DOUT * 2;
 #pragma unroll
             for (int t = 0; t < OT; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = 32 * t + 8 * g + 4 * h;
-                    const float4 a4 = *reinterpret_cast<const float4*>(av + c);
-                    uint32_t b[4];
-                    float v[4];
+                for (int gp = 0; gp < 4; gp += 2) {
+                    uint2 pk[2];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        b[j] = f32_to_bf16(acc[t][4 * g + j]);
-                        v[j] = bf16_to_f32(b[j]);
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int g = gp + gg;
+                        const int c = 32 * t + 8 * g + 4 * h;
+                        const float4 a4 = *reinterpret_cast<const float4*>(av + c);
+                        uint32_t b[4];
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            b[j] = f32_to_bf16(acc[t][4 * g + j]);
+                            v[j] = bf16_to_f32(b[j]);
+                        }
+                        float p = v[0] * a4.x;
+                        p = fmaf(v[1], a4.y, p); p = fmaf(v[2], a4.z, p); p = fmaf(v[3], a4.w, p);
+                        head_part[t * 4 + g] = p;
+                        total += p;
+                        pk[gg] = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
                     }
-                    float p = v[0] * a4.x;
-                    p = fmaf(v[1], a4.y, p); p = fmaf(v[2], a4.z, p); p = fmaf(v[3], a4.w, p);
-                    head_part[t * 4 + g] = p;
-                    total += p;
-                    if (ok_cur) *reinterpret_cast<uint2*>(Hg + (size_t)nd_cur * DOUT + c) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+                    // the two half-waves hold columns 8g..8g+3 / 8g+4..8g+7 of the node: one v_permlane32_swap per dword
+                    // turns two 8-byte stores per lane into one 16-byte store (lower half: group gp, upper half: group gp+1)
+                    const auto rx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                    const auto ry = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                    if (ok_cur)
+                        *reinterpret_cast<uint4*>(Hrow + 64 * t + 16 * gp + 16 * h) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
                 }
             if (HEADS == 1) {
-                total += __shfl_xor(total, 32, 64);
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(total), __float_as_uint(total), false, false);
+                total += __uint_as_float(h ? r[0] : r[1]);
                 if (ok_cur && h == 0) a.S[nd_cur] = total;
             } else {                                   // 8-wide heads: head 4t+g = this lane's 4 columns + the other half's
                 float p[OT * 4];
 #pragma unroll
-                for (int q = 0; q < OT * 4; ++q) p[q] = head_part[q] + __shfl_xor(head_part[q], 32, 64);
+                for (int q = 0; q < OT * 4; ++q) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(head_part[q]), __float_as_uint(head_part[q]), false, false);
+                    p[q] = head_part[q] + __uint_as_float(h ? r[0] : r[1]);
+                }
                 // half 0 stores heads 0..3 (+8..11), half 1 heads 4..7 (+12..15): one 16-byte store per lane and group
 #pragma unroll
                 for (int q0 = 0; q0 < OT * 4; q0 += 8) {
@@ -177,20 +192,33 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
 #pragma unroll
             for (int t = 0; t < OT; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = 32 * t + 8 * g + 4 * h;
-                    float v[4];
+                for (int gp = 0; gp < 4; gp += 2) {
+                    float v[2][4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = acc[t][4 * g + j];
-                        if (DROP) v[j] = feat_bits(salt, nd_cur, c + j) >= a.drop_thr ? v[j] * a.drop_scale : 0.f;
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int c = 32 * t + 8 * (gp + gg) + 4 * h;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[gg][j] = acc[t][4 * (gp + gg) + j];
+                            if (DROP) v[gg][j] = feat_bits(salt, nd_cur, c + j) >= a.drop_thr ? v[gg][j] * a.drop_scale : 0.f;
+                        }
                     }
-                    if (!ok_cur) continue;
                     if constexpr (sizeof(TO) == 4) {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow * DIN + c) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        const uint32_t lo = f32_to_bf16(v[0]) | (f32_to_bf16(v[1]) << 16), hi = f32_to_bf16(v[2]) | (f32_to_bf16(v[3]) << 16);
-                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + orow * DIN + c) = make_uint2(lo, hi);
+                        if (!ok_cur) continue;
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg)
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow * DIN + 32 * t + 8 * (gp + gg) + 4 * h) =
+                                make_float4(v[gg][0], v[gg][1], v[gg][2], v[gg][3]);
+                    } else {    // bf16 rows: the half-waves exchange one group each -> one 16-byte store per lane (see the forward)
+                        uint2 pk[2];
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg)
+                            pk[gg] = make_uint2(f32_to_bf16(v[gg][0]) | (f32_to_bf16(v[gg][1]) << 16), f32_to_bf16(v[gg][2]) | (f32_to_bf16(v[gg][3]) << 16));
+                        const auto rx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                        const auto ry = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                        if (ok_cur)
+                            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.out) + orow * DIN * 2 + 64 * t + 16 * gp + 16 * h) =
+                                make_uint4(rx[0], ry[0], rx[1], ry[1]);
                     }
                 }
         }
