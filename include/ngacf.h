@@ -111,6 +111,8 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  *   gout [N,d] dtype (the gradient arrives in the storage type of `out`)   out [N,d] dtype (forward output)
  *   agg, R: as saved by the forward
  *   G float[N][d], Gn [N][d] dtype, ST float[N][heads] (the t table): workspace    dH float[N][d], dS float[N][heads]: results
+ *   G may be NULL when this call runs both steps (no NGACF_SKIP_NODE): step 2 then recomputes g from gout and out, bit for bit,
+ *   and the 4-byte-per-element table is neither written nor read back
  *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows */
 int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                    const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void prop_bwd_node_kernel(const PropBwdArgs a)
     }
     p = lanes_sum<SH::LPH>(p);
     if (!ok) return;
-    store_f32<VEC>(a.G + n * D + q * VEC, g);
+    if (a.G) store_f32<VEC>(a.G + n * D + q * VEC, g);      // G == NULL: step 2 recomputes g from gout and out (same arithmetic)
     Slice<T>::store(static_cast<T*>(a.Gn) + n * D + q * VEC, gn);
     if ((q * VEC) % HW == 0) a.Tn[n * HEADS + head] = p;
 }
@@ -179,12 +179,19 @@ __device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<S
     for (int j = 0; j < VEC; ++j) acc[j] = fmaf(wgt, gv[j], acc[j]);
 }
 
-template <int D, int HEADS, int VEC>
+template <typename T, int D, int HEADS, int VEC>
 __device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum) {
     constexpr int HW = D / HEADS;
     float g[VEC], o[VEC];
-    if (a.flags & NGACF_RESIDUAL) load_f32<VEC>(a.G + (size_t)row * D + q * VEC, g);
-    else {
+    if ((a.flags & NGACF_RESIDUAL) && a.G) load_f32<VEC>(a.G + (size_t)row * D + q * VEC, g);
+    else if (a.flags & NGACF_RESIDUAL) {           // g = gout * ELU'(out), exactly as step 1 computed it (no 4-byte G table)
+        Slice<T>::load(static_cast<const T*>(a.gout) + (size_t)row * D + q * VEC, g);
+        if (a.flags & NGACF_ELU) {
+            Slice<T>::load(static_cast<const T*>(a.out) + (size_t)row * D + q * VEC, o);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) g[j] *= o[j] > 0.f ? 1.f : o[j] + 1.f;
+        }
+    } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) g[j] = 0.f;
     }
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
             }
             colv = coln;
         }
-        if (live) finish_row_b<D, HEADS, VEC>(a, row, q, head, acc, dsum);
+        if (live) finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
         return;
     }
 
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
         if ((q * VEC) % HW == 0) a.part_r[(size_t)part * HEADS + head] = dsum;
         return;
     }
-    finish_row_b<D, HEADS, VEC>(a, row, q, head, acc, dsum);
+    finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
 }
 
 template <typename T, int D, int HEADS>
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256) void prop_bwd_split_kernel(const PropBwdArgs a
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     dsum = group_sum<LPR, WAVE>(dsum);
     if (slot != 0) return;
-    finish_row_b<D, HEADS, VEC>(a, row, q, head, acc, dsum);
+    finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
 }
 
 template <typename T, int D, int HEADS>
@@ -368,7 +375,8 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
         return NGACF_E_ARG;
     if (nu_lo < 0 || nu_n < 0 || ni_lo < 0 || ni_n < 0 || nu_lo + nu_n > U || ni_lo + ni_n > N - U) return NGACF_E_ARG;
     if (N == 0) return 0;
-    if (!S_src || !G || !Gn || !ST) return NGACF_E_ARG;
+    if (!S_src || !Gn || !ST) return NGACF_E_ARG;
+    if (!G && !(do_node && do_edges && !gout_local)) return NGACF_E_ARG;   // G may be left out only when one call runs both steps on global-row gout
     if (do_node && (!out || !agg || !R || !gout)) return NGACF_E_ARG;
     if (do_edges) {
         if (!col || !rowptr || !H || !S_dst || !avec || !dH || !dS) return NGACF_E_ARG;

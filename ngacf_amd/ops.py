@@ -175,7 +175,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     go = _chk(gout, "gout", H.dtype, N * d, dev)
     pp = _plan_ptrs(plan, dev)
     f32 = dict(dtype=torch.float32, device=dev)
-    G, dH = torch.empty(N, d, **f32), torch.empty(N, d, **f32)
+    dH = torch.empty(N, d, **f32)                 # (no G table: one call runs both steps, step 2 recomputes g = gout * ELU'(out))
     Gn = torch.empty(N, d, dtype=H.dtype, device=dev)
     t, dS = torch.empty(N, heads, **f32), torch.empty(N, heads, **f32)
     pa = torch.empty(max(plan.nparts, 1), d, **f32)
@@ -185,7 +185,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
         dS.zero_()
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, ss, ap,
-                                  op, gp, rp, go, G.data_ptr(), Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
+                                  op, gp, rp, go, 0, Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
                                   dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
                                   float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_bwd")
     return dH, dS
