@@ -255,7 +255,10 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float (&f)[8]) {
                       f32_to_bf16(f[4]) | (f32_to_bf16(f[5]) << 16), f32_to_bf16(f[6]) | (f32_to_bf16(f[7]) << 16));
 }
 
-template <typename TX, int DIN, int DOUT, int HEADS, bool DROP>
+// WITH_DX: the same workgroup also produces dX = mask * (dH @ W^T) for its tile -- the dH tile is already in LDS as bf16
+// (the separate dX kernel reads and rounds the same values), node on the lane as in transform_mfma.hip: the wave takes
+// the 32-node half (wave & 1) and the output column tiles of (wave >> 1).
+template <typename TX, int DIN, int DOUT, int HEADS, bool DROP, bool WITH_DX>
 __global__ __launch_bounds__(256) void transform_dw_mfma_kernel(const TransBwdArgs a) {
     constexpr int TN = 64;                               // nodes per tile
     constexpr int SX = DIN * 2 + 64, SG = DOUT * 2 + 64;  // LDS row strides (bytes): 4 consecutive rows on disjoint 16-bank windows
@@ -265,6 +268,8 @@ __global__ __launch_bounds__(256) void transform_dw_mfma_kernel(const TransBwdAr
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     char* Xs = lds_raw;                                  // [TN][SX]
     char* Gs = lds_raw + TN * SX;                        // [TN][SG]
+    constexpr int DKS = DOUT / 16, DOT = DIN / 32;       // dX: k-steps over dout, 32-column tiles of din
+    dw_bf16x8* Af = reinterpret_cast<dw_bf16x8*>(lds_raw + TN * SX + TN * SG);   // [DKS][DOT][64] W^T fragments (WITH_DX)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave >> 1, wc = wave & 1;
     const uint32_t salt = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
@@ -362,6 +367,17 @@ __global__ __launch_bounds__(256) void transform_dw_mfma_kernel(const TransBwdAr
 
     int tile = bl;
     if (tile < ntiles) fetch(tile);
+    if constexpr (WITH_DX) {     // A[i][k] = W[type][i][k], i over din, k over dout (built under the first tile's loads)
+        const float* M = a.W + (size_t)(users ? 0 : 1) * DIN * DOUT;
+        for (int slot = tid; slot < DKS * DOT * 64; slot += 256) {
+            const int l = slot & 63, t = (slot >> 6) % DOT, sk = (slot >> 6) / DOT;
+            const int i = 32 * t + (l & 31), k0 = 16 * sk + 8 * (l >> 5);
+            dw_bf16x8 fr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fr[j] = static_cast<__bf16>(M[(size_t)i * DOUT + k0 + j]);
+            Af[slot] = fr;
+        }
+    }
     for (; tile < ntiles; tile += nb) {
         __syncthreads();                                  // everyone done reading the previous tile
         stage();
@@ -385,6 +401,57 @@ __global__ __launch_bounds__(256) void transform_dw_mfma_kernel(const TransBwdAr
 #pragma unroll
                 for (int j = 0; j < CW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if constexpr (WITH_DX) {
+            const int sub = wave & 1, r = lane & 31, hh = lane >> 5;
+            const int node = rbeg + tile * TN + 32 * sub + r;
+            const bool okn = node < rend;
+            dw_bf16x8 gb[DKS];
+#pragma unroll
+            for (int sk = 0; sk < DKS; ++sk)
+                gb[sk] = *reinterpret_cast<const dw_bf16x8*>(Gs + (32 * sub + r) * SG + (16 * sk + 8 * hh) * 2);
+            constexpr int TPW = DOT / 2;                     // column tiles of this wave
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) {
+                const int t = (wave >> 1) * TPW + tt;
+                dw_f32x16 dacc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dacc[e] = 0.f;
+#pragma unroll
+                for (int sk = 0; sk < DKS; ++sk)
+                    dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[(sk * DOT + t) * 64 + lane], gb[sk], dacc, 0, 0, 0);
+                // lane: node r (+ half hh); dacc[4g + j] = dX column 32t + 8g + 4hh + j
+                const size_t orow = (size_t)(node - xoff);
+#pragma unroll
+                for (int gp = 0; gp < 4; gp += 2) {
+                    float v[2][4];
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[gg][j] = dacc[4 * (gp + gg) + j];
+                            if (DROP) v[gg][j] = feat_bits(salt, node, 32 * t + 8 * (gp + gg) + 4 * hh + j) >= a.drop_thr ? v[gg][j] * a.drop_scale : 0.f;
+                        }
+                    if constexpr (sizeof(TX) == 4) {
+                        if (okn) {
+#pragma unroll
+                            for (int gg = 0; gg < 2; ++gg)
+                                *reinterpret_cast<float4*>(static_cast<float*>(a.dX) + orow * DIN + 32 * t + 8 * (gp + gg) + 4 * hh) =
+                                    make_float4(v[gg][0], v[gg][1], v[gg][2], v[gg][3]);
+                        }
+                    } else {
+                        uint2 pk[2];
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg)
+                            pk[gg] = make_uint2(f32_to_bf16(v[gg][0]) | (f32_to_bf16(v[gg][1]) << 16), f32_to_bf16(v[gg][2]) | (f32_to_bf16(v[gg][3]) << 16));
+                        const auto rx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                        const auto ry = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                        if (okn)
+                            *reinterpret_cast<uint4*>(static_cast<char*>(a.dX) + orow * DIN * 2 + 64 * t + 16 * gp + 16 * hh) =
+                                make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                    }
+                }
+            }
         }
     }
 
@@ -441,12 +508,16 @@ int transform_dx_mfma(const float* dH, const float* W, void* dX, int dx_dtype, i
                       int u_lo, int u_n, int i_lo, int i_n, int x_local,
                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st);   // transform_mfma.hip
 
+constexpr bool FUSE_DX_INTO_DW = true;     // 14.7 us fused against 10.2 (dW) + 9.4 (dX) us as two launches, bitwise the same dX
+
 template <typename TX, typename TH, int DIN, int DOUT, int HEADS>
 static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool drop, hipStream_t st) {
     const int tu = (a.u_n + TM - 1) / TM, ti = (a.i_n + TM - 1) / TM;
     if (tu + ti == 0) return 0;
-    if (a.dX == nullptr) {
-        // caller asked for the weight gradients only (the dX half runs in another call, possibly on another stream)
+    // bf16 storage with both halves requested: dX comes out of the dW kernel (its dH tile is already in LDS)
+    const bool fuse_dx = FUSE_DX_INTO_DW && sizeof(TH) == 2 && a.dX != nullptr && dW != nullptr;
+    if (a.dX == nullptr || fuse_dx) {
+        // nothing here: weight gradients only, or dX fused below
     } else if constexpr (sizeof(TH) == 2) {   // bf16 storage: dX on the matrix cores
         const int rc = transform_dx_mfma(a.dH, a.W, a.dX, sizeof(TX) == 2 ? NGACF_BF16 : NGACF_F32, a.U, a.I, DIN, DOUT, HEADS, a.u_lo, a.u_n, a.i_lo, a.i_n, a.x_local,
                                          a.drop_p, a.seed, a.seed_dev, st);
@@ -481,8 +552,13 @@ static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool dr
         if constexpr (sizeof(TH) == 2) {
             constexpr size_t lm = (size_t)64 * (DIN * 2 + 64) + (size_t)64 * (DOUT * 2 + 64);
             static_assert(lm >= 256 * 8 * sizeof(float), "davec fold reuses the tile image");
-            if (drop) hipLaunchKernelGGL((transform_dw_mfma_kernel<TX, DIN, DOUT, HEADS, true>), dim3(a.nbu + a.nbi), dim3(256), lm, st, a);
-            else      hipLaunchKernelGGL((transform_dw_mfma_kernel<TX, DIN, DOUT, HEADS, false>), dim3(a.nbu + a.nbi), dim3(256), lm, st, a);
+            constexpr size_t lx = lm + (size_t)(DOUT / 16) * (DIN / 32) * 64 * 16;      // + W^T fragments of the fused dX
+            if (fuse_dx) {
+                auto k = drop ? transform_dw_mfma_kernel<TX, DIN, DOUT, HEADS, true, true> : transform_dw_mfma_kernel<TX, DIN, DOUT, HEADS, false, true>;
+                if (lx > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lx);
+                hipLaunchKernelGGL(k, dim3(a.nbu + a.nbi), dim3(256), lx, st, a);
+            } else if (drop) hipLaunchKernelGGL((transform_dw_mfma_kernel<TX, DIN, DOUT, HEADS, true, false>), dim3(a.nbu + a.nbi), dim3(256), lm, st, a);
+            else             hipLaunchKernelGGL((transform_dw_mfma_kernel<TX, DIN, DOUT, HEADS, false, false>), dim3(a.nbu + a.nbi), dim3(256), lm, st, a);
         } else if (drop) {
             auto k = transform_bwd_dw_kernel<TX, TH, DIN, DOUT, HEADS, true>;
             if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
