@@ -155,12 +155,15 @@ int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg, const floa
                         int U, int N, int d, int heads, int flags,
                         int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream);
 
-/* Pair scoring: score[b] = sum_c F[u[b],c] * F[U + i[b],c]   (SPUIGACF.py:49-52). */
+/* Pair scoring: score[b] = sum_c F[u[b],c] * F[U + i[b],c]   (SPUIGACF.py:49-52).
+ * Index safety: the reference's advanced indexing raises on an out-of-range id (:49-50).  Here a pair with
+ * u[b] outside [0,U) or i[b] outside [0,I) is never turned into an address: its score is NaN, the backward skips it,
+ * and each such pair adds 1 to *bad_index (int32 device counter, may be NULL) for the host to raise on. */
 int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
-                    float* score, int B, int U, int d, void* stream);
+                    float* score, int32_t* bad_index, int B, int U, int I, int d, void* stream);
 /* gF[u[b]] += g[b] * F[U+i[b]],  gF[U+i[b]] += g[b] * F[u[b]]   (float atomics; gF float[N][d]) */
 int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
-                    const float* gscore, float* gF, int B, int U, int d, void* stream);
+                    const float* gscore, float* gF, int32_t* bad_index, int B, int U, int I, int d, void* stream);
 
 /* BPR loss  -mean(log(sigmoid(pos - neg)))  (graphattention/BPRLoss.py:8-9).
  * loss is a single float; the function overwrites it (no pre-zeroing needed). */
@@ -180,18 +183,21 @@ int ngacf_spmm_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  * (train_ptr/train_items: CSR over users, items ascending inside a row), best first, ties to the lower item id.
  * Replaces the host-side ranking of train_eval_Gowalla.py:274-354 (per-block score transfer) and :370-385
  * (heapq.nlargest(K, ...) per user in a process pool); the [B][I] score matrix is never materialised.
- * top_items[b][r] = -1 (top_scores = -FLT_MAX) when user b has fewer than r+1 candidates.  d in {64, 128}. */
+ * top_items[b][r] = -1 (top_scores = -FLT_MAX) when user b has fewer than r+1 candidates.  d in {64, 128}.
+ * A users[b] outside [0,U) is never dereferenced: its row comes back all -1 and *bad_index (may be NULL) is bumped. */
 int ngacf_eval_topk(const void* F, int dtype, const int64_t* users, int B, int U, int I, int d,
                     const uint8_t* pool_mask, const int64_t* train_ptr, const int32_t* train_items,
-                    int K, int32_t* top_items, float* top_scores, void* stream);
+                    int K, int32_t* top_items, float* top_scores, int32_t* bad_index, void* stream);
 
 /* BPR pair sampler: for batch row r, u = users[offset + (offset_dev ? *offset_dev : 0) + r]; pos = a uniform draw from
  * the user's train positives (CSR train_ptr/train_items, items ascending); neg = a uniform draw from
  * pool_items[0..P) that is not a train positive of u (rejection, at most 64 rounds; rows that fail bump *unresolved).
  * Replaces data/loadGowalla.py:63-77 (per-user Python sets + random.choice per row).  Randomness: counter hash of
- * (seed + *seed_dev, row, round) -- host restatement: ngacf_amd/rng.py:sample_pairs_host. */
-int ngacf_sample_pairs(const int64_t* users, long long offset, const int64_t* offset_dev,
-                       const int64_t* train_ptr, const int32_t* train_items,
+ * (seed + *seed_dev, row, round) -- host restatement: ngacf_amd/rng.py:sample_pairs_host.
+ * users has n_rows entries and train_ptr n_users + 1: a batch row past n_rows (a device offset that ran beyond the
+ * epoch) or a user id outside [0, n_users) is clamped, never dereferenced, and counted in *unresolved. */
+int ngacf_sample_pairs(const int64_t* users, long long n_rows, long long offset, const int64_t* offset_dev,
+                       const int64_t* train_ptr, int n_users, const int32_t* train_items,
                        const int32_t* pool_items, int P, uint64_t seed, const uint64_t* seed_dev,
                        int64_t* u_out, int64_t* pos_out, int64_t* neg_out, int* unresolved, int B, void* stream);
 

@@ -33,13 +33,13 @@ SIGNATURES = {
     "ngacf_transform_bwd_rows": [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                  _f, _u64, _p, _p],
     "ngacf_prop_bwd_node": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    "ngacf_score_fwd": [_p, _i, _p, _p, _p, _i, _i, _i, _p],
-    "ngacf_score_bwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    "ngacf_score_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ngacf_score_bwd": [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ngacf_bpr_fwd": [_p, _p, _p, _i, _p],
     "ngacf_bpr_bwd": [_p, _p, _p, _p, _p, _i, _p],
     "ngacf_spmm_fwd": [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p],
-    "ngacf_sample_pairs": [_p, ctypes.c_longlong, _p, _p, _p, _p, _i, _u64, _p, _p, _p, _p, _p, _i, _p],
-    "ngacf_eval_topk": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p],
+    "ngacf_sample_pairs": [_p, ctypes.c_longlong, ctypes.c_longlong, _p, _p, _i, _p, _p, _i, _u64, _p, _p, _p, _p, _p, _i, _p],
+    "ngacf_eval_topk": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
     "ngacf_dropout_bits": [_i, _u64, _p, _p, _p, _p, _i, _p],
 }
 

@@ -42,8 +42,15 @@ struct TopkArgs {
     const int32_t* train_items;    // sorted inside a row
     int32_t* top_items;            // [B][K], -1 when a user has fewer than K candidates
     float* top_scores;             // [B][K]
+    int* bad;                      // optional: number of users[] entries outside [0, U) (their rows come back all -1)
     int B, U, I, K;
 };
+
+// users[ub] clamped into the table: an out-of-range id must never become an address (it is reported through a.bad)
+__device__ __forceinline__ int64_t tk_user(const TopkArgs& a, int ub) {
+    const int64_t u = a.users[ub];
+    return u < 0 ? 0 : (u >= a.U ? (int64_t)a.U - 1 : u);
+}
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
         const int ub = u0 + i;
         int deg = 0;
         if (ub < a.B) {
-            const int64_t u = a.users[ub];
+            const int64_t u = tk_user(a, ub);
             const int64_t p0 = a.train_ptr[u];
             deg = (int)(a.train_ptr[u + 1] - p0);
             if (lane < deg && lane < TK_CACHE) c_item[i][lane] = a.train_items[p0 + lane];
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
 
     // ---- A operand: this lane's user row (users past the batch end take the last one and never select) ------
     const int my_u = u0 + col < a.B ? u0 + col : a.B - 1;
-    const T* urow = static_cast<const T*>(a.F) + (size_t)a.users[my_u] * D;
+    const T* urow = static_cast<const T*>(a.F) + (size_t)tk_user(a, my_u) * D;
     float af[BF ? 1 : NA];
     tk_bf16x8 ab[BF ? NA : 1];
     if constexpr (BF) {
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
         bool member = false;
         for (int c = 0; c < nc; ++c) member |= i_t == c_item[ui][c];          // broadcast reads
         if (deg > TK_CACHE && live && !member && i_t > c_item[ui][TK_CACHE - 1]) {
-            const int64_t p0 = a.train_ptr[a.users[u0 + ui]];
+            const int64_t p0 = a.train_ptr[tk_user(a, u0 + ui)];
             int lo = TK_CACHE, hi = deg;                                       // per-lane binary search over the uncached tail
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
@@ -246,6 +253,15 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
     for (int ui = wave; ui < 32; ui += 4) {
         const int ub = u0 + ui;
         if (ub >= a.B) continue;
+        const int64_t uraw = a.users[ub];
+        if (uraw < 0 || uraw >= a.U) {                       // not a user: no ranking, flagged
+            if (lane < K) {
+                a.top_items[(size_t)ub * K + lane] = -1;
+                a.top_scores[(size_t)ub * K + lane] = TK_NEG;
+            }
+            if (lane == 0 && a.bad) atomicAdd(a.bad, 1);
+            continue;
+        }
         int total = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) total += l_cnt[w][ui];
@@ -283,13 +299,13 @@ using namespace ngacf;
 
 extern "C" int ngacf_eval_topk(const void* F, int dtype, const int64_t* users, int B, int U, int I, int d,
                                const uint8_t* pool_mask, const int64_t* train_ptr, const int32_t* train_items,
-                               int K, int32_t* top_items, float* top_scores, void* stream) {
+                               int K, int32_t* top_items, float* top_scores, int32_t* bad_index, void* stream) {
     if (B < 0 || U <= 0 || I <= 0 || K <= 0 || K > TK_MAXK) return NGACF_E_ARG;
     if (B == 0) return 0;
     if (!F || !users || !pool_mask || !train_ptr || !train_items || !top_items || !top_scores) return NGACF_E_ARG;
     TopkArgs a;
     a.F = F; a.users = users; a.pool = pool_mask; a.train_ptr = train_ptr; a.train_items = train_items;
-    a.top_items = top_items; a.top_scores = top_scores; a.B = B; a.U = U; a.I = I; a.K = K;
+    a.top_items = top_items; a.top_scores = top_scores; a.bad = bad_index; a.B = B; a.U = U; a.I = I; a.K = K;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((B + 31) / 32), block(256);
     if (dtype == NGACF_F32 && d == 64) hipLaunchKernelGGL((eval_topk_kernel<float, 64>), grid, block, 0, st, a);

@@ -11,9 +11,9 @@ namespace ngacf {
 
 constexpr int SAMPLER_MAX_ROUNDS = 64;
 
-__global__ __launch_bounds__(256) void sample_pairs_kernel(const int64_t* __restrict__ users, long long offset,
+__global__ __launch_bounds__(256) void sample_pairs_kernel(const int64_t* __restrict__ users, long long n_rows, long long offset,
                                                            const int64_t* __restrict__ offset_dev,
-                                                           const int64_t* __restrict__ train_ptr,
+                                                           const int64_t* __restrict__ train_ptr, int n_users,
                                                            const int32_t* __restrict__ train_items,
                                                            const int32_t* __restrict__ pool_items, int P,
                                                            uint64_t seed, const uint64_t* __restrict__ seed_dev,
@@ -23,7 +23,14 @@ __global__ __launch_bounds__(256) void sample_pairs_kernel(const int64_t* __rest
     if (r >= B) return;
     const uint32_t salt = salt_of(seed + (seed_dev ? *seed_dev : 0ull), 0x5A17u);
     const long long off = offset + (offset_dev ? *offset_dev : 0ll);
-    const int64_t u = users[off + r];
+    // a row past the end of the interaction list (or a user id outside the CSR) is never dereferenced: it samples
+    // for the last valid row / user 0 and is counted in *unresolved, which the epoch loop checks
+    long long at = off + r;
+    bool oob = at < 0 || at >= n_rows;
+    if (oob) at = n_rows - 1;
+    int64_t u = users[at];
+    if (u < 0 || u >= n_users) { oob = true; u = 0; }
+    if (oob) atomicAdd(unresolved, 1);
     const int64_t p0 = train_ptr[u];
     const int deg = (int)(train_ptr[u + 1] - p0);
     // positive: index floor(bits * deg / 2^32)
@@ -50,15 +57,16 @@ __global__ __launch_bounds__(256) void sample_pairs_kernel(const int64_t* __rest
 
 using namespace ngacf;
 
-extern "C" int ngacf_sample_pairs(const int64_t* users, long long offset, const int64_t* offset_dev,
-                                  const int64_t* train_ptr, const int32_t* train_items,
+extern "C" int ngacf_sample_pairs(const int64_t* users, long long n_rows, long long offset, const int64_t* offset_dev,
+                                  const int64_t* train_ptr, int n_users, const int32_t* train_items,
                                   const int32_t* pool_items, int P, uint64_t seed, const uint64_t* seed_dev,
                                   int64_t* u_out, int64_t* pos_out, int64_t* neg_out, int* unresolved, int B, void* stream) {
-    if (B < 0 || P <= 0 || offset < 0) return NGACF_E_ARG;
+    if (B < 0 || P <= 0 || offset < 0 || n_rows < 0 || n_users <= 0) return NGACF_E_ARG;
+    if (B > 0 && n_rows == 0) return NGACF_E_ARG;
     if (B == 0) return 0;
     if (!users || !train_ptr || !train_items || !pool_items || !u_out || !pos_out || !neg_out || !unresolved) return NGACF_E_ARG;
     hipLaunchKernelGGL(sample_pairs_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       users, offset, offset_dev, train_ptr, train_items, pool_items, P, seed, seed_dev,
+                       users, n_rows, offset, offset_dev, train_ptr, n_users, train_items, pool_items, P, seed, seed_dev,
                        u_out, pos_out, neg_out, unresolved, B);
     NGACF_CHECK_LAUNCH();
     return 0;

@@ -7,21 +7,28 @@ namespace ngacf {
 template <typename T, int D>
 __global__ __launch_bounds__(256) void score_fwd_kernel(const T* __restrict__ F, const int64_t* __restrict__ u,
                                                         const int64_t* __restrict__ it, float* __restrict__ score,
-                                                        int B, int U) {
+                                                        int* __restrict__ bad, int B, int U, int I) {
     constexpr int VEC = Slice<T>::VEC, LPR = D / VEC, PPW = WAVE / LPR;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = wave * PPW + lane / LPR, q = lane % LPR;
     const bool ok = b < B;
     const int bb = ok ? b : B - 1;
+    // the reference raises on an out-of-range index (SPUIGACF.py:49-50); here such a pair never becomes an address:
+    // its score is NaN and it is counted in *bad (ops.raise_if_bad_indices)
+    const int64_t ub = u[bb], ib = it[bb];
+    const bool in = ub >= 0 && ub < U && ib >= 0 && ib < I;
     float x[VEC], y[VEC];
-    Slice<T>::load(F + (size_t)u[bb] * D + q * VEC, x);
-    Slice<T>::load(F + (size_t)(it[bb] + U) * D + q * VEC, y);
+    Slice<T>::load(F + (size_t)(in ? ub : 0) * D + q * VEC, x);
+    Slice<T>::load(F + (size_t)(in ? ib + U : 0) * D + q * VEC, y);
     float p = 0.f;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) p = fmaf(x[j], y[j], p);
     p = group_sum<1, LPR>(p);
-    if (ok && q == 0) score[b] = p;
+    if (ok && q == 0) {
+        score[b] = in ? p : __int_as_float(0x7fc00000);
+        if (!in && bad) atomicAdd(bad, 1);
+    }
 }
 
 // gF[u] += g * F[i], gF[i] += g * F[u].  A lane owns one column, so every atomic wave-instruction adds 256
@@ -30,7 +37,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const T* __restrict__ F,
 template <typename T, int D>
 __global__ __launch_bounds__(256) void score_bwd_kernel(const T* __restrict__ F, const int64_t* __restrict__ u,
                                                         const int64_t* __restrict__ it, const float* __restrict__ g,
-                                                        float* __restrict__ gF, int B, int U) {
+                                                        float* __restrict__ gF, int* __restrict__ bad, int B, int U, int I) {
     constexpr int PPW = 4;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -38,7 +45,12 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const T* __restrict__ F,
     for (int k = 0; k < PPW; ++k) {
         const int b = wave * PPW + k;
         if (b >= B) return;
-        const size_t ur = (size_t)u[b], ir = (size_t)(it[b] + U);
+        const int64_t ub = u[b], ib = it[b];
+        if (ub < 0 || ub >= U || ib < 0 || ib >= I) {       // out-of-range pair: no write anywhere, counted
+            if (lane == 0 && bad) atomicAdd(bad, 1);
+            continue;
+        }
+        const size_t ur = (size_t)ub, ir = (size_t)(ib + U);
         const float gb = g[b];
 #pragma unroll
         for (int c = lane; c < D; c += 64) {
@@ -101,8 +113,8 @@ using namespace ngacf;
 extern "C" const char* ngacf_version(void) { return "ngacf-hip 0.1 (gfx950)"; }
 
 extern "C" int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
-                               float* score, int B, int U, int d, void* stream) {
-    if (B < 0) return NGACF_E_ARG;
+                               float* score, int32_t* bad_index, int B, int U, int I, int d, void* stream) {
+    if (B < 0 || U <= 0 || I <= 0) return NGACF_E_ARG;
     if (B == 0) return 0;
     if (!F || !u || !i || !score) return NGACF_E_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -110,7 +122,7 @@ extern "C" int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const
     {                                                                                                      \
         constexpr int PPB = 4 * WAVE / (D / Slice<T>::VEC);                                                \
         hipLaunchKernelGGL((score_fwd_kernel<T, D>), dim3((B + PPB - 1) / PPB), dim3(256), 0, st,          \
-                           static_cast<const T*>(F), u, i, score, B, U);                                   \
+                           static_cast<const T*>(F), u, i, score, bad_index, B, U, I);                                   \
         NGACF_CHECK_LAUNCH();                                                                              \
         return 0;                                                                                          \
     }
@@ -123,8 +135,8 @@ extern "C" int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const
 }
 
 extern "C" int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
-                               const float* gscore, float* gF, int B, int U, int d, void* stream) {
-    if (B < 0) return NGACF_E_ARG;
+                               const float* gscore, float* gF, int32_t* bad_index, int B, int U, int I, int d, void* stream) {
+    if (B < 0 || U <= 0 || I <= 0) return NGACF_E_ARG;
     if (B == 0) return 0;
     if (!F || !u || !i || !gscore || !gF) return NGACF_E_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -132,7 +144,7 @@ extern "C" int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const
     {                                                                                                      \
         constexpr int PPB = 16;                                                                            \
         hipLaunchKernelGGL((score_bwd_kernel<T, D>), dim3((B + PPB - 1) / PPB), dim3(256), 0, st,          \
-                           static_cast<const T*>(F), u, i, gscore, gF, B, U);                              \
+                           static_cast<const T*>(F), u, i, gscore, gF, bad_index, B, U, I);                              \
         NGACF_CHECK_LAUNCH();                                                                              \
         return 0;                                                                                          \
     }

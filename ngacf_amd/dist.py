@@ -103,7 +103,7 @@ class _ShardedStage(torch.autograd.Function):
     """One propagation stage on this rank's rows.  Input/output are LOCAL ([n_local, d], users first)."""
 
     @staticmethod
-    def forward(ctx, X, W, avec, part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed, h_dtype, seed_dev=None):
+    def forward(ctx, X, W, avec, part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed, h_dtype, seed_dev=None, grad_mode=True):
         X = X.contiguous()
         W, avec = W.contiguous().float(), avec.contiguous().float()
         dev, N, dout = X.device, part.N, W.shape[2]
@@ -112,7 +112,7 @@ class _ShardedStage(torch.autograd.Function):
         sd = {} if seed_dev is None else {"seed_dev": seed_dev}        # (the CPU test stand-in has no device seeds)
         be.transform_fwd_rows(X, W, avec, H, S, part.Up, part.Ip, heads, part.win, True, feat_drop_p, seed, **sd)
         comm.all_gather_rows(H)            # S stays local: source scores are recomputed from the gathered rows
-        need = any(ctx.needs_input_grad[:3])
+        need = grad_mode and any(ctx.needs_input_grad[:3])    # (grad mode is off inside forward(): the caller's comes in)
         res = be.prop_fwd(plan, H, S, S, avec, heads, alpha, True, True, True, drop_p, seed, save=need, **sd)
         out = res[0] if need else res
         if need:
@@ -135,7 +135,7 @@ class _ShardedStage(torch.autograd.Function):
         dX, dW, da = be.transform_bwd_rows(X, W, H, dH, dS, part.Up, part.Ip, heads, part.win, True, feat_drop_p, seed, **sd)
         if not comm.defer_weight_reduce:
             comm.all_reduce_sum(dW, da)
-        return (dX.to(X.dtype), dW, da) + (None,) * 11
+        return (dX.to(X.dtype), dW, da) + (None,) * 12
 
 
 class _GatherRows(torch.autograd.Function):
@@ -259,7 +259,7 @@ class ShardedSPUIGACF(nn.Module):
         for s, layers in enumerate(self.gat._stages()):
             W, avec = self.gat.stage_params(s)
             x = _ShardedStage.apply(x, W, avec, self.part, plan, self.comm, self.be, len(layers), layers[0].alpha,
-                                    drop, drop, NF.stage_seed(base, s), self.compute_dtype, seed_dev)
+                                    drop, drop, NF.stage_seed(base, s), self.compute_dtype, seed_dev, torch.is_grad_enabled())
         return x
 
     def propagate(self, mask):
@@ -380,7 +380,7 @@ def bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, hbm_peak, em
                 if rank == 0:
                     emit(text)
         if hard:                                   # a rank may be stuck inside a collective: leave without teardown
-            os._exit(0)
+            os._exit(3)                            # (non-zero: a stalled capture must not look like a clean run)
 
     dog = threading.Timer(float(os.environ.get("NGACF_DIST_GRAPH_TIMEOUT", "90")), finish, (eager_line, True))
     dog.daemon = True

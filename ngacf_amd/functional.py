@@ -13,12 +13,14 @@ class _Stage(torch.autograd.Function):
     SpUIGraphAttentionLayer heads computes in SPUIGACF.py:212 (or the out_att call :214)."""
 
     @staticmethod
-    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev=None, residual=True):
+    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev=None, residual=True, grad_mode=True):
         X = X.contiguous()
         W = W.contiguous().float()
         avec = avec.contiguous().float()
         H, S = ops.transform_fwd(X, W, avec, plan.U, plan.I, heads, h_dtype, feat_drop_p, seed, seed_dev)
-        need = any(ctx.needs_input_grad[:3])
+        # needs_input_grad ignores torch.no_grad() and grad mode is always off inside forward(): the caller's mode comes in as
+        # an argument, so an eval / no_grad forward does not allocate and write the backward's agg [N,d] fp32 + R tables
+        need = grad_mode and any(ctx.needs_input_grad[:3])
         if need:
             out, agg, R = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, save=True,
                                        seed_dev=seed_dev)
@@ -35,13 +37,13 @@ class _Stage(torch.autograd.Function):
         gout = gout.contiguous().to(H.dtype)              # already H's type under autograd: no cast kernel
         dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, alpha, elu, residual, None, drop_p, seed, seed_dev)
         dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
-        return dX, dW, da, None, None, None, None, None, None, None, None, None, None
+        return (dX, dW, da) + (None,) * 11
 
 
 def stage(X, W, avec, plan, heads, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=0.0, seed=0, h_dtype=None, seed_dev=None,
           residual=True):
     return _Stage.apply(X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed,
-                        X.dtype if h_dtype is None else h_dtype, seed_dev, residual)
+                        X.dtype if h_dtype is None else h_dtype, seed_dev, residual, torch.is_grad_enabled())
 
 
 def stage_seed(base, s):

@@ -40,6 +40,9 @@ class GraphedBPRStep:
         if data is not None:
             from . import ops
             from .train_eval import SAMPLE_STRIDE
+            if data.train_u.numel() < batch_size:
+                raise ValueError("GraphedBPRStep samples full batches: %d interaction rows < batch size %d"
+                                 % (data.train_u.numel(), batch_size))
             self.offset = torch.zeros(1, dtype=torch.int64, device=dev)       # first row of the batch in train_u
             self.sample_seed = torch.zeros(1, dtype=torch.int64, device=dev)
             self.unresolved = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -112,12 +115,19 @@ class GraphedBPRStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up off the capture: plans, caches, allocator
             for _ in range(warmup):
+                if data is not None:
+                    self.offset.zero_()                     # every warm-up step samples rows [0, B): n >= B is all it needs
                 step()
+            if data is not None:
+                self.offset.zero_()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         optim.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.loss = step()
+        if data is not None:                                # (the capture itself does not execute; begin_epoch() resets anyway)
+            self.offset.zero_()
+            self.unresolved.zero_()
         if saved is not None:                               # undo the warm-up updates, in place (the graph holds these tensors)
             with torch.no_grad():
                 for p, v in zip(model.parameters(), saved[0]):

@@ -218,31 +218,73 @@ def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0, seed_de
     return dX, dW, da
 
 
-def _idx(t, name, B, dev, hi):
-    p = _chk(t, name, torch.int64, B, dev)
-    return p
+# ---------------------------------------------------------------------------------------------------------
+# index safety of the data-dependent gathers.  The VALUES of userIdx / itemIdx / users live on the device, so they
+# cannot be range-checked here without a synchronisation per call; the kernels check them instead: an out-of-range
+# id is never turned into an address (score = NaN, no gradient written, top-K row = -1) and is counted in a
+# per-device int32 counter.  raise_if_bad_indices() turns the count into the IndexError the reference's advanced
+# indexing raises (SPUIGACF.py:49-50) -- like a CUDA device-side assert it surfaces at the next host check, which the
+# train / eval loops do where they synchronise anyway (loss.item(), metric transfer).  NGACF_SYNC_INDEX_CHECK=1 checks
+# after every scoring call (one sync each; debugging).
+# ---------------------------------------------------------------------------------------------------------
+_BAD = {}
+SYNC_INDEX_CHECK = __import__("os").environ.get("NGACF_SYNC_INDEX_CHECK") == "1"
+
+
+def _bad_counter(dev):
+    c = _BAD.get(dev)
+    if c is None:
+        c = _BAD[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return c
+
+
+def bad_index_count(dev=None):
+    """Out-of-range indices seen by the scoring / ranking kernels since the last reset (synchronises)."""
+    return sum(int(c.item()) for d, c in _BAD.items() if dev is None or d == torch.device(dev))
+
+
+def raise_if_bad_indices(dev=None):
+    n = bad_index_count(dev)
+    if n:
+        for d, c in _BAD.items():
+            if dev is None or d == torch.device(dev):
+                c.zero_()
+        raise IndexError("%d user/item index value(s) out of range reached the scoring kernels (their scores are NaN, "
+                         "their gradients were dropped)" % n)
+
+
+def _idx(t, name, B, dev):
+    return _chk(t, name, torch.int64, B, dev)
 
 
 def score_fwd(F, u, i, U):
     dev, d, B = F.device, F.shape[1], u.numel()
     if d not in SUPPORTED_D or F.dtype not in _DT:
         raise ValueError("unsupported F: d=%d dtype=%s" % (d, F.dtype))
+    I = F.shape[0] - U
+    if not 0 < U < F.shape[0]:
+        raise ValueError("F has %d rows, U=%d" % (F.shape[0], U))
     fp = _chk(F, "F", None, F.shape[0] * d, dev)
     score = torch.empty(B, dtype=torch.float32, device=dev)
     if B:
-        _lib.check(lib.ngacf_score_fwd(fp, _DT[F.dtype], _idx(u, "userIdx", B, dev, U), _idx(i, "itemIdx", B, dev, 0),
-                                       score.data_ptr(), B, U, d, _stream()), "ngacf_score_fwd")
+        _lib.check(lib.ngacf_score_fwd(fp, _DT[F.dtype], _idx(u, "userIdx", B, dev), _idx(i, "itemIdx", B, dev),
+                                       score.data_ptr(), _bad_counter(dev).data_ptr(), B, U, I, d, _stream()), "ngacf_score_fwd")
+        if SYNC_INDEX_CHECK:
+            raise_if_bad_indices(dev)
     return score
 
 
 def score_bwd(F, u, i, gscore, U):
     dev, d, B = F.device, F.shape[1], u.numel()
+    I = F.shape[0] - U
+    if not 0 < U < F.shape[0]:
+        raise ValueError("F has %d rows, U=%d" % (F.shape[0], U))
     fp = _chk(F, "F", None, F.shape[0] * d, dev)
     gF = torch.zeros(F.shape[0], d, dtype=torch.float32, device=dev)
     if B:
         gp = _chk(gscore, "gscore", torch.float32, B, dev)
-        _lib.check(lib.ngacf_score_bwd(fp, _DT[F.dtype], _idx(u, "userIdx", B, dev, U), _idx(i, "itemIdx", B, dev, 0),
-                                       gp, gF.data_ptr(), B, U, d, _stream()), "ngacf_score_bwd")
+        _lib.check(lib.ngacf_score_bwd(fp, _DT[F.dtype], _idx(u, "userIdx", B, dev), _idx(i, "itemIdx", B, dev),
+                                       gp, gF.data_ptr(), _bad_counter(dev).data_ptr(), B, U, I, d, _stream()), "ngacf_score_bwd")
     return gF
 
 
@@ -391,7 +433,8 @@ def eval_topk(F, users, U, I, pool_mask, train_ptr, train_items, K=20):
                                        _chk(pool_mask, "pool_mask", torch.uint8, I, dev),
                                        _chk(train_ptr, "train_ptr", torch.int64, U + 1, dev),
                                        _chk(train_items, "train_items", torch.int32, train_items.numel(), dev),
-                                       K, top_i.data_ptr(), top_s.data_ptr(), _stream()), "ngacf_eval_topk")
+                                       K, top_i.data_ptr(), top_s.data_ptr(), _bad_counter(dev).data_ptr(), _stream()),
+                   "ngacf_eval_topk")
     return top_i, top_s
 
 
@@ -406,9 +449,12 @@ def sample_pairs(train_u, offset, B, train_ptr, train_items32, pool_items32, see
         unresolved = torch.zeros(1, dtype=torch.int32, device=dev)
     if B:
         U = train_ptr.numel() - 1
+        n_rows = train_u.numel()
+        if offset < 0 or (offset_dev is None and offset + B > n_rows):
+            raise ValueError("batch rows [%d, %d) run past the %d interaction rows" % (offset, offset + B, n_rows))
         _chk(out, "out", torch.int64, 3 * B, dev)
-        _lib.check(lib.ngacf_sample_pairs(_chk(train_u, "train_u", torch.int64, train_u.numel(), dev), int(offset), _sd(offset_dev, dev),
-                                          _chk(train_ptr, "train_ptr", torch.int64, U + 1, dev),
+        _lib.check(lib.ngacf_sample_pairs(_chk(train_u, "train_u", torch.int64, n_rows, dev), n_rows, int(offset), _sd(offset_dev, dev),
+                                          _chk(train_ptr, "train_ptr", torch.int64, U + 1, dev), U,
                                           _chk(train_items32, "train_items", torch.int32, train_items32.numel(), dev),
                                           _chk(pool_items32, "pool_items", torch.int32, pool_items32.numel(), dev),
                                           pool_items32.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, _sd(seed_dev, dev),

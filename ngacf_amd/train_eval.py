@@ -134,7 +134,9 @@ def train_bpr(model, batch_size, data, adj, optim, lossfn, generator=None, log_e
         if log_every and b % log_every == 0:
             print("  batch %d/%d loss %.5f" % (b, n_batches, float(loss.detach())), flush=True)
     if int(unres) != 0:
-        raise RuntimeError("negative sampling did not converge (a user is positive on the whole item pool)")
+        raise RuntimeError("negative sampling did not converge (a user is positive on the whole item pool), or a "
+                           "batch row / user id outside the interaction table reached the sampler")
+    ops.raise_if_bad_indices(data.device)                             # (the epoch's one host check of the index counters)
     return float(total) / n                                           # :144 (sum of batch means / rows)
 
 
@@ -204,6 +206,7 @@ def eval_neg_all(model, batch_size, data, adj, user_batch=1 << 20, return_scores
         for k in res:
             res[k] += m[k]
     out = {k: v.cpu().numpy() for k, v in res.items()}
+    ops.raise_if_bad_indices(data.device)
     out["auc"] = 0.0                                                  # the reference reports 0 (:385)
     if return_scores:
         return out, users, torch.cat(kept)

@@ -78,7 +78,7 @@ def test_library_loaded_and_rejects_bad_shapes(dev):
     # a table of 2^32 bytes or more does not fit the 32-bit row offsets: refused, not wrapped
     rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1 << 24, 64, 8, 0.2, 0.0, 0, 0, 3, 0)
     assert rc == -2
-    assert _lib.lib.ngacf_score_fwd(0, 0, 0, 0, 0, 5, 1, 64, 0) == -1
+    assert _lib.lib.ngacf_score_fwd(0, 0, 0, 0, 0, 0, 5, 1, 1, 64, 0) == -1
 
 
 # ---------------------------------------------------------------------------
@@ -405,6 +405,43 @@ def test_score_and_bpr_kernels(dev):
     assert _maxabs(gp, want_g) < 1e-7 and _maxabs(gn, -want_g) < 1e-7
     # empty batch
     assert ops.score_fwd(_t(F, dev), _t(u[:0], dev), _t(it[:0], dev), U).numel() == 0
+
+
+def test_out_of_range_indices_never_become_addresses(dev):
+    """ADVICE r1: userIdx / itemIdx values are data on the device.  The reference's indexing raises (SPUIGACF.py:49-50);
+    here a bad pair scores NaN, its gradient is dropped (no wild atomicAdd), the good pairs are untouched, and the host
+    check raises IndexError."""
+    from ngacf_amd import ops
+    rs = np.random.RandomState(3)
+    U, I, B = 100, 80, 512
+    F = rs.randn(U + I, 64).astype(np.float32)
+    u, it = rs.randint(0, U, B), rs.randint(0, I, B)
+    bad = np.array([5, 17, 100, 333])
+    u[5], it[17], u[100], it[333] = U, I, -1, 1 << 40          # item id U+I-1 < it < ... : would alias a user row / wrap
+    ops.raise_if_bad_indices(dev)                               # clean slate
+    Fd, g = _t(F, dev), _t(rs.randn(B).astype(np.float32), dev)
+    sc = ops.score_fwd(Fd, _t(u, dev), _t(it, dev), U).cpu().numpy()
+    good = np.setdiff1d(np.arange(B), bad)
+    assert np.isnan(sc[bad]).all() and not np.isnan(sc[good]).any()
+    assert np.abs(sc[good] - np.sum(F[u[good]] * F[it[good] + U], 1)).max() < 1e-4
+    gF = ops.score_bwd(Fd, _t(u, dev), _t(it, dev), g, U).cpu().numpy()
+    ref = np.zeros_like(F, dtype=np.float64)
+    gg = g.cpu().numpy()
+    np.add.at(ref, u[good], gg[good, None] * F[it[good] + U]); np.add.at(ref, it[good] + U, gg[good, None] * F[u[good]])
+    assert np.abs(gF - ref).max() < 1e-3
+    assert ops.bad_index_count(dev) == 8                        # 4 in the forward, 4 in the backward
+    with pytest.raises(IndexError):
+        ops.raise_if_bad_indices(dev)
+    assert ops.bad_index_count(dev) == 0
+    # the module surface: a drop-in forward with a bad index ends in the same IndexError at the host check
+    import ngacf_amd
+    torch.manual_seed(0)
+    m = ngacf_amd.SPUIGACF(6, 5, 64, [64, 64], 0.0).to(dev).eval()
+    edge = torch.tensor([[0, 1, 2, 3, 4, 5], [0, 1, 2, 3, 4, 0]], device=dev)
+    s = m(torch.tensor([0, 6], device=dev), torch.tensor([1, 1], device=dev), edge)
+    assert bool(torch.isnan(s[1])) and not bool(torch.isnan(s[0]))
+    with pytest.raises(IndexError):
+        ops.raise_if_bad_indices(dev)
 
 
 def test_g7_static_spmm(dev):

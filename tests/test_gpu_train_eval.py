@@ -255,6 +255,63 @@ def test_pair_sampler_kernel_matches_host_statement_and_semantics():
     a, _ = ops.sample_pairs(users, 0, 512, d.train_ptr, d.train_items32, d.pool_items32, 12000, offset_dev=off, seed_dev=sd)
     b, _ = ops.sample_pairs(users, 100, 512, d.train_ptr, d.train_items32, d.pool_items32, 12345)
     assert torch.equal(a, b)
+    # rows past the end of the interaction list are refused on the host when the offset is a host value ...
+    with pytest.raises(ValueError):
+        ops.sample_pairs(users, B - 100, 512, d.train_ptr, d.train_items32, d.pool_items32, 1)
+    # ... and clamped + counted (never dereferenced) when a device counter ran past the epoch
+    off = torch.tensor([B - 100], dtype=torch.int64, device=dev)
+    c, unres = ops.sample_pairs(users, 0, 512, d.train_ptr, d.train_items32, d.pool_items32, 1, offset_dev=off)
+    assert int(unres) == 412 and bool((c[0][100:] == users[B - 1]).all())
+    # a user id outside the CSR: clamped + counted
+    wild = users.clone(); wild[7] = U + 1000
+    _, unres = ops.sample_pairs(wild, 0, 64, d.train_ptr, d.train_items32, d.pool_items32, 1)
+    assert int(unres) == 1
+
+
+@pytest.mark.gpu
+def test_graphed_step_with_sampler_on_a_table_shorter_than_three_batches():
+    """the capture's warm-up steps used to advance the device row offset (3 x B rows) -- with B <= n < 3B the
+    sampler read past train_u.  Every warm-up step now samples rows [0, B)."""
+    import ngacf_amd
+    from ngacf_amd.graphs import GraphedBPRStep
+    from ngacf_amd.train_eval import Interactions
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(2)
+    U, I, B = 30, 40, 256
+    tu = np.concatenate([np.arange(U), rs.randint(0, U, 300 - U)]); ti = rs.randint(0, I, 300)      # n = 300: B <= n < 2B
+    d = Interactions(tu, ti, np.arange(U), rs.randint(0, I, U), U, I, dev)
+    adj = d.adjacency()
+    torch.manual_seed(0)
+    m = ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.1).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+    gs = GraphedBPRStep(m, ngacf_amd.BPRLoss(), opt, adj, B, data=d, preserve_state=True)
+    assert int(gs.unresolved) == 0 and int(gs.offset) == 0
+    gs.begin_epoch(11)
+    gs.replay()
+    torch.cuda.synchronize()
+    assert int(gs.unresolved) == 0 and int(gs.offset) == B and bool(torch.isfinite(gs.loss))
+    assert torch.equal(gs.upn[0], d.train_u[:B])
+    with pytest.raises(ValueError):
+        GraphedBPRStep(m, ngacf_amd.BPRLoss(), opt, adj, 512, data=d)
+
+
+@pytest.mark.gpu
+def test_eval_topk_flags_users_outside_the_table():
+    from ngacf_amd import ops
+    dev = torch.device("cuda:0")
+    U, I, K = 50, 70, 20
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    F = torch.randn(U + I, 64, device=dev, generator=g)
+    ptr = torch.zeros(U + 1, dtype=torch.long, device=dev)
+    items = torch.zeros(1, dtype=torch.int32, device=dev)
+    pool = torch.ones(I, dtype=torch.uint8, device=dev)
+    users = torch.tensor([3, U + 7, 4, -2], device=dev)
+    ops.raise_if_bad_indices(dev)
+    top, _ = ops.eval_topk(F, users, U, I, pool, ptr, items, K)
+    ref, _ = ops.eval_topk(F, users[[0, 2]].contiguous(), U, I, pool, ptr, items, K)
+    assert torch.equal(top[[0, 2]], ref) and bool((top[[1, 3]] == -1).all())
+    with pytest.raises(IndexError):
+        ops.raise_if_bad_indices(dev)
 
 
 @pytest.mark.gpu
