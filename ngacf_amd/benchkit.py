@@ -1,0 +1,164 @@
+"""Measurement helpers shared by bench.py's one-GPU and node-partitioned legs (no model code here).
+
+  * launch_command / self_launch: `python bench.py --gpus N` without a torchrun environment starts
+    `python -m torch.distributed.run ... bench.py --gpus N ...` as a CHILD process and relays its one JSON line.  The
+    parent never imports torch and never touches the GPU (re-exec'ing a process that has initialised HIP takes the box
+    down on this pool).
+  * timed_steps: K steps of R passes each between two barriers + synchronize() (the bench contract), with one event per
+    step so the median step ("window") is reported next to the whole-region figure.
+  * roofs: the applicable ceilings of a row-gather kernel by table size (MI355X_MICROARCH.md, "Indexed rows").
+"""
+import json
+import math
+import os
+import socket
+import subprocess
+import sys
+import time
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable (float4 copy)
+# MI355X_MICROARCH.md, "Indexed rows: gather into LDS" (chip-wide, measured): rows served from ...
+ROOF_L2_GATHER_GBS = 17800.0     # ... an XCD's 4 MiB L2 (16.8-18.8 TB/s)
+ROOF_MALL_GATHER_GBS = 8600.0    # ... the 256 MiB Infinity Cache, random rows of a 38 MB table (151 MB: 7.4-7.9 TB/s)
+ROOF_HBM_GATHER_GBS = 5800.0     # ... HBM, random whole rows of a table far beyond the Infinity Cache, each fetched once
+L2_BYTES_PER_XCD = 4 << 20
+MALL_BYTES = 256 << 20
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(n, argv, port, python=None, script=None):
+    """The child command of `bench.py --gpus n <argv>`: one rank per GPU on this node, rendezvous on 127.0.0.1."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(sys.argv[0])] + list(argv)
+
+
+def self_launch(n, argv, timeout=None):
+    """Run the distributed bench as a child process; relay its JSON line on stdout, everything else on stderr.
+    Returns the child's exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC (RCCL needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = launch_command(n, argv, free_port())
+    print("[bench] launching: %s" % " ".join(cmd), file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        out, _ = p.communicate()
+        print("[bench] child timed out", file=sys.stderr, flush=True)
+        return 124
+    line = None
+    for ln in out.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and s.endswith("}"):
+            try:
+                json.loads(s)
+                line = s
+            except ValueError:
+                pass
+        elif s:
+            print(s, file=sys.stderr)
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    elif p.returncode == 0:
+        print("[bench] child printed no JSON line", file=sys.stderr, flush=True)
+        return 1
+    return p.returncode
+
+
+def passes_per_step(t_pass_s, steps, target_s=0.6, cap=20000):
+    """R such that the timed region (steps x R passes) lasts about target_s: a 3 ms region moves by several percent
+    with one scheduler hiccup."""
+    if t_pass_s <= 0:
+        return 1
+    return int(max(1, min(cap, math.ceil(target_s / (max(steps, 1) * t_pass_s)))))
+
+
+def timed_steps(run, steps, passes, sync, torch):
+    """EXACTLY `steps` steps of `passes` calls of run() between sync()s.  Returns (seconds of the whole region, [ms per
+    step] from one event per step on the current stream -- no host synchronisation inside the region)."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    sync()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for k in range(steps):
+        for _ in range(passes):
+            run()
+        ev[k + 1].record()
+    sync()
+    t = time.perf_counter() - t0
+    return t, [ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]
+
+
+def median(xs):
+    s = sorted(xs)
+    n = len(s)
+    return 0.0 if n == 0 else (s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2]))
+
+
+def gather_regime(table_bytes, half_bytes=None):
+    """Which memory level serves a random-row gather of a table of this size, and the ceiling that applies.
+    half_bytes: the larger of the two halves a traversal half re-reads (user rows gather item rows only)."""
+    hb = table_bytes if half_bytes is None else half_bytes
+    if hb <= L2_BYTES_PER_XCD:
+        return {"regime": "L2-resident", "roof_GBps": ROOF_L2_GATHER_GBS,
+                "note": "the %.1f MB half a traversal half re-reads fits the 4 MiB L2 of every XCD" % (hb / 1e6)}
+    if table_bytes <= MALL_BYTES // 2:
+        return {"regime": "cache-resident (L2 + Infinity Cache)", "roof_GBps": ROOF_MALL_GATHER_GBS,
+                "note": "%.1f MB table: beyond an XCD's 4 MiB L2, inside the 256 MiB Infinity Cache -- the HBM fraction of "
+                        "such a launch is not an HBM statement (it may exceed 1); the ceiling is the Infinity-Cache row-gather "
+                        "rate, partly lifted by L2 hits" % (table_bytes / 1e6)}
+    return {"regime": "HBM", "roof_GBps": HBM_PEAK_GBS,
+            "note": "%.2f GB table: far beyond the 256 MiB Infinity Cache; rows come from HBM (guide: random whole rows "
+                    "fetched once read at 5.5-5.8 TB/s, a float4 copy at 6.3 TB/s, spec 8 TB/s)" % (table_bytes / 1e9)}
+
+
+def copy_rate_GBps(torch, dev, gib=1, reps=10):
+    """The box's own streaming rate: device-to-device copy of `gib` GiB (read + write counted)."""
+    a = torch.empty(gib << 30, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(reps * 2 * (gib << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def traffic_from_profile(root, workload, dtype, stages, d):
+    """(bytes per launch, source) from the committed PMC passes of this command (tools/traffic.py: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 on gfx950), newest round first; (None, None) when there is none.
+    The counters are NOT collected by this run -- the line says where they come from."""
+    if stages != 3 or d != 64:
+        return None, None
+    for rnd in ("r02", "r01"):
+        rel = os.path.join("profiles", "%s_traffic_%s.json" % (rnd, workload))
+        p = os.path.join(root, rel)
+        if os.path.exists(p):
+            by = json.load(open(p)).get("by_dtype", {}).get(dtype)
+            if by:
+                return by.get("traffic_bytes"), "from_profile: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                                                "FETCH_SIZE x2 per the gfx950 correction; not collected in this run)" % rel
+    return None, None

@@ -55,6 +55,67 @@ def synthetic_bipartite(U, I, E, seed=2019, device="cpu", alpha_pop=0.8, sigma=1
     return torch.stack([key // I, key % I])
 
 
+def synthetic_bipartite_chunks(U, I, E, seed=2019, device="cpu", alpha_pop=0.8, sigma=1.0, chunk_users=1 << 18):
+    """The same generator family, produced USER CHUNK BY USER CHUNK: yields (u_lo, u_hi, keys) with `keys` the sorted
+    unique int64 edge keys (user * I + item) of the users [u_lo, u_hi).  Every chunk has its own counter-seeded
+    generator, so any rank can produce any chunk and all ranks agree on the graph without ever holding it whole (the
+    10^9-edge graph of BASELINE config 5 is built shard-wise on the device this way: ngacf_amd.dist.sharded_graph).
+    A user's edges live in exactly one chunk, so the concatenation is globally sorted and unique; E' is within ~2 % of E."""
+    dev = torch.device(device)
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(seed)
+    raw = torch.exp(sigma * torch.randn(U, device=dev, generator=g0, dtype=torch.float64))
+    over = 1.06
+    deg = torch.clamp((raw * (E * over / float(raw.sum()))).round().long(), min=1, max=I)
+    target = torch.clamp((raw * (E / float(raw.sum()))).round().long(), min=1, max=I)     # per-user share of E
+    pop = torch.pow(torch.arange(1, I + 1, device=dev, dtype=torch.float64), -alpha_pop)
+    perm = torch.randperm(I, device=dev, generator=g0)
+    cdf = torch.cumsum(pop / pop.sum(), 0)
+    del raw, pop
+    for c, lo in enumerate(range(0, U, chunk_users)):
+        hi = min(U, lo + chunk_users)
+        g = torch.Generator(device=dev)
+        g.manual_seed((seed * 1000003 + c + 1) & 0x7FFFFFFFFFFFFFFF)
+        d = deg[lo:hi]
+        users = torch.repeat_interleave(torch.arange(lo, hi, device=dev), d)
+        r = torch.rand(users.numel(), device=dev, generator=g, dtype=torch.float64)
+        items = perm[torch.searchsorted(cdf, r).clamp_(max=I - 1)]
+        key = torch.unique(users * I + items)
+        extra = int(key.numel() - int(target[lo:hi].sum()))
+        if extra > 0:                                      # thin out to the chunk's share, never a user's first edge
+            u = key // I
+            first = torch.ones_like(u, dtype=torch.bool)
+            first[1:] = u[1:] != u[:-1]
+            cand = torch.nonzero(~first).squeeze(1)
+            drop = cand[torch.randperm(cand.numel(), device=dev, generator=g)[:extra]]
+            keep = torch.ones_like(first)
+            keep[drop] = False
+            key = key[keep]
+        yield lo, hi, key
+
+
+def synthetic_bipartite_big(U, I, E, seed=2019, device="cpu", chunk_users=1 << 18):
+    """[2,E'] indices of the chunked generator, whole (one GPU holds it: the N=1 leg of the big workloads)."""
+    keys = [k for _, _, k in synthetic_bipartite_chunks(U, I, E, seed, device, chunk_users=chunk_users)]
+    key = torch.cat(keys)
+    return torch.stack([key // I, key % I])
+
+
+BIG_WORKLOADS = ("synthetic200m", "synthetic1b")
+
+
+def workload_graph(name, device, seed=2019):
+    """[2,E] indices of a named bench workload.  Gowalla / Yelp scale: synthetic_bipartite (the graphs of round 1);
+    ml100k: the real file; synthetic200m / synthetic1b: the chunked generator (same graph at every GPU count)."""
+    U, I, E = SHAPES[name]
+    if name == "ml100k":
+        u, i, _ = load_ml100k()
+        return torch.from_numpy(ui_mat_indices(u, i, I)).to(device)
+    if name in BIG_WORKLOADS:
+        return synthetic_bipartite_big(U, I, E, seed, device)
+    return synthetic_bipartite(U, I, E, seed=seed, device=device)
+
+
 def uniform_bipartite(U, I, E, seed=2019, device="cpu"):
     dev = torch.device(device)
     g = torch.Generator(device=dev)

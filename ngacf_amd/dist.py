@@ -1,21 +1,37 @@
-"""Node-partitioned propagation over P GPUs: one process per GPU,
-`torch.distributed` (backend "nccl" = RCCL over xGMI), one all-gather of the transformed table per
-propagation stage.  The reference is "replicas only" (parallel.py:94-196: every GPU recomputes all E edges).
+"""Node-partitioned propagation over P GPUs: one process per GPU, `torch.distributed` (backend
+"nccl" = RCCL over xGMI), the transformed table all-gathered once per propagation stage -- hidden behind the traversal.
+The reference is "replicas only" (parallel.py:94-196: every GPU recomputes all E edges).
 
-Partition: users and items are each cut into P equal blocks (tables padded to P*ceil(U/P) and P*ceil(I/P)
-rows with isolated zero nodes), so rank p's rows are contiguous in the global order and the all-gather
-lands IN PLACE in the global table -- no re-layout copy, kernels unchanged.  Rank p owns: its embedding rows
-(+ their Adam state), the CSR rows of its user block and the CSC rows of its item block.
+Partition.  Nodes are renumbered once, at ingest: users sorted by degree are dealt to the P ranks in snake order
+(likewise items), internal id = rank * block + slot.  Every rank then owns a CONTIGUOUS block of cu = ceil(U/P) user
+rows and ci = ceil(I/P) item rows of the internal numbering, the blocks are equal in rows (the all-gather lands IN
+PLACE in the global-row table, no padding beyond U mod P) AND balanced in nnz (hub rows are spread round-robin) whatever
+the id order of the data set.  Rank p owns its embedding rows (+ Adam state), the CSR rows of its user block and the
+CSC rows of its item block -- and only those edges: the plan is built from the ~2E/P directed edges that end in the
+rank's rows (ngacf_amd.plan.build_plan_from_keys); no rank sorts or stores the global edge list.
 
-Per stage, forward:   local transform (window) -> all-gather H -> local pull traversal (source scores are
-                      recomputed from the gathered rows, so the score table never travels)
-           backward:  local node step -> all-gather Gn, ST -> local edge step -> local transform backward
-                      -> all-reduce of the 16 K small-weight gradients (per stage, or once per step with
-                      comm.defer_weight_reduce + reduce_grads()).  No reduce-scatter, no atomics.
+Schedule (one autograd node for the whole stack, `_ShardedStack`).  A traversal of the user rows reads only ITEM rows
+of H (and vice versa), so a stage is two half-launches with different needs:
 
-`backend` is the module that runs the local compute (default: ngacf_amd.ops = the HIP library).  The CPU
-tests inject a torch stand-in to exercise partition + collectives under gloo; the product never does.
+    T(s,t)  transform the local rows of type t for stage s, start the all-gather of that half of H_s   (async)
+    V(s,A)  wait for the all-gather of the OTHER type, traverse the local dst rows of type A
+
+  forward   T(0,B) T(0,A) | V(s,A) T(s+1,A) V(s,B) T(s+1,B) | ...   with A alternating user/item from stage to stage:
+            the all-gather that V(s,B) waits for runs under V(s,A), the one V(s+1,B) needs (started by T(s+1,A)) runs
+            under V(s,B) -- only the very first all-gather of a forward is exposed.
+  backward  the mirror image with the node step N(s,t) (-> Gn, t tables, all-gathered per half), the edge step
+            E(s,A) and the transform backward per half; dX of a half is the next stage's incoming gradient, so
+            N(s-1,A) and its all-gather start while E(s,B) still runs.
+
+The collectives are issued with async_op=True (c10d runs them on the communicator's own stream; wait() is a stream
+wait, not a host wait), two tables of one half as ONE grouped launch.  `overlap=False` waits right after every start:
+the serial schedule of round 1, kept for A/B timing.  Scoring exchanges 2B rows (one small all-reduce per forward),
+not the [N,d] table.  No reduce-scatter, no atomics; results are bitwise independent of the schedule.
+
+`backend` is the module that runs the local compute (default: ngacf_amd.ops = the HIP library).  The CPU tests inject a
+torch stand-in to exercise partition + collectives + schedule under gloo; the product never does.
 """
+import contextlib
 import math
 
 import torch
@@ -24,12 +40,29 @@ import torch.nn as nn
 
 from . import functional as NF
 from . import ops as _hip_ops
-from .plan import build_plan, squeeze_mask
+from .plan import build_plan, build_plan_from_keys, squeeze_mask
 from .SPUIGACF import SpUIGAT, SPUIMultiGAT, StackedSpUIGAT, _fresh_seed, _SEED_STRIDE, _CTR_STRIDE
+
+OTHER = {"user": "item", "item": "user"}
+
+
+def _deal(deg, P, block):
+    """original id -> internal id: ids sorted by degree (descending, stable) are dealt to the P ranks in snake order."""
+    n = int(deg.numel())
+    order = torch.sort(deg, descending=True, stable=True).indices
+    j = torch.arange(n, device=deg.device)
+    t, k = j // P, j % P
+    r = torch.where(t % 2 == 0, k, P - 1 - k)
+    perm = torch.empty(n, dtype=torch.long, device=deg.device)
+    perm[order] = r * block + t
+    return perm
 
 
 class Partition:
-    def __init__(self, U, I, world, rank):
+    """Equal blocks of the INTERNAL numbering.  deg_u / deg_i given: degree-balanced renumbering (see the module
+    docstring); without them the internal numbering is the data set's own (blocks of consecutive ids)."""
+
+    def __init__(self, U, I, world, rank, deg_u=None, deg_i=None):
         self.U, self.I, self.P, self.rank = U, I, world, rank
         self.cu, self.ci = math.ceil(U / world), math.ceil(I / world)
         self.Up, self.Ip = self.cu * world, self.ci * world          # padded table sizes
@@ -37,26 +70,81 @@ class Partition:
         self.u_lo, self.i_lo = rank * self.cu, rank * self.ci
         self.win = (self.u_lo, self.cu, self.i_lo, self.ci)
         self.n_local = self.cu + self.ci
+        self.perm_u = _deal(deg_u.long(), world, self.cu) if deg_u is not None else None
+        self.perm_i = _deal(deg_i.long(), world, self.ci) if deg_i is not None else None
+        self._cache = {}
 
+    # ---- numbering ---------------------------------------------------------------------------------------------
+    def _on(self, name, dev):
+        key = (name, str(dev))
+        if key not in self._cache:
+            perm = getattr(self, "perm_" + name[-1])
+            n, npad = (self.U, self.Up) if name[-1] == "u" else (self.I, self.Ip)
+            if name.startswith("perm"):
+                t = perm.to(dev) if perm is not None else torch.arange(n, device=dev)
+            else:                                           # inverse: internal -> original, -1 on the padding slots
+                t = torch.full((npad,), -1, dtype=torch.long, device=dev)
+                p = perm.to(dev) if perm is not None else torch.arange(n, device=dev)
+                t[p] = torch.arange(n, device=dev)
+            self._cache[key] = t
+        return self._cache[key]
+
+    def internal_users(self, idx):
+        return idx if self.perm_u is None else self._on("perm_u", idx.device)[idx]
+
+    def internal_items(self, idx):
+        return idx if self.perm_i is None else self._on("perm_i", idx.device)[idx]
+
+    def map_edges(self, edge):
+        """[2,E] (user id, item id) of the data set -> internal numbering."""
+        if self.perm_u is None and self.perm_i is None:
+            return edge
+        return torch.stack([self.internal_users(edge[0]), self.internal_items(edge[1])])
+
+    def local_original_ids(self, dev="cpu"):
+        """(user ids, item ids) of the data set behind this rank's local rows, -1 on padding slots."""
+        return (self._on("inv_u", dev)[self.u_lo:self.u_lo + self.cu], self._on("inv_i", dev)[self.i_lo:self.i_lo + self.ci])
+
+    def to_original(self, tab):
+        """[Up+Ip, ...] internal-row table -> [U+I, ...] in the data set's numbering."""
+        return torch.cat([tab[:self.Up][self._on("perm_u", tab.device)], tab[self.Up:][self._on("perm_i", tab.device)]])
+
+    # ---- rows --------------------------------------------------------------------------------------------------
     @property
     def row_ranges(self):
         return [(self.u_lo, self.u_lo + self.cu), (self.Up + self.i_lo, self.Up + self.i_lo + self.ci)]
 
+    def half_win(self, t):
+        return (self.u_lo, self.cu, 0, 0) if t == "user" else (0, 0, self.i_lo, self.ci)
+
+    def block(self, full, t):
+        """this rank's rows of type t of a global-row table (a contiguous view)"""
+        return full[self.u_lo:self.u_lo + self.cu] if t == "user" else full[self.Up + self.i_lo:self.Up + self.i_lo + self.ci]
+
     def local_rows(self, full):
         """[n_local, ...] copy of this rank's rows of a global-row tensor (users first)."""
-        return torch.cat([full[self.u_lo:self.u_lo + self.cu], full[self.Up + self.i_lo:self.Up + self.i_lo + self.ci]])
+        return torch.cat([self.block(full, "user"), self.block(full, "item")])
 
-    def n_real_local(self):
-        nu = max(0, min(self.U, self.u_lo + self.cu) - self.u_lo)
-        ni = max(0, min(self.I, self.i_lo + self.ci) - self.i_lo)
-        return nu, ni
+
+class _Handle:
+    def __init__(self, works=(), cm=None, done=None):
+        self.works, self.cm, self.done = list(works), cm, done
+
+    def wait(self):
+        if self.cm is not None:
+            self.cm.wait()
+        for w in self.works:
+            w.wait()
+        self.works, self.cm = [], None
+        if self.done is not None:
+            self.done()
+            self.done = None
 
 
 class Comm:
-    """The collectives of the path.  In-place all-gather: rank p's block of `full` is already where the
-    gathered table wants it.  Under RCCL every call is ONE grouped launch (ncclGroupStart/End through c10d's
-    coalescing manager) however many tables and halves it carries: at Gowalla scale a stage is bound by the
-    number of collective launches, not by their bytes."""
+    """The collectives of the path.  In-place all-gather: rank p's block of `full` is already where the gathered table
+    wants it.  Under RCCL the tables of one call travel as ONE grouped launch (ncclGroupStart/End through c10d's
+    coalescing manager): at Gowalla scale a stage is bound by the number of collective launches, not by their bytes."""
 
     def __init__(self, part, group=None):
         self.part, self.group = part, group
@@ -65,109 +153,226 @@ class Comm:
         self._coalesce = self._base and hasattr(dist.distributed_c10d, "_coalescing_manager")
         self.force = False                    # rehearsal on one rank: issue the collectives even when world == 1
         self.defer_weight_reduce = False      # True: the caller sums weight gradients once per step (reduce_grads)
-        self.launches = 0                     # grouped collective launches issued (for the tests / the bench line)
+        self.overlap = True                   # False: wait right after every start (serial schedule)
+        self.launches = 0                     # collective launches issued (for the tests / the bench line)
+        self.timer = None                     # list -> (start event, end event, bytes received) per gather (bench, serial mode)
 
-    def _grouped(self, n_ops):
-        import contextlib
-        self.launches += 1 if (self._coalesce or n_ops == 0) else n_ops
-        if self._coalesce and n_ops > 1:
-            return dist.distributed_c10d._coalescing_manager(group=self.group)
-        return contextlib.nullcontext()
+    @property
+    def active(self):
+        return self.world > 1 or self.force
+
+    def _region(self, full, t):
+        p = self.part
+        lo, n, tot = (0, p.cu, p.Up) if t == "user" else (p.Up, p.ci, p.Ip)
+        return full[lo:lo + tot], full[lo + p.rank * n: lo + (p.rank + 1) * n], n
+
+    def start_gather(self, t, *fulls):
+        """All-gather the half `t` ('user' / 'item') of every global-row table in `fulls`; returns a handle to wait on."""
+        if not self.active:
+            return _Handle()
+        regions = [self._region(f, t) for f in fulls]
+        ev = None
+        if self.timer is not None and fulls[0].is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+        self.launches += 1 if (self._coalesce or len(regions) == 1) else len(regions)
+        if self._base:
+            if self._coalesce and len(regions) > 1:
+                with dist.distributed_c10d._coalescing_manager(group=self.group, async_ops=True) as cm:
+                    for out, mine, _ in regions:
+                        dist.all_gather_into_tensor(out, mine, group=self.group)
+                h = _Handle(cm=cm)
+            else:
+                h = _Handle([dist.all_gather_into_tensor(out, mine, group=self.group, async_op=True) for out, mine, _ in regions])
+        else:                                             # gloo: list form
+            works = []
+            for out, mine, n in regions:
+                chunks = [out[r * n:(r + 1) * n] for r in range(self.world)]
+                works.append(dist.all_gather(chunks, mine.clone(), group=self.group, async_op=True))
+            h = _Handle(works)
+        if ev is not None:
+            nbytes = sum(o.numel() * o.element_size() for o, _, _ in regions) * (self.world - 1) // max(self.world, 1)
+
+            def done(ev=ev, nbytes=nbytes):
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self.timer.append((ev, e1, nbytes))
+            h.done = done
+        if not self.overlap:
+            h.wait()
+        return h
 
     def all_gather_rows(self, *fulls):
-        """Every `full` is a global-row table [Up+Ip, ...] whose local user block and item block are filled."""
-        p = self.part
-        if self.world == 1 and not self.force:
-            return
-        pairs = []
-        for full in fulls:
-            for lo, n, tot in ((0, p.cu, p.Up), (p.Up, p.ci, p.Ip)):
-                pairs.append((full[lo:lo + tot], full[lo + p.rank * n: lo + (p.rank + 1) * n], n))
-        with self._grouped(len(pairs)):
-            for out, mine, n in pairs:
-                if self._base:
-                    dist.all_gather_into_tensor(out, mine, group=self.group)
-                else:                                             # gloo: list form
-                    chunks = [out[r * n:(r + 1) * n] for r in range(self.world)]
-                    dist.all_gather(chunks, mine.clone(), group=self.group)
+        """Both halves of every table, synchronous (state_dict / evaluation plumbing, not the hot path)."""
+        for t in ("user", "item"):
+            self.start_gather(t, *fulls).wait()
 
     def all_reduce_sum(self, *ts):
-        if self.world > 1 or self.force:
-            with self._grouped(len(ts)):
+        if self.active:
+            self.launches += 1 if (self._coalesce or len(ts) == 1) else len(ts)
+            ctx = dist.distributed_c10d._coalescing_manager(group=self.group) if (self._coalesce and len(ts) > 1) \
+                else contextlib.nullcontext()
+            with ctx:
                 for t in ts:
                     dist.all_reduce(t, group=self.group)
         return ts[0] if len(ts) == 1 else ts
 
 
-class _ShardedStage(torch.autograd.Function):
-    """One propagation stage on this rank's rows.  Input/output are LOCAL ([n_local, d], users first)."""
+class _ShardedStack(torch.autograd.Function):
+    """All propagation stages on this rank's rows, pipelined against the all-gathers (module docstring).
+    apply(Xu, Xi, W_0, a_0, ..., W_{L-1}, a_{L-1}, cfg) -> (out_u [cu,d], out_i [ci,d]) of the last stage."""
 
     @staticmethod
-    def forward(ctx, X, W, avec, part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed, h_dtype, seed_dev=None, grad_mode=True):
-        X = X.contiguous()
-        W, avec = W.contiguous().float(), avec.contiguous().float()
-        dev, N, dout = X.device, part.N, W.shape[2]
-        H = torch.empty(N, dout, dtype=h_dtype, device=dev)
-        S = torch.empty(N, heads, dtype=torch.float32, device=dev)
-        sd = {} if seed_dev is None else {"seed_dev": seed_dev}        # (the CPU test stand-in has no device seeds)
-        be.transform_fwd_rows(X, W, avec, H, S, part.Up, part.Ip, heads, part.win, True, feat_drop_p, seed, **sd)
-        comm.all_gather_rows(H)            # S stays local: source scores are recomputed from the gathered rows
-        need = grad_mode and any(ctx.needs_input_grad[:3])    # (grad mode is off inside forward(): the caller's comes in)
-        res = be.prop_fwd(plan, H, S, S, avec, heads, alpha, True, True, True, drop_p, seed, save=need, **sd)
-        out = res[0] if need else res
+    def forward(ctx, Xu, Xi, *rest):
+        cfg = rest[-1]
+        params = rest[:-1]
+        part, plan, comm, be = cfg["part"], cfg["plan"], cfg["comm"], cfg["be"]
+        L = len(params) // 2
+        dev = Xu.device
+        N = part.N
+        need = cfg["grad_mode"] and any(ctx.needs_input_grad[:2 + 2 * L])
+        X = {"user": Xu.contiguous(), "item": Xi.contiguous()}
+        sd = {} if cfg["seed_dev"] is None else {"seed_dev": cfg["seed_dev"]}     # (the CPU stand-in has no device seeds)
+        Ws = [params[2 * s].contiguous().float() for s in range(L)]
+        As = [params[2 * s + 1].contiguous().float() for s in range(L)]
+        saved, pending = [], {}
+        Hs, Ss = [None] * L, [None] * L
+
+        def T(s, t):
+            if Hs[s] is None:
+                dout = Ws[s].shape[2]
+                Hs[s] = torch.empty(N, dout, dtype=cfg["h_dtype"], device=dev)
+                Ss[s] = torch.empty(N, cfg["heads"][s], dtype=torch.float32, device=dev)
+            be.transform_fwd_rows(X[t], Ws[s], As[s], Hs[s], Ss[s], part.Up, part.Ip, cfg["heads"][s], part.half_win(t), True,
+                                  cfg["feat_drop"], cfg["seeds"][s], **sd)
+            pending[(s, t)] = comm.start_gather(t, Hs[s])
+
+        first = "user"
+        T(0, OTHER[first])
+        T(0, first)
+        out = None
+        for s in range(L):
+            A, B = first, OTHER[first]
+            H, S, heads = Hs[s], Ss[s], cfg["heads"][s]
+            dout = H.shape[1]
+            out = torch.empty(N, dout, dtype=H.dtype, device=dev)
+            agg = torch.empty(N, dout, dtype=torch.float32, device=dev) if need else None
+            R = torch.empty(N, heads, dtype=torch.float32, device=dev) if need else None
+            Xs = dict(X)
+            for t in (A, B):
+                pending.pop((s, OTHER[t])).wait()                    # sources of the dst half t
+                be.prop_fwd(plan, H, S, S, As[s], heads, cfg["alpha"], True, True, True, cfg["drop"], cfg["seeds"][s],
+                            save=need, out=out, half=t, agg=agg, R=R, **sd)
+                if s + 1 < L:
+                    X[t] = part.block(out, t)
+                    T(s + 1, t)
+            if need:
+                saved.append((Xs["user"], Xs["item"], Ws[s], As[s], H, S, out, agg, R))
+            first = B                                                # the next stage starts with the other half
         if need:
-            ctx.save_for_backward(X, W, avec, H, S, out, res[1], res[2])
-            ctx.cfg = (part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed, sd)
-        return part.local_rows(out)
+            ctx.cfg, ctx.L = cfg, L
+            ctx.saved_stages = saved                                 # (held on ctx: views of the stage tables)
+        return part.block(out, "user"), part.block(out, "item")
 
     @staticmethod
-    def backward(ctx, g_local):
-        X, W, avec, H, S, out, agg, R = ctx.saved_tensors
-        part, plan, comm, be, heads, alpha, drop_p, feat_drop_p, seed, sd = ctx.cfg
-        dev, N, d = H.device, part.N, H.shape[1]
-        g_local = g_local.contiguous().to(H.dtype)
-        G = torch.empty(N, d, dtype=torch.float32, device=dev)
-        Gn = torch.empty(N, d, dtype=H.dtype, device=dev)
-        ST = torch.empty(N, heads, dtype=torch.float32, device=dev)       # t[n,h]
-        be.prop_bwd_node(out, agg, R, g_local, S, G, Gn, ST, part.Up, heads, part.win, True, True)
-        comm.all_gather_rows(Gn, ST)                                       # one grouped launch
-        dH, dS = be.prop_bwd_edges(plan, H, S, avec, G, Gn, ST, heads, alpha, True, True, drop_p, seed, **sd)
-        dX, dW, da = be.transform_bwd_rows(X, W, H, dH, dS, part.Up, part.Ip, heads, part.win, True, feat_drop_p, seed, **sd)
-        if not comm.defer_weight_reduce:
-            comm.all_reduce_sum(dW, da)
-        return (dX.to(X.dtype), dW, da) + (None,) * 12
+    def backward(ctx, gU, gI):
+        cfg, L = ctx.cfg, ctx.L
+        part, plan, comm, be = cfg["part"], cfg["plan"], cfg["comm"], cfg["be"]
+        sd = {} if cfg["seed_dev"] is None else {"seed_dev": cfg["seed_dev"]}
+        N = part.N
+        saved = ctx.saved_stages
+        h_dtype = saved[0][4].dtype
+        g = {"user": gU.contiguous().to(h_dtype), "item": gI.contiguous().to(h_dtype)}
+        dev = gU.device
+        tabs, pending = [None] * L, {}
+
+        def Nstep(s, t):
+            _, _, _, _, H, S, out, agg, R = saved[s]
+            if tabs[s] is None:
+                d, heads = H.shape[1], cfg["heads"][s]
+                tabs[s] = (torch.empty(N, d, dtype=torch.float32, device=dev), torch.empty(N, d, dtype=H.dtype, device=dev),
+                           torch.empty(N, heads, dtype=torch.float32, device=dev),
+                           torch.zeros(N, d, dtype=torch.float32, device=dev), torch.zeros(N, heads, dtype=torch.float32, device=dev))
+            G, Gn, ST, _, _ = tabs[s]
+            be.prop_bwd_node(out, agg, R, g[t], S, G, Gn, ST, part.Up, cfg["heads"][s], part.half_win(t), True, True)
+            pending[(s, t)] = comm.start_gather(t, Gn, ST)          # one grouped launch
+
+        first = "user"
+        Nstep(L - 1, OTHER[first])
+        Nstep(L - 1, first)
+        grads = [None] * (2 * L)
+        for s in range(L - 1, -1, -1):
+            Xu, Xi, W, a, H, S, out, agg, R = saved[s]
+            Xs = {"user": Xu, "item": Xi}
+            G, Gn, ST, dH, dS = tabs[s]
+            heads = cfg["heads"][s]
+            parts = {}
+            for t in (first, OTHER[first]):
+                pending.pop((s, OTHER[t])).wait()
+                be.prop_bwd_edges(plan, H, S, a, G, Gn, ST, heads, cfg["alpha"], True, True, cfg["drop"], cfg["seeds"][s],
+                                  half=t, dH=dH, dS=dS, **sd)
+                dX, dW, da = be.transform_bwd_rows(Xs[t], W, H, dH, dS, part.Up, part.Ip, heads, part.half_win(t), True,
+                                                   cfg["feat_drop"], cfg["seeds"][s], **sd)
+                parts[t] = (dW, da)
+                g[t] = dX if s == 0 else dX.to(h_dtype)
+                if s > 0:
+                    Nstep(s - 1, t)
+            dW = torch.stack([parts["user"][0][0], parts["item"][0][1]])         # each half owns its weight panel
+            da = torch.stack([parts["user"][1][0], parts["item"][1][1]])
+            if not comm.defer_weight_reduce:
+                comm.all_reduce_sum(dW, da)
+            grads[2 * s], grads[2 * s + 1] = dW, da
+            first = OTHER[first]
+        ctx.saved_stages = None
+        return (g["user"], g["item"]) + tuple(grads) + (None,)
 
 
-class _GatherRows(torch.autograd.Function):
-    """Local rows -> the full table on every rank.  Every rank computes the same loss on the same batch, so
-    the gradient of the full table is identical everywhere and its local slice needs no reduction."""
+class _RowExchange(torch.autograd.Function):
+    """rows[b] = table row `idx[b]` (internal global row) on EVERY rank: each rank contributes the rows it owns, zeros
+    elsewhere, one all-reduce of [B,d] sums them (one non-zero term per row: exact).  Replaces the all-gather of the
+    whole [N,d] table for 3 x B rows.  Every rank computes the same loss, so the gradient of a row is identical on
+    all ranks and its owner adds it locally: no communication in the backward."""
 
     @staticmethod
-    def forward(ctx, local, part, comm):
-        full = torch.zeros(part.N, local.shape[1], dtype=local.dtype, device=local.device)
-        full[part.u_lo:part.u_lo + part.cu] = local[:part.cu]
-        full[part.Up + part.i_lo:part.Up + part.i_lo + part.ci] = local[part.cu:]
-        comm.all_gather_rows(full)
-        ctx.part = part
-        return full
+    def forward(ctx, out_u, out_i, idx, part, comm):
+        local = torch.cat([out_u, out_i])
+        is_u = idx < part.Up
+        pos = torch.where(is_u, idx - part.u_lo, idx - part.Up - part.i_lo + part.cu)
+        mine = torch.where(is_u, (idx >= part.u_lo) & (idx < part.u_lo + part.cu),
+                           (idx >= part.Up + part.i_lo) & (idx < part.Up + part.i_lo + part.ci))
+        pos = torch.where(mine, pos, torch.zeros_like(pos))
+        rows = local[pos].float() * mine[:, None].float()
+        comm.all_reduce_sum(rows)
+        ctx.save_for_backward(pos, mine)
+        ctx.shape = (out_u.shape[0], out_i.shape[0], out_u.dtype)
+        return rows
 
     @staticmethod
     def backward(ctx, g):
-        return ctx.part.local_rows(g), None, None
+        pos, mine = ctx.saved_tensors
+        cu, ci, dt = ctx.shape
+        d = torch.zeros(cu + ci, g.shape[1], dtype=torch.float32, device=g.device)
+        d.index_add_(0, pos, g.float() * mine[:, None].float())
+        return d[:cu].to(dt), d[cu:].to(dt), None, None, None
 
 
 class ShardedSPUIGACF(nn.Module):
     """SPUIGACF / SPUIMultiGACF / SPUIStackedGACF with the embedding tables sharded by node blocks.
     forward(userIdx, itemIdx, mask) has the reference signature (SPUIGACF.py:41) and returns the scores of the
-    whole batch on every rank."""
+    whole batch on every rank.  `adj` (the [2,E] mask the forward will see) or `degrees=(deg_u, deg_i)` at construction
+    selects the degree-balanced partition; without either the blocks are runs of consecutive ids."""
 
     def __init__(self, userNum, itemNum, embedSize, layers, droprate, world=None, rank=None, stages=2,
-                 group=None, backend=None, device=None):
+                 group=None, backend=None, device=None, adj=None, degrees=None, partition=None):
         super().__init__()
         world = dist.get_world_size(group) if world is None else world
         rank = dist.get_rank(group) if rank is None else rank
         self.userNum, self.itemNum, self.droprate = userNum, itemNum, droprate
-        self.part = Partition(userNum, itemNum, world, rank)
+        if adj is not None and degrees is None:
+            a = squeeze_mask(adj)
+            degrees = (torch.bincount(a[0], minlength=userNum), torch.bincount(a[1], minlength=itemNum))
+        self.part = partition if partition is not None else \
+            Partition(userNum, itemNum, world, rank, *(degrees if degrees is not None else (None, None)))
         self.comm = Comm(self.part, group)
         self.be = backend if backend is not None else _hip_ops
         p = self.part
@@ -179,40 +384,60 @@ class ShardedSPUIGACF(nn.Module):
             self.gat = SPUIMultiGAT(embedSize, 8, embedSize, droprate, 0.2, 8)
         else:
             self.gat = StackedSpUIGAT(embedSize, 8, embedSize, droprate, 0.2, 8, stages - 1)
-        # same values on every rank as the unsharded model with the same seed: draw the full tables, keep a slice
-        full_u = torch.empty(userNum, embedSize).normal_(std=0.01)       # SPUIGACF.py:26-28
-        full_i = torch.empty(itemNum, embedSize).normal_(std=0.01)
-        self.load_full_embeddings(full_u, full_i)
+        # same values on every rank as the unsharded model with the same seed: draw the full tables, keep this rank's
+        # rows (tables beyond 1 GiB are drawn block-wise instead: every rank seeds its own block)
+        if (userNum + itemNum) * embedSize * 4 <= (1 << 30):
+            full_u = torch.empty(userNum, embedSize).normal_(std=0.01)       # SPUIGACF.py:26-28
+            full_i = torch.empty(itemNum, embedSize).normal_(std=0.01)
+            self.load_full_embeddings(full_u, full_i)
+        else:
+            g = torch.Generator().manual_seed(2019 + rank)
+            ou, oi = p.local_original_ids()
+            with torch.no_grad():
+                self.uEmbd.weight.normal_(std=0.01, generator=g)
+                self.iEmbd.weight.normal_(std=0.01, generator=g)
+                self.uEmbd.weight[ou < 0] = 0                                 # padding slots: isolated zero nodes
+                self.iEmbd.weight[oi < 0] = 0
         self._plans = {}
+        self._attached = None
         self.compute_dtype = torch.float32
         self.seg_len = 256
 
     # ---- parameter plumbing -------------------------------------------------------------------------------
     def load_full_embeddings(self, full_u, full_i):
-        p = self.part
-        nu, ni = p.n_real_local()
+        ou, oi = self.part.local_original_ids(full_u.device)
         with torch.no_grad():
-            self.uEmbd.weight.zero_()
-            self.iEmbd.weight.zero_()
-            self.uEmbd.weight[:nu] = full_u[p.u_lo:p.u_lo + nu]
-            self.iEmbd.weight[:ni] = full_i[p.i_lo:p.i_lo + ni]
+            for w, full, ids in ((self.uEmbd.weight, full_u, ou), (self.iEmbd.weight, full_i, oi)):
+                w.zero_()                                           # padding slots: isolated zero nodes
+                ok = ids >= 0
+                w[ok.to(w.device)] = full[ids[ok]].to(w.device, w.dtype)
 
     def load_full_state_dict(self, sd):
-        """Take an unsharded (reference-keyed) state_dict: slice the embedding rows, copy the rest."""
+        """Take an unsharded (reference-keyed) state_dict: pick this rank's embedding rows, copy the rest."""
         self.load_full_embeddings(sd["uEmbd.weight"], sd["iEmbd.weight"])
         self.gat.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("gat.")})
 
-    def full_state_dict(self):
-        """The reference-keyed state_dict on every rank (all-gather of the embedding shards)."""
+    def _gathered(self, u_local, i_local):
         p = self.part
-        dev = self.uEmbd.weight.device
-        tab = torch.zeros(p.N, self.uEmbd.weight.shape[1], device=dev)
-        tab[p.u_lo:p.u_lo + p.cu] = self.uEmbd.weight.detach()
-        tab[p.Up + p.i_lo:p.Up + p.i_lo + p.ci] = self.iEmbd.weight.detach()
+        tab = torch.zeros(p.N, u_local.shape[1], device=u_local.device, dtype=u_local.dtype)
+        p.block(tab, "user").copy_(u_local)
+        p.block(tab, "item").copy_(i_local)
         self.comm.all_gather_rows(tab)
-        sd = {"uEmbd.weight": tab[:p.U].clone(), "iEmbd.weight": tab[p.Up:p.Up + p.I].clone()}
+        return p.to_original(tab)
+
+    def full_state_dict(self):
+        """The reference-keyed state_dict on every rank (all-gather of the embedding shards, data-set numbering)."""
+        full = self._gathered(self.uEmbd.weight.detach(), self.iEmbd.weight.detach())
+        sd = {"uEmbd.weight": full[:self.userNum].clone(), "iEmbd.weight": full[self.userNum:].clone()}
         sd.update({"gat." + k: v.detach().clone() for k, v in self.gat.state_dict().items()})
         return sd
+
+    def local_grads_original(self):
+        """((user ids, grad rows), (item ids, grad rows), padding-slot grads) of this rank's embedding gradients, ids in
+        the data set's numbering."""
+        ou, oi = self.part.local_original_ids(self.uEmbd.weight.device)
+        gu, gi = self.uEmbd.weight.grad, self.iEmbd.weight.grad
+        return (ou[ou >= 0], gu[ou >= 0]), (oi[oi >= 0], gi[oi >= 0]), torch.cat([gu[ou < 0], gi[oi < 0]])
 
     def reduce_grads(self):
         """With comm.defer_weight_reduce: sum the stage-weight gradients over the ranks in ONE grouped all-reduce,
@@ -221,14 +446,20 @@ class ShardedSPUIGACF(nn.Module):
         if gs:
             self.comm.all_reduce_sum(*gs)
 
-    # ---- forward ------------------------------------------------------------------------------------------
+    # ---- graph ---------------------------------------------------------------------------------------------
+    def attach_plan(self, plan):
+        """Use a plan built elsewhere (sharded_graph: the global edge list never exists); forward's `mask` is then ignored."""
+        self._attached = plan
+
     def _plan(self, mask):
+        if self._attached is not None:
+            return self._attached
         mask = squeeze_mask(mask)
         key = (mask.data_ptr(), tuple(mask.shape), mask._version, self.seg_len)
         if key not in self._plans:
             p = self.part
             self._plans.clear()
-            self._plans[key] = build_plan(mask, p.Up, p.Ip, seg_len=self.seg_len, require_user_edges=False,
+            self._plans[key] = build_plan(p.map_edges(mask.long()), p.Up, p.Ip, seg_len=self.seg_len, require_user_edges=False,
                                           row_range=p.row_ranges)
         return self._plans[key]
 
@@ -245,7 +476,9 @@ class ShardedSPUIGACF(nn.Module):
         if getattr(self, "_seed_ctr", None) is not None:
             self._seed_ctr.add_(_CTR_STRIDE)
 
+    # ---- forward ------------------------------------------------------------------------------------------
     def propagate_local(self, mask):
+        """(out_u [cu,d], out_i [ci,d]): this rank's rows of the propagated embeddings."""
         plan = self._plan(mask)
         drop = self.droprate if self.training else 0.0
         seed_dev = None
@@ -255,86 +488,189 @@ class ShardedSPUIGACF(nn.Module):
             seed_dev = self._seed_ctr
         else:
             base = _fresh_seed() if drop > 0 else 0                      # same CPU generator state on every rank
-        x = torch.cat([self.uEmbd.weight, self.iEmbd.weight], 0)
-        for s, layers in enumerate(self.gat._stages()):
-            W, avec = self.gat.stage_params(s)
-            x = _ShardedStage.apply(x, W, avec, self.part, plan, self.comm, self.be, len(layers), layers[0].alpha,
-                                    drop, drop, NF.stage_seed(base, s), self.compute_dtype, seed_dev, torch.is_grad_enabled())
-        return x
+        stages = self.gat._stages()
+        params = []
+        for s in range(len(stages)):
+            params.extend(self.gat.stage_params(s))
+        cfg = {"part": self.part, "plan": plan, "comm": self.comm, "be": self.be, "heads": [len(l) for l in stages],
+               "alpha": stages[0][0].alpha, "drop": drop, "feat_drop": drop,
+               "seeds": [NF.stage_seed(base, s) for s in range(len(stages))], "h_dtype": self.compute_dtype,
+               "seed_dev": seed_dev, "grad_mode": torch.is_grad_enabled()}
+        return _ShardedStack.apply(self.uEmbd.weight, self.iEmbd.weight, *params, cfg)
 
     def propagate(self, mask):
-        """Full [Up+Ip, d] table of propagated embeddings (items start at row Up)."""
-        return _GatherRows.apply(self.propagate_local(mask), self.part, self.comm)
+        """The full [U+I, d] table of propagated embeddings in the data set's numbering, on every rank (evaluation)."""
+        out_u, out_i = self.propagate_local(mask)
+        return self._gathered(out_u.detach(), out_i.detach())
 
     def forward(self, userIdx, itemIdx, mask):
-        F = self.propagate(mask)
-        return self.be.score(F, userIdx, itemIdx, self.part.Up) if hasattr(self.be, "score") \
-            else NF.score(F, userIdx, itemIdx, self.part.Up)
+        out_u, out_i = self.propagate_local(mask)
+        p = self.part
+        B = userIdx.numel()
+        idx = torch.cat([p.internal_users(userIdx.long()), p.internal_items(itemIdx.long()) + p.Up])
+        rows = _RowExchange.apply(out_u, out_i, idx, p, self.comm)                  # [2B, d]: user rows then item rows
+        ar = torch.arange(B, device=rows.device)
+        score = self.be.score if hasattr(self.be, "score") else NF.score
+        return score(rows, ar, ar, B)                                                # SPUIGACF.py:49-52
+
+
+# ---------------------------------------------------------------------------------------------------------
+# graphs that never exist whole: the chunked generator, kept shard by shard
+# ---------------------------------------------------------------------------------------------------------
+def sharded_graph(shape, world, rank, dev, seed=2019, seg_len=256, chunk_users=1 << 18):
+    """(Partition, plan, E, first_chunk_edges) of a chunk-generated graph for rank `rank` of `world`: every rank runs the
+    chunked generator (ngacf_amd.data.synthetic_bipartite_chunks; any rank can produce any chunk) twice -- degrees first,
+    then the edges, of which it keeps only those ending in its rows.  Peak memory: one chunk + the rank's shard.
+    shape = (U, I, E) or a workload name.  first_chunk_edges: the [2,e] edges of the first user chunk in the data set's
+    numbering (the CPU baseline's sample)."""
+    from . import data as D
+    U, I, E_target = D.SHAPES[shape] if isinstance(shape, str) else shape
+    deg_u = torch.zeros(U, dtype=torch.long, device=dev)
+    deg_i = torch.zeros(I, dtype=torch.long, device=dev)
+    E = 0
+    for lo, hi, key in D.synthetic_bipartite_chunks(U, I, E_target, seed, dev, chunk_users=chunk_users):
+        deg_u[lo:hi] = torch.bincount(key // I - lo, minlength=hi - lo)
+        deg_i += torch.bincount(key % I, minlength=I)
+        E += int(key.numel())
+    part = Partition(U, I, world, rank, deg_u, deg_i)
+    del deg_u, deg_i
+    pu, pi = part._on("perm_u", dev), part._on("perm_i", dev)
+    csr, csc, first = [], [], None
+    for lo, hi, key in D.synthetic_bipartite_chunks(U, I, E_target, seed, dev, chunk_users=chunk_users):
+        if first is None:
+            first = torch.stack([key // I, key % I])
+        iu, ii = pu[key // I], pi[key % I]
+        m = (iu >= part.u_lo) & (iu < part.u_lo + part.cu)
+        csr.append(iu[m] * part.Ip + ii[m])
+        m = (ii >= part.i_lo) & (ii < part.i_lo + part.ci)
+        csc.append(ii[m] * part.Up + iu[m])
+    csr_key = torch.sort(torch.cat(csr)).values
+    del csr
+    csc_key = torch.sort(torch.cat(csc)).values
+    del csc
+    plan = build_plan_from_keys(csr_key, csc_key, part.Up, part.Ip, part.row_ranges, seg_len)
+    return part, plan, E, first
 
 
 # ---------------------------------------------------------------------------------------------------------
 # bench.py --gpus N (N > 1): strong scaling of the named workload over a node partition
 # ---------------------------------------------------------------------------------------------------------
-def bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, hbm_peak, emit=print):
+def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
     """Strong scaling of the named workload over a node partition.  Order of events: (1) forward timed with eager
-    launches, (2) train step timed with eager launches, (3) the forward again as ONE replayed hipGraph (kernels +
-    grouped RCCL launches).  (3) replaces (1)'s number only if it completes; a watchdog prints the eager line and
+    launches (+ per-launch kernel events, + all-gather events in a serial pass), (2) train step timed with eager
+    launches, (3) the forward again as ONE replayed hipGraph (kernels + RCCL launches), (4) the train step as one
+    hipGraph.  (3)/(4) replace the eager numbers only if they complete; a watchdog prints the best line so far and
     exits if the captured path stalls, so a capture problem can never cost the measurement."""
     import json
     import os
+    import sys
     import threading
     import time
-    from . import data as D
+    from . import benchkit as BK, data as D
     torch.manual_seed(2019)
-    edge = D.synthetic_bipartite(U, I, E_target, seed=2019, device=dev)   # same graph on every rank (same device type)
-    E = int(edge.shape[1])
-    model = ShardedSPUIGACF(U, I, d, [64, 64], args.droprate, world, rank, stages=args.stages).to(dev)
+    U, I, E_target = D.SHAPES[wl]
+    big = wl in D.BIG_WORKLOADS
+    if big:
+        part, plan, E, sample_edge = sharded_graph(wl, world, rank, dev, seg_len=args.seg_len)
+        model = ShardedSPUIGACF(U, I, d, [64, 64], args.droprate, world, rank, stages=args.stages, partition=part).to(dev)
+        model.attach_plan(plan)
+        edge = torch.zeros(2, 1, dtype=torch.long, device=dev)          # placeholder mask (the plan is attached)
+    else:
+        edge = D.workload_graph(wl, dev)                                # same graph on every rank (same device type)
+        E = int(edge.shape[1])
+        sample_edge = edge
+        model = ShardedSPUIGACF(U, I, d, [64, 64], args.droprate, world, rank, stages=args.stages, adj=edge).to(dev)
+        model.seg_len = args.seg_len
+        plan = model._plan(edge)
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model.seg_len = args.seg_len
     L = len(model.gat._stages())
     model.comm.force = world == 1                 # one-rank rehearsal (NGACF_BENCH_FORCE_DIST=1): still issue the collectives
     model.comm.defer_weight_reduce = True
-    trav = L * 2 * E                              # all ranks together traverse every edge once per forward
+    model.comm.overlap = not args.no_overlap
+    trav = L * 2 * E                              # all ranks together traverse every edge once per pass
+    part = model.part
 
     def sync():
         dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, warmup, steps):
-        for _ in range(warmup):
-            fn()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        sync()
-        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    def allmax(x):
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t)
 
-    def line(t_fwd, launch, launches_fwd, extra):
-        out = {"metric": "propagation edges/sec (directed edge traversals, forward, all stages)",
-               "value": round(trav * args.steps / t_fwd, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(1e3 * t_fwd / args.steps, 4), "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "%s-scale bipartite graph U=%d I=%d E=%d, d=%d, L=%d stages, node-partitioned over %d GPUs"
-                                      % (args.workload, U, I, E, d, L, world),
-                          "edges_directed_per_step": trav, "launch": launch,
-                          "parallelism": "node partition x%d, 1 grouped all-gather launch per stage (%d per forward)"
-                                         % (world, launches_fwd)},
-               "roofline": None, "cpu_baseline": None}
-        out.update(extra)
-        return json.dumps(out)
-
-    # ---- (1) forward, eager ------------------------------------------------------------------------------------
     model.eval()
     fwd = lambda: model.propagate_local(edge)
+
+    # ---- (1) forward, eager --------------------------------------------------------------------------------
     with torch.no_grad():
         model.comm.launches = 0
         fwd()
         launches_fwd = model.comm.launches
-        t_eager = timed(fwd, args.warmup, args.steps)
-    extra = {"ms_per_step_eager": round(1e3 * t_eager / args.steps, 4)}
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fwd()
+        sync()
+        t_pass = allmax((time.perf_counter() - t0) / 5)
+        R = args.passes_per_step or BK.passes_per_step(t_pass, args.steps, args.target_seconds)
+        for _ in range(args.warmup):
+            fwd()
+        t_eager, win_eager = BK.timed_steps(fwd, args.steps, R, sync, torch)
+        t_eager = allmax(t_eager)
+        # per-launch kernel durations (this rank) and all-gather durations (serial pass: start -> wait)
+        n_probe = max(args.steps, 10 if big else 50)
+        with _hip_ops.KernelTimer("ngacf_prop_fwd") as kt:
+            for _ in range(n_probe):
+                fwd()
+            torch.cuda.synchronize()
+        durs = kt.durations_ms()
+        model.comm.overlap, model.comm.timer = False, []
+        for _ in range(n_probe):
+            fwd()
+        torch.cuda.synchronize()
+        ag = [(a.elapsed_time(b), nb) for a, b, nb in model.comm.timer]
+        model.comm.overlap, model.comm.timer = not args.no_overlap, None
+    n_launch = len(durs) // n_probe                                          # 2 half-launches per stage
+    stage_ms = sum(durs) / n_probe / L                                       # both halves of a stage
+    local_edges = plan.n_edges_directed
+    bytes_stage = local_edges * (4 + d * elem) + part.n_local * (2 * d * elem + 8)
+    achieved = -allmax(-bytes_stage / (stage_ms * 1e-3) / 1e9)               # the slowest rank's rate (min over ranks)
+    regime = BK.gather_regime(part.N * d * elem, max(part.Up, part.Ip) * d * elem)
+    ag_ms = sum(x for x, _ in ag) / max(len(ag), 1)
+    ag_bytes = sum(nb for _, nb in ag) / max(len(ag), 1)
+    roofline = {"bound": "hbm", "kernel": "prop_fwd_kernel (ngacf_prop_fwd: 2 half-launches per stage), slowest rank",
+                "achieved": round(achieved, 1), "peak": BK.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / BK.HBM_PEAK_GBS, 4),
+                "traffic": None, "regime": regime["regime"], "regime_note": regime["note"],
+                "applicable_roof_GBps": regime["roof_GBps"], "frac_of_applicable_roof": round(achieved / regime["roof_GBps"], 4),
+                "bytes_per_stage_per_rank": int(bytes_stage), "avg_stage_kernel_us": round(stage_ms * 1e3, 2),
+                "launches_per_forward": n_launch, "local_directed_edges": int(local_edges),
+                "allgather": {"per_forward": launches_fwd, "avg_us_serial": round(ag_ms * 1e3, 2),
+                              "avg_bytes_received_per_rank": int(ag_bytes),
+                              "GBps_received_per_rank": round(ag_bytes / max(ag_ms * 1e-3, 1e-12) / 1e9, 1) if ag else None,
+                              "note": "one async all-gather per half-table per stage (in place, RCCL); serial-pass "
+                                      "duration start -> wait, rank 0"}}
+    extra = {"ms_per_step_eager": round(1e3 * t_eager / args.steps, 4), "roofline": roofline}
+
+    def line(t_fwd, windows, launch, extra):
+        med = BK.median(windows)
+        out = {"metric": "propagation edges/sec (directed edge traversals, forward, all stages)",
+               "value": round(trav * R * args.steps / t_fwd, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(1e3 * t_fwd / args.steps, 4), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "%s-scale bipartite graph U=%d I=%d E=%d, d=%d, L=%d stages, node-partitioned over %d GPUs"
+                                      % (wl, U, I, E, d, L, world),
+                          "passes_per_step": R, "edges_directed_per_pass": trav, "edges_directed_per_step": trav * R,
+                          "launch": launch,
+                          "parallelism": "degree-balanced node partition x%d, sharded plan (%d of %d directed edges on rank 0), "
+                                         "%d async half-table all-gathers per forward, %s"
+                                         % (world, local_edges, 2 * E, launches_fwd,
+                                            "overlapped with the traversal of the other half" if model.comm.overlap else "serial")},
+               "ms_per_pass": round(1e3 * t_fwd / args.steps / R, 5), "timed_region_s": round(t_fwd, 4),
+               "value_median_window": round(trav * R / (med * 1e-3), 1) if med > 0 else None,
+               "roofline": None, "cpu_baseline": None}
+        out.update(extra)
+        return json.dumps(out)
 
     # ---- (2) train step, eager ---------------------------------------------------------------------------------
     if not args.no_train:
@@ -354,16 +690,49 @@ def bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, hbm_peak, em
             loss.backward()
             model.reduce_grads()                                          # one grouped all-reduce of the stage weights
             opt.step()
-        ksteps = max(2, min(args.steps, 20))
         model.comm.launches = 0
         step()
         per_step = model.comm.launches
-        t_tr = timed(step, min(args.warmup, 3), ksteps)
+        sync()
+        t0 = time.perf_counter()
+        step()
+        sync()
+        ksteps = int(max(min(args.steps, 20), min(500, 0.3 / max(allmax(time.perf_counter() - t0), 1e-6))))
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(ksteps):
+            step()
+        sync()
+        t_tr = allmax(time.perf_counter() - t0)
         extra.update({"bpr_pairs_per_s": round(B * ksteps / t_tr, 1), "train_ms_per_step": round(1e3 * t_tr / ksteps, 3),
                       "train_steps": ksteps, "batch": B, "collective_launches_per_train_step": per_step})
         model.eval()
 
-    eager_line = line(t_eager, "eager", launches_fwd, extra)
+    # ---- CPU baseline (rank 0; the others wait at the next barrier) ---------------------------------------------
+    if not args.no_cpu_baseline:
+        names = [["gat." + n for n in nm] for nm in model.gat.stage_layer_names()]
+        sd_full = None if big else model.full_state_dict()       # collective: every rank calls it
+        if rank == 0:
+            try:
+                if big:                            # the sample's rows only: never the whole table on one rank
+                    su = int(sample_edge[0].max()) + 1
+                    items, inv = torch.unique(sample_edge[1], return_inverse=True)
+                    e_c = torch.stack([sample_edge[0], inv]).cpu()
+                    sdc = {"gat." + k: v.detach().float().cpu() for k, v in model.gat.state_dict().items()}
+                    gen = torch.Generator().manual_seed(1)
+                    sdc["uEmbd.weight"] = torch.empty(su, d).normal_(std=0.01, generator=gen)
+                    sdc["iEmbd.weight"] = torch.empty(int(items.numel()), d).normal_(std=0.01, generator=gen)
+                    extra["cpu_baseline"] = cpu_baseline_leg(torch, sdc, names, e_c, su, int(items.numel()), L, args.cpu_budget,
+                                                             "the subgraph of the first %d users of the %s graph (%d edges, %d items touched)"
+                                                             % (su, wl, int(e_c.shape[1]), int(items.numel())))
+                else:
+                    extra["cpu_baseline"] = cpu_baseline_leg(torch, {k: v.float().cpu() for k, v in sd_full.items()}, names,
+                                                             edge.cpu(), U, I, L, args.cpu_budget, "the whole %s graph" % wl)
+            except Exception as e:                 # the baseline must not cost the measurement
+                print("[bench] cpu_baseline failed: %r" % (e,), file=sys.stderr, flush=True)
+        dist.barrier()
+
+    eager_line = line(t_eager, win_eager, "eager", extra)
     if getattr(args, "eager", False) or os.environ.get("NGACF_DIST_GRAPH") == "0":
         if rank == 0:
             emit(eager_line)
@@ -373,16 +742,22 @@ def bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, hbm_peak, em
     # ---- (3) forward as one hipGraph, under a watchdog -----------------------------------------------------------
     lock, done = threading.Lock(), []
 
-    def finish(text, hard):
+    def finish(text, hard, tag=None):
         with lock:
             if not done:
                 done.append(1)
                 if rank == 0:
+                    if tag:
+                        text = json.dumps(dict(json.loads(text), graph_fallback=tag))
                     emit(text)
-        if hard:                                   # a rank may be stuck inside a collective: leave without teardown
-            os._exit(3)                            # (non-zero: a stalled capture must not look like a clean run)
+        if hard:
+            # A rank may be stuck inside a collective: leave without teardown.  Exit status 0: the eager measurement in
+            # the line is complete and valid; what failed is the optional captured re-run, and the line says so
+            # (graph_fallback) instead of the process status.
+            os._exit(0)
 
-    dog = threading.Timer(float(os.environ.get("NGACF_DIST_GRAPH_TIMEOUT", "90")), finish, (eager_line, True))
+    timeout = float(os.environ.get("NGACF_DIST_GRAPH_TIMEOUT", "120"))
+    dog = threading.Timer(timeout, finish, (eager_line, True, "timeout: hipGraph capture/replay of the sharded forward stalled"))
     dog.daemon = True
     dog.start()
     try:
@@ -396,17 +771,20 @@ def bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, hbm_peak, em
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 fwd()
-            t_graph = timed(graph.replay, args.warmup, args.steps)
+            for _ in range(args.warmup):
+                graph.replay()
+            t_graph, win_graph = BK.timed_steps(graph.replay, args.steps, R, sync, torch)
+            t_graph = allmax(t_graph)
     except Exception as e:                         # capture refused here (maybe not on the peers): the eager numbers stand
-        import sys
         print("[bench] sharded hipGraph capture not used: %r" % (e,), file=sys.stderr, flush=True)
-        finish(eager_line, True)
+        finish(eager_line, True, "capture failed: %r" % (e,))
     better = t_graph < t_eager                     # t_* are already max-over-ranks: every rank decides alike
-    best = line(t_graph, "hipGraph replay (kernels + grouped RCCL launches)", launches_fwd, extra) if better else eager_line
+    glaunch = "hipGraph replay (kernels + RCCL launches)"
+    best = line(t_graph, win_graph, glaunch, extra) if better else eager_line
     # ---- (4) the train step as one hipGraph (sampler-free: fixed batch, as in (2)), same watchdog ------------------
     if not args.no_train:
         dog.cancel()
-        dog = threading.Timer(float(os.environ.get("NGACF_DIST_GRAPH_TIMEOUT", "90")), finish, (best, True))
+        dog = threading.Timer(timeout, finish, (best, True, "timeout: hipGraph capture/replay of the sharded train step stalled"))
         dog.daemon = True
         dog.start()
         try:
@@ -415,17 +793,22 @@ def bench_main(args, ng, rank, world, dev, U, I, E_target, d, elem, hbm_peak, em
             opt_g = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True, fused=True)
             gs = GraphedBPRStep(model, lossfn, opt_g, edge, B, concurrent_forwards=False, after_backward=model.reduce_grads)
             upn = torch.stack([ub, pb, nb])
-            t_trg = timed(lambda: gs(upn), min(args.warmup, 3), ksteps)
+            for _ in range(3):
+                gs(upn)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(ksteps):
+                gs(upn)
+            sync()
+            t_trg = allmax(time.perf_counter() - t0)
             if t_trg < t_tr:
                 extra = dict(extra, bpr_pairs_per_s=round(B * ksteps / t_trg, 1), train_ms_per_step=round(1e3 * t_trg / ksteps, 3),
-                             train_launch="hipGraph replay (kernels + grouped RCCL launches + fused Adam)",
+                             train_launch="hipGraph replay (kernels + RCCL launches + fused Adam)",
                              train_ms_per_step_eager=round(1e3 * t_tr / ksteps, 3))
-                best = line(t_graph, "hipGraph replay (kernels + grouped RCCL launches)", launches_fwd, extra) if better \
-                    else line(t_eager, "eager", launches_fwd, extra)
+                best = line(t_graph, win_graph, glaunch, extra) if better else line(t_eager, win_eager, "eager", extra)
         except Exception as e:
-            import sys
             print("[bench] sharded hipGraph train step not used: %r" % (e,), file=sys.stderr, flush=True)
-            finish(best, True)
+            finish(best, True, "train-step capture failed: %r" % (e,))
     dog.cancel()
     finish(best, False)
     dist.destroy_process_group()

@@ -104,7 +104,11 @@ def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.
     return H, S
 
 
-def _plan_ptrs(plan, dev):
+def _plan_ptrs(plan, dev, half=None):
+    """The plan arguments of ngacf_prop_fwd / ngacf_prop_bwd.  half = "user" / "item": only that half of the launch's
+    work order ([user long segments][user short rows] / [item long segments][item short rows]) -- the lists are
+    contiguous per half, so a half is a pointer offset and a count; partial-sum slots keep their global numbers.
+    The node-partitioned path launches the halves separately to run one under the other's all-gather."""
     if plan.device != dev:
         raise ValueError("plan is on %s, tensors on %s" % (plan.device, dev))
     segs = _chk(plan.segs, "plan.segs", torch.int32, plan.nseg * 4, dev) if plan.nseg else 0
@@ -112,7 +116,17 @@ def _plan_ptrs(plan, dev):
     col = _chk(plan.col, "plan.col", torch.int32, plan.n_edges_directed, dev) if plan.n_edges_directed else 0
     srow = _chk(plan.srow, "plan.srow", torch.int32, plan.nshort, dev) if plan.nshort else 0
     rowptr = _chk(plan.rowptr32, "plan.rowptr32", torch.int32, plan.N + 1, dev)
-    return (segs, plan.nseg, split, plan.nsplit, srow, plan.nshort, plan.nseg_user, plan.nshort_user, rowptr, col)
+    if half is None:
+        return (segs, plan.nseg, split, plan.nsplit, srow, plan.nshort, plan.nseg_user, plan.nshort_user, rowptr, col)
+    if INKERNEL_HUB_FINISH:
+        raise ValueError("half launches use the two-kernel hub-row path (unset NGACF_INKERNEL_HUB)")
+    if half == "user":
+        return (segs, plan.nseg_user, split, plan.nsplit_user, srow, plan.nshort_user, plan.nseg_user, plan.nshort_user, rowptr, col)
+    if half == "item":
+        ns, nsh, nsp = plan.nseg - plan.nseg_user, plan.nshort - plan.nshort_user, plan.nsplit - plan.nsplit_user
+        return (segs + 16 * plan.nseg_user if ns else 0, ns, split + 12 * plan.nsplit_user if nsp else 0, nsp,
+                srow + 4 * plan.nshort_user if nsh else 0, nsh, 0, 0, rowptr, col)
+    raise ValueError("half must be None, 'user' or 'item'")
 
 
 # Hub rows can be finished by their last-arriving slice inside the launch (sc1 stores + agent-scope ticket/acquire,
@@ -130,8 +144,9 @@ def _hub(plan, dev):
 
 
 def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
-             drop_p=0.0, seed=0, save=False, out=None, seed_dev=None):
-    """One propagation stage over plan's dst rows.  Returns out (and agg, R when save=True)."""
+             drop_p=0.0, seed=0, save=False, out=None, seed_dev=None, half=None, agg=None, R=None):
+    """One propagation stage over plan's dst rows.  Returns out (and agg, R when save=True).
+    half = "user" / "item": only the user / item dst rows (two calls with the same out / agg / R cover the stage)."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
     if score_from_row is None:
@@ -142,12 +157,17 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     sd = _chk(S_dst, "S_dst", torch.float32, N * heads, dev)
     ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
     ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
-    pp = _plan_ptrs(plan, dev)
+    pp = _plan_ptrs(plan, dev, half)
     if out is None:
         out = torch.empty(N, d, dtype=H.dtype, device=dev)
     op = _chk(out, "out", H.dtype, N * d, dev)
-    agg = torch.empty(N, d, dtype=torch.float32, device=dev) if save else None
-    R = torch.empty(N, heads, dtype=torch.float32, device=dev) if save else None
+    if save:
+        agg = torch.empty(N, d, dtype=torch.float32, device=dev) if agg is None else agg
+        R = torch.empty(N, heads, dtype=torch.float32, device=dev) if R is None else R
+        _chk(agg, "agg", torch.float32, N * d, dev)
+        _chk(R, "R", torch.float32, N * heads, dev)
+    else:
+        agg = R = None
     pa = torch.empty(max(plan.nparts, 1), d, dtype=torch.float32, device=dev)
     pr = torch.empty(max(plan.nparts, 1), heads, dtype=torch.float32, device=dev)
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
@@ -395,8 +415,9 @@ def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local
 
 
 def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=True, score_from_row=True,
-                   drop_p=0.0, seed=0, seed_dev=None):
-    """Step 2 alone (G, Gn, ST ready for every source row).  Returns dH, dS (rows of the plan valid)."""
+                   drop_p=0.0, seed=0, seed_dev=None, half=None, dH=None, dS=None):
+    """Step 2 alone (G, Gn, ST ready for every source row).  Returns dH, dS (rows of the plan valid).
+    half = "user" / "item": only those dst rows, written into the dH / dS given (or fresh zeroed tables)."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
     hp = _chk(H, "H", None, N * d, dev)
@@ -405,9 +426,12 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     gp = _chk(G, "G", torch.float32, N * d, dev)
     gn = _chk(Gn, "Gn", H.dtype, N * d, dev)
     st = _chk(ST, "ST", torch.float32, N * heads, dev)
-    pp = _plan_ptrs(plan, dev)
+    pp = _plan_ptrs(plan, dev, half)
     f32 = dict(dtype=torch.float32, device=dev)
-    dH, dS = torch.zeros(N, d, **f32), torch.zeros(N, heads, **f32)
+    dH = torch.zeros(N, d, **f32) if dH is None else dH
+    dS = torch.zeros(N, heads, **f32) if dS is None else dS
+    _chk(dH, "dH", torch.float32, N * d, dev)
+    _chk(dS, "dS", torch.float32, N * heads, dev)
     pa = torch.empty(max(plan.nparts, 1), d, **f32)
     pr = torch.empty(max(plan.nparts, 1), heads, **f32)
     flags = (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) | _lib.FLAG_SKIP_NODE

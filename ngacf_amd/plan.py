@@ -32,7 +32,7 @@ class GraphPlan:
         # short rows (degree <= short_max), sorted by degree descending: one lane group per row
         self.srow = srow if srow is not None else torch.empty(0, dtype=torch.int32, device=col.device)
         self.nshort, self.short_max = int(self.srow.shape[0]), short_max
-        self.nseg_user, self.nshort_user = self.nseg, self.nshort       # build_plan sets the user/item split
+        self.nseg_user, self.nshort_user, self.nsplit_user = self.nseg, self.nshort, self.nsplit   # build_plan sets the user/item split
         self.rowptr32 = rowptr.to(torch.int32).contiguous()
         # hub rows: slot -> hub row, and one arrival counter per hub row (zero between launches)
         if self.nsplit:
@@ -57,7 +57,7 @@ class GraphPlan:
         p = GraphPlan(self.U, self.I, self.E, self.rowptr.to(device), self.col.to(device),
                       self.segs.to(device), self.split.to(device), self.nparts, self.seg_len,
                       self.row_lo, self.row_hi, self.srow.to(device), self.short_max, self.row_ranges)
-        p.nseg_user, p.nshort_user = self.nseg_user, self.nshort_user
+        p.nseg_user, p.nshort_user, p.nsplit_user = self.nseg_user, self.nshort_user, self.nsplit_user
         return p
 
 
@@ -93,7 +93,9 @@ def squeeze_mask(mask):
 def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None, short_max=64):
     """indices: [2,E] (or [1,2,E], run under DataParallel: SPUIGACF.py:42 squeezes it) integer
     tensor.  Duplicate pairs are merged like `.coalesce()`.  `row_range=(lo,hi)` -- or a list of such
-    ranges -- keeps only those dst rows (node partition of ngacf_amd/dist.py); sources stay global."""
+    ranges -- keeps only those dst rows (node partition of ngacf_amd/dist.py); sources stay global.
+    With a row range only the edges that END in the range are kept, sorted and stored (a rank of a P-way partition
+    holds ~2E/P column indices, not 2E): the filter is one pass over the E pairs, no global sort."""
     indices = squeeze_mask(indices)
     if indices.dim() != 2 or indices.shape[0] != 2:
         raise ValueError("indices must be [2,E], got %s" % (tuple(indices.shape),))
@@ -105,19 +107,29 @@ def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True,
     if idx.shape[1]:
         if int(idx[0].min()) < 0 or int(idx[0].max()) >= U or int(idx[1].min()) < 0 or int(idx[1].max()) >= I:
             raise ValueError("edge endpoint out of range for U=%d, I=%d" % (U, I))
-    key = torch.unique(idx[0] * I + idx[1])                  # row-major sorted + unique == coalesce()
-    eu, ei = key // I, key % I
-    E = int(key.numel())
-    deg_u = torch.bincount(eu, minlength=U)
-    deg_i = torch.bincount(ei, minlength=I)
-    if require_user_edges and U and int(deg_u.min()) == 0:
-        # the reference asserts e_rowsum != 0 for every user (SPUIGACF.py:368)
-        raise ValueError("user %d has no interaction: the reference asserts on a zero attention row-sum"
-                         % int(torch.argmin(deg_u)))
-    rowptr = torch.zeros(N + 1, dtype=torch.long, device=dev)
-    rowptr[1:] = torch.cumsum(torch.cat([deg_u, deg_i]), 0)
-    by_item = torch.sort(ei * U + eu).values                 # CSC order: item-major, users ascending
-    col = torch.cat([ei + U, by_item % U]).to(torch.int32).contiguous()
+    ranges = _ranges(row_range, N)
+    eu, ei = idx[0], idx[1]
+    if row_range is None:
+        csr_key = torch.unique(eu * I + ei)                  # row-major sorted + unique == coalesce()
+        csc_key = torch.sort((csr_key % I) * U + csr_key // I).values      # CSC order: item-major, users ascending
+    else:
+        in_u = torch.zeros(eu.numel(), dtype=torch.bool, device=dev)
+        in_i = torch.zeros(eu.numel(), dtype=torch.bool, device=dev)
+        for lo, hi in ranges:
+            in_u |= (eu >= lo) & (eu < hi)
+            in_i |= (ei + U >= lo) & (ei + U < hi)
+        csr_key = torch.unique(eu[in_u] * I + ei[in_u])
+        csc_key = torch.unique(ei[in_i] * U + eu[in_i])
+    if require_user_edges and row_range is None and U:
+        deg_u = torch.bincount(csr_key // I, minlength=U)
+        if int(deg_u.min()) == 0:
+            # the reference asserts e_rowsum != 0 for every user (SPUIGACF.py:368)
+            raise ValueError("user %d has no interaction: the reference asserts on a zero attention row-sum"
+                             % int(torch.argmin(deg_u)))
+    return build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len, short_max)
+
+
+def _ranges(row_range, N):
     if row_range is None:
         ranges = [(0, N)]
     elif isinstance(row_range[0], (tuple, list)):
@@ -127,6 +139,25 @@ def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True,
     for lo, hi in ranges:
         if not 0 <= lo <= hi <= N:
             raise ValueError("row range %s outside [0, %d]" % ((lo, hi), N))
+    return ranges
+
+
+def build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len=256, short_max=64):
+    """The plan of the dst rows in `ranges` from the two sorted, unique key arrays a rank owns:
+         csr_key = user * I + item   for every edge whose USER row is in the ranges,
+         csc_key = item * U + user   for every edge whose ITEM row is in the ranges
+    (a full plan passes every edge in both).  rowptr keeps global-row indexing -- N+1 int32, empty outside the ranges --
+    so the kernels are the same for whole and sharded plans; `col` holds only these edges."""
+    dev = csr_key.device
+    N = U + I
+    if csr_key.numel() + csc_key.numel() >= 2 ** 31:
+        raise ValueError("a plan's directed edges must stay below 2^31 (int32 edge offsets)")
+    deg_u = torch.bincount(csr_key // I, minlength=U) if csr_key.numel() else torch.zeros(U, dtype=torch.long, device=dev)
+    deg_i = torch.bincount(csc_key // U, minlength=I) if csc_key.numel() else torch.zeros(I, dtype=torch.long, device=dev)
+    E = int(csr_key.numel())
+    rowptr = torch.zeros(N + 1, dtype=torch.long, device=dev)
+    rowptr[1:] = torch.cumsum(torch.cat([deg_u, deg_i]), 0)
+    col = torch.cat([csr_key % I + U, csc_key % U]).to(torch.int32).contiguous()
     lo, hi = ranges[0][0], ranges[-1][1]
     rows = torch.cat([torch.arange(a, b, device=dev) for a, b in ranges])
     deg = rowptr[rows + 1] - rowptr[rows]
@@ -148,7 +179,7 @@ def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True,
     split = torch.cat([split_u, split_i]).contiguous()
     nparts = np_u + np_i
     plan = GraphPlan(U, I, E, rowptr, col, segs, split, nparts, seg_len, lo, hi, srow, short_max, ranges)
-    plan.nseg_user, plan.nshort_user = int(seg_u.shape[0]), int(nshort_user)
+    plan.nseg_user, plan.nshort_user, plan.nsplit_user = int(seg_u.shape[0]), int(nshort_user), int(split_u.shape[0])
     validate_plan(plan)
     return plan
 
@@ -174,6 +205,8 @@ def validate_plan(p):
     if p.nsplit:
         sp = p.split.long()
         assert int((sp[:, 1] + sp[:, 2]).max()) <= p.nparts and int(sp[:, 1].min()) >= 0
+        assert 0 <= p.nsplit_user <= p.nsplit and bool((sp[:p.nsplit_user, 0] < p.U).all()) and bool((sp[p.nsplit_user:, 0] >= p.U).all()), \
+            "hub rows: users first, then items"
         ps = p.part_split.long()
         assert ps.numel() == p.nparts and bool((sp[ps, 1] <= torch.arange(p.nparts, device=ps.device)).all()) \
             and bool((torch.arange(p.nparts, device=ps.device) < sp[ps, 1] + sp[ps, 2]).all()), "slot -> hub row map is inconsistent"
