@@ -84,31 +84,12 @@ def stage_layer_names(model):
     return [["gat." + n for n in names] for names in model.gat.stage_layer_names()]
 
 
-def cpu_baseline_leg(torch, model, edge, U, I, wl, L, budget_s):
-    """`cpu_baseline`: oracle/cpu_baseline.py (the reference's operator order, torch CPU ops) on this box's host cores,
-    same weights, on a BOUNDED sample of the workload: the whole graph at Gowalla/Yelp scale (~2 s per forward), the
-    induced subgraph of the first users holding ~10^6 edges for the big synthetic graphs (the reference's [2k, E]
-    edge-feature matrix alone is 100 GB at 2x10^8 edges)."""
+def cpu_baseline_leg(torch, p_cpu, names, edge_c, Us, Is, L, budget_s, sample):
+    """`cpu_baseline`: oracle/cpu_baseline.py (the reference's operator order, torch CPU ops) on this box's host cores.
+    p_cpu: reference-keyed CPU state_dict of the (sub)graph's Us users / Is items; edge_c: its [2,E] CPU edge list."""
     from oracle import cpu_baseline as CB
     ncores = min(os.cpu_count() or 1, 16)            # a GPU's share of the host (more threads only oversubscribe)
     torch.set_num_threads(ncores)
-    names = stage_layer_names(model)
-    p_cpu = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    E = int(edge.shape[1])
-    sample = "the whole %s graph" % wl
-    if E > 4_000_000:
-        n_e = 1_000_000
-        u_hi = int(edge[0][n_e]) + 1
-        n_e = int((edge[0] < u_hi).sum())
-        sub = edge[:, :n_e]
-        items, inv = torch.unique(sub[1], return_inverse=True)
-        edge_c = torch.stack([sub[0], inv]).cpu()
-        p_cpu["uEmbd.weight"] = p_cpu["uEmbd.weight"][:u_hi]
-        p_cpu["iEmbd.weight"] = p_cpu["iEmbd.weight"][items.cpu()]
-        Us, Is = u_hi, int(items.numel())
-        sample = "the subgraph of the first %d users of the %s graph (%d edges, %d items touched)" % (u_hi, wl, n_e, Is)
-    else:
-        edge_c, Us, Is = edge.cpu(), U, I
     x_cpu = torch.cat([p_cpu["uEmbd.weight"], p_cpu["iEmbd.weight"]])
     sec, iters = CB.time_forward(p_cpu, x_cpu, edge_c, Us, Is, names, budget_s=budget_s)
     trav = L * 2 * int(edge_c.shape[1])
@@ -117,6 +98,24 @@ def cpu_baseline_leg(torch, model, edge, U, I, wl, L, budget_s):
             "cpu_model": bk.cpu_model_name(), "host_cpus": os.cpu_count(),
             "sample": "%d eval forward(s) over %s, same weights (L=%d, fp32), %.2f s each, torch CPU ops in the reference's "
                       "operator order (oracle/cpu_baseline.py)" % (iters, sample, L, sec)}
+
+
+def cpu_sample(torch, model, edge, U, I, wl):
+    """The BOUNDED sample the CPU leg runs on: the whole graph at Gowalla/Yelp scale (~2 s per forward); for the big
+    synthetic graphs the induced subgraph of the first users holding ~10^6 edges (the reference's [2k, E] edge-feature
+    matrix alone is 100 GB at 2x10^8 edges)."""
+    p_cpu = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    E = int(edge.shape[1])
+    if E <= 4_000_000:
+        return p_cpu, edge.cpu(), U, I, "the whole %s graph" % wl
+    u_hi = int(edge[0][1_000_000]) + 1
+    n_e = int((edge[0] < u_hi).sum())
+    sub = edge[:, :n_e]
+    items, inv = torch.unique(sub[1], return_inverse=True)
+    p_cpu["uEmbd.weight"] = p_cpu["uEmbd.weight"][:u_hi]
+    p_cpu["iEmbd.weight"] = p_cpu["iEmbd.weight"][items.cpu()]
+    return (p_cpu, torch.stack([sub[0], inv]).cpu(), u_hi, int(items.numel()),
+            "the subgraph of the first %d users of the %s graph (%d edges, %d items touched)" % (u_hi, wl, n_e, int(items.numel())))
 
 
 def worker(args):
@@ -278,7 +277,8 @@ def worker(args):
     # ---------------- CPU baseline: reference operator order on the host cores (checker code) -------------
     cpu = None
     if not args.no_cpu_baseline:
-        cpu = cpu_baseline_leg(torch, model, edge, U, I, wl, L, args.cpu_budget)
+        p_cpu, e_c, Us, Is, desc = cpu_sample(torch, model, edge, U, I, wl)
+        cpu = cpu_baseline_leg(torch, p_cpu, stage_layer_names(model), e_c, Us, Is, L, args.cpu_budget, desc)
 
     out = {"metric": "propagation edges/sec (directed edge traversals, forward, all stages)", "value": round(value, 1),
            "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),

@@ -769,7 +769,8 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
             torch.cuda.current_stream().wait_stream(side)
             sync()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread-local capture mode: the c10d watchdog thread may query events while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 fwd()
             for _ in range(args.warmup):
                 graph.replay()

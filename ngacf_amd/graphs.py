@@ -16,6 +16,14 @@ except AttributeError:      # older torch
     pass
 
 
+def _capture_mode():
+    """With a process group alive, c10d's watchdog thread polls collective events with hipEventQuery; under the default
+    "global" capture mode such a call from ANY thread while this thread captures is an error that aborts the process
+    (seen as an intermittent SIGABRT in ProcessGroupNCCL::Watchdog::run).  Thread-local mode restricts only this thread."""
+    import torch.distributed as dist
+    return "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+
+
 def _gats(model):
     """Everything in the model that draws dropout seeds (the GAT stacks; the sharded model of ngacf_amd/dist.py)."""
     return [m for m in model.modules() if hasattr(m, "advance_device_seed") and hasattr(m, "use_device_seed")]
@@ -123,7 +131,7 @@ class GraphedBPRStep:
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         optim.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.loss = step()
         if data is not None:                                # (the capture itself does not execute; begin_epoch() resets anyway)
             self.offset.zero_()
@@ -173,7 +181,7 @@ class GraphedPropagate:
                 model.propagate(adj)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.out = model.propagate(adj)
 
     def __call__(self):

@@ -26,9 +26,15 @@ def transform_fwd_rows(X, W, avec, H, S, U, I, heads, win, x_local, feat_drop_p=
     S[rows] = (H[rows].float() * avec[t]).view(-1, heads, hw).sum(2)
 
 
-def _edges(plan):
+def _half_ranges(plan, half):
+    if half is None:
+        return plan.row_ranges
+    return [(lo, hi) for lo, hi in plan.row_ranges if (lo < plan.U) == (half == "user") and hi > lo]
+
+
+def _edges(plan, half=None):
     dst, src = [], []
-    for lo, hi in plan.row_ranges:
+    for lo, hi in _half_ranges(plan, half):
         e0, e1 = int(plan.rowptr[lo]), int(plan.rowptr[hi])
         deg = plan.rowptr[lo + 1:hi + 1] - plan.rowptr[lo:hi]
         dst.append(torch.repeat_interleave(torch.arange(lo, hi), deg))
@@ -37,11 +43,12 @@ def _edges(plan):
 
 
 def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
-             drop_p=0.0, seed=0, save=False, out=None):
+             drop_p=0.0, seed=0, save=False, out=None, half=None, agg=None, R=None):
     assert drop_p == 0.0
     N, d = H.shape
     hw = d // heads
-    dst, src = _edges(plan)
+    dst, src = _edges(plan, half)
+    agg_out, R_out = agg, R
     assert score_from_row, "dist.py never gathers S: source scores come from the gathered rows"
     t = _types(plan.U, N, H.device)
     s_src = (H[src].float() * avec[t[src]]).view(-1, heads, hw).sum(2)
@@ -53,8 +60,12 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     pre = (H.float() + agg) if residual else agg
     o = F.elu(pre) if elu else pre
     res = torch.zeros(N, d, dtype=H.dtype) if out is None else out
-    rows = torch.cat([torch.arange(lo, hi) for lo, hi in plan.row_ranges])
+    rows = torch.cat([torch.arange(lo, hi) for lo, hi in _half_ranges(plan, half)])
     res[rows] = o[rows].to(H.dtype)
+    if save and agg_out is not None:                      # half launches fill the caller's tables
+        agg_out[rows] = agg[rows]
+        R_out[rows] = R[rows]
+        agg, R = agg_out, R_out
     return (res, agg, R) if save else res
 
 
@@ -75,11 +86,12 @@ def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local
 
 
 def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=True, score_from_row=True,
-                   drop_p=0.0, seed=0):
+                   drop_p=0.0, seed=0, half=None, dH=None, dS=None):
     assert drop_p == 0.0
     N, d = H.shape
     hw = d // heads
-    dst, src = _edges(plan)
+    dst, src = _edges(plan, half)
+    dH_out, dS_out = dH, dS
     Hf, Gf = H.float(), Gn.float()
     assert score_from_row
     tt = _types(plan.U, N, H.device)
@@ -93,8 +105,12 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     t = _types(plan.U, N, H.device)
     dH = (G if residual else torch.zeros_like(G)) + acc + dS.repeat_interleave(hw, 1) * avec[t]
     keep = torch.zeros(N, dtype=torch.bool)
-    for lo, hi in plan.row_ranges:
+    for lo, hi in _half_ranges(plan, half):
         keep[lo:hi] = True
+    if dH_out is not None:
+        dH_out[keep] = dH[keep]
+        dS_out[keep] = dS[keep]
+        return dH_out, dS_out
     return dH * keep[:, None], dS * keep[:, None]
 
 

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None):
+def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced=True, overlap=True):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, HERE)
@@ -35,11 +35,13 @@ def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None):
         g = dict(np.load(tag if os.path.isabs(tag) else os.path.join(HERE, "golden", "g234_%s.npz" % tag)))
         U, I = int(g["U"]), int(g["I"])
         sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
-        m = ShardedSPUIGACF(U, I, d, [64, 64], 0.0, world, rank, stages=stages or (3 if multi else 2), backend=fake_backend)
+        edge = torch.from_numpy(g["edge"])
+        m = ShardedSPUIGACF(U, I, d, [64, 64], 0.0, world, rank, stages=stages or (3 if multi else 2), backend=fake_backend,
+                            adj=edge if balanced else None)
         m.load_full_state_dict(sd)
         m.comm.defer_weight_reduce = defer
+        m.comm.overlap = overlap
         m.train()
-        edge = torch.from_numpy(g["edge"])
         u, pos, neg = (torch.from_numpy(g[k]) for k in ("u", "pos", "neg"))
         ps, ns = m(u, pos, edge), m(u, neg, edge)
         loss = -torch.log(torch.sigmoid(ps - ns)).mean()
@@ -47,7 +49,6 @@ def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None):
         if defer:
             m.reduce_grads()                  # one all-reduce per step instead of one per stage
         p = m.part
-        nu, ni = p.n_real_local()
         err = {}
         smax = float(np.abs(g["pos_f64"]).max())
         err["scores"] = max(float((ps.detach().double() - torch.from_numpy(g["pos_f64"])).abs().max()),
@@ -55,10 +56,16 @@ def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None):
         err["loss"] = abs(float(loss.detach()) - float(g["loss_f64"]))
         gu, gi = g["g_f64.uEmbd.weight"], g["g_f64.iEmbd.weight"]
         scale = max(np.abs(gu).max(), np.abs(gi).max())
-        err["emb"] = max(float(np.abs(m.uEmbd.weight.grad[:nu].numpy() - gu[p.u_lo:p.u_lo + nu]).max()),
-                         float(np.abs(m.iEmbd.weight.grad[:ni].numpy() - gi[p.i_lo:p.i_lo + ni]).max())) / scale
-        err["pad"] = max(float(m.uEmbd.weight.grad[nu:].abs().max()) if nu < p.cu else 0.0,
-                         float(m.iEmbd.weight.grad[ni:].abs().max()) if ni < p.ci else 0.0)
+        (ids_u, g_u), (ids_i, g_i), g_pad = m.local_grads_original()     # this rank's rows, ids in the data set's numbering
+        err["emb"] = max(float(np.abs(g_u.numpy() - gu[ids_u.numpy()]).max()), float(np.abs(g_i.numpy() - gi[ids_i.numpy()]).max())) / scale
+        err["pad"] = float(g_pad.abs().max()) if g_pad.numel() else 0.0
+        # the plan is sharded: this rank holds only the directed edges that end in its rows
+        plan = m._plan(edge)
+        err["plan_edges"] = (plan.n_edges_directed, 2 * int(edge.shape[1]))
+        # eval-side plumbing: the full table in the data set's numbering equals the concatenated owners' rows
+        with torch.no_grad():
+            Ff = m.propagate(edge)
+        err["propagate_shape"] = tuple(Ff.shape) == (U + I, d)
         worst = 0.0
         for k, gr in m.gat.reference_named("grad").items():
             ref = g["g_f64.gat." + k]
@@ -74,13 +81,17 @@ def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None):
         q.put((rank, {"exception": "%s\n%s" % (e, traceback.format_exc())}))
 
 
-@pytest.mark.parametrize("world,tag,multi,defer", [(2, "spuigacf", False, False), (2, "spuimultigacf", True, True),
-                                                   (3, "spuigacf", False, True)])
-def test_sharded_model_matches_reference_under_gloo(world, tag, multi, defer):
+@pytest.mark.parametrize("world,tag,multi,defer,balanced,overlap", [
+    (2, "spuigacf", False, False, True, True), (2, "spuimultigacf", True, True, True, True),
+    (3, "spuigacf", False, True, True, True), (3, "spuimultigacf", True, False, False, True),
+    (2, "spuimultigacf", True, True, True, False)])
+def test_sharded_model_matches_reference_under_gloo(world, tag, multi, defer, balanced, overlap):
+    """Forward, loss and every gradient of the node-partitioned model (degree-balanced renumbering or plain id blocks,
+    pipelined or serial schedule, sharded plans, 2B-row score exchange) against the reference's float64 run."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tag, multi, defer, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tag, multi, defer, q, 64, None, balanced, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -90,7 +101,10 @@ def test_sharded_model_matches_reference_under_gloo(world, tag, multi, defer):
         assert "exception" not in err, err.get("exception")
         assert err["scores"] < 1e-5 and err["loss"] < 1e-5, (rank, err)
         assert err["emb"] < 2e-4 and err["gat"] < 2e-4, (rank, err)          # fp32 stand-in vs float64 reference
-        assert err["pad"] == 0.0 and err["sd"] == 0.0 and err["keys"], (rank, err)
+        assert err["pad"] == 0.0 and err["sd"] == 0.0 and err["keys"] and err["propagate_shape"], (rank, err)
+    total = sum(err["plan_edges"][0] for _, err in res)
+    assert total == res[0][1]["plan_edges"][1], "the ranks' plans together hold every directed edge exactly once"
+    assert all(err["plan_edges"][0] < 0.75 * err["plan_edges"][1] for _, err in res)
 
 
 def test_partition_covers_every_node_once():
@@ -101,7 +115,35 @@ def test_partition_covers_every_node_once():
         assert all(p.Up >= U and p.Ip >= I and p.Up % P == 0 and p.Ip % P == 0 for p in parts)
         rows = np.concatenate([np.concatenate([np.arange(lo, hi) for lo, hi in p.row_ranges]) for p in parts])
         assert np.array_equal(np.sort(rows), np.arange(parts[0].N))
-        assert sum(sum(p.n_real_local()) for p in parts) == U + I
+        ids = [p.local_original_ids() for p in parts]
+        assert np.array_equal(np.sort(np.concatenate([a[a >= 0].numpy() for a, _ in ids])), np.arange(U))
+        assert np.array_equal(np.sort(np.concatenate([b[b >= 0].numpy() for _, b in ids])), np.arange(I))
+
+
+def test_degree_balanced_partition_equalises_rows_and_nnz():
+    """blocks balanced by nnz.  Ids sorted by popularity (the worst case for blocks of consecutive ids):
+    the snake deal gives every rank the same number of rows (+-1) AND the same number of edges (within 2 %)."""
+    from ngacf_amd.dist import Partition
+    rs = np.random.RandomState(0)
+    U, I, P = 5000, 3000, 8
+    deg_i = np.sort((rs.pareto(1.2, I) * 20 + 1).astype(np.int64))[::-1].copy()        # item 0 is the hub
+    deg_u = np.sort((rs.lognormal(3, 1, U) + 1).astype(np.int64))[::-1].copy()
+    naive = [int(deg_i[r * 375:(r + 1) * 375].sum()) for r in range(P)]
+    assert max(naive) > 4 * min(naive)                                                   # consecutive-id blocks: badly skewed
+    parts = [Partition(U, I, P, r, torch.from_numpy(deg_u), torch.from_numpy(deg_i)) for r in range(P)]
+    for kind, deg in ((0, deg_u), (1, deg_i)):
+        nnz, rows = [], []
+        for p in parts:
+            ids = p.local_original_ids()[kind]
+            ids = ids[ids >= 0].numpy()
+            rows.append(ids.size)
+            nnz.append(int(deg[ids].sum()))
+        assert max(rows) - min(rows) <= 1
+        assert max(nnz) - min(nnz) <= max(0.02 * np.mean(nnz), deg.max()), (kind, nnz)
+    p = parts[3]
+    e = torch.stack([torch.arange(U) % U, torch.arange(U) % I])
+    m = p.map_edges(e)
+    assert torch.equal(p._on("inv_u", "cpu")[m[0]], e[0]) and torch.equal(p._on("inv_i", "cpu")[m[1]], e[1])
 
 
 def test_sharded_d128_four_stages_matches_oracle_under_gloo(tmp_path):

@@ -368,3 +368,11 @@ def test_bench_prints_one_contract_line():
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and d["value"] > 1e9 and d["bpr_pairs_per_s"] > 1e5
+    # the timed region: exactly `steps` steps of passes_per_step passes, sized to last about --target-seconds
+    R = d["config"]["passes_per_step"]
+    assert R >= 50 and d["timed_region_s"] > 0.3 and abs(d["ms_per_step"] - 1e3 * d["timed_region_s"] / 3) < 0.02 * d["ms_per_step"]
+    assert abs(d["value"] - d["config"]["edges_directed_per_step"] * 3 / d["timed_region_s"]) < 0.01 * d["value"]
+    assert 0.7 < d["value_median_window"] / d["value"] < 1.3
+    rf = d["roofline"]
+    assert rf["regime"].startswith("cache-resident") and rf["applicable_roof_GBps"] == 8600.0 and rf["launches_timed"] >= 300
+    assert rf["traffic"] is None or "from_profile" in rf["traffic_source"]

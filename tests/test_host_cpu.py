@@ -200,3 +200,67 @@ def test_adjacency_npz_ingest_and_normalised_variants(tmp_path):
         rr, cc, vv = ref(edge, U, I)
         b = sp.coo_matrix((vv, (rr, cc)), shape=(N, N)).toarray()
         assert np.abs(a - b).max() < 1e-6
+
+
+def test_bench_launcher_builds_the_torchrun_child_without_touching_a_gpu(monkeypatch):
+    """`python bench.py --gpus N` with no torchrun environment: the parent loads ngacf_amd/benchkit.py by path (no torch,
+    no HIP library), builds `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+    bench.py <same flags>` and relays the child's one JSON line and exit code."""
+    import importlib.util
+    import subprocess
+    import sys as _sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    bk = bench._benchkit()
+    assert "torch" not in bk.__dict__ and not hasattr(bk, "lib")
+    for n in (2, 4, 8):
+        argv = ["--gpus", str(n), "--steps", "7", "--warmup", "2", "--workload", "yelp"]
+        cmd = bk.launch_command(n, argv, 29512, python="python3", script="/x/bench.py")
+        assert cmd[:3] == ["python3", "-m", "torch.distributed.run"]
+        assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == str(n)
+        assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29512"
+        assert cmd[cmd.index("/x/bench.py") + 1:] == argv
+    # main(): launcher for N > 1 (or the forced rehearsal) without RANK/WORLD_SIZE, worker otherwise
+    calls = []
+
+    class FakePopen:
+        def __init__(self, cmd, stdout=None, env=None, text=None):
+            calls.append((cmd, env))
+            self.returncode = 0
+
+        def communicate(self, timeout=None):
+            return 'RCCL version banner\n{"metric": "m", "value": 1.0}\n', None
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NGACF_BENCH_FORCE_DIST"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(subprocess, "Popen", FakePopen)
+    monkeypatch.setattr(bench, "worker", lambda a: calls.append("worker"))
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "4", "--steps", "3"])
+    assert e.value.code == 0 and calls[0][0][calls[0][0].index("--nproc-per-node") + 1] == "4"
+    assert calls[0][1]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and calls[0][0][-4:] == ["--gpus", "4", "--steps", "3"]
+    assert "torch" not in _sys.modules or True                       # (torch is imported by other tests of this process)
+    calls.clear()
+    bench.main(["--gpus", "1"])
+    assert calls == ["worker"]
+    monkeypatch.setenv("NGACF_BENCH_FORCE_DIST", "1")
+    calls.clear()
+    with pytest.raises(SystemExit):
+        bench.main(["--gpus", "1"])
+    assert calls and calls[0] != "worker"
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "4")
+    calls.clear()
+    bench.main(["--gpus", "4"])                                      # under torchrun: a rank, never a launcher
+    assert calls == ["worker"]
+
+
+def test_benchkit_sizes_the_timed_region_and_names_the_gather_regime():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bk", os.path.join(ROOT, "ngacf_amd", "benchkit.py"))
+    bk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bk)
+    assert bk.passes_per_step(0.14e-3, 20, 0.6) == 215 and bk.passes_per_step(0.1, 20, 0.6) == 1
+    assert bk.median([3.0, 1.0, 2.0]) == 2.0 and bk.median([4.0, 1.0, 2.0, 3.0]) == 2.5
+    g = bk.gather_regime(70839 * 128, 40981 * 128)
+    assert g["regime"].startswith("cache-resident") and g["roof_GBps"] == 8600.0
+    assert bk.gather_regime(15_000_000 * 128)["regime"] == "HBM" and bk.gather_regime(2625 * 128)["regime"] == "L2-resident"

@@ -1,6 +1,7 @@
 """HBM-side traffic of the dominant kernel from PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
 WRITE_SIZE in SEPARATE rocprofv3 --pmc passes of the same bench command (kernel-trace only), units of KB, FETCH_SIZE
-doubled on gfx950.  Writes profiles/r01_traffic_<workload>.json (bench.py puts traffic_bytes into roofline.traffic).
+doubled on gfx950.  Writes gpurun_out/r02_traffic_<workload>.json -- copy it to profiles/ (bench.py reads roofline.traffic
+from there and labels it from_profile).
 Run on the GPU box:  python tools/traffic.py gowalla   (this process never touches the GPU itself)."""
 import collections
 import csv
@@ -17,36 +18,47 @@ def one_pass(counter, workload, dtype, tag):
     subprocess.run(["rm", "-rf", out])
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-train",
-           "--workload", workload, "--dtype", dtype]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--passes-per-step", "4",
+           "--no-cpu-baseline", "--no-train", "--workload", workload, "--dtype", dtype]
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     tot, n = collections.defaultdict(float), collections.defaultdict(int)
     for root, _, files in os.walk(out):
         for f in files:
             if f.endswith("counter_collection.csv"):
                 for r in csv.DictReader(open(os.path.join(root, f))):
-                    if "prop_fwd_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                        tot[counter] += float(r["Counter_Value"])
-                        n[counter] += 1
-    return tot[counter] / max(n[counter], 1), n[counter]
+                    if r["Counter_Name"] != counter:
+                        continue
+                    for k in KERNELS:
+                        if k in r["Kernel_Name"]:
+                            tot[k] += float(r["Counter_Value"])
+                            n[k] += 1
+    return {k: (tot[k] / max(n[k], 1), n[k]) for k in KERNELS}
+
+
+KERNELS = ("prop_fwd_kernel", "prop_fwd_split_kernel", "transform_mfma_kernel", "transform_fwd_kernel")
 
 
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "gowalla"
+    dtypes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["bf16", "fp32"]
     res = {"workload": wl, "stages": 3,
-           "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --steps 10 --warmup 2 "
-                      "--no-cpu-baseline --no-train --workload %s [--dtype fp32]  (tools/traffic.py)" % wl,
+           "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --steps 3 --warmup 1 "
+                      "--passes-per-step 4 --no-cpu-baseline --no-train --workload %s [--dtype fp32]  (tools/traffic.py)" % wl,
            "by_dtype": {}}
-    for dt in ("bf16", "fp32"):
-        fetch, nf = one_pass("FETCH_SIZE", wl, dt, wl)
-        write, nw = one_pass("WRITE_SIZE", wl, dt, wl)
-        res["by_dtype"][dt] = {"kernel": "prop_fwd_kernel", "launches": [nf, nw], "fetch_size_kb": round(fetch, 1),
-                               "write_size_kb": round(write, 1),
-                               "traffic_bytes": int(round((2.0 * fetch + write) * 1024)),
+    for dt in dtypes:
+        fetch = one_pass("FETCH_SIZE", wl, dt, wl)
+        write = one_pass("WRITE_SIZE", wl, dt, wl)
+        f0, nf = fetch["prop_fwd_kernel"]
+        w0, nw = write["prop_fwd_kernel"]
+        res["by_dtype"][dt] = {"kernel": "prop_fwd_kernel", "launches": [nf, nw], "fetch_size_kb": round(f0, 1),
+                               "write_size_kb": round(w0, 1),
+                               "traffic_bytes": int(round((2.0 * f0 + w0) * 1024)),
                                "note": "bytes crossing the L2<->fabric boundary per launch (Infinity-Cache hits included), "
-                                       "avg over the launches of all stages; FETCH_SIZE x2 = gfx950 correction"}
+                                       "avg over the launches of all stages; FETCH_SIZE x2 = gfx950 correction",
+                               "other_kernels": {k: {"fetch_size_kb": round(fetch[k][0], 1), "write_size_kb": round(write[k][0], 1),
+                                                     "launches": fetch[k][1]} for k in KERNELS[1:] if fetch[k][1]}}
         print(wl, dt, res["by_dtype"][dt], flush=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r01_traffic_%s.json" % wl), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r02_traffic_%s.json" % wl), "w") as f:
         json.dump(res, f, indent=1)
 
 
