@@ -613,7 +613,7 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
             fwd()
         sync()
         t_pass = allmax((time.perf_counter() - t0) / 5)
-        R = args.passes_per_step or BK.passes_per_step(t_pass, args.steps, args.target_seconds)
+        R = R_eager = args.passes_per_step or BK.passes_per_step(t_pass, args.steps, args.target_seconds)
         for _ in range(args.warmup):
             fwd()
         t_eager, win_eager = BK.timed_steps(fwd, args.steps, R, sync, torch)
@@ -650,9 +650,10 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
                               "GBps_received_per_rank": round(ag_bytes / max(ag_ms * 1e-3, 1e-12) / 1e9, 1) if ag else None,
                               "note": "one async all-gather per half-table per stage (in place, RCCL); serial-pass "
                                       "duration start -> wait, rank 0"}}
-    extra = {"ms_per_step_eager": round(1e3 * t_eager / args.steps, 4), "roofline": roofline}
+    extra = {"ms_per_pass_eager": round(1e3 * t_eager / args.steps / R, 5), "roofline": roofline}
 
-    def line(t_fwd, windows, launch, extra):
+    def line(t_fwd, windows, launch, extra, R=None):
+        R = R_eager if R is None else R
         med = BK.median(windows)
         out = {"metric": "propagation edges/sec (directed edge traversals, forward, all stages)",
                "value": round(trav * R * args.steps / t_fwd, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
@@ -774,14 +775,20 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
                 fwd()
             for _ in range(args.warmup):
                 graph.replay()
-            t_graph, win_graph = BK.timed_steps(graph.replay, args.steps, R, sync, torch)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                graph.replay()
+            sync()                                 # the replayed pass is shorter than the eager one: its own pass count
+            R_graph = args.passes_per_step or BK.passes_per_step(allmax((time.perf_counter() - t0) / 5), args.steps, args.target_seconds)
+            t_graph, win_graph = BK.timed_steps(graph.replay, args.steps, R_graph, sync, torch)
             t_graph = allmax(t_graph)
     except Exception as e:                         # capture refused here (maybe not on the peers): the eager numbers stand
         print("[bench] sharded hipGraph capture not used: %r" % (e,), file=sys.stderr, flush=True)
         finish(eager_line, True, "capture failed: %r" % (e,))
-    better = t_graph < t_eager                     # t_* are already max-over-ranks: every rank decides alike
+    better = t_graph / R_graph < t_eager / R_eager    # t_* are already max-over-ranks: every rank decides alike
     glaunch = "hipGraph replay (kernels + RCCL launches)"
-    best = line(t_graph, win_graph, glaunch, extra) if better else eager_line
+    best = line(t_graph, win_graph, glaunch, extra, R_graph) if better else eager_line
     # ---- (4) the train step as one hipGraph (sampler-free: fixed batch, as in (2)), same watchdog ------------------
     if not args.no_train:
         dog.cancel()
@@ -806,7 +813,7 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
                 extra = dict(extra, bpr_pairs_per_s=round(B * ksteps / t_trg, 1), train_ms_per_step=round(1e3 * t_trg / ksteps, 3),
                              train_launch="hipGraph replay (kernels + RCCL launches + fused Adam)",
                              train_ms_per_step_eager=round(1e3 * t_tr / ksteps, 3))
-                best = line(t_graph, win_graph, glaunch, extra) if better else line(t_eager, win_eager, "eager", extra)
+                best = line(t_graph, win_graph, glaunch, extra, R_graph) if better else line(t_eager, win_eager, "eager", extra)
         except Exception as e:
             print("[bench] sharded hipGraph train step not used: %r" % (e,), file=sys.stderr, flush=True)
             finish(best, True, "train-step capture failed: %r" % (e,))
