@@ -306,9 +306,13 @@ def _big_graph_check(dev, workload, dt, n_rows=1500):
     import time
     U, I, E = D.SHAPES[workload]
     t0 = time.time()
-    edge = D.synthetic_bipartite(U, I, E, seed=2019, device=dev)
+    edge = D.workload_graph(workload, dev)                 # the chunked generator: the graph bench.py runs
+    torch.cuda.synchronize()
+    print("%s: graph of %d edges generated in %.1f s" % (workload, edge.shape[1], time.time() - t0), flush=True)
     plan = build_plan(edge, U, I)
     del edge
+    torch.cuda.synchronize()
+    print("%s: plan built at %.1f s (nshort %d, nseg %d, hub rows %d)" % (workload, time.time() - t0, plan.nshort, plan.nseg, plan.nsplit), flush=True)
     N, d = U + I, 64
     g = torch.Generator(device=dev).manual_seed(1)
     Xf = torch.randn(N, d, device=dev, generator=g) * 0.3
