@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as NF
+from .SPUIGACF import _PlanCache
 from .plan import build_plan
 from .SPUIGACF import _fresh_seed
 
@@ -27,21 +28,17 @@ def _edges_of(adj):
     return adj.nonzero().t()
 
 
-class _CoverPlans:
-    def __init__(self):
-        self._d = {}
+class _CoverPlans(_PlanCache):
+    """Plans of the double cover, cached like the bipartite ones (the entry holds the keyed `adj`, see _PlanCache)."""
 
     def get(self, adj, N, seg_len=256):
-        key = (adj.data_ptr(), tuple(adj.shape), adj._version, N, seg_len)
-        p = self._d.get(key)
-        if p is None:
-            self._d.clear()
+        def build():
             edge = _edges_of(adj)
             # a node without any outgoing edge has a zero attention row sum: the reference divides by it and trips its
             # NaN assert (SPGA.py:406,411); build_plan raises instead
-            p = build_plan(edge, N, N, seg_len=seg_len, device=edge.device if edge.is_cuda else None)
-            self._d[key] = p
-        return p
+            return build_plan(edge, N, N, seg_len=seg_len, device=edge.device if edge.is_cuda else None)
+        key_t = adj if not adj.is_sparse else adj._values()
+        return super().get(key_t, N, N, seg_len, builder=build)
 
 
 def _cover_stage(x, W, a_dst, a_src, plan, heads, alpha, elu, drop_p, h_dtype=None):

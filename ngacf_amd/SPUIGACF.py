@@ -27,22 +27,58 @@ _SEED_STRIDE = 0x1E3779B97F4A7C15
 _CTR_STRIDE = 0x2545F4914F6CDD1D          # device-counter step (odd, unrelated to the per-call stride)
 
 
+def _content_digest(t):
+    """(sum, weighted sum) of an integer tensor: changes when any element changes or two elements swap.  One device
+    reduction + a host read (a synchronisation): used only by the opt-in check below."""
+    f = t.reshape(-1).long()
+    w = (torch.arange(f.numel(), device=f.device) % 65521) + 1
+    return int(f.sum()), int((f * w).sum())
+
+
+_VERIFY_PLAN_DIGEST = __import__("os").environ.get("NGACF_PLAN_DIGEST") == "1"
+
+
 class _PlanCache:
-    """Per-module cache of graph plans keyed by the identity of the `mask` tensor the
-    caller passes on every forward (train_eval_Gowalla.py:131-132 passes the same `adj`)."""
+    """Per-module cache of graph plans keyed by the `mask` tensor the caller passes on every forward
+    (train_eval_Gowalla.py:131-132 passes the same `adj`; :106 re-uploads it every epoch).
+
+    The key is (address, shape, device, in-place version counter) AND the entry holds a reference to the keyed tensor:
+    while an entry lives its storage cannot be freed, so a DIFFERENT adjacency can never be allocated at the cached
+    address (address + shape alone would silently reuse the old plan).  A new tensor -- even with equal
+    content -- has its own storage and gets its own plan (one build per epoch under the reference's loop); an in-place
+    write bumps `_version`.  Writes that bypass the version counter (`.data`, raw pointers) are the caller's to announce
+    (invalidate()); NGACF_PLAN_DIGEST=1 verifies a content digest on every hit (one sync each: debugging).
+    Cost of holding the reference: the mask's bytes stay allocated per entry (at most _PLAN_CACHE_MAX)."""
 
     def __init__(self):
         self._d = {}
 
-    def get(self, indices, U, I, seg_len):
+    def invalidate(self):
+        self._d.clear()
+
+    def get(self, indices, U, I, seg_len, builder=None):
         key = (indices.data_ptr(), tuple(indices.shape), str(indices.device), indices._version, U, I, seg_len)
-        p = self._d.get(key)
-        if p is None:
+        hit = self._d.get(key)
+        if hit is not None and _VERIFY_PLAN_DIGEST and hit[2] != _content_digest(indices):
+            raise RuntimeError("the adjacency tensor changed under a cached plan without a version bump "
+                               "(a write through .data or a raw pointer): call invalidate()")
+        if hit is None:
             if len(self._d) >= _PLAN_CACHE_MAX:
                 self._d.pop(next(iter(self._d)))
-            p = build_plan(indices, U, I, seg_len=seg_len, device=indices.device if indices.is_cuda else None)
-            self._d[key] = p
-        return p
+            build = builder or (lambda: build_plan(indices, U, I, seg_len=seg_len, device=indices.device if indices.is_cuda else None))
+            hit = (build(), indices, _content_digest(indices) if _VERIFY_PLAN_DIGEST else None)
+            self._d[key] = hit
+        return hit[0]
+
+
+def _refuse_replica(module):
+    """nn.DataParallel (the reference's --parallel path, parallel.py:94-130) shallow-copies the module per device and
+    runs the replicas on threads: every replica would redo the whole propagation (that is what the reference does) and
+    the stage / table caches of this module are not built for it.  Refuse loudly instead of reading another device's
+    weights; the multi-GPU path is ngacf_amd.dist.ShardedSPUIGACF (one process per GPU, node-partitioned)."""
+    if getattr(module, "_is_replica", False):
+        raise RuntimeError("ngacf_amd modules cannot run as nn.DataParallel replicas (reference --parallel True, "
+                           "parallel.py:94-130): use ngacf_amd.dist.ShardedSPUIGACF under torchrun (one process per GPU)")
 
 
 def _fresh_seed():
@@ -134,6 +170,7 @@ class SpUIGraphAttentionLayer(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def forward(self, uidx, iidx, features, indices):
+        _refuse_replica(self)
         U, I = int(uidx.numel()), int(iidx.numel())
         plan = self._plans.get(squeeze_mask(indices), U, I, self.seg_len)
         p = self.droprate if self.training else 0.0
@@ -243,6 +280,7 @@ class _GATBase(nn.Module):
                 p_._version                                            # (copy_ above already bumped the versions)
 
     def _run(self, uidx, iidx, features, adj):
+        _refuse_replica(self)
         U, I = int(uidx.numel()), int(iidx.numel())
         plan = self._plans.get(squeeze_mask(adj), U, I, self.seg_len)
         p = self.dropout if self.training else 0.0
@@ -409,6 +447,7 @@ class _CFBase(nn.Module):
         return idx[0], idx[1], self._features()
 
     def propagate(self, mask):
+        _refuse_replica(self)
         uidx, iidx, features = self.getFeatureMat()
         return self.gat(uidx, iidx, features, squeeze_mask(mask))        # :42-46
 

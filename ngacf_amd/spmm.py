@@ -58,6 +58,15 @@ class StaticPropagation:
         return _SpMM.apply(X, self.plan, self.val, self.plan_t, self.val_t, self_loop)
 
 
+def plain_adj_coo(indices, U, I, rating=None):
+    """`plain_adj` of data/loadGowalla.py:184-205: the (U+I) x (U+I) block matrix [[0, R], [R^T, 0]] with the ratings as
+    values (ones when `rating` is None), as COO (rows, cols, vals); duplicates are summed by the plan builder like
+    scipy's / torch's coalesce."""
+    u, i = indices[0].long(), indices[1].long() + U
+    v = torch.ones(u.numel(), dtype=torch.float32, device=indices.device) if rating is None else rating.float()
+    return torch.cat([u, i]), torch.cat([i, u]), torch.cat([v, v])
+
+
 def mean_adj_coo(indices, U, I):
     """`mean_adj` of data/loadGowalla.py:186-227: D^-1/2 A D^-1/2 over the (U+I)x(U+I) bipartite block matrix,
     as COO (rows, cols, vals) on the device of `indices` ([2,E], items not offset)."""

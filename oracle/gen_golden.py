@@ -218,7 +218,7 @@ def g7_static_spmm(edge, U, I):
 
 
 def g7b_norm_adj(edge, U, I):
-    """adj_type 'norm_adj' and 'plain_adj' straight from the reference's buildLaplacianMat."""
+    """adj_type 'norm_adj' straight from the reference's buildLaplacianMat ('plain_adj': g7c_plain_adj)."""
     import pandas as pd
     from data.loadGowalla import buildLaplacianMat
     rt = pd.DataFrame({"userId": edge[0], "itemId": edge[1], "rating": np.ones(edge.shape[1])})
@@ -226,6 +226,19 @@ def g7b_norm_adj(edge, U, I):
     L.sort_indices()
     L = L.tocoo()
     save("g7b_norm_adj", edge=edge, U=U, I=I, row=L.row.astype(np.int64), col=L.col.astype(np.int64), val=L.data.astype(np.float64))
+
+
+def g7c_plain_adj(edge, U, I):
+    """adj_type 'plain_adj' from the reference's buildLaplacianMat, with non-trivial ratings."""
+    import pandas as pd
+    from data.loadGowalla import buildLaplacianMat
+    rating = (np.random.RandomState(5).randint(1, 6, edge.shape[1])).astype(np.float64)
+    rt = pd.DataFrame({"userId": edge[0], "itemId": edge[1], "rating": rating})
+    L = buildLaplacianMat(rt, U, I, "plain_adj").tocsr()
+    L.sort_indices()
+    L = L.tocoo()
+    save("g7c_plain_adj", edge=edge, U=U, I=I, rating=rating, shape=np.array(L.shape), row=L.row.astype(np.int64),
+         col=L.col.astype(np.int64), val=L.data.astype(np.float64))
 
 
 def g8_metrics():
@@ -285,10 +298,116 @@ def g9_g10_ml100k():
          F_abs_sum=np.float64(np.abs(Fo.astype(np.float64)).sum()), **gat)
 
 
+def g13_ref_checkpoint(edge, U, I):
+    """A checkpoint as the REFERENCE writes it (run_Gowalla.py:142-143: {'model': state_dict, 'optim': Adam state_dict})
+    after two training steps, the batch of a third step, and the reference's parameters after that third step: the
+    resume test loads the checkpoint into this package's model + optimizer (different parameter layout) and must land on
+    the same parameters.  droprate 0 (masks cannot be matched); SPUIMultiGACF so that two fused 8-head stages are covered."""
+    torch.manual_seed(23)
+    m = R.SPUIMultiGACF(U, I, 64, [64, 64], 0.0, useCuda=False)
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30.0)
+        m.iEmbd.weight.mul_(30.0)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-5)             # run_Gowalla.py:114
+    rs = np.random.RandomState(29)
+    e_t = torch.from_numpy(edge)
+    B = 48
+    batches = [(rs.randint(0, U, B).astype(np.int64), rs.randint(0, I, B).astype(np.int64), rs.randint(0, I, B).astype(np.int64))
+               for _ in range(3)]
+
+    def step(b):
+        u, p_, n = (torch.from_numpy(x) for x in b)
+        opt.zero_grad()
+        with CpuDevice():
+            loss = RB.BPRLoss()(m(u, p_, e_t), m(u, n, e_t))
+        loss.backward()
+        opt.step()
+        return float(loss)
+    losses = [step(batches[0]), step(batches[1])]
+    out = {"p." + k_: v for k_, v in sd_numpy(m).items()}
+    osd = opt.state_dict()
+    names = [k_ for k_, _ in m.named_parameters()]
+    for j, pid in enumerate(osd["param_groups"][0]["params"]):
+        st = osd["state"][pid]
+        out["o.%d.exp_avg" % j] = st["exp_avg"].numpy().copy()
+        out["o.%d.exp_avg_sq" % j] = st["exp_avg_sq"].numpy().copy()
+        out["o.%d.step" % j] = np.float64(float(st["step"]))
+    g = osd["param_groups"][0]
+    losses.append(step(batches[2]))
+    out.update({"q." + k_: v for k_, v in sd_numpy(m).items()})                    # parameters after the third step
+    save("g13_ref_checkpoint", edge=edge, U=U, I=I, u=batches[2][0], pos=batches[2][1], neg=batches[2][2],
+         lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
+         param_names=np.array(names), losses=np.array(losses), **out)
+
+
+def g11_factors(U, I, seed=7):
+    rs = np.random.RandomState(seed)
+    cont = (rs.randn(U, 64).astype(np.float32).astype(np.float64), rs.randn(I, 64).astype(np.float32).astype(np.float64))
+    ties = (rs.randint(-2, 3, (U, 64)).astype(np.float64), rs.randint(-2, 3, (I, 64)).astype(np.float64))
+    return {"cont": cont, "ties": ties}
+
+
+def g11_eval_neg_all():
+    """A8 pin (ii): the reference's OWN eval_neg_all (train_eval_Gowalla.py:274-354: user batches of 64,
+    item batches, report_one_user in a process pool, heapq.nlargest, metrics.py) on a FIXED score table, for the ml100k
+    split the reference's runner makes: seeds as run_Gowalla.py:191-193, then train_test_split(rt, test_size=0.2) (:80),
+    train_pos_neg_exclude_test (:85), test_positives (:87).  The model is a stand-in that returns S[u, i] from a seeded
+    table -- once with continuous scores, once with small-integer scores (thousands of exact ties: pins the tie order of
+    heapq.nlargest over the reference's Python sets).  Shims: Tensor.cuda -> identity, torch.cuda.empty_cache -> no-op."""
+    import pandas as pd
+    from sklearn.model_selection import train_test_split
+    import train_eval_Gowalla as TE
+    from data.loadGowalla import load100KRatings, train_pos_neg_exclude_test, test_positives
+    seed = 2019
+    torch.manual_seed(seed)                               # run_Gowalla.py:191-193
+    np.random.seed(seed)
+    rt = load100KRatings(REF + "/data/1K")                # read-only; get_adj_mat (which writes an .npz there) is not called
+    U, I = int(rt["userId"].max()), int(rt["itemId"].max())
+    rt["userId"] = rt["userId"] - 1
+    rt["itemId"] = rt["itemId"] - 1
+    train_df, test_df_rows = train_test_split(rt, test_size=0.2)                       # :80
+    train_pos_neg = train_pos_neg_exclude_test(rt, train_df)                           # :85
+    test_df = test_positives(test_df_rows)                                             # :87
+    # score tables of rank 64, S = A @ B^T, so that the device path can be fed the same scores as propagated embeddings
+    # F = [A; B] (tests/test_gpu_train_eval.py); integer factors make the tie table exact in fp32 on both sides
+    tables = {k: (a @ b.T).astype(np.float32) for k, (a, b) in g11_factors(U, I).items()}
+
+    class Table(torch.nn.Module):
+        def __init__(self, t):
+            super().__init__()
+            self.t = torch.from_numpy(t)
+
+        def forward(self, u, i, adj):
+            return self.t[u, i]
+    real_cuda, real_empty = torch.Tensor.cuda, torch.cuda.empty_cache
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.empty_cache = lambda: None
+    out = {}
+    try:
+        for tag, tab in tables.items():
+            res = TE.eval_neg_all(Table(tab), 2048, test_df, train_pos_neg, np.zeros((2, 1), dtype=np.int64), I, False)
+            for k in ("precision", "recall", "ndcg", "hit_ratio"):
+                out["%s.%s" % (tag, k)] = np.asarray(res[k], dtype=np.float64)
+            out["%s.auc" % tag] = np.float64(res["auc"])
+    finally:
+        torch.Tensor.cuda, torch.cuda.empty_cache = real_cuda, real_empty
+    save("g11_eval_neg_all", U=U, I=I, seed=seed, table_seed=7,
+         train_rows=train_df.index.values.astype(np.int32), test_rows=test_df_rows.index.values.astype(np.int32),
+         n_train_users=len(train_pos_neg), n_test_users=len(test_df),
+         test_users_order=test_df["userId"].values.astype(np.int32), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-g11" in sys.argv:
+        return g11_eval_neg_all()
     edge = toy_graph()
     U, I = 50, 40
+    if "--only-g7c" in sys.argv:
+        return g7c_plain_adj(edge[:, edge[1] < 37], U, 37)
+    if "--only-g13" in sys.argv:
+        return g13_ref_checkpoint(edge, U, I)
     if "--only-g7b" in sys.argv:                      # added after the first batch: leaves the other fixtures untouched
         return g7b_norm_adj(edge[:, edge[1] < 37], U, 37)
     g1_layers(edge, U, I)
@@ -298,8 +417,11 @@ def main():
     g6_spga()
     g7_static_spmm(edge[:, edge[1] < 37], U, 37)      # buildLaplacianMat infers shapes from max ids
     g7b_norm_adj(edge[:, edge[1] < 37], U, 37)
+    g7c_plain_adj(edge[:, edge[1] < 37], U, 37)
     g8_metrics()
     g9_g10_ml100k()
+    g11_eval_neg_all()
+    g13_ref_checkpoint(edge, U, I)
 
 
 if __name__ == "__main__":

@@ -268,6 +268,17 @@ def mean_adj(edge, U, I, rating=None):
     return L.row, L.col, L.data
 
 
+def plain_adj(edge, U, I, rating=None):
+    """data/loadGowalla.py:184-205 adj_type == 'plain_adj': vstack([R placed at column offset U, R^T])."""
+    N = U + I
+    r = np.ones(edge.shape[1]) if rating is None else np.asarray(rating, dtype=np.float64)
+    A = sp.coo_matrix((np.concatenate([r, r]),
+                       (np.concatenate([edge[0], edge[1] + U]), np.concatenate([edge[1] + U, edge[0]]))), shape=(N, N)).tocsr()
+    A.sum_duplicates()
+    A = A.tocoo()
+    return A.row, A.col, A.data
+
+
 def norm_adj(edge, U, I):
     """data/loadGowalla.py:196-222 adj_type == 'norm_adj': normalize_adj(adj + selfLoop)."""
     N = U + I

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 import ngacf_amd
-from ngacf_amd import data as D
+from ngacf_amd import checkpoint as CK, data as D
 from ngacf_amd.train_eval import Interactions, eval_neg_all, train_bpr
 
 
@@ -82,9 +82,10 @@ def main(args):
                              capturable=not args.eager, fused=not args.eager)
     os.makedirs("ckpts", exist_ok=True)
     if args.resume_from:
-        ck = torch.load("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, args.resume_from), map_location=dev)
-        model.load_state_dict(ck["model"])
-        optim.load_state_dict(ck["optim"])
+        # a checkpoint of the reference (run_Gowalla.py:143) or of this runner: both halves in the reference's layout;
+        # the optimizer state is converted to the fused stage parameters (ngacf_amd/checkpoint.py)
+        CK.load_checkpoint("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, args.resume_from), model, optim, map_location=dev)
+        print("=> loaded checkpoint 'ckpts/{}_{:03d}.pkl'".format(args.model, args.resume_from))
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed)
     history = []
@@ -94,8 +95,7 @@ def main(args):
         torch.cuda.synchronize()
         print("------epoch:{}, train_loss:{:5f}, time consuming:{:.2f}s".format(epoch, loss, time.time() - t0), flush=True)
         if (epoch + 1) % args.save_every == 0:
-            torch.save({"model": model.state_dict(), "optim": optim.state_dict()},
-                       "ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, epoch + 1))
+            CK.save_checkpoint("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, epoch + 1), model, optim)
         if (epoch + 1) % args.eval_every == 0:
             t0 = time.time()
             m = eval_neg_all(model, args.batch_size, data, adj)
@@ -132,6 +132,11 @@ def parse(argv=None):
     p.add_argument("--data_root", type=str, default="")
     p.add_argument("--synthetic", type=str, default="", choices=["", "ml100k", "gowalla", "yelp"])
     a = p.parse_args(argv)
+    if a.parallel:
+        # the reference's --parallel True wraps the model in nn.DataParallel (parallel.py:94-130): every GPU redoes the whole
+        # propagation.  This package's modules refuse to run as replicas; the multi-GPU path is one process per GPU
+        raise SystemExit("--parallel True (nn.DataParallel replicas) is not supported: the multi-GPU path is "
+                         "ngacf_amd.dist.ShardedSPUIGACF under torchrun, e.g. `python bench.py --gpus 8`")
     if a.adj_type != "ui_mat" or a.train_mode != "PairSampling" or a.eval_mode != "AllNeg":
         raise SystemExit("the accelerated path is --adj_type ui_mat --train_mode PairSampling --eval_mode AllNeg (README.md:13-29)")
     return a

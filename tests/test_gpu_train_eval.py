@@ -56,6 +56,32 @@ def test_eval_neg_all_matches_oracle_on_same_scores():
     assert res["recall"][3] > 0
 
 
+@pytest.mark.parametrize("tag,dt", [("cont", torch.float32), ("ties", torch.float32), ("ties", torch.bfloat16)])
+def test_eval_neg_all_matches_the_references_own_eval_on_a_fixed_score_table(tag, dt):
+    """A8 pin (ii) on the device path: train_eval.eval_neg_all (one ngacf_eval_topk launch) against the REFERENCE's own
+    eval_neg_all run (tests/golden/g11_eval_neg_all.npz: the reference's seeded ml100k split, a fixed rank-64 score table
+    handed to the device as the propagated embeddings).  'ties': small-integer factors -> thousands of exact ties, exact in
+    fp32 and in bf16; 'cont': continuous scores (fp32 MFMA products are exact, sums differ in order: a flip needs two
+    of a user's top-20 boundary scores within ~1e-6 of each other)."""
+    from test_oracle_golden import _g11_factors, g11_split
+    from ngacf_amd.train_eval import Interactions, eval_neg_all
+    dev = torch.device("cuda:0")
+    u, i, tr, te, g = g11_split()
+    U, I = int(g["U"]), int(g["I"])
+    A, B = _g11_factors(U, I)[tag]
+    data = Interactions(u[tr], i[tr], u[te], i[te], U, I, dev)
+
+    class Table:
+        def eval(self):
+            return self
+
+        def propagate(self, adj):
+            return torch.from_numpy(np.concatenate([A, B])).to(dev).to(dt)
+    got = eval_neg_all(Table(), 2048, data, data.adjacency())
+    for k in ("precision", "recall", "ndcg", "hit_ratio"):
+        assert np.allclose(got[k], g["%s.%s" % (tag, k)], rtol=0, atol=1e-12), (k, got[k], g["%s.%s" % (tag, k)])
+
+
 def test_ml100k_two_epochs_reach_reference_metrics():
     import ngacf_amd
     from ngacf_amd.train_eval import Interactions, eval_neg_all, train_bpr
@@ -376,3 +402,76 @@ def test_bench_prints_one_contract_line():
     rf = d["roofline"]
     assert rf["regime"].startswith("cache-resident") and rf["applicable_roof_GBps"] == 8600.0 and rf["launches_timed"] >= 300
     assert rf["traffic"] is None or "from_profile" in rf["traffic_source"]
+
+
+@pytest.mark.gpu
+def test_resume_from_a_reference_checkpoint_lands_on_the_references_next_step():
+    """run_Gowalla.py:127-130 with a checkpoint the REFERENCE wrote after two steps (tests/golden/g13: model + 53-entry
+    Adam state): load it into this package's model + optimizer (8 fused parameters), take the reference's third batch,
+    and compare every parameter with the reference's own third step."""
+    import tempfile
+    import ngacf_amd
+    from ngacf_amd import checkpoint as CK
+    from conftest import load_golden
+    from test_host_cpu import _reference_checkpoint
+    dev = torch.device("cuda:0")
+    g = load_golden("g13_ref_checkpoint")
+    U, I = int(g["U"]), int(g["I"])
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "SPUIMultiGACF_ml100k_002.pkl")
+        names = _reference_checkpoint(g, path)
+        m = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev).train()
+        for fused in (False, True):
+            opt = torch.optim.Adam(m.parameters(), lr=123.0, weight_decay=0.5, capturable=fused, fused=fused)
+            CK.load_checkpoint(path, m, opt, map_location=dev)
+            edge = torch.from_numpy(g["edge"]).to(dev)
+            u, pos, neg = (torch.from_numpy(g[k]).to(dev) for k in ("u", "pos", "neg"))
+            opt.zero_grad()
+            loss = ngacf_amd.BPRLoss()(m(u, pos, edge), m(u, neg, edge))
+            loss.backward()
+            opt.step()
+            assert abs(float(loss.detach()) - float(g["losses"][2])) < 1e-4 * abs(float(g["losses"][2]))
+            sd = m.state_dict()
+            for k in names:
+                before, after = g["p." + k], g["q." + k]
+                step = np.abs(after - before).max()
+                err = float((sd[k].cpu() - torch.from_numpy(after)).abs().max())
+                assert err < 2e-3 * step + 1e-7, (fused, k, err, step)       # the update itself is ~lr = 0.01 per element
+
+
+@pytest.mark.gpu
+def test_run_gowalla_csv_branch_and_refused_flags(tmp_path, monkeypatch):
+    """run_Gowalla.py's Gowalla/Yelp branch (reference: loadGowalla, data/loadGowalla.py:35-39 -- headerless
+    `userId,itemId,rating` rows in g_train.csv / g_test.csv): one epoch + evaluation + checkpoint + resume on a small pair of
+    CSV files the test writes; --parallel True and the non-accelerated modes are refused with a message."""
+    import run_Gowalla as RG
+    rs = np.random.RandomState(5)
+    U, I = 60, 45
+    uu = np.concatenate([np.arange(U), rs.randint(0, U, 1400)]); ii = np.concatenate([rs.randint(0, I, U), rs.randint(0, I, 1400)])
+    key = np.unique(uu.astype(np.int64) * I + ii)
+    uu, ii = key // I, key % I
+    perm = rs.permutation(len(uu))
+    te, tr = perm[:len(uu) // 5], perm[len(uu) // 5:]
+    root = tmp_path / "Gowalla"
+    root.mkdir()
+    for name, rows in (("g_train.csv", tr), ("g_test.csv", te)):
+        with open(root / name, "w") as f:
+            for r in rows:
+                f.write("%d,%d,1\n" % (uu[r], ii[r]))
+    monkeypatch.chdir(tmp_path)
+    args = RG.parse(["--dataset", "Gowalla", "--data_root", str(tmp_path), "--epochs", "2", "--eval_every", "1", "--save_every", "1",
+                     "--batch_size", "256", "--droprate", "0.1"])
+    torch.manual_seed(args.seed); np.random.seed(args.seed)
+    hist = RG.main(args)
+    assert len(hist) == 2 and np.isfinite(hist[1][1]) and 0.0 <= hist[1][2]["recall"][3] <= 1.0
+    assert os.path.exists(tmp_path / "ckpts" / "SPUIGACF_Gowalla_002.pkl")
+    ck = torch.load(tmp_path / "ckpts" / "SPUIGACF_Gowalla_002.pkl")
+    assert len(ck["optim"]["param_groups"][0]["params"]) == 29 and "gat.attention_3.W_u" in ck["model"]   # the reference's layout
+    args2 = RG.parse(["--dataset", "Gowalla", "--data_root", str(tmp_path), "--epochs", "3", "--eval_every", "1", "--save_every", "5",
+                      "--batch_size", "256", "--resume_from", "2"])
+    hist2 = RG.main(args2)
+    assert len(hist2) == 1 and hist2[0][0] == 2 and np.isfinite(hist2[0][1])
+    with pytest.raises(SystemExit, match="parallel"):
+        RG.parse(["--parallel", "True"])
+    with pytest.raises(SystemExit):
+        RG.parse(["--adj_type", "mean_adj"])

@@ -155,3 +155,59 @@ def test_g7b_norm_adj_matches_reference_builder():
     assert np.abs(sp.coo_matrix((v, (r, c)), shape=(N, N)).toarray() - ref).max() < 1e-12
     r, c, v = norm_adj_coo(torch.from_numpy(edge), U, I)
     assert np.abs(sp.coo_matrix((v.numpy().astype(np.float64), (r.numpy(), c.numpy())), shape=(N, N)).toarray() - ref).max() < 1e-6
+
+
+def test_g7c_plain_adj_matches_reference_builder():
+    """adj_type 'plain_adj' (data/loadGowalla.py:184-205) as the reference's own buildLaplacianMat produced it, with
+    ratings as values: pins the oracle restatement and ngacf_amd.spmm.plain_adj_coo (through the plan builder's coalesce)."""
+    import scipy.sparse as sp
+    import torch
+    from ngacf_amd.spmm import plain_adj_coo
+    g = load_golden("g7c_plain_adj")
+    U, I, edge, rating = int(g["U"]), int(g["I"]), g["edge"], g["rating"]
+    N = U + I
+    assert tuple(g["shape"]) == (N, N)
+    ref = sp.coo_matrix((g["val"], (g["row"], g["col"])), shape=(N, N)).toarray()
+    r, c, v = O.plain_adj(edge, U, I, rating)
+    assert np.abs(sp.coo_matrix((v, (r, c)), shape=(N, N)).toarray() - ref).max() == 0
+    r, c, v = plain_adj_coo(torch.from_numpy(edge), U, I, torch.from_numpy(rating))
+    assert np.abs(sp.coo_matrix((v.numpy().astype(np.float64), (r.numpy(), c.numpy())), shape=(N, N)).toarray() - ref).max() == 0
+
+
+def _g11_factors(U, I, seed=7):
+    """The rank-64 score tables of oracle/gen_golden.py:g11_factors (data: seeded draws), S = A @ B^T."""
+    rs = np.random.RandomState(seed)
+    cont = (rs.randn(U, 64).astype(np.float32).astype(np.float64), rs.randn(I, 64).astype(np.float32).astype(np.float64))
+    ties = (rs.randint(-2, 3, (U, 64)).astype(np.float64), rs.randint(-2, 3, (I, 64)).astype(np.float64))
+    return {"cont": cont, "ties": ties}
+
+
+def g11_split():
+    """(u, i of ml100k in file order, train rows, test rows, fixture) of the reference's seeded train_test_split."""
+    from ngacf_amd import data as D
+    g = load_golden("g11_eval_neg_all")
+    u, i, _ = D.load_ml100k()
+    return u, i, g["train_rows"].astype(np.int64), g["test_rows"].astype(np.int64), g
+
+
+@pytest.mark.parametrize("tag", ["cont", "ties"])
+def test_g11_eval_all_items_matches_the_references_eval_neg_all(tag):
+    """A8 pin (ii): oracle.eval_all_items against the reference's own eval_neg_all (train_eval_Gowalla.py:274-354) on a
+    fixed score table and the reference's seeded ml100k split -- per-K precision / recall / ndcg / hit_ratio, with the
+    normaliser len(train_pos_neg) and (table 'ties') the tie order of heapq.nlargest over the reference's sets."""
+    u, i, tr, te, g = g11_split()
+    U, I = int(g["U"]), int(g["I"])
+    A, B = _g11_factors(U, I)[tag]
+    S = (A @ B.T).astype(np.float32)
+    train_pos, test_pos = {}, {}
+    for a, b in zip(u[tr], i[tr]):
+        train_pos.setdefault(int(a), set()).add(int(b))
+    for a, b in zip(u[te], i[te]):
+        test_pos.setdefault(int(a), set()).add(int(b))
+    assert len(train_pos) == int(g["n_train_users"]) and len(test_pos) == int(g["n_test_users"])
+    users = [int(x) for x in g["test_users_order"] if int(x) in train_pos]       # the merge at :307
+    pool = set(int(x) for x in np.unique(i))
+    got = O.eval_all_items(S[users], users, train_pos, test_pos, pool, float(len(train_pos)))
+    for k in ("precision", "recall", "ndcg", "hit_ratio"):
+        assert np.allclose(got[k], g["%s.%s" % (tag, k)], rtol=0, atol=1e-12), (k, got[k], g["%s.%s" % (tag, k)])
+    assert float(g[tag + ".auc"]) == 0.0
