@@ -290,9 +290,19 @@ def _rows_f64(X, W, avec, plan, rows, heads, U, alpha=0.2, max_edges=1 << 24):
         Ss = (Hs * as_).view(-1, heads, hw).sum(2)
         s = Sd[owner] + Ss
         e = torch.exp(-torch.where(s > 0, s, alpha * s))
-        R = torch.zeros(i1 - i0, heads, dtype=torch.float64, device=dev).index_add_(0, owner, e)
-        num = torch.zeros(i1 - i0, d, dtype=torch.float64, device=dev).index_add_(
-            0, owner, (e[:, :, None] * Hs.view(-1, heads, hw)).reshape(-1, d))
+        # per-row sums over CONTIGUOUS edge segments: prefix sums + differences (an index_add_ would funnel the millions of
+        # float64 atomic adds of a hub row into 64 addresses -- minutes at 4.7 M edges).  |terms| = O(1), <= 1.6e7 of them:
+        # the prefix sums carry ~1e-9 absolute error, five orders below the bound being checked.
+        def seg_sum(v):
+            if v.shape[0] == 0:
+                return torch.zeros(i1 - i0, v.shape[1], dtype=v.dtype, device=dev)
+            cs = torch.cumsum(v, 0)
+            hi_ = torch.cumsum(cnt, 0)
+            top = cs[(hi_ - 1).clamp_min(0)]
+            bot = torch.where((start > 0)[:, None], cs[(start - 1).clamp_min(0)], torch.zeros_like(top))
+            return torch.where((cnt > 0)[:, None], top - bot, torch.zeros_like(top))
+        R = seg_sum(e)
+        num = seg_sum((e[:, :, None] * Hs.view(-1, heads, hw)).reshape(-1, d))
         Rw = R.repeat_interleave(hw, 1)
         pre = Hd + torch.where(Rw > 0, num / Rw.clamp_min(1e-300), torch.zeros_like(num))
         out[i0:i1] = torch.nn.functional.elu(pre)
