@@ -10,3 +10,4 @@ from .plan import GraphPlan, build_plan                        # noqa: F401
 from .SPUIGACF import (SPUIGACF, SPUIGAGPCF, SPUIMultiGACF, SPUIStackedGACF, GPLayer, SpUIGAT, SPUIMultiGAT,   # noqa: F401
                        SpUIGraphAttentionLayer, set_compute_dtype)
 from . import SPGA                                             # noqa: F401,E402  (SPGA.SpGraphAttentionLayer, SPGA.SpGAT)
+from . import modules                                          # noqa: F401,E402  (dense multi-head attention: MultiHeadAttention, ATTLayer, GACFV1, GACFMask)

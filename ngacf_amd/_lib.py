@@ -41,6 +41,8 @@ SIGNATURES = {
     "ngacf_sample_pairs": [_p, ctypes.c_longlong, ctypes.c_longlong, _p, _p, _i, _p, _p, _i, _u64, _p, _p, _p, _p, _p, _i, _p],
     "ngacf_eval_topk": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
     "ngacf_dropout_bits": [_i, _u64, _p, _p, _p, _p, _i, _p],
+    "ngacf_mha_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _i, _p],
+    "ngacf_mha_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _i, _p],
 }
 
 

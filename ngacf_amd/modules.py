@@ -1,0 +1,248 @@
+"""Drop-in surface of the reference's dense multi-head attention (graphattention/modules.py) and of the two model
+families built on it, backed by the HIP flash-style kernel ngacf_mha_fwd / ngacf_mha_bwd (csrc/mha.hip):
+
+  attention(q, k, v, d_k, mask=None, dropout=None)                      modules.py:32-46
+  MultiHeadAttention(heads, dim, dropout=0.1).forward(q, k, v, mask)    modules.py:62-107   (same parameters / keys)
+  ATTLayer(dim, heads, dropout).forward(userFeatures, itemFeatures)     modules.py:7-18
+  ATTLayer_mask(dim, heads, dropout).forward(features, mask)            modules.py:20-30
+  GALayer / GACFV1_layer / GACFV1                                       GACFmodel1.py:13-115
+  GPLayer / GACFV2_layer / GACFMask                                     GACFMask.py:22-136
+
+What differs from the reference is how the attention core runs: the [heads, Nq, Nk] score and probability tensors are
+never materialised (the reference holds both, plus autograd's copies), the q/k/v projections are read in place (no
+view/transpose/contiguous), the Laplacian products go through the static-weight traversal (ngacf_spmm_fwd), and the
+per-call Python index lists / sparse `L + I` additions of the reference (GACFmodel1.py:33-34,71-76) are gone.
+O(Nq*Nk) work remains: this path is for ml100k / ml1m sized graphs, as in the reference.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .SPUIGACF import _fresh_seed
+
+
+class _MHACore(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d_k) [masked]) -> dropout -> @ v for all heads, on [N, dim] projections."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, mask_u8, heads, drop_p, seed, bf16_operands):
+        Q, K, V = Q.contiguous().float(), K.contiguous().float(), V.contiguous().float()
+        O, LSE = ops.mha_fwd(Q, K, V, heads, mask_u8, drop_p, seed, None, bf16_operands)
+        ctx.save_for_backward(Q, K, V, O, LSE)
+        ctx.cfg = (mask_u8, heads, drop_p, seed, bf16_operands)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        Q, K, V, O, LSE = ctx.saved_tensors
+        mask_u8, heads, drop_p, seed, bf16_operands = ctx.cfg
+        dQ, dK, dV = ops.mha_bwd(Q, K, V, O, LSE, dO.contiguous().float(), heads, mask_u8, drop_p, seed, None, bf16_operands)
+        return dQ, dK, dV, None, None, None, None, None
+
+
+class _MaskCache:
+    """`mask == 0` test of modules.py:36 precomputed once per mask tensor as uint8 [Nq, Nk] (the entry holds the keyed
+    tensor, see SPUIGACF._PlanCache)."""
+
+    def __init__(self):
+        self._hit = None
+
+    def get(self, mask):
+        key = (mask.data_ptr(), tuple(mask.shape), str(mask.device), mask._version)
+        if self._hit is None or self._hit[0] != key:
+            self._hit = (key, mask, (mask != 0).to(torch.uint8).contiguous())
+        return self._hit[2]
+
+
+def attention(q, k, v, d_k, mask=None, dropout=None):
+    """modules.py:32-46 with the reference's layout: q [h, Nq, d_k], k, v [h, Nk, d_k] -> [h, Nq, d_k].
+    `dropout`: an nn.Dropout (its p and training flag are honoured; masks come from the counter hash)."""
+    h, Nq, dk = q.shape
+    assert dk == d_k
+    flat = lambda t: t.transpose(0, 1).reshape(t.shape[1], h * dk)
+    p = dropout.p if (dropout is not None and dropout.training) else 0.0
+    m8 = None if mask is None else (mask != 0).to(torch.uint8).contiguous()
+    O = _MHACore.apply(flat(q), flat(k), flat(v), m8, h, p, _fresh_seed() if p > 0 else 0, False)
+    return O.view(Nq, h, dk).transpose(0, 1)
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, heads, dim, dropout=0.1):
+        super().__init__()
+        self.att = None
+        self.dim, self.d_k, self.h = dim, dim // heads, heads
+        self.q_linear = nn.Linear(dim, dim)
+        self.v_linear = nn.Linear(dim, dim)
+        self.k_linear = nn.Linear(dim, dim)
+        self.dropout = nn.Dropout(dropout)
+        self.out = nn.Linear(dim, dim)
+        for lin in (self.q_linear, self.v_linear, self.k_linear, self.out):       # modules.py:80-91
+            nn.init.xavier_uniform_(lin.weight)
+            lin.bias.data.zero_()
+        self.bf16_operands = False          # True: matrix-core operands rounded to bf16 (fp32 softmax / accumulation)
+        self._masks = _MaskCache()
+
+    def forward(self, q, k, v, mask=None):
+        # the projections are plain library GEMMs; their [N, dim] outputs ARE the per-head layout the kernel reads
+        Q, K, V = self.q_linear(q), self.k_linear(k), self.v_linear(v)
+        p = self.dropout.p if self.training else 0.0
+        m8 = None if mask is None else self._masks.get(mask)
+        concat = _MHACore.apply(Q, K, V, m8, self.h, p, _fresh_seed() if p > 0 else 0, self.bf16_operands)
+        return self.out(concat)                                                   # :104-106
+
+
+class ATTLayer(nn.Module):
+    def __init__(self, dim, heads, dropout):
+        super().__init__()
+        self.att_user = MultiHeadAttention(heads, dim, dropout)
+        self.att_item = MultiHeadAttention(heads, dim, dropout)
+
+    def forward(self, userFeatures, itemFeatures):
+        u = self.att_item(itemFeatures, userFeatures, userFeatures)               # :14 (items query the users ...)
+        i = self.att_user(userFeatures, itemFeatures, itemFeatures)               # (... and the result is named user side)
+        return torch.cat([u, i], dim=0)
+
+
+class ATTLayer_mask(nn.Module):
+    def __init__(self, dim, heads, dropout):
+        super().__init__()
+        self.att = MultiHeadAttention(heads, dim, dropout)
+
+    def forward(self, features, mask):
+        return self.att(features, features, features, mask)
+
+
+class _Laplacian:
+    """The fixed N x N Laplacian of a model as a static-weight propagation (built on first use, per device)."""
+
+    def __init__(self, adj, N):
+        self._adj, self._N, self._prop = adj, N, None
+
+    def get(self, dev):
+        if self._prop is None or self._prop.plan.device != dev:
+            from .spmm import StaticPropagation
+            if isinstance(self._adj, (tuple, list)):
+                r, c, v = self._adj
+            else:
+                a = self._adj.coalesce()
+                r, c, v = a.indices()[0], a.indices()[1], a.values()
+            self._prop = StaticPropagation(r.to(dev), c.to(dev), v.to(dev).float(), self._N)
+        return self._prop
+
+
+def _check_width(d):
+    if d not in (64, 128):
+        raise ValueError("layer widths must be 64 or 128 on the accelerated path (got %d)" % d)
+
+
+class GALayer(nn.Module):
+    """GACFmodel1.py:13-40."""
+
+    def __init__(self, input_dim, out_dim, heads, dropout):
+        super().__init__()
+        _check_width(input_dim)
+        self.att = ATTLayer(input_dim, heads, dropout)
+        self.affine1 = nn.Linear(input_dim, out_dim)
+        self.affine2 = nn.Linear(input_dim, out_dim)
+        for lin in (self.affine1, self.affine2):
+            nn.init.xavier_uniform_(lin.weight)
+            lin.bias.data.zero_()
+
+    def forward(self, userFeatures, itemFeatures, propagation):
+        features = self.att(userFeatures, itemFeatures)
+        f1 = torch.relu(self.affine1(propagation(features, self_loop=True)))                    # (L + I) @ features
+        f2 = torch.relu(self.affine2(propagation(features * features, self_loop=False)))        # L @ (features ⊙ features)
+        return f1 + f2
+
+
+class GACFV1_layer(nn.Module):
+    def __init__(self, userNum, itemNum, adj, embedSize=256, layers=(256, 128, 64), droprate=0.2, useCuda=True):
+        super().__init__()
+        self.useCuda, self.userNum, self.itemNum, self.droprate = useCuda, userNum, itemNum, droprate
+        self.uEmbd = nn.Embedding(userNum, embedSize)
+        self.iEmbd = nn.Embedding(itemNum, embedSize)
+        self.GALayers = nn.ModuleList(GALayer(a, b, 8, droprate) for a, b in zip(layers[:-1], layers[1:]))
+        self._lap = _Laplacian(adj, userNum + itemNum)
+        nn.init.normal_(self.uEmbd.weight, std=0.01)
+        nn.init.normal_(self.iEmbd.weight, std=0.01)
+
+    def forward(self, userIdx, itemIdx):
+        U = self.userNum
+        features = torch.cat([self.uEmbd.weight, self.iEmbd.weight], dim=0)
+        prop = self._lap.get(features.device)
+        final = [features]
+        for ga in self.GALayers:
+            features = ga(features[:U], features[U:], prop)
+            final.append(features)
+        return torch.cat(final, dim=1)
+
+
+class GACFV1(nn.Module):
+    def __init__(self, userNum, itemNum, adj, embedSize, layers, droprate, useCuda=True):
+        super().__init__()
+        self.userNum = userNum
+        self.gacf = GACFV1_layer(userNum, itemNum, adj, embedSize, layers, droprate)
+
+    def forward(self, userIdx, itemIdx):
+        e = self.gacf(userIdx, itemIdx)
+        return torch.sum(e[userIdx] * e[itemIdx + self.userNum], dim=1)
+
+
+class GPLayer(nn.Module):
+    """GACFMask.py:22-32: features -> (L + I) @ features."""
+
+    def forward(self, features, propagation, selfLoop=True):
+        return propagation(features, self_loop=bool(selfLoop))
+
+
+class GACFV2_layer(nn.Module):
+    """GACFMask.py:35-106: per layer masked self-attention over all nodes, (L + I) propagation, Linear, ReLU; all stage
+    outputs concatenated."""
+
+    def __init__(self, userNum, itemNum, adj, embedSize=256, layers=(256, 128, 64), droprate=0.2, useCuda=True):
+        super().__init__()
+        self.useCuda, self.userNum, self.itemNum, self.droprate = useCuda, userNum, itemNum, droprate
+        self.uEmbd = nn.Embedding(userNum, embedSize)
+        self.iEmbd = nn.Embedding(itemNum, embedSize)
+        self.ATTlayers, self.GPlayers, self.Affinelayers = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for a, b in zip(layers[:-1], layers[1:]):
+            _check_width(a)
+            self.ATTlayers.append(ATTLayer_mask(a, 8, droprate))
+            self.GPlayers.append(GPLayer())
+            self.Affinelayers.append(nn.Linear(a, b))
+        self._lap = _Laplacian(adj, userNum + itemNum)
+        nn.init.normal_(self.uEmbd.weight, std=0.01)
+        nn.init.normal_(self.iEmbd.weight, std=0.01)
+        for m in self.Affinelayers:
+            nn.init.xavier_uniform_(m.weight)
+            m.bias.data.zero_()
+
+    def forward(self, userIdx, itemIdx, mask):
+        features = torch.cat([self.uEmbd.weight, self.iEmbd.weight], dim=0)
+        prop = self._lap.get(features.device)
+        final = [features]
+        for att, gp, aff in zip(self.ATTlayers, self.GPlayers, self.Affinelayers):
+            features = torch.relu(aff(gp(att(features, mask), prop, True)))
+            final.append(features)
+        return torch.cat(final, dim=1)
+
+
+class GACFMask(nn.Module):
+    def __init__(self, userNum, itemNum, adj, embedSize, layers, droprate, useCuda=True):
+        super().__init__()
+        self.userNum = userNum
+        self.gacf = GACFV2_layer(userNum, itemNum, adj, embedSize, layers, droprate)
+
+    def forward(self, userIdx, itemIdx, mask):
+        e = self.gacf(userIdx, itemIdx, mask)
+        return torch.sum(e[userIdx] * e[itemIdx + self.userNum], dim=1)
+
+
+def attention_flops(Nq, Nk, dim):
+    """2 * (q k^T) + 2 * (p v) over all heads: 4 * Nq * Nk * dim flop (forward)."""
+    return 4.0 * Nq * Nk * dim
+
+
+def attention_exps(Nq, Nk, heads):
+    return float(Nq) * Nk * heads
+

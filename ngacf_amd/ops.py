@@ -56,7 +56,7 @@ def _timed(name, fn, *args):
     return rc
 
 
-def _chk(t, name, dtype, numel, dev):
+def _chk(t, name, dtype, numel, dev, align=16):
     if t is None:
         raise ValueError("%s is required" % name)
     if not t.is_cuda or t.device != dev:
@@ -67,8 +67,8 @@ def _chk(t, name, dtype, numel, dev):
         raise ValueError("%s must be contiguous" % name)
     if t.numel() != numel:
         raise ValueError("%s must have %d elements, has %d" % (name, numel, t.numel()))
-    if t.data_ptr() % 16:
-        raise ValueError("%s must be 16-byte aligned" % name)
+    if t.data_ptr() % align:
+        raise ValueError("%s must be %d-byte aligned" % (name, align))
     return t.data_ptr()
 
 
@@ -274,7 +274,7 @@ def raise_if_bad_indices(dev=None):
 
 
 def _idx(t, name, B, dev):
-    return _chk(t, name, torch.int64, B, dev)
+    return _chk(t, name, torch.int64, B, dev, align=8)       # read element-wise: a row of a packed [3, B] batch is fine
 
 
 def score_fwd(F, u, i, U):
@@ -341,6 +341,42 @@ def spmm_fwd(plan, val, X, self_loop=True):
     _lib.check(lib.ngacf_spmm_fwd(segs, nseg, split, nsplit, col, vp, xp, _DT[X.dtype], out.data_ptr(),
                                   pa.data_ptr(), N, d, int(bool(self_loop)), _stream()), "ngacf_spmm_fwd")
     return out
+
+
+def mha_fwd(Q, K, V, heads, mask=None, drop_p=0.0, seed=0, seed_dev=None, bf16_operands=False):
+    """O [Nq,dim], LSE [Nq,heads] = ngacf_mha_fwd(Q [Nq,dim], K [Nk,dim], V [Nk,dim], mask uint8 [Nq,Nk] | None)."""
+    dev, (Nq, dim), Nk = Q.device, Q.shape, K.shape[0]
+    if dim % heads or dim // heads not in (8, 16, 32):
+        raise ValueError("unsupported attention shape: dim=%d heads=%d (d_k must be 8, 16 or 32)" % (dim, heads))
+    qp = _chk(Q, "Q", torch.float32, Nq * dim, dev)
+    kp = _chk(K, "K", torch.float32, Nk * dim, dev)
+    vp = _chk(V, "V", torch.float32, Nk * dim, dev)
+    mp = _chk(mask, "mask", torch.uint8, Nq * Nk, dev) if mask is not None else 0
+    O = torch.empty(Nq, dim, dtype=torch.float32, device=dev)
+    LSE = torch.empty(Nq, heads, dtype=torch.float32, device=dev)
+    if Nq and Nk:
+        _lib.check(_timed("ngacf_mha_fwd", lib.ngacf_mha_fwd, qp, kp, vp, mp, O.data_ptr(), LSE.data_ptr(), Nq, Nk, dim, heads,
+                          float(drop_p), int(seed), _sd(seed_dev, dev), int(bool(bf16_operands)), _stream()), "ngacf_mha_fwd")
+    return O, LSE
+
+
+def mha_bwd(Q, K, V, O, LSE, dO, heads, mask=None, drop_p=0.0, seed=0, seed_dev=None, bf16_operands=False):
+    """dQ, dK, dV of ngacf_mha_fwd."""
+    dev, (Nq, dim), Nk = Q.device, Q.shape, K.shape[0]
+    qp = _chk(Q, "Q", torch.float32, Nq * dim, dev)
+    kp = _chk(K, "K", torch.float32, Nk * dim, dev)
+    vp = _chk(V, "V", torch.float32, Nk * dim, dev)
+    op = _chk(O, "O", torch.float32, Nq * dim, dev)
+    lp = _chk(LSE, "LSE", torch.float32, Nq * heads, dev)
+    gp = _chk(dO, "dO", torch.float32, Nq * dim, dev)
+    mp = _chk(mask, "mask", torch.uint8, Nq * Nk, dev) if mask is not None else 0
+    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+    delta = torch.empty(Nq, heads, dtype=torch.float32, device=dev)
+    if Nq and Nk:
+        _lib.check(lib.ngacf_mha_bwd(qp, kp, vp, mp, op, lp, gp, dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), delta.data_ptr(),
+                                     Nq, Nk, dim, heads, float(drop_p), int(seed), _sd(seed_dev, dev), int(bool(bf16_operands)),
+                                     _stream()), "ngacf_mha_bwd")
+    return dQ, dK, dV
 
 
 def dropout_bits(kind, seed, a, b, c=None):

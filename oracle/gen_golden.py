@@ -341,6 +341,93 @@ def g13_ref_checkpoint(edge, U, I):
          param_names=np.array(names), losses=np.array(losses), **out)
 
 
+def g14_dense_mha(edge, U, I):
+    """N4: the dense multi-head attention of graphattention/modules.py -- MultiHeadAttention (:62-107) with
+    and without mask (sizes that are not multiples of 32; one fully masked query row -> uniform attention), outputs and
+    float64 gradients of every input and weight; ATTLayer (:7-18); and the two models built on it: GACFV1
+    (GACFmodel1.py) and GACFMask (GACFMask.py) forward scores on the toy graph with the reference's mean_adj Laplacian."""
+    import pandas as pd
+    import graphattention.modules as RMod
+    import graphattention.GACFmodel1 as G1
+    import graphattention.GACFMask as GM
+    from data.loadGowalla import buildLaplacianMat, scipySP_torchSP
+    rs = np.random.RandomState(31)
+    Nq, Nk, dim, heads = 45, 70, 64, 8
+    out = {}
+    q_in, k_in = (rs.randn(Nq, dim) * 0.7).astype(np.float32).astype(np.float64), (rs.randn(Nk, dim) * 0.7).astype(np.float32).astype(np.float64)
+    mask = (rs.rand(Nq, Nk) < 0.3).astype(np.float32)
+    mask[3] = 0.0                                           # a fully masked row: softmax over -1e9 everywhere = uniform
+    mask[np.arange(Nq), rs.randint(0, Nk, Nq)] = np.where(np.arange(Nq) == 3, 0.0, 1.0)
+    G = rs.randn(Nq, dim).astype(np.float32).astype(np.float64)
+    torch.manual_seed(37)
+    mha32 = RMod.MultiHeadAttention(heads, dim, dropout=0.0)
+    with torch.no_grad():
+        for lin in (mha32.q_linear, mha32.k_linear, mha32.v_linear, mha32.out):
+            lin.bias.normal_(std=0.1)                       # the reference zeroes them at init; trained values are not zero
+    for k_, v in mha32.state_dict().items():
+        out["mha.p." + k_] = v.numpy().copy()
+    for tag, mk in (("nomask", None), ("mask", mask)):
+        for dt_name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            m = RMod.MultiHeadAttention(heads, dim, dropout=0.0).to(dt)
+            m.load_state_dict({k_: v.to(dt) for k_, v in mha32.state_dict().items()})
+            q = torch.tensor(q_in, dtype=dt, requires_grad=True)
+            kv = torch.tensor(k_in, dtype=dt, requires_grad=True)
+            o = m(q, kv, kv, None if mk is None else torch.tensor(mk, dtype=dt))
+            out["mha.%s.out_%s" % (tag, dt_name)] = o.detach().numpy()
+            if dt_name == "f64":
+                (o * torch.tensor(G)).sum().backward()
+                out["mha.%s.g.q_in" % tag] = q.grad.numpy().astype(np.float32)      # (float64 values, stored as float32)
+                out["mha.%s.g.kv_in" % tag] = kv.grad.numpy().astype(np.float32)
+                for k_, p_ in m.named_parameters():
+                    out["mha.%s.g.%s" % (tag, k_)] = p_.grad.numpy().astype(np.float32)
+    # ATTLayer: users attend to items and items to users (:14)
+    torch.manual_seed(41)
+    att = RMod.ATTLayer(dim, heads, 0.0)
+    for k_, v in att.state_dict().items():
+        out["att.p." + k_] = v.numpy().copy()
+    out["att.out"] = att(torch.tensor(q_in, dtype=torch.float32), torch.tensor(k_in, dtype=torch.float32)).detach().numpy()
+    # the two model families on the toy graph
+    e37 = edge[:, edge[1] < 37]
+    I37 = 37
+    rt = pd.DataFrame({"userId": e37[0], "itemId": e37[1], "rating": np.ones(e37.shape[1])})
+    L = scipySP_torchSP(buildLaplacianMat(rt, U, I37, "mean_adj")).coalesce()
+    N = U + I37
+    dense_adj = torch.zeros(N, N)
+    dense_adj[torch.from_numpy(e37[0]), torch.from_numpy(e37[1]) + U] = 1.0
+    dense_adj = dense_adj + dense_adj.t() + torch.eye(N)     # a node attends to its neighbours and itself
+    B = 40
+    u = rs.randint(0, U, B).astype(np.int64)
+    it = rs.randint(0, I37, B).astype(np.int64)
+    real_cuda = (torch.Tensor.cuda, torch.nn.Module.cuda)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    try:
+        with CpuDevice():
+            torch.manual_seed(43)
+            m1 = G1.GACFV1(U, I37, L, 64, [64, 64], 0.0, useCuda=False)
+            m1.gacf.useCuda = False
+            with torch.no_grad():
+                m1.gacf.uEmbd.weight.mul_(30.0); m1.gacf.iEmbd.weight.mul_(30.0)
+            m1.eval()
+            s1 = m1(torch.from_numpy(u), torch.from_numpy(it))
+            torch.manual_seed(47)
+            m2 = GM.GACFMask(U, I37, L, 64, [64, 64], 0.0, useCuda=False)
+            m2.gacf.useCuda = False
+            with torch.no_grad():
+                m2.gacf.uEmbd.weight.mul_(30.0); m2.gacf.iEmbd.weight.mul_(30.0)
+            m2.eval()
+            s2 = m2(torch.from_numpy(u), torch.from_numpy(it), dense_adj)
+    finally:
+        torch.Tensor.cuda, torch.nn.Module.cuda = real_cuda
+    for k_, v in m1.state_dict().items():
+        out["v1.p." + k_] = v.numpy().copy()
+    for k_, v in m2.state_dict().items():
+        out["mk.p." + k_] = v.numpy().copy()
+    save("g14_dense_mha", q_in=q_in.astype(np.float32), k_in=k_in.astype(np.float32), mask=mask.astype(np.uint8), G=G.astype(np.float32), heads=heads, edge=e37, U=U, I=I37,
+         L_row=L.indices()[0].numpy(), L_col=L.indices()[1].numpy(), L_val=L.values().numpy(),
+         dense_adj=dense_adj.numpy().astype(np.uint8), u=u, item=it, v1_scores=s1.detach().numpy(), mk_scores=s2.detach().numpy(), **out)
+
+
 def g11_factors(U, I, seed=7):
     rs = np.random.RandomState(seed)
     cont = (rs.randn(U, 64).astype(np.float32).astype(np.float64), rs.randn(I, 64).astype(np.float32).astype(np.float64))
@@ -408,6 +495,8 @@ def main():
         return g7c_plain_adj(edge[:, edge[1] < 37], U, 37)
     if "--only-g13" in sys.argv:
         return g13_ref_checkpoint(edge, U, I)
+    if "--only-g14" in sys.argv:
+        return g14_dense_mha(edge, U, I)
     if "--only-g7b" in sys.argv:                      # added after the first batch: leaves the other fixtures untouched
         return g7b_norm_adj(edge[:, edge[1] < 37], U, 37)
     g1_layers(edge, U, I)
@@ -422,6 +511,7 @@ def main():
     g9_g10_ml100k()
     g11_eval_neg_all()
     g13_ref_checkpoint(edge, U, I)
+    g14_dense_mha(edge, U, I)
 
 
 if __name__ == "__main__":

@@ -293,6 +293,72 @@ def norm_adj(edge, U, I):
 
 
 # --------------------------------------------------------------------------
+# dense multi-head attention (graphattention/modules.py:32-107)
+# --------------------------------------------------------------------------
+def multi_head_attention(p, q, k, v, heads, mask=None, prob_mask=None, prefix=""):
+    """MultiHeadAttention.forward (modules.py:92-107) with `attention` (:32-46).  p: reference-keyed parameters
+    ({prefix}q_linear.weight [dim,dim] ... out.bias); mask [Nq,Nk] (0 = masked -> score -1e9); prob_mask [heads,Nq,Nk]:
+    dropout multipliers applied to the softmax probabilities (:41-42)."""
+    lin = lambda x, n: x @ p[prefix + n + ".weight"].T + p[prefix + n + ".bias"]
+    dim = q.shape[1]
+    dk = dim // heads
+    split = lambda x: x.reshape(-1, heads, dk).transpose(1, 0, 2)                    # :96-98  [h, N, d_k]
+    Q, K, V = split(lin(q, "q_linear")), split(lin(k, "k_linear")), split(lin(v, "v_linear"))
+    scores = Q @ K.transpose(0, 2, 1) / np.sqrt(dk)                                  # :33
+    if mask is not None:
+        scores = np.where(np.asarray(mask)[None] == 0, -1e9, scores)                 # :36
+    scores = scores - scores.max(-1, keepdims=True)
+    P = np.exp(scores)
+    P = P / P.sum(-1, keepdims=True)                                                 # :41
+    if prob_mask is not None:
+        P = P * prob_mask
+    concat = (P @ V).transpose(1, 0, 2).reshape(-1, dim)                             # :104
+    return lin(concat, "out")
+
+
+def att_layer(p, users, items, heads, prefix=""):
+    """ATTLayer.forward (modules.py:13-18)."""
+    u = multi_head_attention(p, items, users, users, heads, prefix=prefix + "att_item.")
+    i = multi_head_attention(p, users, items, items, heads, prefix=prefix + "att_user.")
+    return np.concatenate([u, i], 0)
+
+
+def gacfv1_scores(p, L, u, it, U, I, heads=8):
+    """GACFV1.forward (GACFmodel1.py:87-115, GALayer :29-40); L: scipy sparse N x N Laplacian."""
+    F = np.concatenate([p["gacf.uEmbd.weight"], p["gacf.iEmbd.weight"]])
+    N = U + I
+    L1 = L + sp.eye(N, format="csr")
+    final = [F]
+    s = 0
+    while "gacf.GALayers.%d.affine1.weight" % s in p:
+        pre = "gacf.GALayers.%d." % s
+        A = att_layer(p, F[:U], F[U:], heads, pre + "att.")
+        f1 = np.maximum(L1 @ A @ p[pre + "affine1.weight"].T + p[pre + "affine1.bias"], 0)
+        f2 = np.maximum(L @ (A * A) @ p[pre + "affine2.weight"].T + p[pre + "affine2.bias"], 0)
+        F = f1 + f2
+        final.append(F)
+        s += 1
+    E = np.concatenate(final, 1)
+    return np.sum(E[u] * E[it + U], 1)
+
+
+def gacfmask_scores(p, L, mask, u, it, U, I, heads=8):
+    """GACFMask.forward (GACFMask.py:89-136)."""
+    F = np.concatenate([p["gacf.uEmbd.weight"], p["gacf.iEmbd.weight"]])
+    N = U + I
+    L1 = L + sp.eye(N, format="csr")
+    final = [F]
+    s = 0
+    while "gacf.Affinelayers.%d.weight" % s in p:
+        A = multi_head_attention(p, F, F, F, heads, mask, prefix="gacf.ATTlayers.%d.att." % s)
+        F = np.maximum(L1 @ A @ p["gacf.Affinelayers.%d.weight" % s].T + p["gacf.Affinelayers.%d.bias" % s], 0)
+        final.append(F)
+        s += 1
+    E = np.concatenate(final, 1)
+    return np.sum(E[u] * E[it + U], 1)
+
+
+# --------------------------------------------------------------------------
 # metrics (graphattention/metrics.py) and eval ranking (train_eval_Gowalla.py)
 # --------------------------------------------------------------------------
 def precision_at_k(r, k):                                 # metrics.py:10-21

@@ -83,26 +83,46 @@ def test_eval_neg_all_matches_the_references_own_eval_on_a_fixed_score_table(tag
 
 
 def test_ml100k_two_epochs_reach_reference_metrics():
+    """The README smoke run (README.md:13-15: ml100k, lr 0.002, wd 1e-6, droprate 0.2, 2 epochs) on the REFERENCE'S split
+    (g11: train_test_split under seed 2019), five sampler seeds, against the reference's own runs of the same command on
+    the same split (tests/golden/g12: oracle/ref_train_probe.py, three seeds of the `random` module the reference never
+    seeds).  The reference's run-to-run spread is large (Recall@20 0.234 .. 0.272), so the statement is distributional:
+    every run here inside the reference's range widened by half its width, the mean inside the range widened by a quarter."""
     import ngacf_amd
+    from conftest import load_golden
+    from test_oracle_golden import g11_split
     from ngacf_amd.train_eval import Interactions, eval_neg_all, train_bpr
     dev = torch.device("cuda:0")
-    u, i, tr, te = _split()
+    u, i, tr, te, _ = g11_split()
+    ref = load_golden("g12_ref_ml100k_train")
+    nref = len(ref["random_seeds"])
     U, I = 943, 1682
     data = Interactions(u[tr], i[tr], u[te], i[te], U, I, dev)
     adj = data.adjacency()
-    torch.manual_seed(2019)
-    model = ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.2).to(dev)
-    optim = torch.optim.Adam(model.parameters(), lr=0.002, weight_decay=1e-6)      # README.md:15
-    gen = torch.Generator(device=dev); gen.manual_seed(2019)
-    losses = [train_bpr(model, 2048, data, adj, optim, ngacf_amd.BPRLoss(), gen) for _ in range(2)]
-    m = eval_neg_all(model, 2048, data, adj)
-    print("ml100k 2 epochs: loss", losses, {k: np.round(v, 4).tolist() for k, v in m.items() if k != "auc"})
-    assert losses[1] < losses[0] < 0.7 / 2048 * 1.05               # per-row normalisation of the reference (:144)
-    # reference (survey probe, seed 2019, `random` unseeded): Recall@20 0.245, Precision@20 0.208, HR@20 0.906,
-    # NDCG@20 0.558 (inflated definition).  Sampling differs (device RNG), so a band, not equality.
-    assert 0.18 < m["recall"][3] < 0.32, m["recall"]
-    assert 0.15 < m["precision"][3] < 0.27, m["precision"]
-    assert 0.80 < m["hit_ratio"][3] <= 1.0 and 0.45 < m["ndcg"][3] < 0.70
+    runs = []
+    for seed in range(5):
+        torch.manual_seed(2019)                                        # the model init of run_Gowalla.py:191
+        model = ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.2).to(dev)
+        optim = torch.optim.Adam(model.parameters(), lr=0.002, weight_decay=1e-6)      # README.md:15
+        gen = torch.Generator(device=dev); gen.manual_seed(1000 + seed)               # the sampler: the free variable
+        torch.manual_seed(77 + seed)                                   # dropout seeds
+        losses = [train_bpr(model, 2048, data, adj, optim, ngacf_amd.BPRLoss(), gen) for _ in range(2)]
+        m = eval_neg_all(model, 2048, data, adj)
+        runs.append((losses, m))
+        print("ml100k seed %d: loss %s" % (seed, np.round(losses, 7).tolist()), {k: np.round(v, 4).tolist() for k, v in m.items() if k != "auc"})
+    ref_loss = np.array([ref["loss.%d" % j] for j in range(nref)])
+    print("reference losses", ref_loss.tolist())
+    for key in ("recall", "precision", "ndcg", "hit_ratio"):
+        r = np.array([ref["%s.%d" % (key, j)][3] for j in range(nref)])                # @20
+        ours = np.array([m[key][3] for _, m in runs])
+        w = r.max() - r.min()
+        print("%s@20: reference %s  here %s" % (key, np.round(r, 4).tolist(), np.round(ours, 4).tolist()))
+        assert (ours > r.min() - 0.5 * w).all() and (ours < r.max() + 0.5 * w).all(), (key, ours, r)
+        assert r.min() - 0.25 * w < ours.mean() < r.max() + 0.25 * w, (key, ours.mean(), r)
+    # the per-row loss normalisation of the reference (:144) and its level: epoch losses within 15 % of the reference's
+    ours_loss = np.array([l for l, _ in runs])
+    assert (ours_loss[:, 1] < ours_loss[:, 0]).all()
+    assert np.all(np.abs(ours_loss.mean(0) / ref_loss.mean(0) - 1.0) < 0.15), (ours_loss.mean(0), ref_loss.mean(0))
 
 
 def test_graphed_step_equals_eager_and_redraws_dropout():

@@ -174,6 +174,30 @@ def test_g7c_plain_adj_matches_reference_builder():
     assert np.abs(sp.coo_matrix((v.numpy().astype(np.float64), (r.numpy(), c.numpy())), shape=(N, N)).toarray() - ref).max() == 0
 
 
+def test_g14_dense_multi_head_attention_and_the_models_on_it():
+    """N4: the numpy restatement of graphattention/modules.py (MultiHeadAttention with / without mask incl. a fully
+    masked row, ATTLayer) and of GACFV1 / GACFMask against the reference's own outputs."""
+    import scipy.sparse as sp
+    g = load_golden("g14_dense_mha")
+    q, kv, heads = g["q_in"].astype(np.float64), g["k_in"].astype(np.float64), int(g["heads"])
+    p = {k[len("mha.p."):]: v.astype(np.float64) for k, v in g.items() if k.startswith("mha.p.")}
+    for tag, mask in (("nomask", None), ("mask", g["mask"])):
+        out = O.multi_head_attention(p, q, kv, kv, heads, mask)
+        assert np.abs(out - g["mha.%s.out_f64" % tag]).max() < 1e-10
+        assert np.abs(out - g["mha.%s.out_f32" % tag]).max() < 1e-4
+    pa = {k[len("att.p."):]: v.astype(np.float64) for k, v in g.items() if k.startswith("att.p.")}
+    assert np.abs(O.att_layer(pa, q, kv, heads) - g["att.out"]).max() < 1e-5
+    U, I = int(g["U"]), int(g["I"])
+    N = U + I
+    L = sp.coo_matrix((g["L_val"].astype(np.float64), (g["L_row"], g["L_col"])), shape=(N, N)).tocsr()
+    p1 = {k[len("v1.p."):]: v.astype(np.float64) for k, v in g.items() if k.startswith("v1.p.")}
+    s1 = O.gacfv1_scores(p1, L, g["u"], g["item"], U, I)
+    assert np.abs(s1 - g["v1_scores"]).max() < 1e-4 * max(np.abs(g["v1_scores"]).max(), 1.0)
+    p2 = {k[len("mk.p."):]: v.astype(np.float64) for k, v in g.items() if k.startswith("mk.p.")}
+    s2 = O.gacfmask_scores(p2, L, g["dense_adj"], g["u"], g["item"], U, I)
+    assert np.abs(s2 - g["mk_scores"]).max() < 1e-4 * max(np.abs(g["mk_scores"]).max(), 1.0)
+
+
 def _g11_factors(U, I, seed=7):
     """The rank-64 score tables of oracle/gen_golden.py:g11_factors (data: seeded draws), S = A @ B^T."""
     rs = np.random.RandomState(seed)
