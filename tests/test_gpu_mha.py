@@ -52,7 +52,14 @@ def test_g14_multi_head_attention_forward_and_gradients(dev, tag, bf16):
     (out * _t(g["G"], dev)).sum().backward()
     errs = {"q_in": _rel(q.grad, g["mha.%s.g.q_in" % tag]), "kv_in": _rel(kv.grad, g["mha.%s.g.kv_in" % tag])}
     for k, p in m.named_parameters():
-        errs[k] = _rel(p.grad, g["mha.%s.g.%s" % (tag, k)])
+        if k == "k_linear.bias":
+            # softmax is invariant to a constant added to every key: this gradient is analytically 0 (the reference's
+            # float64 run leaves ~1e-17); compare it on the scale of its neighbour, the k weight gradient
+            scale = float(np.abs(g["mha.%s.g.k_linear.weight" % tag]).max())
+            errs[k] = float(p.grad.abs().max()) / scale
+            assert np.abs(g["mha.%s.g.%s" % (tag, k)]).max() < 1e-12 * scale
+        else:
+            errs[k] = _rel(p.grad, g["mha.%s.g.%s" % (tag, k)])
     assert max(errs.values()) < (4e-2 if bf16 else 2e-5), errs
     if tag == "mask":                                     # the fully masked row: uniform attention over all keys
         V = torch.nn.functional.linear(kv.detach(), m.v_linear.weight, m.v_linear.bias)
