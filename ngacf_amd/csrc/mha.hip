@@ -28,9 +28,10 @@ struct MhaArgs {
     const float* Q;        // [Nq][dim]
     const float* K;        // [Nk][dim]
     const float* V;        // [Nk][dim]
-    const uint8_t* mask;   // [Nq][Nk], 0 = masked (score -1e9); NULL = no mask
+    const uint32_t* mask;  // [Nq][ceil(Nk/32)] bit (k & 31) of word k / 32: 0 = masked (score -1e9); NULL = no mask
     float* O;              // [Nq][dim]
-    float* LSE;            // [Nq][heads]  log-sum-exp of the (scaled, masked) scores
+    float* LSE;            // [Nq][heads][2]  running max m and sum l = sum_k exp(s - m) of the (scaled, masked) scores, kept apart:
+                           // a fully masked row has m = -1e9, where m + log(l) would lose log(l) to fp32 rounding
     const float* dO;       // backward
     float* dQ;
     float* dK;
@@ -164,24 +165,15 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs a) {
         const int kr = min(k0 + col, a.Nk - 1);
         mha_f32x16 s = tile_xyT<BF, DK>(a.K + (size_t)kr * a.dim + h * DK, qrow, kh);
         float tmax = -INFINITY;
+        const uint32_t mw = a.mask ? a.mask[(size_t)qc * ((a.Nk + 31) >> 5) + (k0 >> 5)] : 0xffffffffu;   // this query, these 32 keys
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int kb = k0 + 8 * g + 4 * kh;                     // 4 consecutive keys of this lane
-            uint32_t mk = 0x01010101u;
-            if (a.mask) {
-                const uint8_t* mp = a.mask + (size_t)qc * a.Nk + kb;
-                mk = 0u;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mk |= (kb + j < a.Nk ? (uint32_t)(mp[j] != 0) : 0u) << (8 * j);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = s[4 * g + j] * a.scale;
-                v = ((mk >> (8 * j)) & 1u) ? v : MHA_MASKED;        // masked_fill(mask == 0, -1e9)
-                v = kb + j < a.Nk ? v : -INFINITY;                  // key tail
-                s[4 * g + j] = v;
-                tmax = fmaxf(tmax, v);
-            }
+        for (int e = 0; e < 16; ++e) {
+            const int r = acc_row(e, kh);
+            float v = s[e] * a.scale;
+            v = ((mw >> r) & 1u) ? v : MHA_MASKED;                  // masked_fill(mask == 0, -1e9)
+            v = k0 + r < a.Nk ? v : -INFINITY;                      // key tail
+            s[e] = v;
+            tmax = fmaxf(tmax, v);
         }
         tmax = fmaxf(tmax, half_swap(tmax));
         const float mnew = fmaxf(m, tmax);
@@ -203,7 +195,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs a) {
     if (!qv) return;
     // o: rows = feature c, columns = queries.  This lane (query q, half kh) holds the features 8g + 4kh + (0..3)
     store_accT<DK>(a.O + (size_t)q * a.dim + h * DK, o, kh, 1.f / l);
-    if (kh == 0) a.LSE[(size_t)q * a.heads + h] = m + __logf(l);
+    if (kh == 0) *reinterpret_cast<float2*>(a.LSE + 2 * ((size_t)q * a.heads + h)) = make_float2(m, 1.f / l);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -228,7 +220,7 @@ __global__ __launch_bounds__(256) void mha_bwd_q_kernel(const MhaArgs a) {
     float delta = 0.f;
 #pragma unroll
     for (int j = 0; j < DK; ++j) delta = fmaf(dorow[j], orow[j], delta);
-    const float lse = a.LSE[(size_t)qc * a.heads + h];
+    const float2 ml = *reinterpret_cast<const float2*>(a.LSE + 2 * ((size_t)qc * a.heads + h));   // (max, 1 / sum)
     mha_f32x16 dq;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[e] = 0.f;
@@ -236,20 +228,17 @@ __global__ __launch_bounds__(256) void mha_bwd_q_kernel(const MhaArgs a) {
         const int kr = min(k0 + col, a.Nk - 1);
         mha_f32x16 s = tile_xyT<BF, DK>(a.K + (size_t)kr * a.dim + h * DK, qrow, kh);
         const mha_f32x16 dp = tile_xyT<BF, DK>(a.V + (size_t)kr * a.dim + h * DK, dorow, kh);
+        const uint32_t mw = a.mask ? a.mask[(size_t)qc * ((a.Nk + 31) >> 5) + (k0 >> 5)] : 0xffffffffu;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int kb = k0 + 8 * g + 4 * kh;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int e = 4 * g + j, key = kb + j;
-                const bool inr = key < a.Nk;
-                const bool open = !a.mask || (inr && a.mask[(size_t)qc * a.Nk + key] != 0);
-                const float sv = open ? s[e] * a.scale : MHA_MASKED;
-                const float p = inr ? __expf(sv - lse) : 0.f;
-                float dpe = dp[e];
-                if (DROP) dpe *= drop_mul(a, salt_h, qc, key);
-                s[e] = (open && inr) ? p * (dpe - delta) * a.scale : 0.f;
-            }
+        for (int e = 0; e < 16; ++e) {
+            const int r = acc_row(e, kh), key = k0 + r;
+            const bool inr = key < a.Nk;
+            const bool open = (mw >> r) & 1u;
+            const float sv = open ? s[e] * a.scale : MHA_MASKED;
+            const float p = inr ? __expf(sv - ml.x) * ml.y : 0.f;
+            float dpe = dp[e];
+            if (DROP) dpe *= drop_mul(a, salt_h, qc, key);
+            s[e] = (open && inr) ? p * (dpe - delta) * a.scale : 0.f;
         }
         accum_zT_t<BF, DK>(dq, a.K + (size_t)k0 * a.dim + h * DK, a.dim, a.Nk - k0, s, lane);
     }
@@ -288,9 +277,10 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const MhaArgs a) {
             const int q = q0 + acc_row(e, kh);
             const bool inr = q < a.Nq && kv;
             const int qq = q < a.Nq ? q : a.Nq - 1;
-            const bool open = !a.mask || (inr && a.mask[(size_t)qq * a.Nk + kc] != 0);
+            const bool open = !a.mask || ((a.mask[(size_t)qq * ((a.Nk + 31) >> 5) + (kc >> 5)] >> (kc & 31)) & 1u);
             const float sv = open ? s[e] * a.scale : MHA_MASKED;
-            const float p = inr ? __expf(sv - a.LSE[(size_t)qq * a.heads + h]) : 0.f;
+            const float2 ml = *reinterpret_cast<const float2*>(a.LSE + 2 * ((size_t)qq * a.heads + h));
+            const float p = inr ? __expf(sv - ml.x) * ml.y : 0.f;
             const float mul = DROP ? drop_mul(a, salt_h, qq, kc) : 1.f;
             pd[e] = p * mul;
             s[e] = (open && inr) ? p * (dp[e] * mul - a.delta[(size_t)qq * a.heads + h]) * a.scale : 0.f;
@@ -344,7 +334,7 @@ static int mha_dispatch(MhaArgs& a, bool backward, float drop_p, int bf16_operan
     return NGACF_E_SHAPE;
 }
 
-extern "C" int ngacf_mha_fwd(const float* Q, const float* K, const float* V, const uint8_t* mask, float* O, float* LSE,
+extern "C" int ngacf_mha_fwd(const float* Q, const float* K, const float* V, const uint32_t* mask, float* O, float* LSE,
                              int Nq, int Nk, int dim, int heads, float drop_p, uint64_t seed, const uint64_t* seed_dev,
                              int bf16_operands, void* stream) {
     if (!Q || !K || !V || !O || !LSE) return NGACF_E_ARG;
@@ -354,7 +344,7 @@ extern "C" int ngacf_mha_fwd(const float* Q, const float* K, const float* V, con
     return mha_dispatch(a, false, drop_p, bf16_operands, stream);
 }
 
-extern "C" int ngacf_mha_bwd(const float* Q, const float* K, const float* V, const uint8_t* mask, const float* O,
+extern "C" int ngacf_mha_bwd(const float* Q, const float* K, const float* V, const uint32_t* mask, const float* O,
                              const float* LSE, const float* dO, float* dQ, float* dK, float* dV, float* delta,
                              int Nq, int Nk, int dim, int heads, float drop_p, uint64_t seed, const uint64_t* seed_dev,
                              int bf16_operands, void* stream) {

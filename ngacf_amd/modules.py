@@ -41,8 +41,8 @@ class _MHACore(torch.autograd.Function):
 
 
 class _MaskCache:
-    """`mask == 0` test of modules.py:36 precomputed once per mask tensor as uint8 [Nq, Nk] (the entry holds the keyed
-    tensor, see SPUIGACF._PlanCache)."""
+    """`mask == 0` test of modules.py:36 precomputed once per mask tensor as packed bits (ops.pack_mask_bits: one 32-bit word
+    per query and key tile; the entry holds the keyed tensor, see SPUIGACF._PlanCache)."""
 
     def __init__(self):
         self._hit = None
@@ -50,7 +50,7 @@ class _MaskCache:
     def get(self, mask):
         key = (mask.data_ptr(), tuple(mask.shape), str(mask.device), mask._version)
         if self._hit is None or self._hit[0] != key:
-            self._hit = (key, mask, (mask != 0).to(torch.uint8).contiguous())
+            self._hit = (key, mask, ops.pack_mask_bits(mask))
         return self._hit[2]
 
 
@@ -61,7 +61,7 @@ def attention(q, k, v, d_k, mask=None, dropout=None):
     assert dk == d_k
     flat = lambda t: t.transpose(0, 1).reshape(t.shape[1], h * dk)
     p = dropout.p if (dropout is not None and dropout.training) else 0.0
-    m8 = None if mask is None else (mask != 0).to(torch.uint8).contiguous()
+    m8 = None if mask is None else ops.pack_mask_bits(mask)
     O = _MHACore.apply(flat(q), flat(k), flat(v), m8, h, p, _fresh_seed() if p > 0 else 0, False)
     return O.view(Nq, h, dk).transpose(0, 1)
 

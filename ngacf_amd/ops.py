@@ -343,17 +343,37 @@ def spmm_fwd(plan, val, X, self_loop=True):
     return out
 
 
+def pack_mask_bits(mask):
+    """[Nq, Nk] tensor (anything comparable with 0; modules.py:36 tests `mask == 0`) -> int32 [Nq, ceil(Nk/32)], bit (k & 31)
+    of word k // 32 set where mask[q, k] != 0: the layout ngacf_mha_fwd / _bwd read (one word per query and key tile)."""
+    Nq, Nk = mask.shape
+    W = (Nk + 31) // 32
+    m = torch.zeros(Nq, W * 32, dtype=torch.int64, device=mask.device)
+    m[:, :Nk] = (mask != 0)
+    w = (m.view(Nq, W, 32) << torch.arange(32, device=mask.device)).sum(2)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+
+
+def _mask_bits(mask, Nq, Nk, dev):
+    if mask is None:
+        return 0
+    if mask.dtype != torch.int32 or tuple(mask.shape) != (Nq, (Nk + 31) // 32):
+        mask = pack_mask_bits(mask)
+    return _chk(mask, "mask bits", torch.int32, Nq * ((Nk + 31) // 32), dev, align=4)
+
+
 def mha_fwd(Q, K, V, heads, mask=None, drop_p=0.0, seed=0, seed_dev=None, bf16_operands=False):
-    """O [Nq,dim], LSE [Nq,heads] = ngacf_mha_fwd(Q [Nq,dim], K [Nk,dim], V [Nk,dim], mask uint8 [Nq,Nk] | None)."""
+    """O [Nq,dim], LSE [Nq,heads,2] = ngacf_mha_fwd(Q [Nq,dim], K [Nk,dim], V [Nk,dim], mask).  mask: None, the packed
+    int32 words of pack_mask_bits, or any [Nq, Nk] tensor (packed here, per call: cache the packed form for repeated use)."""
     dev, (Nq, dim), Nk = Q.device, Q.shape, K.shape[0]
     if dim % heads or dim // heads not in (8, 16, 32):
         raise ValueError("unsupported attention shape: dim=%d heads=%d (d_k must be 8, 16 or 32)" % (dim, heads))
     qp = _chk(Q, "Q", torch.float32, Nq * dim, dev)
     kp = _chk(K, "K", torch.float32, Nk * dim, dev)
     vp = _chk(V, "V", torch.float32, Nk * dim, dev)
-    mp = _chk(mask, "mask", torch.uint8, Nq * Nk, dev) if mask is not None else 0
+    mp = _mask_bits(mask, Nq, Nk, dev)
     O = torch.empty(Nq, dim, dtype=torch.float32, device=dev)
-    LSE = torch.empty(Nq, heads, dtype=torch.float32, device=dev)
+    LSE = torch.empty(Nq, heads, 2, dtype=torch.float32, device=dev)
     if Nq and Nk:
         _lib.check(_timed("ngacf_mha_fwd", lib.ngacf_mha_fwd, qp, kp, vp, mp, O.data_ptr(), LSE.data_ptr(), Nq, Nk, dim, heads,
                           float(drop_p), int(seed), _sd(seed_dev, dev), int(bool(bf16_operands)), _stream()), "ngacf_mha_fwd")
@@ -367,9 +387,9 @@ def mha_bwd(Q, K, V, O, LSE, dO, heads, mask=None, drop_p=0.0, seed=0, seed_dev=
     kp = _chk(K, "K", torch.float32, Nk * dim, dev)
     vp = _chk(V, "V", torch.float32, Nk * dim, dev)
     op = _chk(O, "O", torch.float32, Nq * dim, dev)
-    lp = _chk(LSE, "LSE", torch.float32, Nq * heads, dev)
+    lp = _chk(LSE, "LSE", torch.float32, Nq * heads * 2, dev)
     gp = _chk(dO, "dO", torch.float32, Nq * dim, dev)
-    mp = _chk(mask, "mask", torch.uint8, Nq * Nk, dev) if mask is not None else 0
+    mp = _mask_bits(mask, Nq, Nk, dev)
     dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
     delta = torch.empty(Nq, heads, dtype=torch.float32, device=dev)
     if Nq and Nk:
