@@ -355,11 +355,13 @@ def pack_mask_bits(mask):
 
 
 def _mask_bits(mask, Nq, Nk, dev):
+    """(pointer, tensor to keep alive until the launch is queued): a mask packed here is a temporary -- dropping it before
+    the launch would hand its block to the next allocation (the output table) while the pointer is still in use."""
     if mask is None:
-        return 0
+        return 0, None
     if mask.dtype != torch.int32 or tuple(mask.shape) != (Nq, (Nk + 31) // 32):
         mask = pack_mask_bits(mask)
-    return _chk(mask, "mask bits", torch.int32, Nq * ((Nk + 31) // 32), dev, align=4)
+    return _chk(mask, "mask bits", torch.int32, Nq * ((Nk + 31) // 32), dev, align=4), mask
 
 
 def mha_fwd(Q, K, V, heads, mask=None, drop_p=0.0, seed=0, seed_dev=None, bf16_operands=False):
@@ -371,7 +373,7 @@ def mha_fwd(Q, K, V, heads, mask=None, drop_p=0.0, seed=0, seed_dev=None, bf16_o
     qp = _chk(Q, "Q", torch.float32, Nq * dim, dev)
     kp = _chk(K, "K", torch.float32, Nk * dim, dev)
     vp = _chk(V, "V", torch.float32, Nk * dim, dev)
-    mp = _mask_bits(mask, Nq, Nk, dev)
+    mp, _keep = _mask_bits(mask, Nq, Nk, dev)
     O = torch.empty(Nq, dim, dtype=torch.float32, device=dev)
     LSE = torch.empty(Nq, heads, 2, dtype=torch.float32, device=dev)
     if Nq and Nk:
@@ -389,7 +391,7 @@ def mha_bwd(Q, K, V, O, LSE, dO, heads, mask=None, drop_p=0.0, seed=0, seed_dev=
     op = _chk(O, "O", torch.float32, Nq * dim, dev)
     lp = _chk(LSE, "LSE", torch.float32, Nq * heads * 2, dev)
     gp = _chk(dO, "dO", torch.float32, Nq * dim, dev)
-    mp = _mask_bits(mask, Nq, Nk, dev)
+    mp, _keep = _mask_bits(mask, Nq, Nk, dev)
     dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
     delta = torch.empty(Nq, heads, dtype=torch.float32, device=dev)
     if Nq and Nk:

@@ -46,6 +46,7 @@ def main():
     ut, it = torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev) + U
     mask[ut, it] = 1; mask[it, ut] = 1
     mask[torch.arange(N), torch.arange(N)] = 1
+    mask = ops.pack_mask_bits(mask)                        # packed once, as MultiHeadAttention's cache does
     g = torch.Generator(device=dev).manual_seed(0)
     X = torch.randn(N, a.dim, device=dev, generator=g)
     G = torch.randn(N, a.dim, device=dev, generator=g)
