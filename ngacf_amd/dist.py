@@ -156,10 +156,11 @@ class Comm:
         self.overlap = True                   # False: wait right after every start (serial schedule)
         self.launches = 0                     # collective launches issued (for the tests / the bench line)
         self.timer = None                     # list -> (start event, end event, bytes received) per gather (bench, serial mode)
+        self.dry_run = False                  # tools/shard_compute.py: one rank's kernels of a P-way partition, no collectives
 
     @property
     def active(self):
-        return self.world > 1 or self.force
+        return (self.world > 1 or self.force) and not self.dry_run
 
     def _region(self, full, t):
         p = self.part
