@@ -55,6 +55,7 @@ def parse(argv=None):
     ap.add_argument("--target-seconds", type=float, default=0.6, help="length of the timed region the pass count R is sized for")
     ap.add_argument("--passes-per-step", type=int, default=0, help="R (0 = sized from --target-seconds)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: serial all-gather -> traversal schedule")
+    ap.add_argument("--no-probe", action="store_true", help="skip the 10^9-edge scaling probe of the default (gowalla) line")
     return ap.parse_args(argv)
 
 
@@ -295,6 +296,15 @@ def worker(args):
            "roofline": roofline, "cpu_baseline": cpu}
     if train:
         out.update(train)
+    if wl == "gowalla" and d == 64 and not args.no_probe:
+        # the same forward on the 10^9-edge graph (BASELINE config 5) at this GPU count: the regime where the node partition
+        # can pay; lets one `bench.py --gpus N` sweep yield a second strong-scaling curve (ngacf_amd.dist.scaling_probe)
+        try:
+            from ngacf_amd.dist import scaling_probe
+            out["scaling_probe"] = scaling_probe(args, 1, 0, dev, d)
+        except Exception as e:
+            print("[bench] scaling probe failed: %r" % (e,), file=sys.stderr, flush=True)
+            out["scaling_probe"] = {"error": repr(e)}
     emit(json.dumps(out))
 
 

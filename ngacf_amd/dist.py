@@ -554,6 +554,92 @@ def sharded_graph(shape, world, rank, dev, seed=2019, seg_len=256, chunk_users=1
 
 
 # ---------------------------------------------------------------------------------------------------------
+# the scaling probe of the default bench line: the forward on the 10^9-edge graph (BASELINE config 5)
+# ---------------------------------------------------------------------------------------------------------
+PROBE_WORKLOAD = "synthetic1b"
+
+
+def scaling_probe(args, world, rank, dev, d=64):
+    """The eval forward of the 10^9-edge synthetic graph (10 M x 5 M, mean degree 133: the configuration where a rank's
+    traversal lasts about as long as its all-gather) at THIS GPU count -- reported inside the default
+    Gowalla line so that one `bench.py --gpus N` sweep also yields a strong-scaling curve in the regime where the node
+    partition can pay.  world == 1: the plain single-GPU model (the best one-GPU implementation is the baseline);
+    world > 1: the sharded model (chunk-generated shards, pipelined all-gathers), replayed as a hipGraph when the capture
+    completes.  Returns a dict (rank-independent)."""
+    import time
+    from . import benchkit as BK, data as D
+    wl = PROBE_WORKLOAD
+    U, I, _ = D.SHAPES[wl]
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    elem = 2 if args.dtype == "bf16" else 4
+    t_setup = time.perf_counter()
+    if world == 1:
+        import ngacf_amd as ng
+        edge = D.workload_graph(wl, dev)
+        E = int(edge.shape[1])
+        model = ng.SPUIMultiGACF(U, I, d, [64, 64], 0.0).to(dev).eval()
+        ng.set_compute_dtype(model, dt)
+        fwd = lambda: model.propagate(edge)
+        sync = torch.cuda.synchronize
+        allmax = lambda x: x
+        local_edges, n_local = 2 * E, U + I
+    else:
+        part, plan, E, _ = sharded_graph(wl, world, rank, dev, seg_len=args.seg_len)
+        model = ShardedSPUIGACF(U, I, d, [64, 64], 0.0, world, rank, stages=3, partition=part).to(dev).eval()
+        model.attach_plan(plan)
+        model.compute_dtype = dt
+        model.comm.overlap = not args.no_overlap
+        edge = torch.zeros(2, 1, dtype=torch.long, device=dev)
+        fwd = lambda: model.propagate_local(edge)
+
+        def sync():
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        def allmax(x):
+            t = torch.tensor([x], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t)
+        local_edges, n_local = plan.n_edges_directed, part.n_local
+    L = 3
+    setup_s = time.perf_counter() - t_setup
+    K = max(3, min(args.steps, 10))
+    with torch.no_grad():
+        fwd()
+        sync()
+        with _hip_ops.KernelTimer("ngacf_prop_fwd") as kt:
+            for _ in range(3):
+                fwd()
+            torch.cuda.synchronize()
+        durs = kt.durations_ms()
+        t_eager, _ = BK.timed_steps(fwd, K, 1, sync, torch)
+        t_eager = allmax(t_eager)
+        best, launch = t_eager, "eager"
+        try:
+            graph = torch.cuda.CUDAGraph()
+            mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+            with torch.cuda.graph(graph, capture_error_mode=mode):
+                fwd()
+            graph.replay()
+            t_graph, _ = BK.timed_steps(graph.replay, K, 1, sync, torch)
+            t_graph = allmax(t_graph)
+            if t_graph < best:
+                best, launch = t_graph, "hipGraph replay"
+        except Exception as e:                                     # the eager number stands
+            import sys
+            print("[bench] probe capture not used: %r" % (e,), file=sys.stderr, flush=True)
+    stage_ms = sum(durs) / 3 / L
+    bytes_stage = local_edges * (4 + d * elem) + n_local * (2 * d * elem + 8)
+    achieved = -allmax(-bytes_stage / (stage_ms * 1e-3) / 1e9)
+    return {"workload": "%s bipartite graph U=%d I=%d E=%d, d=%d, L=3, eval forward" % (wl, U, I, E, d), "n_gpus": world,
+            "value": round(L * 2 * E * K / best, 1), "unit": "edges/s", "ms_per_pass": round(1e3 * best / K, 3), "passes": K,
+            "launch": launch, "ms_per_pass_eager": round(1e3 * t_eager / K, 3), "dtype": args.dtype,
+            "prop_fwd_GBps_slowest_rank": round(achieved, 1), "prop_fwd_frac_of_hbm_peak": round(achieved / BK.HBM_PEAK_GBS, 4),
+            "stage_kernel_ms": round(stage_ms, 3), "local_directed_edges": int(local_edges), "setup_s": round(setup_s, 1),
+            "schedule": "1 GPU" if world == 1 else ("pipelined half-table all-gathers" if not args.no_overlap else "serial all-gathers")}
+
+
+# ---------------------------------------------------------------------------------------------------------
 # bench.py --gpus N (N > 1): strong scaling of the named workload over a node partition
 # ---------------------------------------------------------------------------------------------------------
 def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
@@ -819,5 +905,18 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
             print("[bench] sharded hipGraph train step not used: %r" % (e,), file=sys.stderr, flush=True)
             finish(best, True, "train-step capture failed: %r" % (e,))
     dog.cancel()
+    # ---- (5) the scaling probe on the 10^9-edge graph (default workload only), same watchdog ---------------------
+    if wl == "gowalla" and not args.no_probe:
+        dog = threading.Timer(float(os.environ.get("NGACF_PROBE_TIMEOUT", "240")), finish,
+                              (best, True, "timeout: the scaling probe stalled (headline numbers complete)"))
+        dog.daemon = True
+        dog.start()
+        try:
+            probe = scaling_probe(args, world, rank, dev, d)
+            best = json.dumps(dict(json.loads(best), scaling_probe=probe))
+        except Exception as e:
+            print("[bench] scaling probe failed: %r" % (e,), file=sys.stderr, flush=True)
+            best = json.dumps(dict(json.loads(best), scaling_probe={"error": repr(e)}))
+        dog.cancel()
     finish(best, False)
     dist.destroy_process_group()

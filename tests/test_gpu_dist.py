@@ -143,4 +143,6 @@ def test_bench_distributed_path_rehearsal_on_one_rank():
     rf = d["roofline"]
     assert rf and rf["frac"] > 0 and rf["allgather"]["per_forward"] == 6 and rf["allgather"]["avg_us_serial"] > 0
     assert d["cpu_baseline"] and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    pr = d["scaling_probe"]                                              # the 10^9-edge forward through the same N>1 code path
+    assert "error" not in pr and pr["n_gpus"] == 1 and pr["value"] > 1e10 and 0.5 < pr["prop_fwd_frac_of_hbm_peak"] < 1.2, pr
     assert d["ms_per_pass_eager"] > 0 and d["bpr_pairs_per_s"] > 1e5 and d["collective_launches_per_train_step"] > 0

@@ -401,7 +401,7 @@ def test_bench_prints_one_contract_line():
     import sys
     from conftest import ROOT
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-budget", "2"],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
@@ -422,6 +422,8 @@ def test_bench_prints_one_contract_line():
     rf = d["roofline"]
     assert rf["regime"].startswith("cache-resident") and rf["applicable_roof_GBps"] == 8600.0 and rf["launches_timed"] >= 300
     assert rf["traffic"] is None or "from_profile" in rf["traffic_source"]
+    pr = d["scaling_probe"]                                              # the same forward on the 10^9-edge graph, one GPU
+    assert "error" not in pr and pr["n_gpus"] == 1 and pr["value"] > 3e10 and pr["prop_fwd_frac_of_hbm_peak"] > 0.7, pr
 
 
 @pytest.mark.gpu
