@@ -6,7 +6,8 @@
 // for h heads of width d_k = dim / h over Nq queries x Nk keys (ATTLayer: users x items and items x users; ATTLayer_mask:
 // all N nodes against all N nodes with the adjacency as mask).  The reference materialises the [h, Nq, Nk] score tensor
 // twice (scores and probabilities: 2 x 220 MB at ml100k, N = 2625) plus the autograd copies; here it never exists:
-// flash-style, one wave per (head, 32-query block), keys streamed in tiles of 32 with a running max / sum.
+// flash-style, one workgroup per (head, 32-query block), keys streamed in tiles of 32 (every 4th tile per wave) with a
+// running max / sum per wave, merged once at the end.
 //
 // Q, K, V are read straight from the [N, dim] outputs of the linear layers (head h = columns h*d_k ..): the
 // view/transpose/contiguous of :96-98 and :104 costs nothing.  Matrix cores (gfx950):
@@ -142,15 +143,37 @@ __device__ __forceinline__ float drop_mul(const MhaArgs& a, uint32_t salt_h, int
     return edge_bits(salt_h, (uint32_t)q, (uint32_t)k) >= a.drop_thr ? a.drop_scale : 0.f;
 }
 
+// Sum the 16 accumulator registers of the workgroup's four waves (each wave took every 4th tile of the streamed side):
+// waves 1..3 park theirs in LDS, wave 0 adds them in wave order (deterministic).  `scale_own`: wave 0's own factor.
+__device__ __forceinline__ void fold_waves(mha_f32x16& acc, float (*buf)[16][64], int wv, int lane, const float (&f)[4]) {
+    if (wv > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) buf[wv - 1][e][lane] = acc[e];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float v = acc[e] * f[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v = fmaf(buf[w - 1][e][lane], f[w], v);
+            acc[e] = v;
+        }
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------------
-// forward: wave per (head, 32-query block); lane = query
+// forward: workgroup per (head, 32-query block), its four waves take every 4th key tile; lane = query.
+// (One wave per block left 664 waves on 1024 SIMDs at ml100k with an exposed load -> MFMA -> exp chain of 83 tiles each.)
 // ---------------------------------------------------------------------------------------------------------
 template <bool BF, int DK, bool DROP>
 __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs a) {
-    const int lane = threadIdx.x & 63, col = lane & 31, kh = lane >> 5;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float red[3][16][64];
+    __shared__ float ml[2][4][64];
+    const int lane = threadIdx.x & 63, col = lane & 31, kh = lane >> 5, wv = threadIdx.x >> 6;
+    const int w = blockIdx.x;
     const int qblocks = (a.Nq + 31) / 32;
-    if (w >= qblocks * a.heads) return;
     const int h = w / qblocks, q0 = (w % qblocks) * 32;
     const int q = q0 + col;
     const bool qv = q < a.Nq;
@@ -161,7 +184,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.f;
     float m = -INFINITY, l = 0.f;
-    for (int k0 = 0; k0 < a.Nk; k0 += 32) {
+    for (int k0 = 32 * wv; k0 < a.Nk; k0 += 128) {
         const int kr = min(k0 + col, a.Nk - 1);
         mha_f32x16 s = tile_xyT<BF, DK>(a.K + (size_t)kr * a.dim + h * DK, qrow, kh);
         float tmax = -INFINITY;
@@ -192,10 +215,24 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs a) {
         m = mnew;
         accum_zT_t<BF, DK>(o, a.V + (size_t)k0 * a.dim + h * DK, a.dim, a.Nk - k0, s, lane);
     }
-    if (!qv) return;
+    // merge the four waves' (max, sum, O) for each query: M = max m_w, factor_w = exp(m_w - M)  (a wave without tiles has
+    // m = -inf, l = 0: factor 0)
+    ml[0][wv][lane] = m;
+    ml[1][wv][lane] = l;
+    __syncthreads();
+    float M = -INFINITY, f[4], L = 0.f;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) M = fmaxf(M, ml[0][x][lane]);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        f[x] = __expf(ml[0][x][lane] - M);
+        L = fmaf(ml[1][x][lane], f[x], L);
+    }
+    fold_waves(o, red, wv, lane, f);
+    if (wv != 0 || !qv) return;
     // o: rows = feature c, columns = queries.  This lane (query q, half kh) holds the features 8g + 4kh + (0..3)
-    store_accT<DK>(a.O + (size_t)q * a.dim + h * DK, o, kh, 1.f / l);
-    if (kh == 0) *reinterpret_cast<float2*>(a.LSE + 2 * ((size_t)q * a.heads + h)) = make_float2(m, 1.f / l);
+    store_accT<DK>(a.O + (size_t)q * a.dim + h * DK, o, kh, 1.f / L);
+    if (kh == 0) *reinterpret_cast<float2*>(a.LSE + 2 * ((size_t)q * a.heads + h)) = make_float2(M, 1.f / L);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -205,10 +242,10 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 template <bool BF, int DK, bool DROP>
 __global__ __launch_bounds__(256) void mha_bwd_q_kernel(const MhaArgs a) {
-    const int lane = threadIdx.x & 63, col = lane & 31, kh = lane >> 5;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, col = lane & 31, kh = lane >> 5, wv = threadIdx.x >> 6;
+    const int w = blockIdx.x;
     const int qblocks = (a.Nq + 31) / 32;
-    if (w >= qblocks * a.heads) return;
     const int h = w / qblocks, q0 = (w % qblocks) * 32;
     const int q = q0 + col;
     const bool qv = q < a.Nq;
@@ -224,7 +261,7 @@ __global__ __launch_bounds__(256) void mha_bwd_q_kernel(const MhaArgs a) {
     mha_f32x16 dq;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[e] = 0.f;
-    for (int k0 = 0; k0 < a.Nk; k0 += 32) {
+    for (int k0 = 32 * wv; k0 < a.Nk; k0 += 128) {
         const int kr = min(k0 + col, a.Nk - 1);
         mha_f32x16 s = tile_xyT<BF, DK>(a.K + (size_t)kr * a.dim + h * DK, qrow, kh);
         const mha_f32x16 dp = tile_xyT<BF, DK>(a.V + (size_t)kr * a.dim + h * DK, dorow, kh);
@@ -242,7 +279,9 @@ __global__ __launch_bounds__(256) void mha_bwd_q_kernel(const MhaArgs a) {
         }
         accum_zT_t<BF, DK>(dq, a.K + (size_t)k0 * a.dim + h * DK, a.dim, a.Nk - k0, s, lane);
     }
-    if (!qv) return;
+    const float one[4] = {1.f, 1.f, 1.f, 1.f};
+    fold_waves(dq, red, wv, lane, one);
+    if (wv != 0 || !qv) return;
     store_accT<DK>(a.dQ + (size_t)q * a.dim + h * DK, dq, kh, 1.f);
     if (kh == 0) a.delta[(size_t)q * a.heads + h] = delta;
 }
@@ -253,10 +292,10 @@ __global__ __launch_bounds__(256) void mha_bwd_q_kernel(const MhaArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 template <bool BF, int DK, bool DROP>
 __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const MhaArgs a) {
-    const int lane = threadIdx.x & 63, col = lane & 31, kh = lane >> 5;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, col = lane & 31, kh = lane >> 5, wv = threadIdx.x >> 6;
+    const int w = blockIdx.x;
     const int kblocks = (a.Nk + 31) / 32;
-    if (w >= kblocks * a.heads) return;
     const int h = w / kblocks, k0 = (w % kblocks) * 32;
     const int key = k0 + col;
     const bool kv = key < a.Nk;
@@ -267,7 +306,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const MhaArgs a) {
     mha_f32x16 dk, dv;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
-    for (int q0 = 0; q0 < a.Nq; q0 += 32) {
+    for (int q0 = 32 * wv; q0 < a.Nq; q0 += 128) {
         const int qr = min(q0 + col, a.Nq - 1);
         mha_f32x16 s = tile_xyT<BF, DK>(a.Q + (size_t)qr * a.dim + h * DK, krow, kh);          // rows = queries, lane = key
         const mha_f32x16 dp = tile_xyT<BF, DK>(a.dO + (size_t)qr * a.dim + h * DK, vrow, kh);
@@ -288,7 +327,10 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const MhaArgs a) {
         accum_zT_t<BF, DK>(dv, a.dO + (size_t)q0 * a.dim + h * DK, a.dim, a.Nq - q0, pd, lane);
         accum_zT_t<BF, DK>(dk, a.Q + (size_t)q0 * a.dim + h * DK, a.dim, a.Nq - q0, s, lane);
     }
-    if (!kv) return;
+    const float one[4] = {1.f, 1.f, 1.f, 1.f};
+    fold_waves(dv, red, wv, lane, one);
+    fold_waves(dk, red, wv, lane, one);
+    if (wv != 0 || !kv) return;
     store_accT<DK>(a.dK + (size_t)key * a.dim + h * DK, dk, kh, 1.f);
     store_accT<DK>(a.dV + (size_t)key * a.dim + h * DK, dv, kh, 1.f);
 }
@@ -296,7 +338,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const MhaArgs a) {
 template <bool BF, int DK>
 static int launch_mha(const MhaArgs& a, bool backward, bool drop, hipStream_t st) {
     const int qw = ((a.Nq + 31) / 32) * a.heads, kw = ((a.Nk + 31) / 32) * a.heads;
-    const dim3 block(256), gq((qw + 3) / 4), gk((kw + 3) / 4);
+    const dim3 block(256), gq(qw), gk(kw);                           // one workgroup (4 waves) per 32-row block and head
     if (!backward) {
         if (drop) hipLaunchKernelGGL((mha_fwd_kernel<BF, DK, true>), gq, block, 0, st, a);
         else      hipLaunchKernelGGL((mha_fwd_kernel<BF, DK, false>), gq, block, 0, st, a);
