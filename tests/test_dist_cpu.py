@@ -181,3 +181,28 @@ def test_sharded_d128_four_stages_matches_oracle_under_gloo(tmp_path):
         assert err["scores"] < 1e-5 and err["loss"] < 1e-5, (rank, err)
         assert err["emb"] < 5e-4 and err["gat"] < 5e-4, (rank, err)
         assert err["pad"] == 0.0 and err["sd"] == 0.0 and err["keys"], (rank, err)
+
+
+def test_chunk_generated_shards_assemble_the_whole_graph():
+    """ngacf_amd.dist.sharded_graph (the 10^9-edge workloads: every rank runs the chunked generator and keeps only the edges
+    ending in its rows): the ranks agree on the partition, their shards together hold every directed edge exactly once, and
+    each shard's plan equals the plan built by filtering the whole (renumbered) edge list."""
+    from ngacf_amd import data as D
+    from ngacf_amd.dist import sharded_graph
+    from ngacf_amd.plan import build_plan
+    shape = (300, 200, 5000)
+    whole = D.synthetic_bipartite_big(*shape, seed=11, device="cpu", chunk_users=64)
+    E = int(whole.shape[1])
+    assert 3500 < E <= 5000 and int(torch.bincount(whole[0], minlength=300).min()) >= 1     # (duplicates are merged: dense toy graph)
+    world = 3
+    shards = [sharded_graph(shape, world, r, "cpu", seed=11, seg_len=16, chunk_users=64) for r in range(world)]
+    assert all(e == E for _, _, e, _ in shards)
+    assert all(torch.equal(shards[0][0].perm_u, p.perm_u) and torch.equal(shards[0][0].perm_i, p.perm_i) for p, _, _, _ in shards)
+    assert sum(pl.n_edges_directed for _, pl, _, _ in shards) == 2 * E
+    for part, plan, _, first in shards:
+        ref = build_plan(part.map_edges(whole), part.Up, part.Ip, seg_len=16, require_user_edges=False, row_range=part.row_ranges)
+        assert torch.equal(plan.rowptr, ref.rowptr) and torch.equal(plan.col, ref.col)
+        assert torch.equal(plan.segs, ref.segs) and torch.equal(plan.srow, ref.srow) and torch.equal(plan.split, ref.split)
+        assert torch.equal(first, whole[:, :first.shape[1]])                    # the CPU baseline's sample: the first user chunk
+    nnz = [pl.n_edges_directed for _, pl, _, _ in shards]
+    assert max(nnz) - min(nnz) < 0.05 * (2 * E / world)                        # degree-balanced shards
