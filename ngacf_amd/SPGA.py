@@ -111,3 +111,101 @@ class SpGAT(nn.Module):
         x = F.dropout(x, self.dropout, training=self.training)                                   # :354
         o, ko = self.out_att, self.out_att.out_features
         return _cover_stage(x, o.W, o.a[0, :ko], o.a[0, ko:], plan, 1, o.alpha, True, p)         # :355 (ELU outside)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the model wrappers of graphattention/SPGA.py:85-316 (the reference's run_Mask.py that drove them is absent; kept for
+# completeness of the SPGA family).  `adj` = the N x N Laplacian (torch sparse COO or a (rows, cols, vals) triple) for the
+# GPLayer products, `mask` = the N x N adjacency SpGAT attends over (dense, sparse, or a [2,E] edge list).
+# ---------------------------------------------------------------------------------------------------------
+class _SPGABase(nn.Module):
+    def _embeddings(self, userNum, itemNum, embedSize, droprate, useCuda):
+        self.useCuda, self.userNum, self.itemNum, self.droprate = useCuda, userNum, itemNum, droprate
+        self.uEmbd = nn.Embedding(userNum, embedSize)
+        self.iEmbd = nn.Embedding(itemNum, embedSize)
+
+    def _init_weight_(self):
+        nn.init.normal_(self.uEmbd.weight, std=0.01)
+        nn.init.normal_(self.iEmbd.weight, std=0.01)
+
+    def _features(self):
+        return torch.cat([self.uEmbd.weight, self.iEmbd.weight], dim=0)
+
+    def _score(self, features, userIdx, itemIdx):
+        return torch.sum(features[userIdx] * features[itemIdx + self.userNum], dim=1)
+
+    def _propagation(self, dev):
+        from .modules import _Laplacian
+        if getattr(self, "_lap", None) is None:
+            object.__setattr__(self, "_lap", _Laplacian(self.LaplacianMat, self.userNum + self.itemNum))
+        return self._lap.get(dev)
+
+
+class GPLayer(nn.Module):
+    """SPGA.py:318-328: (L + I) @ features."""
+
+    def forward(self, features, propagation, selfLoop=True):
+        return propagation(features, self_loop=bool(selfLoop))
+
+
+class SPGACF(_SPGABase):
+    """SPGA.py:85-149: embeddings -> SpGAT over the mask -> dot-product score."""
+
+    def __init__(self, userNum, itemNum, adj, embedSize, layers, droprate, useCuda=True):
+        super().__init__()
+        self._embeddings(userNum, itemNum, embedSize, droprate, useCuda)
+        self.gat = SpGAT(nfeat=embedSize, nhid=8, nclass=embedSize, dropout=droprate, nheads=8, alpha=0.2)
+        self._init_weight_()
+
+    def forward(self, userIdx, itemIdx, mask):
+        return self._score(self.gat(self._features(), mask), userIdx, itemIdx)
+
+
+class MultiLayerSPGA(_SPGABase):
+    """SPGA.py:151-234: per layer SpGAT -> (L + I) propagation -> Linear -> ReLU; all stage outputs concatenated."""
+
+    def __init__(self, userNum, itemNum, adj, embedSize, layers, droprate, useCuda=True):
+        super().__init__()
+        self._embeddings(userNum, itemNum, embedSize, droprate, useCuda)
+        self.GATlayers, self.GPlayers, self.Affinelayers = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        self.LaplacianMat = adj
+        dims = [embedSize] + list(layers)                                # :172 (without mutating the caller's list)
+        for From, To in zip(dims[:-1], dims[1:]):
+            self.GATlayers.append(SpGAT(nfeat=From, nhid=8, nclass=From, dropout=droprate, nheads=8, alpha=0.2))
+            self.GPlayers.append(GPLayer())
+            self.Affinelayers.append(nn.Linear(From, To))
+        self._init_weight_()
+
+    def forward(self, userIdx, itemIdx, mask):
+        features = self._features()
+        prop = self._propagation(features.device)
+        final = [features]
+        for gat, gp, aff in zip(self.GATlayers, self.GPlayers, self.Affinelayers):
+            features = torch.relu(aff(gp(gat(features, mask), prop, True)))
+            final.append(features)
+        return self._score(torch.cat(final, dim=1), userIdx, itemIdx)
+
+
+class SPGAMGP(_SPGABase):
+    """SPGA.py:236-316: one SpGAT, then len(layers) x [(L + I) propagation -> Linear -> ReLU], concatenated."""
+
+    def __init__(self, userNum, itemNum, adj, embedSize, layers, droprate, useCuda=True):
+        super().__init__()
+        self._embeddings(userNum, itemNum, embedSize, droprate, useCuda)
+        self.GPlayers, self.Affinelayers = nn.ModuleList(), nn.ModuleList()
+        self.LaplacianMat = adj
+        self.gat = SpGAT(nfeat=embedSize, nhid=8, nclass=embedSize, dropout=droprate, nheads=8, alpha=0.2)
+        dims = [embedSize] + list(layers)
+        for From, To in zip(dims[:-1], dims[1:]):
+            self.GPlayers.append(GPLayer())
+            self.Affinelayers.append(nn.Linear(From, To))
+        self._init_weight_()
+
+    def forward(self, userIdx, itemIdx, mask):
+        features = self.gat(self._features(), mask)
+        prop = self._propagation(features.device)
+        final = [features]
+        for gp, aff in zip(self.GPlayers, self.Affinelayers):
+            features = torch.relu(aff(gp(features, prop, True)))
+            final.append(features)
+        return self._score(torch.cat(final, dim=1), userIdx, itemIdx)

@@ -428,6 +428,44 @@ def g14_dense_mha(edge, U, I):
          dense_adj=dense_adj.numpy().astype(np.uint8), u=u, item=it, v1_scores=s1.detach().numpy(), mk_scores=s2.detach().numpy(), **out)
 
 
+def g15_spga_models(edge, U, I):
+    """The SPGA family's model wrappers (SPGA.py:85-316): SPGACF, MultiLayerSPGA, SPGAMGP forward scores on the toy graph
+    (mask = dense bipartite adjacency + self loops over N nodes, Laplacian = the reference's mean_adj), eval mode."""
+    import pandas as pd
+    from data.loadGowalla import buildLaplacianMat, scipySP_torchSP
+    e37 = edge[:, edge[1] < 37]
+    I37 = 37
+    rt = pd.DataFrame({"userId": e37[0], "itemId": e37[1], "rating": np.ones(e37.shape[1])})
+    L = scipySP_torchSP(buildLaplacianMat(rt, U, I37, "mean_adj")).coalesce()
+    N = U + I37
+    dense = torch.zeros(N, N)
+    dense[torch.from_numpy(e37[0]), torch.from_numpy(e37[1]) + U] = 1.0
+    dense = dense + dense.t() + torch.eye(N)
+    rs = np.random.RandomState(53)
+    B = 40
+    u, it = rs.randint(0, U, B).astype(np.int64), rs.randint(0, I37, B).astype(np.int64)
+    out = {}
+    real_cuda = (torch.Tensor.cuda, torch.nn.Module.cuda)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    try:
+        with CpuDevice():
+            for tag, cls, layers in (("spgacf", RS.SPGACF, [64, 64]), ("multi", RS.MultiLayerSPGA, [64]), ("mgp", RS.SPGAMGP, [64, 64])):
+                torch.manual_seed(59)
+                m = cls(U, I37, L, 64, list(layers), 0.0, useCuda=False)
+                with torch.no_grad():
+                    m.uEmbd.weight.mul_(30.0); m.iEmbd.weight.mul_(30.0)
+                m.eval()
+                sc = m(torch.from_numpy(u), torch.from_numpy(it), dense)
+                out[tag + ".scores"] = sc.detach().numpy()
+                for k_, v in m.state_dict().items():
+                    out[tag + ".p." + k_] = v.numpy().copy()
+    finally:
+        torch.Tensor.cuda, torch.nn.Module.cuda = real_cuda
+    save("g15_spga_models", edge=e37, U=U, I=I37, L_row=L.indices()[0].numpy(), L_col=L.indices()[1].numpy(),
+         L_val=L.values().numpy(), dense_adj=dense.numpy().astype(np.uint8), u=u, item=it, **out)
+
+
 def g11_factors(U, I, seed=7):
     rs = np.random.RandomState(seed)
     cont = (rs.randn(U, 64).astype(np.float32).astype(np.float64), rs.randn(I, 64).astype(np.float32).astype(np.float64))
@@ -497,6 +535,8 @@ def main():
         return g13_ref_checkpoint(edge, U, I)
     if "--only-g14" in sys.argv:
         return g14_dense_mha(edge, U, I)
+    if "--only-g15" in sys.argv:
+        return g15_spga_models(edge, U, I)
     if "--only-g7b" in sys.argv:                      # added after the first batch: leaves the other fixtures untouched
         return g7b_norm_adj(edge[:, edge[1] < 37], U, 37)
     g1_layers(edge, U, I)
@@ -512,6 +552,7 @@ def main():
     g11_eval_neg_all()
     g13_ref_checkpoint(edge, U, I)
     g14_dense_mha(edge, U, I)
+    g15_spga_models(edge, U, I)
 
 
 if __name__ == "__main__":

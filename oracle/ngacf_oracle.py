@@ -243,6 +243,40 @@ def spga_layer_forward(X, W, a, edge, alpha=0.2, concat=True):
     return (elu(hp) if concat else hp).astype(X.dtype)
 
 
+def spgat_forward(p, X, edge, prefix="gat.", nheads=8, alpha=0.2):
+    """SpGAT.forward in eval mode (SPGA.py:351-356): concat of the heads (ELU inside), then ELU(out_att)."""
+    heads = [spga_layer_forward(X, p["%sattention_%d.W" % (prefix, h)], p["%sattention_%d.a" % (prefix, h)], edge, alpha, True)
+             for h in range(nheads)]
+    x = np.concatenate(heads, 1)
+    return elu(spga_layer_forward(x, p[prefix + "out_att.W"], p[prefix + "out_att.a"], edge, alpha, False))
+
+
+def spga_model_scores(kind, p, L, edge, u, it, U, I):
+    """SPGACF / MultiLayerSPGA / SPGAMGP forward (SPGA.py:85-316), eval mode.  L: scipy N x N Laplacian; edge: [2,E'] the
+    nonzeros of the mask SpGAT attends over."""
+    F = np.concatenate([p["uEmbd.weight"], p["iEmbd.weight"]])
+    L1 = L + sp.eye(U + I, format="csr")
+    if kind == "spgacf":
+        E = spgat_forward(p, F, edge)
+    elif kind == "multi":
+        final, s = [F], 0
+        while "Affinelayers.%d.weight" % s in p:
+            F = spgat_forward(p, F, edge, "GATlayers.%d." % s)
+            F = np.maximum(L1 @ F @ p["Affinelayers.%d.weight" % s].T + p["Affinelayers.%d.bias" % s], 0)
+            final.append(F)
+            s += 1
+        E = np.concatenate(final, 1)
+    else:
+        F = spgat_forward(p, F, edge)
+        final, s = [F], 0
+        while "Affinelayers.%d.weight" % s in p:
+            F = np.maximum(L1 @ F @ p["Affinelayers.%d.weight" % s].T + p["Affinelayers.%d.bias" % s], 0)
+            final.append(F)
+            s += 1
+        E = np.concatenate(final, 1)
+    return np.sum(E[u] * E[it + U], 1)
+
+
 def static_spmm(rows, cols, vals, X, add_self_loop=True):
     """GPLayer.forward (SPUIGACF.py:178-185): (L + I) @ X."""
     N = X.shape[0]

@@ -687,3 +687,26 @@ def test_g6_spga_layer_and_spgat_forward_backward(dev):
     assert _maxabs(Xr.grad, X64.grad.cpu().numpy()) < 2e-4 * float(X64.grad.abs().max())
     for n, p in m.named_parameters():
         assert _maxabs(p.grad, P[n].grad.cpu().numpy()) < 5e-4 * max(float(P[n].grad.abs().max()), 1e-9), n
+
+
+def test_g15_spga_model_wrappers(dev):
+    """SPGACF / MultiLayerSPGA / SPGAMGP (SPGA.py:85-316) on the HIP path against the reference's own scores; the
+    reference's state_dicts load strictly; a backward pass reaches the embeddings."""
+    from ngacf_amd import SPGA
+    g = load_golden("g15_spga_models")
+    U, I = int(g["U"]), int(g["I"])
+    L = (torch.from_numpy(g["L_row"]), torch.from_numpy(g["L_col"]), torch.from_numpy(g["L_val"]))
+    mask = _t(g["dense_adj"], dev).float()
+    u, it = _t(g["u"], dev), _t(g["item"], dev)
+    for kind, cls, layers in (("spgacf", SPGA.SPGACF, [64, 64]), ("multi", SPGA.MultiLayerSPGA, [64]), ("mgp", SPGA.SPGAMGP, [64, 64])):
+        m = cls(U, I, L, 64, layers, 0.0)
+        sd = {k[len(kind) + 3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(kind + ".p.")}
+        res = m.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        m = m.to(dev).eval()
+        sc = m(u, it, mask)
+        want = g[kind + ".scores"]
+        assert _maxabs(sc, want) < 1e-5 * max(float(np.abs(want).max()), 1.0), kind
+        m.train()
+        m(u, it, mask).sum().backward()
+        assert float(m.uEmbd.weight.grad.abs().sum()) > 0 and bool(torch.isfinite(m.uEmbd.weight.grad).all())

@@ -198,6 +198,21 @@ def test_g14_dense_multi_head_attention_and_the_models_on_it():
     assert np.abs(s2 - g["mk_scores"]).max() < 1e-4 * max(np.abs(g["mk_scores"]).max(), 1.0)
 
 
+def test_g15_spga_model_wrappers():
+    """SPGACF / MultiLayerSPGA / SPGAMGP (SPGA.py:85-316): the numpy restatement against the reference's scores."""
+    import scipy.sparse as sp
+    g = load_golden("g15_spga_models")
+    U, I = int(g["U"]), int(g["I"])
+    N = U + I
+    L = sp.coo_matrix((g["L_val"].astype(np.float64), (g["L_row"], g["L_col"])), shape=(N, N)).tocsr()
+    edge = np.stack(np.nonzero(g["dense_adj"]))
+    for kind in ("spgacf", "multi", "mgp"):
+        p = {k[len(kind) + 3:]: v.astype(np.float64) for k, v in g.items() if k.startswith(kind + ".p.")}
+        got = O.spga_model_scores(kind, p, L, edge, g["u"], g["item"], U, I)
+        want = g[kind + ".scores"]
+        assert np.abs(got - want).max() < 1e-4 * max(np.abs(want).max(), 1.0), kind
+
+
 def _g11_factors(U, I, seed=7):
     """The rank-64 score tables of oracle/gen_golden.py:g11_factors (data: seeded draws), S = A @ B^T."""
     rs = np.random.RandomState(seed)
