@@ -5,7 +5,8 @@ families built on it, backed by the HIP flash-style kernel ngacf_mha_fwd / ngacf
   MultiHeadAttention(heads, dim, dropout=0.1).forward(q, k, v, mask)    modules.py:62-107   (same parameters / keys)
   ATTLayer(dim, heads, dropout).forward(userFeatures, itemFeatures)     modules.py:7-18
   ATTLayer_mask(dim, heads, dropout).forward(features, mask)            modules.py:20-30
-  GALayer / GACFV1_layer / GACFV1                                       GACFmodel1.py:13-115
+  GALayer / GACFV1_layer / GACFV1 (and GACFV3, GACFV4, GACFV5)          GACFmodel{1,3,4,5}.py
+  GACFV2                                                                GACFmodel2.py:34-135
   GPLayer / GACFV2_layer / GACFMask                                     GACFMask.py:22-136
 
 What differs from the reference is how the attention core runs: the [heads, Nq, Nk] score and probability tensors are
@@ -136,11 +137,23 @@ def _check_width(d):
 
 
 class GALayer(nn.Module):
-    """GACFmodel1.py:13-40."""
+    """The attention + graph-convolution layer of GACFmodel{1,3,4,5}.py (`GALayer`, same parameters in all four; the
+    variants differ in what feeds the two Laplacian products, graphattention/README.md:3-20):
 
-    def __init__(self, input_dim, out_dim, heads, dropout):
+        variant 1 (GACFmodel1.py:29-40)   f1 = ReLU(aff1((L+I) A)),  f2 = ReLU(aff2(L (A * A)))      A = ATTLayer(users, items)
+        variant 3 (GACFmodel3.py:29-40)   f1 = ReLU(aff1((L+I) A)),  f2 = ReLU(aff2(L A))
+        variant 4 (GACFmodel4.py:30-42)   f1 = ReLU(aff1((L+I) F)),  f2 = ReLU(aff2(L (A * A)))      F = cat(users, items)
+        variant 5 (GACFmodel5.py:30-42)   f1 = ReLU(aff1((L+I) F)),  f2 = ReLU(aff2(L A))
+    """
+    variant = 1
+
+    def __init__(self, input_dim, out_dim, heads, dropout, variant=None):
         super().__init__()
         _check_width(input_dim)
+        if variant is not None:
+            self.variant = variant
+        if self.variant not in (1, 3, 4, 5):
+            raise ValueError("GALayer variant must be 1, 3, 4 or 5")
         self.att = ATTLayer(input_dim, heads, dropout)
         self.affine1 = nn.Linear(input_dim, out_dim)
         self.affine2 = nn.Linear(input_dim, out_dim)
@@ -149,19 +162,23 @@ class GALayer(nn.Module):
             lin.bias.data.zero_()
 
     def forward(self, userFeatures, itemFeatures, propagation):
-        features = self.att(userFeatures, itemFeatures)
-        f1 = torch.relu(self.affine1(propagation(features, self_loop=True)))                    # (L + I) @ features
-        f2 = torch.relu(self.affine2(propagation(features * features, self_loop=False)))        # L @ (features ⊙ features)
+        A = self.att(userFeatures, itemFeatures)
+        first = A if self.variant in (1, 3) else torch.cat([userFeatures, itemFeatures], dim=0)
+        second = A * A if self.variant in (1, 4) else A
+        f1 = torch.relu(self.affine1(propagation(first, self_loop=True)))                       # (L + I) @ .
+        f2 = torch.relu(self.affine2(propagation(second, self_loop=False)))                     # L @ .
         return f1 + f2
 
 
 class GACFV1_layer(nn.Module):
+    variant = 1
+
     def __init__(self, userNum, itemNum, adj, embedSize=256, layers=(256, 128, 64), droprate=0.2, useCuda=True):
         super().__init__()
         self.useCuda, self.userNum, self.itemNum, self.droprate = useCuda, userNum, itemNum, droprate
         self.uEmbd = nn.Embedding(userNum, embedSize)
         self.iEmbd = nn.Embedding(itemNum, embedSize)
-        self.GALayers = nn.ModuleList(GALayer(a, b, 8, droprate) for a, b in zip(layers[:-1], layers[1:]))
+        self.GALayers = nn.ModuleList(GALayer(a, b, 8, droprate, self.variant) for a, b in zip(layers[:-1], layers[1:]))
         self._lap = _Laplacian(adj, userNum + itemNum)
         nn.init.normal_(self.uEmbd.weight, std=0.01)
         nn.init.normal_(self.iEmbd.weight, std=0.01)
@@ -177,15 +194,43 @@ class GACFV1_layer(nn.Module):
         return torch.cat(final, dim=1)
 
 
+class GACFV3_layer(GACFV1_layer):
+    variant = 3
+
+
+class GACFV4_layer(GACFV1_layer):
+    variant = 4
+
+
+class GACFV5_layer(GACFV1_layer):
+    variant = 5
+
+
 class GACFV1(nn.Module):
+    """GACFmodel1.py:87-115 (and, through `_layer`, GACFV3 GACFmodel3.py:99-112, GACFV4 GACFmodel4.py:101-115, GACFV5
+    GACFmodel5.py:102-117): concatenated stage outputs, dot-product score."""
+    _layer = GACFV1_layer
+
     def __init__(self, userNum, itemNum, adj, embedSize, layers, droprate, useCuda=True):
         super().__init__()
         self.userNum = userNum
-        self.gacf = GACFV1_layer(userNum, itemNum, adj, embedSize, layers, droprate)
+        self.gacf = self._layer(userNum, itemNum, adj, embedSize, layers, droprate)
 
     def forward(self, userIdx, itemIdx):
         e = self.gacf(userIdx, itemIdx)
         return torch.sum(e[userIdx] * e[itemIdx + self.userNum], dim=1)
+
+
+class GACFV3(GACFV1):
+    _layer = GACFV3_layer
+
+
+class GACFV4(GACFV1):
+    _layer = GACFV4_layer
+
+
+class GACFV5(GACFV1):
+    _layer = GACFV5_layer
 
 
 class GPLayer(nn.Module):
@@ -196,8 +241,10 @@ class GPLayer(nn.Module):
 
 
 class GACFV2_layer(nn.Module):
-    """GACFMask.py:35-106: per layer masked self-attention over all nodes, (L + I) propagation, Linear, ReLU; all stage
-    outputs concatenated."""
+    """Per layer attention, (L + I) propagation, Linear, ReLU; all stage outputs concatenated.
+    masked=True : GACFMask.py:35-106 -- masked self-attention over all nodes (ATTLayer_mask), forward(u, i, mask);
+    masked=False: GACFmodel2.py:34-120 -- user/item cross attention (ATTLayer), forward(u, i)."""
+    masked = True
 
     def __init__(self, userNum, itemNum, adj, embedSize=256, layers=(256, 128, 64), droprate=0.2, useCuda=True):
         super().__init__()
@@ -207,7 +254,7 @@ class GACFV2_layer(nn.Module):
         self.ATTlayers, self.GPlayers, self.Affinelayers = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
         for a, b in zip(layers[:-1], layers[1:]):
             _check_width(a)
-            self.ATTlayers.append(ATTLayer_mask(a, 8, droprate))
+            self.ATTlayers.append(ATTLayer_mask(a, 8, droprate) if self.masked else ATTLayer(a, 8, droprate))
             self.GPlayers.append(GPLayer())
             self.Affinelayers.append(nn.Linear(a, b))
         self._lap = _Laplacian(adj, userNum + itemNum)
@@ -217,14 +264,33 @@ class GACFV2_layer(nn.Module):
             nn.init.xavier_uniform_(m.weight)
             m.bias.data.zero_()
 
-    def forward(self, userIdx, itemIdx, mask):
+    def forward(self, userIdx, itemIdx, mask=None):
+        U = self.userNum
         features = torch.cat([self.uEmbd.weight, self.iEmbd.weight], dim=0)
         prop = self._lap.get(features.device)
         final = [features]
         for att, gp, aff in zip(self.ATTlayers, self.GPlayers, self.Affinelayers):
-            features = torch.relu(aff(gp(att(features, mask), prop, True)))
+            attended = att(features, mask) if self.masked else att(features[:U], features[U:])
+            features = torch.relu(aff(gp(attended, prop, True)))
             final.append(features)
         return torch.cat(final, dim=1)
+
+
+class GACFV2_plain_layer(GACFV2_layer):
+    masked = False
+
+
+class GACFV2(nn.Module):
+    """GACFmodel2.py:122-135."""
+
+    def __init__(self, userNum, itemNum, adj, embedSize, layers, droprate, useCuda=True):
+        super().__init__()
+        self.userNum = userNum
+        self.gacf = GACFV2_plain_layer(userNum, itemNum, adj, embedSize, layers, droprate)
+
+    def forward(self, userIdx, itemIdx):
+        e = self.gacf(userIdx, itemIdx)
+        return torch.sum(e[userIdx] * e[itemIdx + self.userNum], dim=1)
 
 
 class GACFMask(nn.Module):

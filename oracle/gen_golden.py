@@ -466,6 +466,47 @@ def g15_spga_models(edge, U, I):
          L_val=L.values().numpy(), dense_adj=dense.numpy().astype(np.uint8), u=u, item=it, **out)
 
 
+def g16_gacf_variants(edge, U, I):
+    """GACFV2 .. GACFV5 (GACFmodel2-5.py) forward scores on the toy graph.  V3/V4/V5 have GACFV1's parameter set, so they
+    are run on the parameters already stored in g14 (v1.p.*): only their scores are new; V2 brings its own."""
+    import pandas as pd
+    import graphattention.GACFmodel2 as G2
+    import graphattention.GACFmodel3 as G3
+    import graphattention.GACFmodel4 as G4
+    import graphattention.GACFmodel5 as G5
+    from data.loadGowalla import buildLaplacianMat, scipySP_torchSP
+    g14 = np.load(os.path.join(OUT, "g14_dense_mha.npz"))
+    e37, I37 = g14["edge"], int(g14["I"])
+    rt = pd.DataFrame({"userId": e37[0], "itemId": e37[1], "rating": np.ones(e37.shape[1])})
+    L = scipySP_torchSP(buildLaplacianMat(rt, U, I37, "mean_adj")).coalesce()
+    u, it = torch.from_numpy(g14["u"]), torch.from_numpy(g14["item"])
+    v1 = {k_[len("v1.p."):]: torch.from_numpy(g14[k_]) for k_ in g14.files if k_.startswith("v1.p.")}
+    out = {}
+    real_cuda = (torch.Tensor.cuda, torch.nn.Module.cuda)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    try:
+        with CpuDevice():
+            for tag, cls in (("v3", G3.GACFV3), ("v4", G4.GACFV4), ("v5", G5.GACFV5)):
+                m = cls(U, I37, L, 64, [64, 64], 0.0)
+                m.gacf.useCuda = False
+                m.load_state_dict(v1)
+                m.eval()
+                out[tag + "_scores"] = m(u, it).detach().numpy()
+            torch.manual_seed(61)
+            m2 = G2.GACFV2(U, I37, L, 64, [64, 64], 0.0, useCuda=False)
+            m2.gacf.useCuda = False
+            with torch.no_grad():
+                m2.gacf.uEmbd.weight.mul_(30.0); m2.gacf.iEmbd.weight.mul_(30.0)
+            m2.eval()
+            out["v2_scores"] = m2(u, it).detach().numpy()
+            for k_, v in m2.state_dict().items():
+                out["v2.p." + k_] = v.numpy().copy()
+    finally:
+        torch.Tensor.cuda, torch.nn.Module.cuda = real_cuda
+    save("g16_gacf_variants", **out)
+
+
 def g11_factors(U, I, seed=7):
     rs = np.random.RandomState(seed)
     cont = (rs.randn(U, 64).astype(np.float32).astype(np.float64), rs.randn(I, 64).astype(np.float32).astype(np.float64))
@@ -537,6 +578,8 @@ def main():
         return g14_dense_mha(edge, U, I)
     if "--only-g15" in sys.argv:
         return g15_spga_models(edge, U, I)
+    if "--only-g16" in sys.argv:
+        return g16_gacf_variants(edge, U, I)
     if "--only-g7b" in sys.argv:                      # added after the first batch: leaves the other fixtures untouched
         return g7b_norm_adj(edge[:, edge[1] < 37], U, 37)
     g1_layers(edge, U, I)
@@ -553,6 +596,7 @@ def main():
     g13_ref_checkpoint(edge, U, I)
     g14_dense_mha(edge, U, I)
     g15_spga_models(edge, U, I)
+    g16_gacf_variants(edge, U, I)
 
 
 if __name__ == "__main__":

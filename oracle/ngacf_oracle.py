@@ -357,8 +357,10 @@ def att_layer(p, users, items, heads, prefix=""):
     return np.concatenate([u, i], 0)
 
 
-def gacfv1_scores(p, L, u, it, U, I, heads=8):
-    """GACFV1.forward (GACFmodel1.py:87-115, GALayer :29-40); L: scipy sparse N x N Laplacian."""
+def gacfv1_scores(p, L, u, it, U, I, heads=8, variant=1):
+    """GACFV1.forward (GACFmodel1.py:87-115, GALayer :29-40) and, by `variant`, GACFV3 / V4 / V5 (GACFmodel3.py:29-40,
+    GACFmodel4.py:30-42, GACFmodel5.py:30-42: same parameters, other inputs to the two Laplacian products);
+    L: scipy sparse N x N Laplacian."""
     F = np.concatenate([p["gacf.uEmbd.weight"], p["gacf.iEmbd.weight"]])
     N = U + I
     L1 = L + sp.eye(N, format="csr")
@@ -367,9 +369,25 @@ def gacfv1_scores(p, L, u, it, U, I, heads=8):
     while "gacf.GALayers.%d.affine1.weight" % s in p:
         pre = "gacf.GALayers.%d." % s
         A = att_layer(p, F[:U], F[U:], heads, pre + "att.")
-        f1 = np.maximum(L1 @ A @ p[pre + "affine1.weight"].T + p[pre + "affine1.bias"], 0)
-        f2 = np.maximum(L @ (A * A) @ p[pre + "affine2.weight"].T + p[pre + "affine2.bias"], 0)
+        first = A if variant in (1, 3) else F
+        second = A * A if variant in (1, 4) else A
+        f1 = np.maximum(L1 @ first @ p[pre + "affine1.weight"].T + p[pre + "affine1.bias"], 0)
+        f2 = np.maximum(L @ second @ p[pre + "affine2.weight"].T + p[pre + "affine2.bias"], 0)
         F = f1 + f2
+        final.append(F)
+        s += 1
+    E = np.concatenate(final, 1)
+    return np.sum(E[u] * E[it + U], 1)
+
+
+def gacfv2_scores(p, L, u, it, U, I, heads=8):
+    """GACFV2.forward (GACFmodel2.py:88-135): ATTLayer -> (L + I) -> Linear -> ReLU per layer."""
+    F = np.concatenate([p["gacf.uEmbd.weight"], p["gacf.iEmbd.weight"]])
+    L1 = L + sp.eye(U + I, format="csr")
+    final, s = [F], 0
+    while "gacf.Affinelayers.%d.weight" % s in p:
+        A = att_layer(p, F[:U], F[U:], heads, "gacf.ATTlayers.%d." % s)
+        F = np.maximum(L1 @ A @ p["gacf.Affinelayers.%d.weight" % s].T + p["gacf.Affinelayers.%d.bias" % s], 0)
         final.append(F)
         s += 1
     E = np.concatenate(final, 1)

@@ -156,3 +156,18 @@ def test_ml100k_size_attention_vs_float64(dev, dim, heads):
     # refused shapes
     with pytest.raises(ValueError):
         ops.mha_fwd(Q[:, :48].contiguous(), K[:, :48].contiguous(), V[:, :48].contiguous(), 8)
+
+
+def test_g16_gacf_variants(dev):
+    """GACFV2 .. GACFV5 (GACFmodel2-5.py) on the HIP path against the reference's scores; V3-V5 load GACFV1's state_dict
+    (same parameter names), V2 its own -- strictly."""
+    from ngacf_amd import modules as M
+    g14, g = load_golden("g14_dense_mha"), load_golden("g16_gacf_variants")
+    U, I = int(g14["U"]), int(g14["I"])
+    L = (torch.from_numpy(g14["L_row"]), torch.from_numpy(g14["L_col"]), torch.from_numpy(g14["L_val"]))
+    u, it = torch.from_numpy(g14["u"]).to(dev), torch.from_numpy(g14["item"]).to(dev)
+    for v, cls in ((3, M.GACFV3), (4, M.GACFV4), (5, M.GACFV5)):
+        m = _load(cls(U, I, L, 64, [64, 64], 0.0), g14, "v1.p.").to(dev).eval()
+        assert _rel(m(u, it), g["v%d_scores" % v]) < 1e-5, v
+    m2 = _load(M.GACFV2(U, I, L, 64, [64, 64], 0.0), g, "v2.p.").to(dev).eval()
+    assert _rel(m2(u, it), g["v2_scores"]) < 1e-5

@@ -198,6 +198,23 @@ def test_g14_dense_multi_head_attention_and_the_models_on_it():
     assert np.abs(s2 - g["mk_scores"]).max() < 1e-4 * max(np.abs(g["mk_scores"]).max(), 1.0)
 
 
+def test_g16_gacf_variants():
+    """GACFV2 .. GACFV5 (GACFmodel2-5.py): the numpy restatement against the reference's scores (V3-V5 on g14's V1 parameters)."""
+    import scipy.sparse as sp
+    g14, g = load_golden("g14_dense_mha"), load_golden("g16_gacf_variants")
+    U, I = int(g14["U"]), int(g14["I"])
+    N = U + I
+    L = sp.coo_matrix((g14["L_val"].astype(np.float64), (g14["L_row"], g14["L_col"])), shape=(N, N)).tocsr()
+    p1 = {k[len("v1.p."):]: v.astype(np.float64) for k, v in g14.items() if k.startswith("v1.p.")}
+    for v in (3, 4, 5):
+        got = O.gacfv1_scores(p1, L, g14["u"], g14["item"], U, I, variant=v)
+        want = g["v%d_scores" % v]
+        assert np.abs(got - want).max() < 1e-4 * max(np.abs(want).max(), 1.0), v
+    p2 = {k[len("v2.p."):]: v.astype(np.float64) for k, v in g.items() if k.startswith("v2.p.")}
+    got = O.gacfv2_scores(p2, L, g14["u"], g14["item"], U, I)
+    assert np.abs(got - g["v2_scores"]).max() < 1e-4 * max(np.abs(g["v2_scores"]).max(), 1.0)
+
+
 def test_g15_spga_model_wrappers():
     """SPGACF / MultiLayerSPGA / SPGAMGP (SPGA.py:85-316): the numpy restatement against the reference's scores."""
     import scipy.sparse as sp
