@@ -26,13 +26,15 @@
  *   srow  int32[nshort]  the short dst rows (degree <= plan.short_max): traversed one lane group per row.
  *                        First the user rows (sorted by degree, descending, padded with -1 to a multiple of
  *                        16 = nshort_user entries), then the item rows (sorted likewise)
+ *   hrow  int32[nhub]    the hub rows (plan.seg_len < degree <= plan.hub_cap): ONE WORKGROUP per row, its four waves
+ *                        stride over the row's edges and fold through LDS; the first nhub_user entries are user rows
  *   nseg_user            number of leading entries of `segs` that are user rows; a launch works through
- *                        [user segs][user short rows][item segs][item short rows], so each half re-reads only
- *                        ONE of the two node tables and that table stays L2 resident
+ *                        [user hubs][user segs][user short rows][item hubs][item segs][item short rows], so each
+ *                        half re-reads only ONE of the two node tables and that table stays L2 resident
  *   segs  int32[nseg][4] work items of the long rows {dst row, first edge, one-past-last edge, part}:
- *                        part < 0  -> the segment is the whole row, finished in place;
- *                        part >= 0 -> slice of a hub row, partial sums go to slot `part`
- *   split int32[nsplit][3] {dst row, first part slot, number of slots} for the hub rows
+ *                        part < 0  -> the segment is the whole row (degree <= seg_len), finished in place;
+ *                        part >= 0 -> slice of a row beyond hub_cap, partial sums go to slot `part`
+ *   split int32[nsplit][3] {dst row, first part slot, number of slots} for the rows cut into slices
  */
 #ifndef NGACF_H
 #define NGACF_H
@@ -96,7 +98,8 @@ int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float* W, const f
  * drop_p > 0 applies the edge dropout of :375 (numerators only), mask keyed by
  * (seed, head, user, item) so both directions see the same mask. */
 int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                   const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,
+                   const int32_t* srow, int nshort, int nseg_user, int nshort_user,
+                   const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
                    void* out, float* agg, float* R, float* part_acc, float* part_r,
@@ -115,7 +118,8 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  *   and the 4-byte-per-element table is neither written nor read back
  *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows */
 int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                   const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,
+                   const int32_t* srow, int nshort, int nseg_user, int nshort_user,
+                   const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
                    const void* out, const float* agg, const float* R, const void* gout,

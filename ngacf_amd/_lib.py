@@ -24,9 +24,9 @@ _u64 = ctypes.c_uint64
 # name -> argtypes, exactly the prototypes of include/ngacf.h
 SIGNATURES = {
     "ngacf_transform_fwd": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _p],
-    "ngacf_prop_fwd": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+    "ngacf_prop_fwd": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                        _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p],
-    "ngacf_prop_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
+    "ngacf_prop_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
                        _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p],
     "ngacf_transform_bwd": [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _p],
     "ngacf_transform_fwd_rows": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _p, _p],

@@ -121,28 +121,35 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
 
-// Work order of one traversal launch: [user long segments][user short rows][item long segments][item short rows].
+// Work order of one traversal launch (workgroups, in dispatch order):
+//   [user hub rows][user long segments][user short rows][item hub rows][item long segments][item short rows]
 // User rows gather item rows only and vice versa, so each half of the launch re-reads ONE of the two tables
-// (5 MB instead of 9 MB at Gowalla scale, bf16) and that table largely stays in the 4 MB L2 of each XCD.
+// (5 MB instead of 9 MB at Gowalla scale, bf16) and that table largely stays in the 4 MB L2 of each XCD.  Hub rows
+// (one workgroup per row) lead each half: the longest work starts first.
 struct WorkOrder {
-    int nseg, nseg_u, nshort, nshort_u;    // totals and the leading user parts (nshort_u is a multiple of 16)
-    int nbA, nbB, nbC;                     // workgroups of the first three groups
+    int nseg, nseg_u, nshort, nshort_u, nhub, nhub_u;   // totals and the leading user parts (nshort_u is a multiple of 16)
+    int b0, b1, b2, b3, b4;                             // prefix sums of the first five groups' workgroup counts
 };
-__host__ inline WorkOrder make_order(int nseg, int nseg_u, int nshort, int nshort_u, int epi, int* nblocks) {
+__host__ inline WorkOrder make_order(int nseg, int nseg_u, int nshort, int nshort_u, int nhub, int nhub_u, int epi, int* nblocks) {
     WorkOrder o;
-    o.nseg = nseg; o.nseg_u = nseg_u; o.nshort = nshort; o.nshort_u = nshort_u;
-    o.nbA = (nseg_u + 3) / 4;
-    o.nbB = ((nshort_u + epi - 1) / epi + 3) / 4;
-    o.nbC = (nseg - nseg_u + 3) / 4;
-    *nblocks = o.nbA + o.nbB + o.nbC + (((nshort - nshort_u) + epi - 1) / epi + 3) / 4;
+    o.nseg = nseg; o.nseg_u = nseg_u; o.nshort = nshort; o.nshort_u = nshort_u; o.nhub = nhub; o.nhub_u = nhub_u;
+    o.b0 = nhub_u;
+    o.b1 = o.b0 + (nseg_u + 3) / 4;
+    o.b2 = o.b1 + ((nshort_u + epi - 1) / epi + 3) / 4;
+    o.b3 = o.b2 + (nhub - nhub_u);
+    o.b4 = o.b3 + (nseg - nseg_u + 3) / 4;
+    *nblocks = o.b4 + (((nshort - nshort_u) + epi - 1) / epi + 3) / 4;
     return o;
 }
-// -> is_short, first item of this wave's group (segment index or short-row index), end of the group
-__device__ __forceinline__ void locate(const WorkOrder& o, int block, int wave, int epi, bool& is_short, int& idx, int& end) {
-    if (block < o.nbA) { is_short = false; idx = block * 4 + wave; end = o.nseg_u; }
-    else if (block < o.nbA + o.nbB) { is_short = true; idx = ((block - o.nbA) * 4 + wave) * epi; end = o.nshort_u; }
-    else if (block < o.nbA + o.nbB + o.nbC) { is_short = false; idx = o.nseg_u + (block - o.nbA - o.nbB) * 4 + wave; end = o.nseg; }
-    else { is_short = true; idx = o.nshort_u + ((block - o.nbA - o.nbB - o.nbC) * 4 + wave) * epi; end = o.nshort; }
+enum WorkKind { WORK_HUB = 0, WORK_LONG = 1, WORK_SHORT = 2 };
+// -> kind, first item of this wave's group (hub-row index of the WORKGROUP, segment index or short-row index of the wave), end
+__device__ __forceinline__ void locate(const WorkOrder& o, int block, int wave, int epi, int& kind, int& idx, int& end) {
+    if (block < o.b0) { kind = WORK_HUB; idx = block; end = o.nhub_u; }
+    else if (block < o.b1) { kind = WORK_LONG; idx = (block - o.b0) * 4 + wave; end = o.nseg_u; }
+    else if (block < o.b2) { kind = WORK_SHORT; idx = ((block - o.b1) * 4 + wave) * epi; end = o.nshort_u; }
+    else if (block < o.b3) { kind = WORK_HUB; idx = o.nhub_u + (block - o.b2); end = o.nhub; }
+    else if (block < o.b4) { kind = WORK_LONG; idx = o.nseg_u + (block - o.b3) * 4 + wave; end = o.nseg; }
+    else { kind = WORK_SHORT; idx = o.nshort_u + ((block - o.b4) * 4 + wave) * epi; end = o.nshort; }
 }
 
 #define NGACF_CHECK_LAUNCH()                                   \

@@ -7,8 +7,10 @@
 //   short rows (degree <= plan.short_max, the bulk): one slot per destination row, EPI rows
 //     per wave, rows pre-sorted by degree so the slots of a wave finish together.  No
 //     cross-lane reduction at all; prologue/epilogue amortised over EPI rows.
-//   long rows / slices of hub rows: one wave per segment, slots stride over the edges,
-//     one cross-slot fold at the end; hub rows leave partial sums for a small second kernel.
+//   long rows (degree <= seg_len): one wave per row, slots stride over the edges, one cross-slot fold at the end.
+//   hub rows (degree > seg_len): one WORKGROUP per row -- the four waves stride over the edges and fold through LDS;
+//     dispatched first in their half.  (A second kernel summing per-slice partials cost 5 us per stage, 12 % of a
+//     forward pass, for a few hundred rows.)  Rows beyond plan.hub_cap keep the slice + partial-sum path.
 //
 // The first version (wave per row everywhere) was VALU-issue bound at 540 instructions per
 // 28-edge row (rocprof: profiles/r01_v0_*); this layout needs ~4 VALU per edge.
@@ -21,6 +23,7 @@ struct PropArgs {
     int nseg;
     const int* srow;       // short mode: dst rows sorted by degree, descending
     int nshort;
+    const int* hrow;       // hub mode: one workgroup per row (users first, by degree descending)
     const int* rowptr;     // int32 [N+1]
     const int* col;
     const void* H;
@@ -143,11 +146,70 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
     float rsum = 0.f;
     float av[VEC];
 
-    bool is_short;
-    int widx, wend;
-    locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, is_short, widx, wend);
+    int kind, widx, wend;
+    locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, kind, widx, wend);
+    if (kind == WORK_HUB) {
+        // ------------------------------------------------------------------ hub rows: workgroup per row
+        // The four waves stride over the row's edges (EPI * UNROLL per wave and step); slots fold inside each wave,
+        // waves through LDS in wave order (deterministic); wave 0 finishes the row.  No partial sums in memory.
+        __shared__ float hub_acc[3][D];
+        __shared__ float hub_r[3][HEADS];
+        const int wv = threadIdx.x >> 6;
+        const int row = uniform(a.hrow[widx]);
+        const int beg = uniform(a.rowptr[row]), end = uniform(a.rowptr[row + 1]);
+        const bool dst_is_user = row < a.U;
+        const float s_dst = a.S_dst[(size_t)row * HEADS + head];
+        if (FROM_ROW) {
+            const float* ap = a.avec + (dst_is_user ? D : 0) + q * VEC;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) av[j] = ap[j];
+        }
+        uint32_t salt_h = 0, row_key = 0;
+        if (DROP) {
+            salt_h = salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + head);
+            row_key = dst_is_user ? (uint32_t)row * RNG_K1 : (uint32_t)row * RNG_K2 + salt_h;
+        }
+        for (int base = beg + wv * EPI * UNROLL; base < end; base += 4 * EPI * UNROLL) {
+            int c[UNROLL];
+            bool ok[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int e = base + u * EPI + slot;
+                ok[u] = e < end;
+                c[u] = a.col[ok[u] ? e : end - 1];
+            }
+            float hv[UNROLL][VEC], ss[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                load_slice<T, SHIFT>(a.H, c[u], q, hv[u]);
+                ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[u] * HEADS + head];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                edge_step<T, D, HEADS, FROM_ROW, DROP>(a, hv[u], ss[u], ok[u], c[u], s_dst, av, dst_is_user, row_key, salt_h, acc, rsum);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
+        rsum = group_sum<LPR, WAVE>(rsum);
+        if (wv > 0 && slot == 0) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) hub_acc[wv - 1][q * VEC + j] = acc[j];
+            if ((q * VEC) % SH::HW == 0) hub_r[wv - 1][head] = rsum;
+        }
+        __syncthreads();
+        if (wv == 0 && slot == 0) {
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += hub_acc[x][q * VEC + j];
+                rsum += hub_r[x][head];
+            }
+            finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+        }
+        return;
+    }
     if (widx >= wend) return;
-    if (is_short) {
+    if (kind == WORK_SHORT) {
         // ------------------------------------------------------------------ short rows: slot per row
         const int ridx = widx + slot;
         const int rraw = a.srow[ridx < wend ? ridx : wend - 1];
@@ -328,7 +390,7 @@ template <typename T, int D, int HEADS>
 static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st) {
     constexpr int EPI = Shape<T, D, HEADS>::EPI;
     int nb = 0;
-    a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, EPI, &nb);
+    a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, a.order.nhub, a.order.nhub_u, EPI, &nb);
     if (nb > 0) {
         const dim3 grid(nb), block(256);
         if (from_row) {
@@ -352,7 +414,8 @@ static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, b
 using namespace ngacf;
 
 extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                              const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,
+                              const int32_t* srow, int nshort, int nseg_user, int nshort_user,
+                              const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
                               const int32_t* col, const void* H, int dtype,
                               const float* S_dst, const float* S_src, const float* avec,
                               void* out, float* agg, float* R, float* part_acc, float* part_r,
@@ -362,9 +425,10 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
     if (nseg_user < 0 || nseg_user > nseg || nshort_user < 0 || nshort_user > nshort || (nshort_user % 16 != 0 && nshort_user != nshort))
         return NGACF_E_ARG;
-    if (nseg + nshort == 0) return 0;
+    if (nhub < 0 || nhub_user < 0 || nhub_user > nhub) return NGACF_E_ARG;
+    if (nseg + nshort + nhub == 0) return 0;
     if (!col || !H || !S_dst || !out || !rowptr) return NGACF_E_ARG;
-    if ((nseg > 0 && !segs) || (nshort > 0 && !srow)) return NGACF_E_ARG;
+    if ((nseg > 0 && !segs) || (nshort > 0 && !srow) || (nhub > 0 && !hrow)) return NGACF_E_ARG;
     const bool from_row = (flags & NGACF_SCORE_ROW) != 0;
     if (from_row ? !avec : !S_src) return NGACF_E_ARG;
     if (nsplit > 0 && (!split || !part_acc || !part_r)) return NGACF_E_ARG;
@@ -373,6 +437,7 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
     if ((uint64_t)N * (uint64_t)d * elem >= (1ull << 32)) return NGACF_E_SHAPE;   // 32-bit row offsets
     PropArgs a;
     a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
+    a.hrow = hrow; a.order.nhub = nhub; a.order.nhub_u = nhub_user;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R;
     a.part_acc = part_acc; a.part_r = part_r; a.split = split; a.part_split = part_split;
     a.tickets = (part_split && nsplit > 0) ? tickets : nullptr; a.U = U; a.N = N; a.order.nseg_u = nseg_user; a.order.nshort_u = nshort_user; a.alpha = alpha;

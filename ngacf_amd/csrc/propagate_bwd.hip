@@ -22,6 +22,7 @@ struct PropBwdArgs {
     int nseg;
     const int* srow;
     int nshort;
+    const int* hrow;               // hub rows: one workgroup per row (see propagate.hip)
     const int* rowptr;
     const int* col;
     const void* H;
@@ -215,11 +216,60 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
     float dsum = 0.f;
     RowCtx<VEC> x;
 
-    bool is_short;
-    int widx, wend;
-    locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, is_short, widx, wend);
+    int kind, widx, wend;
+    locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, kind, widx, wend);
+    if (kind == WORK_HUB) {
+        // ------------------------------------------------------------------ hub rows: workgroup per row (as in the forward)
+        __shared__ float hub_acc[3][D];
+        __shared__ float hub_d[3][HEADS];
+        const int wv = threadIdx.x >> 6;
+        const int row = uniform(a.hrow[widx]);
+        const int beg = uniform(a.rowptr[row]), end = uniform(a.rowptr[row + 1]);
+        load_ctx<T, D, HEADS, FROM_ROW, DROP>(a, row, q, head, x);
+        for (int base = beg + wv * EPI * UNROLL; base < end; base += 4 * EPI * UNROLL) {
+            int c[UNROLL];
+            bool ok[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int e = base + u * EPI + slot;
+                ok[u] = e < end;
+                c[u] = a.col[ok[u] ? e : end - 1];
+            }
+            float hv[UNROLL][VEC], gv[UNROLL][VEC];
+            float ss[UNROLL], tc[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                load_row<T, D, HEADS>(a.H, c[u], q, hv[u]);
+                load_row<T, D, HEADS>(a.Gn, c[u], q, gv[u]);
+                tc[u] = a.Tn[(size_t)c[u] * HEADS + head];
+                ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[u] * HEADS + head];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], ok[u], c[u], acc, dsum);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
+        dsum = group_sum<LPR, WAVE>(dsum);
+        if (wv > 0 && slot == 0) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) hub_acc[wv - 1][q * VEC + j] = acc[j];
+            if ((q * VEC) % HW == 0) hub_d[wv - 1][head] = dsum;
+        }
+        __syncthreads();
+        if (wv == 0 && slot == 0) {
+#pragma unroll
+            for (int w2 = 0; w2 < 3; ++w2) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += hub_acc[w2][q * VEC + j];
+                dsum += hub_d[w2][head];
+            }
+            finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
+        }
+        return;
+    }
     if (widx >= wend) return;
-    if (is_short) {
+    if (kind == WORK_SHORT) {
         // ------------------------------------------------------------------ short rows: slot per row
         const int ridx = widx + slot;
         const int rraw = a.srow[ridx < wend ? ridx : wend - 1];
@@ -337,7 +387,7 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
     }
     if (!do_edges) return 0;
     int nb = 0;
-    a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, EPI, &nb);
+    a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, a.order.nhub, a.order.nhub_u, EPI, &nb);
     if (nb > 0) {
         const dim3 grid(nb), block(256);
         if (from_row) {
@@ -361,7 +411,8 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
 using namespace ngacf;
 
 static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                         const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,
+                         const int32_t* srow, int nshort, int nseg_user, int nshort_user,
+                         const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
                          const int32_t* col, const void* H, int dtype,
                          const float* S_dst, const float* S_src, const float* avec,
                          const void* out, const float* agg, const float* R, const void* gout,
@@ -373,6 +424,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
     if (nseg_user < 0 || nseg_user > nseg || nshort_user < 0 || nshort_user > nshort || (nshort_user % 16 != 0 && nshort_user != nshort))
         return NGACF_E_ARG;
+    if (nhub < 0 || nhub_user < 0 || nhub_user > nhub) return NGACF_E_ARG;
     if (nu_lo < 0 || nu_n < 0 || ni_lo < 0 || ni_n < 0 || nu_lo + nu_n > U || ni_lo + ni_n > N - U) return NGACF_E_ARG;
     if (N == 0) return 0;
     if (!S_src || !Gn || !ST) return NGACF_E_ARG;
@@ -380,7 +432,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     if (do_node && (!out || !agg || !R || !gout)) return NGACF_E_ARG;
     if (do_edges) {
         if (!col || !rowptr || !H || !S_dst || !avec || !dH || !dS) return NGACF_E_ARG;
-        if ((nseg > 0 && !segs) || (nshort > 0 && !srow)) return NGACF_E_ARG;
+        if ((nseg > 0 && !segs) || (nshort > 0 && !srow) || (nhub > 0 && !hrow)) return NGACF_E_ARG;
         if (nsplit > 0 && (!split || !part_acc || !part_r)) return NGACF_E_ARG;
     }
     if (!(drop_p >= 0.f && drop_p < 1.f) || !(alpha > 0.f && alpha < 1.f)) return NGACF_E_ARG;
@@ -388,6 +440,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     const bool from_row = (flags & NGACF_SCORE_ROW) != 0;
     PropBwdArgs a;
     a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
+    a.hrow = hrow; a.order.nhub = nhub; a.order.nhub_u = nhub_user;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R; a.gout = gout;
     a.G = G; a.Gn = Gn; a.Tn = ST; a.dH = dH; a.dS = dS; a.part_acc = part_acc; a.part_r = part_r;
     a.U = U; a.N = N; a.nu_lo = nu_lo; a.nu_n = nu_n; a.ni_lo = ni_lo; a.ni_n = ni_n; a.gout_local = gout_local;
@@ -412,7 +465,8 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
 }
 
 extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                              const int32_t* srow, int nshort, int nseg_user, int nshort_user, const int32_t* rowptr,
+                              const int32_t* srow, int nshort, int nseg_user, int nshort_user,
+                              const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
                               const int32_t* col, const void* H, int dtype,
                               const float* S_dst, const float* S_src, const float* avec,
                               const void* out, const float* agg, const float* R, const void* gout,
@@ -421,7 +475,7 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
                               int U, int N, int d, int heads, float alpha,
                               float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
     const bool skip_node = (flags & NGACF_SKIP_NODE) != 0;
-    return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, nseg_user, nshort_user, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
+    return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, nseg_user, nshort_user, hrow, nhub, nhub_user, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
                          G, Gn, ST, dH, dS, part_acc, part_r, U, N, d, heads, alpha, drop_p, seed, seed_dev, flags,
                          0, U, 0, N - U, 0, !skip_node, true, stream);
 }
@@ -430,7 +484,7 @@ extern "C" int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg,
                                    const float* S_src, float* G, void* Gn, float* ST,
                                    int U, int N, int d, int heads, int flags,
                                    int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream) {
-    return prop_bwd_impl(nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, dtype, nullptr, S_src, nullptr,
+    return prop_bwd_impl(nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, dtype, nullptr, S_src, nullptr,
                          out, agg, R, gout, G, Gn, ST, nullptr, nullptr, nullptr, nullptr, U, N, d, heads, 0.2f, 0.f, 0, nullptr, flags,
                          u_lo, u_n, i_lo, i_n, gout_local, true, false, stream);
 }

@@ -116,16 +116,20 @@ def _plan_ptrs(plan, dev, half=None):
     col = _chk(plan.col, "plan.col", torch.int32, plan.n_edges_directed, dev) if plan.n_edges_directed else 0
     srow = _chk(plan.srow, "plan.srow", torch.int32, plan.nshort, dev) if plan.nshort else 0
     rowptr = _chk(plan.rowptr32, "plan.rowptr32", torch.int32, plan.N + 1, dev)
+    hrow = _chk(plan.hrow, "plan.hrow", torch.int32, plan.nhub, dev, align=4) if plan.nhub else 0
     if half is None:
-        return (segs, plan.nseg, split, plan.nsplit, srow, plan.nshort, plan.nseg_user, plan.nshort_user, rowptr, col)
+        return (segs, plan.nseg, split, plan.nsplit, srow, plan.nshort, plan.nseg_user, plan.nshort_user,
+                hrow, plan.nhub, plan.nhub_user, rowptr, col)
     if INKERNEL_HUB_FINISH:
-        raise ValueError("half launches use the two-kernel hub-row path (unset NGACF_INKERNEL_HUB)")
+        raise ValueError("half launches use the two-kernel path for sliced rows (unset NGACF_INKERNEL_HUB)")
     if half == "user":
-        return (segs, plan.nseg_user, split, plan.nsplit_user, srow, plan.nshort_user, plan.nseg_user, plan.nshort_user, rowptr, col)
+        return (segs, plan.nseg_user, split, plan.nsplit_user, srow, plan.nshort_user, plan.nseg_user, plan.nshort_user,
+                hrow, plan.nhub_user, plan.nhub_user, rowptr, col)
     if half == "item":
         ns, nsh, nsp = plan.nseg - plan.nseg_user, plan.nshort - plan.nshort_user, plan.nsplit - plan.nsplit_user
+        nh = plan.nhub - plan.nhub_user
         return (segs + 16 * plan.nseg_user if ns else 0, ns, split + 12 * plan.nsplit_user if nsp else 0, nsp,
-                srow + 4 * plan.nshort_user if nsh else 0, nsh, 0, 0, rowptr, col)
+                srow + 4 * plan.nshort_user if nsh else 0, nsh, 0, 0, hrow + 4 * plan.nhub_user if nh else 0, nh, 0, rowptr, col)
     raise ValueError("half must be None, 'user' or 'item'")
 
 

@@ -4,8 +4,9 @@ run_Gowalla.py:94) turned once into the traversal layout of include/ngacf.h:
 
   col    int32[2E]   CSR of the user rows followed by the CSC of the item rows, sources
                      as global node ids (items offset by U)
-  segs   int32[S,4]  {dst row, beg, end, part}: rows longer than `seg_len` edges are cut
-                     into slices with their own partial-sum slot; longest segments first
+  hrow   int32[H]    hub rows (seg_len < degree <= hub_cap): one workgroup per row, folded through LDS
+  segs   int32[S,4]  {dst row, beg, end, part}: rows of short_max < degree <= seg_len are one segment; rows
+                     beyond hub_cap are cut into slices with their own partial-sum slot; longest first
   split  int32[P,3]  {dst row, first slot, slot count} of the cut rows
 
 Everything is a torch tensor on the graph's device (PyTorch owns the memory).  Built
@@ -17,7 +18,7 @@ import torch
 
 class GraphPlan:
     def __init__(self, U, I, E, rowptr, col, segs, split, nparts, seg_len, row_lo=0, row_hi=None,
-                 srow=None, short_max=0, row_ranges=None):
+                 srow=None, short_max=0, row_ranges=None, hrow=None, nhub_user=0):
         self.U, self.I, self.N, self.E = U, I, U + I, E
         self.rowptr, self.col, self.segs, self.split = rowptr, col, segs, split
         self.nseg, self.nsplit, self.nparts = int(segs.shape[0]), int(split.shape[0]), int(nparts)
@@ -33,6 +34,10 @@ class GraphPlan:
         self.srow = srow if srow is not None else torch.empty(0, dtype=torch.int32, device=col.device)
         self.nshort, self.short_max = int(self.srow.shape[0]), short_max
         self.nseg_user, self.nshort_user, self.nsplit_user = self.nseg, self.nshort, self.nsplit   # build_plan sets the user/item split
+        # hub rows (degree > seg_len, up to hub_cap): one WORKGROUP per row, its four waves stride over the row's edges and
+        # fold through LDS -- no partial sums in memory, no second kernel.  Users first, each half by degree descending.
+        self.hrow = hrow if hrow is not None else torch.empty(0, dtype=torch.int32, device=col.device)
+        self.nhub, self.nhub_user = int(self.hrow.shape[0]), int(nhub_user)
         self.rowptr32 = rowptr.to(torch.int32).contiguous()
         # hub rows: slot -> hub row, and one arrival counter per hub row (zero between launches)
         if self.nsplit:
@@ -56,7 +61,8 @@ class GraphPlan:
     def to(self, device):
         p = GraphPlan(self.U, self.I, self.E, self.rowptr.to(device), self.col.to(device),
                       self.segs.to(device), self.split.to(device), self.nparts, self.seg_len,
-                      self.row_lo, self.row_hi, self.srow.to(device), self.short_max, self.row_ranges)
+                      self.row_lo, self.row_hi, self.srow.to(device), self.short_max, self.row_ranges,
+                      self.hrow.to(device), self.nhub_user)
         p.nseg_user, p.nshort_user, p.nsplit_user = self.nseg_user, self.nshort_user, self.nsplit_user
         return p
 
@@ -90,7 +96,7 @@ def squeeze_mask(mask):
     return mask[0] if mask.dim() == 3 and mask.shape[0] == 1 else mask
 
 
-def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None, short_max=64):
+def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None, short_max=64, hub_cap=None):
     """indices: [2,E] (or [1,2,E], run under DataParallel: SPUIGACF.py:42 squeezes it) integer
     tensor.  Duplicate pairs are merged like `.coalesce()`.  `row_range=(lo,hi)` -- or a list of such
     ranges -- keeps only those dst rows (node partition of ngacf_amd/dist.py); sources stay global.
@@ -126,7 +132,7 @@ def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True,
             # the reference asserts e_rowsum != 0 for every user (SPUIGACF.py:368)
             raise ValueError("user %d has no interaction: the reference asserts on a zero attention row-sum"
                              % int(torch.argmin(deg_u)))
-    return build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len, short_max)
+    return build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len, short_max, hub_cap)
 
 
 def _ranges(row_range, N):
@@ -142,7 +148,15 @@ def _ranges(row_range, N):
     return ranges
 
 
-def build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len=256, short_max=64):
+def default_hub_cap(n_edges_directed):
+    """Largest degree a single workgroup takes.  A workgroup folds ~128 edges per ~0.15 us step while the whole launch
+    streams its edges at ~20 ps each: a row holding up to ~1.5 % of the launch's edges finishes inside the launch when
+    dispatched first (Gowalla scale: 14 k of 2.05 M; 10^9 edges: 4.7 M of 2x10^9).  Rows beyond it fall back to 256-edge
+    slices + the slot-order partial-sum pass."""
+    return max(4096, int(0.015 * n_edges_directed))
+
+
+def build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len=256, short_max=64, hub_cap=None):
     """The plan of the dst rows in `ranges` from the two sorted, unique key arrays a rank owns:
          csr_key = user * I + item   for every edge whose USER row is in the ranges,
          csc_key = item * U + user   for every edge whose ITEM row is in the ranges
@@ -171,14 +185,24 @@ def build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len=256, short_max=
     pad = (-sr[0].numel()) % 16
     nshort_user = sr[0].numel() + pad
     srow = torch.cat([sr[0], torch.full((pad,), -1, dtype=torch.long, device=dev), sr[1]]).to(torch.int32).contiguous()
-    seg_u, split_u, np_u = _segments(rowptr, rows[~is_short & is_user], seg_len)
-    seg_i, split_i, np_i = _segments(rowptr, rows[~is_short & ~is_user], seg_len)
+    # hub rows: seg_len < degree <= hub_cap -> one workgroup each (hub_cap = 0: none, every long row is cut into slices)
+    cap = default_hub_cap(int(col.numel())) if hub_cap is None else int(hub_cap)
+    is_hub = ~is_short & (deg > seg_len) & (deg <= cap)
+    hr = []
+    for m in (is_hub & is_user, is_hub & ~is_user):
+        order = torch.sort(deg[m], descending=True, stable=True).indices
+        hr.append(rows[m][order])
+    hrow = torch.cat(hr).to(torch.int32).contiguous()
+    nhub_user = int(hr[0].numel())
+    seg_u, split_u, np_u = _segments(rowptr, rows[~is_short & ~is_hub & is_user], seg_len)
+    seg_i, split_i, np_i = _segments(rowptr, rows[~is_short & ~is_hub & ~is_user], seg_len)
     seg_i[:, 3] = torch.where(seg_i[:, 3] >= 0, seg_i[:, 3] + np_u, seg_i[:, 3])
     split_i[:, 1] += np_u
     segs = torch.cat([seg_u, seg_i]).contiguous()
     split = torch.cat([split_u, split_i]).contiguous()
     nparts = np_u + np_i
-    plan = GraphPlan(U, I, E, rowptr, col, segs, split, nparts, seg_len, lo, hi, srow, short_max, ranges)
+    plan = GraphPlan(U, I, E, rowptr, col, segs, split, nparts, seg_len, lo, hi, srow, short_max, ranges, hrow, nhub_user)
+    plan.hub_cap = cap
     plan.nseg_user, plan.nshort_user, plan.nsplit_user = int(seg_u.shape[0]), int(nshort_user), int(split_u.shape[0])
     validate_plan(plan)
     return plan
@@ -230,5 +254,13 @@ def validate_plan(p):
         si = p.segs[p.nseg_user:, 0].long()
         assert (su.numel() == 0 or int(su.max()) < p.U) and (si.numel() == 0 or int(si.min()) >= p.U)
     assert int(p.rowptr[-1]) == n2e and int(p.rowptr[-1]) < 2 ** 31
-    covered = n_real_short + (int(torch.unique(p.segs[:, 0]).numel()) if p.nseg else 0)
+    if p.nhub:
+        h = p.hrow.long()
+        assert 0 <= p.nhub_user <= p.nhub and int(h.min()) >= 0 and int(h.max()) < p.N
+        assert bool((h[:p.nhub_user] < p.U).all()) and bool((h[p.nhub_user:] >= p.U).all()), "hub rows: users first, then items"
+        hd = p.rowptr[h + 1] - p.rowptr[h]
+        assert int(hd.min()) > p.seg_len and int(torch.unique(h).numel()) == p.nhub, "hub rows are long rows, each listed once"
+        if p.nseg:
+            assert not bool(torch.isin(h, p.segs[:, 0].long()).any()), "a hub row must not also be a segment row"
+    covered = n_real_short + (int(torch.unique(p.segs[:, 0]).numel()) if p.nseg else 0) + p.nhub
     assert covered == p.n_rows, "every dst row of the plan's ranges must be covered exactly once"

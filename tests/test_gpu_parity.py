@@ -73,10 +73,10 @@ def test_library_loaded_and_rejects_bad_shapes(dev):
     from ngacf_amd import _lib
     assert "gfx950" in ngacf_amd.version()
     # unsupported row width is refused before any launch
-    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 2, 48, 1, 0.2, 0.0, 0, 0, 3, 0)
+    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 2, 48, 1, 0.2, 0.0, 0, 0, 3, 0)
     assert rc == -2
     # a table of 2^32 bytes or more does not fit the 32-bit row offsets: refused, not wrapped
-    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1 << 24, 64, 8, 0.2, 0.0, 0, 0, 3, 0)
+    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1 << 24, 64, 8, 0.2, 0.0, 0, 0, 3, 0)
     assert rc == -2
     assert _lib.lib.ngacf_score_fwd(0, 0, 0, 0, 0, 0, 5, 1, 1, 64, 0) == -1
 

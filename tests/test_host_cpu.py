@@ -39,8 +39,8 @@ def test_plan_matches_scipy_csr_and_covers_every_row():
     g = load_golden("g1_layer_k8_concat")
     U, I = int(g["U"]), int(g["I"])
     edge = g["edge"]
-    for seg, short in ((256, 64), (8, 4), (4, -1), (1 << 20, 1 << 20)):
-        p = build_plan(torch.from_numpy(edge), U, I, seg_len=seg, short_max=short)
+    for seg, short, cap in ((256, 64, None), (8, 4, None), (8, 4, 0), (8, 4, 12), (4, -1, 0), (1 << 20, 1 << 20, None)):
+        p = build_plan(torch.from_numpy(edge), U, I, seg_len=seg, short_max=short, hub_cap=cap)
         A = sp.csr_matrix((np.ones(edge.shape[1]), (edge[0], edge[1])), shape=(U, I))
         At = A.T.tocsr()
         rowptr = np.concatenate([A.indptr, A.indptr[-1] + At.indptr[1:]])
@@ -58,6 +58,15 @@ def test_plan_matches_scipy_csr_and_covers_every_row():
             seen[b:e] += 1
             assert rowptr[r] <= b <= e <= rowptr[r + 1]
         rows_done[np.unique(p.segs.numpy()[:, 0])] += 1 if p.nseg else 0
+        for r in p.hrow.numpy():                        # hub rows: a workgroup takes the whole row
+            seen[rowptr[r]:rowptr[r + 1]] += 1
+            rows_done[r] += 1
+            assert seg < rowptr[r + 1] - rowptr[r] <= p.hub_cap
+        assert (p.hrow.numpy()[:p.nhub_user] < U).all() and (p.hrow.numpy()[p.nhub_user:] >= U).all()
+        if cap == 0:
+            assert p.nhub == 0
+        if cap == 12:
+            assert p.nhub > 0 and p.nsplit > 0          # both paths present
         assert (seen == 1).all() and (rows_done == 1).all()
         for r, p0, n in p.split.numpy():
             parts = sorted(s[3] for s in p.segs.numpy() if s[0] == r)
