@@ -4,9 +4,9 @@ run_Gowalla.py:94) turned once into the traversal layout of include/ngacf.h:
 
   col    int32[2E]   CSR of the user rows followed by the CSC of the item rows, sources
                      as global node ids (items offset by U)
-  hrow   int32[H]    hub rows (seg_len < degree <= hub_cap): one workgroup per row, folded through LDS
-  segs   int32[S,4]  {dst row, beg, end, part}: rows of short_max < degree <= seg_len are one segment; rows
-                     beyond hub_cap are cut into slices with their own partial-sum slot; longest first
+  hrow   int32[H]    hub rows (long_max < degree <= hub_cap): one workgroup per row, folded through LDS
+  segs   int32[S,4]  {dst row, beg, end, part}: rows of short_max < degree <= long_max are one segment (one wave);
+                     rows beyond hub_cap are cut into seg_len slices with their own partial-sum slot; longest first
   split  int32[P,3]  {dst row, first slot, slot count} of the cut rows
 
 Everything is a torch tensor on the graph's device (PyTorch owns the memory).  Built
@@ -96,7 +96,8 @@ def squeeze_mask(mask):
     return mask[0] if mask.dim() == 3 and mask.shape[0] == 1 else mask
 
 
-def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None, short_max=64, hub_cap=None):
+def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None, short_max=64, hub_cap=None,
+               long_max=None):
     """indices: [2,E] (or [1,2,E], run under DataParallel: SPUIGACF.py:42 squeezes it) integer
     tensor.  Duplicate pairs are merged like `.coalesce()`.  `row_range=(lo,hi)` -- or a list of such
     ranges -- keeps only those dst rows (node partition of ngacf_amd/dist.py); sources stay global.
@@ -132,7 +133,7 @@ def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True,
             # the reference asserts e_rowsum != 0 for every user (SPUIGACF.py:368)
             raise ValueError("user %d has no interaction: the reference asserts on a zero attention row-sum"
                              % int(torch.argmin(deg_u)))
-    return build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len, short_max, hub_cap)
+    return build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len, short_max, hub_cap, long_max)
 
 
 def _ranges(row_range, N):
@@ -156,7 +157,7 @@ def default_hub_cap(n_edges_directed):
     return max(4096, int(0.015 * n_edges_directed))
 
 
-def build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len=256, short_max=64, hub_cap=None):
+def build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len=256, short_max=64, hub_cap=None, long_max=None):
     """The plan of the dst rows in `ranges` from the two sorted, unique key arrays a rank owns:
          csr_key = user * I + item   for every edge whose USER row is in the ranges,
          csc_key = item * U + user   for every edge whose ITEM row is in the ranges
@@ -185,24 +186,41 @@ def build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len=256, short_max=
     pad = (-sr[0].numel()) % 16
     nshort_user = sr[0].numel() + pad
     srow = torch.cat([sr[0], torch.full((pad,), -1, dtype=torch.long, device=dev), sr[1]]).to(torch.int32).contiguous()
-    # hub rows: seg_len < degree <= hub_cap -> one workgroup each (hub_cap = 0: none, every long row is cut into slices)
+    # Four classes by degree:  short (<= short_max): a lane group per row;  long (<= long_max): one wave per row;
+    # hub (<= hub_cap): one workgroup per row;  beyond hub_cap: cut into seg_len-edge slices + the partial-sum pass.
+    # long_max = 4 * seg_len by default: a wave folds 32 edges per step, so its longest row is 32 steps (~5 us, dispatched
+    # first) and a hub workgroup has at least 8 steps per wave -- a workgroup per 300-edge row would mostly synchronise
+    # (measured on the 10^9-edge graph, 1.27 M rows above 256 edges: 207 ms per pass against 111 ms).
+    # hub_cap = 0 disables the workgroup path: every row above seg_len is cut into slices (the pre-r02 layout; tests).
     cap = default_hub_cap(int(col.numel())) if hub_cap is None else int(hub_cap)
-    is_hub = ~is_short & (deg > seg_len) & (deg <= cap)
+    lmax = (4 * seg_len if cap > 0 else seg_len) if long_max is None else int(long_max)
+    lmax = max(lmax, short_max) if cap > 0 else seg_len
+    is_hub = ~is_short & (deg > lmax) & (deg <= cap)
+    is_big = ~is_short & ~is_hub & (deg > lmax)
+    is_long = ~is_short & ~is_hub & ~is_big
     hr = []
     for m in (is_hub & is_user, is_hub & ~is_user):
         order = torch.sort(deg[m], descending=True, stable=True).indices
         hr.append(rows[m][order])
     hrow = torch.cat(hr).to(torch.int32).contiguous()
     nhub_user = int(hr[0].numel())
-    seg_u, split_u, np_u = _segments(rowptr, rows[~is_short & ~is_hub & is_user], seg_len)
-    seg_i, split_i, np_i = _segments(rowptr, rows[~is_short & ~is_hub & ~is_user], seg_len)
+
+    def both(sel_user):
+        """segments of the long rows (one each) and of the rows beyond the cap (slices), slices' slots numbered first"""
+        big = _segments(rowptr, rows[is_big & sel_user], seg_len)
+        one = _segments(rowptr, rows[is_long & sel_user], max(lmax, 1))
+        segs_ = torch.cat([big[0], one[0]])
+        order = torch.sort(segs_[:, 2] - segs_[:, 1], descending=True, stable=True).indices    # longest first
+        return segs_[order].contiguous(), big[1], big[2]
+    seg_u, split_u, np_u = both(is_user)
+    seg_i, split_i, np_i = both(~is_user)
     seg_i[:, 3] = torch.where(seg_i[:, 3] >= 0, seg_i[:, 3] + np_u, seg_i[:, 3])
     split_i[:, 1] += np_u
     segs = torch.cat([seg_u, seg_i]).contiguous()
     split = torch.cat([split_u, split_i]).contiguous()
     nparts = np_u + np_i
     plan = GraphPlan(U, I, E, rowptr, col, segs, split, nparts, seg_len, lo, hi, srow, short_max, ranges, hrow, nhub_user)
-    plan.hub_cap = cap
+    plan.hub_cap, plan.long_max = cap, lmax
     plan.nseg_user, plan.nshort_user, plan.nsplit_user = int(seg_u.shape[0]), int(nshort_user), int(split_u.shape[0])
     validate_plan(plan)
     return plan
@@ -259,7 +277,8 @@ def validate_plan(p):
         assert 0 <= p.nhub_user <= p.nhub and int(h.min()) >= 0 and int(h.max()) < p.N
         assert bool((h[:p.nhub_user] < p.U).all()) and bool((h[p.nhub_user:] >= p.U).all()), "hub rows: users first, then items"
         hd = p.rowptr[h + 1] - p.rowptr[h]
-        assert int(hd.min()) > p.seg_len and int(torch.unique(h).numel()) == p.nhub, "hub rows are long rows, each listed once"
+        assert int(hd.min()) > getattr(p, "long_max", p.seg_len) and int(torch.unique(h).numel()) == p.nhub, \
+            "hub rows are beyond long_max, each listed once"
         if p.nseg:
             assert not bool(torch.isin(h, p.segs[:, 0].long()).any()), "a hub row must not also be a segment row"
     covered = n_real_short + (int(torch.unique(p.segs[:, 0]).numel()) if p.nseg else 0) + p.nhub

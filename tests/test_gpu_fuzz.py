@@ -70,13 +70,16 @@ def test_random_stage_forward_backward_vs_oracle(seed):
     if p_drop > 0:                                                          # chain rule through the feature mask
         gX_o = gX_o * rng.keep_scale(rng.feat_bits(dseed, nn_, cc_), p_drop).astype(np.float64)
         X = X_in
-    plan = build_plan(torch.from_numpy(edge).to(dev), U, I, seg_len=seg_len, short_max=short_max)
+    # hub layout: the default (workgroup per row beyond 4 * seg_len), no hubs (slices + partial sums), or both
+    hub_cap = [None, 0, int(rs.randint(1, 200))][seed % 3]
+    long_max = None if seed % 2 else seg_len
+    plan = build_plan(torch.from_numpy(edge).to(dev), U, I, seg_len=seg_len, short_max=short_max, hub_cap=hub_cap, long_max=long_max)
     Xt = torch.from_numpy(X).float().to(dev).requires_grad_(True)
     W = torch.from_numpy(np.stack([np.concatenate([w[0] for w in Wl], 1), np.concatenate([w[1] for w in Wl], 1)])).float().to(dev).requires_grad_(True)
     av = torch.from_numpy(np.stack([np.concatenate([w[2][0, :k] for w in Wl]), np.concatenate([w[2][0, k:] for w in Wl])])).float().to(dev).requires_grad_(True)
     out = NF.stage(Xt, W, av, plan, heads, 0.2, True, p_drop, p_drop, dseed)
     (out * torch.from_numpy(wgt).float().to(dev)).sum().backward()
-    tag = (seed, U, I, edge.shape[1], heads, short_max, seg_len, p_drop)
+    tag = (seed, U, I, edge.shape[1], heads, short_max, seg_len, p_drop, hub_cap, long_max, plan.nhub, plan.nsplit)
     assert float(np.abs(out.detach().cpu().numpy() - out_o).max()) < 1e-4 * max(1.0, float(np.abs(out_o).max())), tag
     assert float(np.abs(Xt.grad.cpu().numpy() - gX_o).max()) < 2e-4 * max(1.0, float(np.abs(gX_o).max())), tag
     gWu = np.concatenate([g[0] for g in gW_o], 1); gWi = np.concatenate([g[1] for g in gW_o], 1)

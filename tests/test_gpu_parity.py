@@ -164,18 +164,24 @@ def test_split_rows_match_unsplit(dev):
     H, S = ops.transform_fwd(X, W, avec, U, I, 8)
     g = torch.randn(U + I, 64, device=dev)                 # fp32 H here, so an fp32 gradient
     ref = None
-    # (seg_len, short_max): all rows as whole-wave segments / cut into slices / every mix of the
-    # slot-per-row mode with the long mode / all rows in the slot-per-row mode
-    for seg, short in ((1 << 20, -1), (64, -1), (8, 4), (256, 64), (16, 30), (1 << 20, 1 << 20)):
-        plan = build_plan(_t(edge, dev), U, I, seg_len=seg, short_max=short)
-        if (seg, short) == (8, 4):
-            assert plan.nsplit > 100 and plan.nshort > 0
+    # (seg_len, short_max, hub_cap, long_max): all rows as whole-wave segments / long rows as workgroup-per-row hubs (the
+    # default) / cut into slices with partial sums (hub_cap 0) / hubs AND slices / every mix of the slot-per-row mode with
+    # the long mode / all rows in the slot-per-row mode
+    for seg, short, cap, lmax in ((1 << 20, -1, None, None), (16, -1, None, None), (8, 4, None, 8), (64, -1, 0, None), (8, 4, 0, None),
+                                  (8, 4, 60, 8), (256, 64, None, None), (16, 30, None, None), (1 << 20, 1 << 20, None, None)):
+        plan = build_plan(_t(edge, dev), U, I, seg_len=seg, short_max=short, hub_cap=cap, long_max=lmax)
+        if (seg, short, cap) == (8, 4, 0):
+            assert plan.nsplit > 100 and plan.nshort > 0 and plan.nhub == 0
+        if (seg, short, cap) == (8, 4, None):
+            assert plan.nhub > 100 and plan.nsplit == 0 and 0 < plan.nhub_user < plan.nhub
+        if cap == 60:
+            assert plan.nhub > 50 and plan.nsplit > 0
         if short == 1 << 20:
-            assert plan.nseg == 0 and int((plan.srow >= 0).sum()) == U + I
+            assert plan.nseg == 0 and plan.nhub == 0 and int((plan.srow >= 0).sum()) == U + I
         out, agg, R = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)
         dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, g, 8)
         if ref is None:
-            assert plan.nsplit == 0 and plan.nshort == 0
+            assert plan.nsplit == 0 and plan.nshort == 0 and plan.nhub == 0
             ref = (out, R, dH, dS)
             continue
         assert float((out - ref[0]).abs().max()) < 1e-5
@@ -603,7 +609,7 @@ def test_inkernel_hub_finish_is_bitwise_equal_to_two_kernel_path(dev):
     W = torch.randn(2, 64, 64, device=dev, generator=g) * 0.2
     avec = torch.randn(2, 64, device=dev, generator=g) * 0.2
     for seg, dt in ((256, torch.float32), (32, torch.bfloat16), (64, torch.float32)):
-        plan = build_plan(edge, U, I, seg_len=seg)
+        plan = build_plan(edge, U, I, seg_len=seg, hub_cap=0)          # the sliced layout this protocol belongs to
         assert plan.nsplit > 400
         H, S = ops.transform_fwd(X.to(dt), W, avec, U, I, 8, dt)
         ref = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)          # default: second kernel finishes the hub rows

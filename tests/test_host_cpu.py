@@ -39,8 +39,9 @@ def test_plan_matches_scipy_csr_and_covers_every_row():
     g = load_golden("g1_layer_k8_concat")
     U, I = int(g["U"]), int(g["I"])
     edge = g["edge"]
-    for seg, short, cap in ((256, 64, None), (8, 4, None), (8, 4, 0), (8, 4, 12), (4, -1, 0), (1 << 20, 1 << 20, None)):
-        p = build_plan(torch.from_numpy(edge), U, I, seg_len=seg, short_max=short, hub_cap=cap)
+    for seg, short, cap, lmax in ((256, 64, None, None), (8, 4, None, None), (2, 1, None, None), (8, 4, 0, None), (8, 4, 12, 8),
+                                  (4, -1, 0, None), (1 << 20, 1 << 20, None, None)):
+        p = build_plan(torch.from_numpy(edge), U, I, seg_len=seg, short_max=short, hub_cap=cap, long_max=lmax)
         A = sp.csr_matrix((np.ones(edge.shape[1]), (edge[0], edge[1])), shape=(U, I))
         At = A.T.tocsr()
         rowptr = np.concatenate([A.indptr, A.indptr[-1] + At.indptr[1:]])
@@ -61,12 +62,14 @@ def test_plan_matches_scipy_csr_and_covers_every_row():
         for r in p.hrow.numpy():                        # hub rows: a workgroup takes the whole row
             seen[rowptr[r]:rowptr[r + 1]] += 1
             rows_done[r] += 1
-            assert seg < rowptr[r + 1] - rowptr[r] <= p.hub_cap
+            assert p.long_max < rowptr[r + 1] - rowptr[r] <= p.hub_cap
         assert (p.hrow.numpy()[:p.nhub_user] < U).all() and (p.hrow.numpy()[p.nhub_user:] >= U).all()
         if cap == 0:
             assert p.nhub == 0
         if cap == 12:
             assert p.nhub > 0 and p.nsplit > 0          # both paths present
+        if seg == 2:
+            assert p.nhub > 0 and p.nsplit == 0 and p.long_max == 8      # default: long_max = 4 * seg_len, no slices
         assert (seen == 1).all() and (rows_done == 1).all()
         for r, p0, n in p.split.numpy():
             parts = sorted(s[3] for s in p.segs.numpy() if s[0] == r)
