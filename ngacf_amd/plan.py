@@ -96,7 +96,7 @@ def squeeze_mask(mask):
     return mask[0] if mask.dim() == 3 and mask.shape[0] == 1 else mask
 
 
-def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None, short_max=64, hub_cap=None,
+def build_plan(indices, U, I, seg_len=256, device=None, require_user_edges=True, row_range=None, short_max=64, hub_cap=0,
                long_max=None):
     """indices: [2,E] (or [1,2,E], run under DataParallel: SPUIGACF.py:42 squeezes it) integer
     tensor.  Duplicate pairs are merged like `.coalesce()`.  `row_range=(lo,hi)` -- or a list of such
@@ -150,14 +150,16 @@ def _ranges(row_range, N):
 
 
 def default_hub_cap(n_edges_directed):
-    """Largest degree a single workgroup takes.  A workgroup folds ~128 edges per ~0.15 us step while the whole launch
-    streams its edges at ~20 ps each: a row holding up to ~1.5 % of the launch's edges finishes inside the launch when
-    dispatched first (Gowalla scale: 14 k of 2.05 M; 10^9 edges: 4.7 M of 2x10^9).  Rows beyond it fall back to 256-edge
-    slices + the slot-order partial-sum pass."""
+    """Largest degree a single workgroup takes when the workgroup-per-row layout is asked for (hub_cap=None).  NOT the
+    default layout: measured, it loses.  A wave's step over 32 edges is latency-bound (~1 us, not the ~0.15 us of the
+    launch-wide average), so a 14 k-edge row in one workgroup is a 110 us tail on a 27 us launch (Gowalla scale: 34 -> 99 us
+    per launch), and on the 10^9-edge graph 1.27 M rows of 300-1000 edges as one workgroup each doubled the wave count for
+    the same edges (111 -> 207 ms per pass).  Per-row parallelism has to grow with the degree -- which is what the
+    256-edge slices + slot-order partial-sum pass do.  Kept as a tested option (build_plan(hub_cap=None))."""
     return max(4096, int(0.015 * n_edges_directed))
 
 
-def build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len=256, short_max=64, hub_cap=None, long_max=None):
+def build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len=256, short_max=64, hub_cap=0, long_max=None):
     """The plan of the dst rows in `ranges` from the two sorted, unique key arrays a rank owns:
          csr_key = user * I + item   for every edge whose USER row is in the ranges,
          csc_key = item * U + user   for every edge whose ITEM row is in the ranges
@@ -186,12 +188,10 @@ def build_plan_from_keys(csr_key, csc_key, U, I, ranges, seg_len=256, short_max=
     pad = (-sr[0].numel()) % 16
     nshort_user = sr[0].numel() + pad
     srow = torch.cat([sr[0], torch.full((pad,), -1, dtype=torch.long, device=dev), sr[1]]).to(torch.int32).contiguous()
-    # Four classes by degree:  short (<= short_max): a lane group per row;  long (<= long_max): one wave per row;
-    # hub (<= hub_cap): one workgroup per row;  beyond hub_cap: cut into seg_len-edge slices + the partial-sum pass.
-    # long_max = 4 * seg_len by default: a wave folds 32 edges per step, so its longest row is 32 steps (~5 us, dispatched
-    # first) and a hub workgroup has at least 8 steps per wave -- a workgroup per 300-edge row would mostly synchronise
-    # (measured on the 10^9-edge graph, 1.27 M rows above 256 edges: 207 ms per pass against 111 ms).
-    # hub_cap = 0 disables the workgroup path: every row above seg_len is cut into slices (the pre-r02 layout; tests).
+    # Classes by degree:  short (<= short_max): a lane group per row;  long (<= long_max): one wave per row;  beyond: cut
+    # into seg_len-edge slices (one wave each) + the slot-order partial-sum pass.  hub_cap = 0 (default): long_max =
+    # seg_len and nothing else.  OPTIONAL workgroup-per-row class (hub_cap = None or > 0): rows of long_max < degree <=
+    # hub_cap take one workgroup each, folded through LDS, long_max = 4 * seg_len -- measured slower (default_hub_cap).
     cap = default_hub_cap(int(col.numel())) if hub_cap is None else int(hub_cap)
     lmax = (4 * seg_len if cap > 0 else seg_len) if long_max is None else int(long_max)
     lmax = max(lmax, short_max) if cap > 0 else seg_len

@@ -167,8 +167,8 @@ def test_split_rows_match_unsplit(dev):
     # (seg_len, short_max, hub_cap, long_max): all rows as whole-wave segments / long rows as workgroup-per-row hubs (the
     # default) / cut into slices with partial sums (hub_cap 0) / hubs AND slices / every mix of the slot-per-row mode with
     # the long mode / all rows in the slot-per-row mode
-    for seg, short, cap, lmax in ((1 << 20, -1, None, None), (16, -1, None, None), (8, 4, None, 8), (64, -1, 0, None), (8, 4, 0, None),
-                                  (8, 4, 60, 8), (256, 64, None, None), (16, 30, None, None), (1 << 20, 1 << 20, None, None)):
+    for seg, short, cap, lmax in ((1 << 20, -1, 0, None), (16, -1, None, None), (8, 4, None, 8), (64, -1, 0, None), (8, 4, 0, None),
+                                  (8, 4, 60, 8), (256, 64, 0, None), (16, 30, None, None), (1 << 20, 1 << 20, 0, None)):
         plan = build_plan(_t(edge, dev), U, I, seg_len=seg, short_max=short, hub_cap=cap, long_max=lmax)
         if (seg, short, cap) == (8, 4, 0):
             assert plan.nsplit > 100 and plan.nshort > 0 and plan.nhub == 0
@@ -609,7 +609,7 @@ def test_inkernel_hub_finish_is_bitwise_equal_to_two_kernel_path(dev):
     W = torch.randn(2, 64, 64, device=dev, generator=g) * 0.2
     avec = torch.randn(2, 64, device=dev, generator=g) * 0.2
     for seg, dt in ((256, torch.float32), (32, torch.bfloat16), (64, torch.float32)):
-        plan = build_plan(edge, U, I, seg_len=seg, hub_cap=0)          # the sliced layout this protocol belongs to
+        plan = build_plan(edge, U, I, seg_len=seg)
         assert plan.nsplit > 400
         H, S = ops.transform_fwd(X.to(dt), W, avec, U, I, 8, dt)
         ref = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)          # default: second kernel finishes the hub rows

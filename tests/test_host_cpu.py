@@ -39,8 +39,8 @@ def test_plan_matches_scipy_csr_and_covers_every_row():
     g = load_golden("g1_layer_k8_concat")
     U, I = int(g["U"]), int(g["I"])
     edge = g["edge"]
-    for seg, short, cap, lmax in ((256, 64, None, None), (8, 4, None, None), (2, 1, None, None), (8, 4, 0, None), (8, 4, 12, 8),
-                                  (4, -1, 0, None), (1 << 20, 1 << 20, None, None)):
+    for seg, short, cap, lmax in ((256, 64, 0, None), (8, 4, None, None), (2, 1, None, None), (8, 4, 0, None), (8, 4, 12, 8),
+                                  (4, -1, 0, None), (1 << 20, 1 << 20, 0, None)):
         p = build_plan(torch.from_numpy(edge), U, I, seg_len=seg, short_max=short, hub_cap=cap, long_max=lmax)
         A = sp.csr_matrix((np.ones(edge.shape[1]), (edge[0], edge[1])), shape=(U, I))
         At = A.T.tocsr()
