@@ -52,6 +52,7 @@ extern "C" {
 #define NGACF_ELU        1   /* apply ELU to h + agg (SPUIGACF.py:395-397 and the outer F.elu :214) */
 #define NGACF_RESIDUAL   2   /* out = h_dst + agg (SPUIGACF.py:383,390); clear for SPGA.py:405-409 */
 #define NGACF_SKIP_NODE  8   /* ngacf_prop_bwd: step 1 was already run by ngacf_prop_bwd_node */
+#define NGACF_GOUT_F32  16  /* ngacf_prop_bwd: gout is float[N][d] whatever the storage dtype (the scored batch's gradient rows, ngacf_score_bwd) */
 #define NGACF_SCORE_ROW  4   /* recompute the source score a_src . h_src from the gathered row
                                 instead of reading S_src (saves 4*heads bytes per edge) */
 
@@ -96,7 +97,15 @@ int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float* W, const f
  *       with both given, the last-arriving slice of a hub row finishes it inside the launch (agent-scope
  *       release/acquire, no waiting); with NULL a small second kernel does (same sums, same order)
  * drop_p > 0 applies the edge dropout of :375 (numerators only), mask keyed by
- * (seed, head, user, item) so both directions see the same mask. */
+ * (seed, head, user, item) so both directions see the same mask.
+ * needed (uint32[ceil(N/32)], bit `row` of the table, or NULL) + rows (int32[nrows]) + short_max: compute only the flagged rows and leave the
+ *   others' out / agg / R untouched.  SPUIGACF.forward reads B user rows and B item rows of the LAST stage's output
+ *   (:49-52); its other ~94 % rows are never used, so the last stage of a scored batch runs with the batch's flags and row
+ *   list (both from ngacf_mark_rows; duplicates and -1 entries allowed in the list).  Rows of degree <= short_max (the
+ *   plan's short_max) are taken from the list, a WAVE each (their few edges are gathered in one or two rounds); longer rows
+ *   from the plan's segments, by flag.  The same terms as the full launch, added in another order for the short rows
+ *   (deterministic; equal to rounding).  srow / nshort are not read.
+ *   Needs NGACF_SCORE_ROW; not combinable with the in-kernel hub finish (part_split / tickets). */
 int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                    const int32_t* srow, int nshort, int nseg_user, int nshort_user,
                    const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
@@ -104,6 +113,7 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    const float* S_dst, const float* S_src, const float* avec,
                    void* out, float* agg, float* R, float* part_acc, float* part_r,
                    const int32_t* part_split, int32_t* tickets,
+                   const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
 
@@ -116,7 +126,14 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  *   G float[N][d], Gn [N][d] dtype, ST float[N][heads] (the t table): workspace    dH float[N][d], dS float[N][heads]: results
  *   G may be NULL when this call runs both steps (no NGACF_SKIP_NODE): step 2 then recomputes g from gout and out, bit for bit,
  *   and the 4-byte-per-element table is neither written nor read back
- *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows */
+ *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows
+ *   needed / rows / nrows / short_max (NULL / NULL / 0 / 0, or the forward's): the forward ran with these flags, i.e. gout is
+ *   zero outside the flagged rows (and out / agg / R are not valid there).  Then Gn and t vanish outside, and an edge with
+ *   both ends outside contributes exactly zero.  Step 1 runs over the list only (Gn / t exist for the batch's rows).  The
+ *   batch's short rows are walked from the list, a wave each (all their edges; Gn / t of a neighbour outside the batch
+ *   count as zero); every other row tests one flag bit per edge, queues the columns that are in the batch (LDS) and
+ *   gathers only those -- still UNROLL edges at a time.  Equal to the unflagged call on a gout that is zero outside, up to
+ *   the order of the additions.  With NGACF_GOUT_F32 gout is float[N][d] (only the batch's rows are read). */
 int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                    const int32_t* srow, int nshort, int nseg_user, int nshort_user,
                    const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
@@ -125,8 +142,18 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    const void* out, const float* agg, const float* R, const void* gout,
                    float* G, void* Gn, float* ST, float* dH, float* dS,
                    float* part_acc, float* part_r,
+                   const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
+
+/* Sets bit u[b] and bit U + i[b] of needed (uint32[ceil((U+I)/32)]) for b < B (after zeroing the table when clear != 0): the rows a scored batch reads
+ * from the last stage (SPUIGACF.py:49-52), for the `needed` argument of ngacf_prop_fwd / ngacf_prop_bwd; and the same rows as
+ * a list: rows[b] = u[b], rows[B + b] = U + i[b] (2B entries; -1 for an id out of range).  u == NULL: items only, rows[b] = U +
+ * i[b] (B entries) -- the negatives of a (user, positive, negative) batch, appended to the list of the first call.
+ * gzero (float[U+I][d] or NULL): the same rows of that table are set to zero -- the rows ngacf_score_bwd will add the batch's
+ * gradient to (ngacf_prop_bwd then reads them with NGACF_GOUT_F32; no other row of the table is ever read). */
+int ngacf_mark_rows(const int64_t* u, const int64_t* i, uint32_t* needed, int32_t* rows, float* gzero, int B, int U, int I, int d,
+                    int clear, void* stream);
 
 /* Backward of ngacf_transform_fwd (autograd of SPUIGACF.py:356-357 and the a.mm of :361).
  *   dX   [N][din] x_dtype       = mask * (dH @ W[type]^T)   (stored in X's type: it is the gradient of X)

@@ -15,6 +15,8 @@ What differs from the reference is only *how* a stage is computed: the eight hea
 stage run as one fused 64-wide pass (weights concatenated on the fly, so checkpoints stay
 interchangeable), and dropout masks come from a counter hash instead of torch's RNG.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -279,7 +281,10 @@ class _GATBase(nn.Module):
             for p_ in self.parameters(recurse=False):
                 p_._version                                            # (copy_ above already bumped the versions)
 
-    def _run(self, uidx, iidx, features, adj):
+    def _run(self, uidx, iidx, features, adj, needed=None, score=None):
+        """needed: ops.BatchRows for the LAST stage (the rows the caller will read); earlier stages run in full.
+        score = (userIdx, [itemIdx, ...]) with needed: return the tuple of score vectors (SPUIGACF.py:49-52) instead of the table
+        -- the last stage and the scoring are one autograd node."""
         _refuse_replica(self)
         U, I = int(uidx.numel()), int(iidx.numel())
         plan = self._plans.get(squeeze_mask(adj), U, I, self.seg_len)
@@ -296,13 +301,20 @@ class _GATBase(nn.Module):
         else:
             base = _fresh_seed() if p > 0 else 0
         x = features
-        for s, layers in enumerate(self._stages()):
+        stages = self._stages()
+        for s, layers in enumerate(stages):
             W, avec = self.stage_params(s)
             # feature dropout in front of every stage (:208,:213) and the ELU behind it (:397 inside
             # the concat layers, :214 around out_att) are fused into the stage
+            if score is not None and needed is not None and s == len(stages) - 1:
+                return NF.stage_score(x, W, avec, plan, len(layers), needed, score[0], score[1], layers[0].alpha, True, p, p,
+                                      NF.stage_seed(base, s), self.compute_dtype, seed_dev)
             x = NF.stage(x, W, avec, plan, len(layers), layers[0].alpha, True, p, p,
-                         NF.stage_seed(base, s), self.compute_dtype, seed_dev)
-            if getattr(self, "debug_asserts", False):
+                         NF.stage_seed(base, s), self.compute_dtype, seed_dev,
+                         needed=needed if s == len(stages) - 1 else None)
+            if getattr(self, "debug_asserts", False) and needed is not None and s == len(stages) - 1:
+                assert not bool(torch.isnan(x[needed.mask()]).any()), "NaN after propagation stage %d" % s
+            elif getattr(self, "debug_asserts", False):
                 # the reference's per-layer checks (SPUIGACF.py:384,391); a device sync each, so off by default.
                 # (:368, "every user has an edge", is enforced once at plan build.)
                 assert not bool(torch.isnan(x).any()), "NaN after propagation stage %d" % s
@@ -339,8 +351,8 @@ class SpUIGAT(_GATBase):
     def _stages(self):
         return [self.attentions, [self.out_att]]
 
-    def forward(self, uidx, iidx, features, adj):
-        return self._run(uidx, iidx, features, adj)
+    def forward(self, uidx, iidx, features, adj, needed=None, score=None):
+        return self._run(uidx, iidx, features, adj, needed, score)
 
 
 class SPUIMultiGAT(_GATBase):
@@ -362,8 +374,8 @@ class SPUIMultiGAT(_GATBase):
     def _stages(self):
         return [self.attentions1, self.attentions2, [self.out_att]]
 
-    def forward(self, uidx, iidx, features, adj):
-        return self._run(uidx, iidx, features, adj)
+    def forward(self, uidx, iidx, features, adj, needed=None, score=None):
+        return self._run(uidx, iidx, features, adj, needed, score)
 
 
 class StackedSpUIGAT(_GATBase):
@@ -387,8 +399,8 @@ class StackedSpUIGAT(_GATBase):
     def _stages(self):
         return self.hidden + [[self.out_att]]
 
-    def forward(self, uidx, iidx, features, adj):
-        return self._run(uidx, iidx, features, adj)
+    def forward(self, uidx, iidx, features, adj, needed=None, score=None):
+        return self._run(uidx, iidx, features, adj, needed, score)
 
 
 class _Table(torch.autograd.Function):
@@ -446,19 +458,39 @@ class _CFBase(nn.Module):
             self._idx = idx
         return idx[0], idx[1], self._features()
 
-    def propagate(self, mask):
+    # A scored batch reads B user rows and B item rows of the LAST stage's output (:49-52): that stage is computed for those
+    # rows only (ngacf_prop_fwd / _bwd `needed`), forward and backward -- same numbers, ~1/17 of the last stage's edges at
+    # B = 2048 on a Gowalla-size graph.  False: every stage in full (A/B timing, tests).
+    sparse_last_stage = os.environ.get("NGACF_SPARSE_LAST", "1") != "0"
+
+    def propagate(self, mask, needed=None, score=None):
         _refuse_replica(self)
         uidx, iidx, features = self.getFeatureMat()
-        return self.gat(uidx, iidx, features, squeeze_mask(mask))        # :42-46
+        return self.gat(uidx, iidx, features, squeeze_mask(mask), needed, score)        # :42-46
+
+    def _batch_rows(self, userIdx, *itemIdxs):
+        _refuse_replica(self)
+        if not self.sparse_last_stage or NF.ops.INKERNEL_HUB_FINISH:
+            return None
+        rows = None
+        d = self.gat.stage_shapes()[-1][1] if torch.is_grad_enabled() else 0          # width of the last stage's output
+        for it in itemIdxs:
+            rows = NF.ops.mark_rows(userIdx.contiguous().long(), it.contiguous().long(), self.userNum, self.itemNum, rows, grad_d=d)
+        return rows
 
     def forward(self, userIdx, itemIdx, mask):
-        features = self.propagate(mask)
-        return NF.score(features, userIdx, itemIdx, self.userNum)    # :49-52
+        rows = self._batch_rows(userIdx, itemIdx)
+        if rows is not None:
+            return self.propagate(mask, rows, (userIdx, [itemIdx]))[0]
+        return NF.score(self.propagate(mask), userIdx, itemIdx, self.userNum)    # :49-52
 
     def forward_pairs(self, userIdx, posIdx, negIdx, mask):
         """OPT-IN, not reference semantics: one propagation shared by the positive and the negative scoring of a
         BPR step (the reference calls forward() twice, train_eval_Gowalla.py:128-129, i.e. two propagations with
         independent dropout masks).  Identical to two forward() calls when droprate == 0 or in eval mode."""
+        rows = self._batch_rows(userIdx, posIdx, negIdx)
+        if rows is not None:
+            return self.propagate(mask, rows, (userIdx, [posIdx, negIdx]))
         features = self.propagate(mask)
         return (NF.score(features, userIdx, posIdx, self.userNum), NF.score(features, userIdx, negIdx, self.userNum))
 

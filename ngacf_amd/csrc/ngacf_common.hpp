@@ -152,6 +152,9 @@ __device__ __forceinline__ void locate(const WorkOrder& o, int block, int wave, 
     else { kind = WORK_SHORT; idx = o.nshort_u + ((block - o.b4) * 4 + wave) * epi; end = o.nshort; }
 }
 
+// row flags of a scored batch: one bit per row (N / 8 bytes: the table of a 10^5-row graph sits in a CU's vector L1)
+__device__ __forceinline__ bool flagged(const uint32_t* __restrict__ bits, int row) { return (bits[row >> 5] >> (row & 31)) & 1u; }
+
 #define NGACF_CHECK_LAUNCH()                                   \
     do {                                                       \
         hipError_t e__ = hipGetLastError();                    \

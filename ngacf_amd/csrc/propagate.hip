@@ -38,6 +38,9 @@ struct PropArgs {
     const int* split;      // {row, first part, parts} of the hub rows
     const int* part_split; // hub row (index into split) of every partial-sum slot
     int* tickets;          // arrival counter per hub row (all zero between launches); NULL = finish in a 2nd kernel
+    const uint32_t* needed; // optional, one bit per row: only rows with needed[row] != 0 are computed (the others' out/agg/R are left untouched)
+    const int* rows;       // with needed: the same rows as a list (duplicates allowed, -1 = skip); its short rows get a lane group each
+    int short_max;         // with needed: degree bound of the plan's short rows
     int U, N;
     WorkOrder order;
     float alpha;
@@ -133,7 +136,7 @@ __device__ __forceinline__ void edge_step(const PropArgs& a, const float (&hv)[S
     for (int j = 0; j < VEC; ++j) acc[j] = fmaf(ev, hv[j], acc[j]);
 }
 
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE>
 __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC, LPR = SH::LPR, EPI = SH::EPI, SHIFT = SH::ROW_SHIFT;
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
         __shared__ float hub_r[3][HEADS];
         const int wv = threadIdx.x >> 6;
         const int row = uniform(a.hrow[widx]);
+        if (SPARSE && !flagged(a.needed, row)) return;                // (block-uniform: no wave reaches the barrier below)
         const int beg = uniform(a.rowptr[row]), end = uniform(a.rowptr[row + 1]);
         const bool dst_is_user = row < a.U;
         const float s_dst = a.S_dst[(size_t)row * HEADS + head];
@@ -262,8 +266,19 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
 
     // ---------------------------------------------------------------------- long rows: wave per segment
     const int w = uniform(widx);
-    const int4 sg = a.segs[w];
-    const int row = uniform(sg.x), beg = uniform(sg.y), end = uniform(sg.z), part = uniform(sg.w);
+    int row, beg, end, part;
+    if (SPARSE && w < a.order.nseg_u) {
+        // SPARSE, first group: the batch's own row list, a WAVE per short row (the lane groups share its edges like a segment's:
+        // a row of 64 edges is two rounds of gathers, not eight).  Longer rows are carried by their segments below.
+        row = uniform(a.rows[w]);
+        if (row < 0) return;                                 // an id out of range (reported by the scoring kernel)
+        beg = uniform(a.rowptr[row]); end = uniform(a.rowptr[row + 1]); part = -1;
+        if (end - beg > a.short_max) return;
+    } else {
+        const int4 sg = a.segs[SPARSE ? w - a.order.nseg_u : w];
+        row = uniform(sg.x); beg = uniform(sg.y); end = uniform(sg.z); part = uniform(sg.w);
+        if (SPARSE && !flagged(a.needed, row)) return;       // (its partial-sum slot stays unwritten: the second kernel skips the row too)
+    }
     const bool dst_is_user = row < a.U;
     const float s_dst = a.S_dst[(size_t)row * HEADS + head];
     if (FROM_ROW) {
@@ -364,6 +379,7 @@ __global__ __launch_bounds__(256) void prop_fwd_split_kernel(const PropArgs a, c
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= nsplit) return;
     const int row = split[3 * w], p0 = split[3 * w + 1], np = split[3 * w + 2];
+    if (a.needed && !flagged(a.needed, row)) return;
     const int slot = lane / LPR, q = lane % LPR, head = (q * VEC) / SH::HW;
     float acc[VEC];
 #pragma unroll
@@ -393,12 +409,15 @@ static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, b
     a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, a.order.nhub, a.order.nhub_u, EPI, &nb);
     if (nb > 0) {
         const dim3 grid(nb), block(256);
-        if (from_row) {
-            if (drop) hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, true, true>), grid, block, 0, st, a);
-            else      hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, true, false>), grid, block, 0, st, a);
+        if (a.needed) {                 // (only with NGACF_SCORE_ROW: checked by the caller)
+            if (drop) hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, true, true, true>), grid, block, 0, st, a);
+            else      hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, true, false, true>), grid, block, 0, st, a);
+        } else if (from_row) {
+            if (drop) hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, true, true, false>), grid, block, 0, st, a);
+            else      hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, true, false, false>), grid, block, 0, st, a);
         } else {
-            if (drop) hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, false, true>), grid, block, 0, st, a);
-            else      hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, false, false>), grid, block, 0, st, a);
+            if (drop) hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, false, true, false>), grid, block, 0, st, a);
+            else      hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, false, false, false>), grid, block, 0, st, a);
         }
         NGACF_CHECK_LAUNCH();
     }
@@ -420,9 +439,13 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
                               const float* S_dst, const float* S_src, const float* avec,
                               void* out, float* agg, float* R, float* part_acc, float* part_r,
                               const int32_t* part_split, int32_t* tickets,
+                              const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                               int U, int N, int d, int heads, float alpha,
                               float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
+    if (needed && part_split && nsplit > 0 && tickets) return NGACF_E_ARG;     // in-kernel hub finish counts arrivals of ALL slices
+    if (needed && !(flags & NGACF_SCORE_ROW)) return NGACF_E_ARG;              // row flags: the SPUIGACF stages only
+    if (needed && (nrows < 0 || (nrows > 0 && !rows))) return NGACF_E_ARG;
     if (nseg_user < 0 || nseg_user > nseg || nshort_user < 0 || nshort_user > nshort || (nshort_user % 16 != 0 && nshort_user != nshort))
         return NGACF_E_ARG;
     if (nhub < 0 || nhub_user < 0 || nhub_user > nhub) return NGACF_E_ARG;
@@ -439,7 +462,10 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
     a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
     a.hrow = hrow; a.order.nhub = nhub; a.order.nhub_u = nhub_user;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R;
-    a.part_acc = part_acc; a.part_r = part_r; a.split = split; a.part_split = part_split;
+    a.part_acc = part_acc; a.part_r = part_r; a.split = split; a.part_split = part_split; a.needed = needed; a.rows = rows; a.short_max = short_max;
+    if (needed) {          // groups: [the batch's row list, a wave per short row][-][all segments, by flag][-]
+        a.nshort = 0; nshort_user = 0; a.nseg = nrows + nseg; nseg_user = nrows;
+    }
     a.tickets = (part_split && nsplit > 0) ? tickets : nullptr; a.U = U; a.N = N; a.order.nseg_u = nseg_user; a.order.nshort_u = nshort_user; a.alpha = alpha;
     a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.seed_dev = seed_dev; a.flags = flags;
     const bool drop = drop_p > 0.f;

@@ -50,6 +50,11 @@ struct PropBwdArgs {
     uint64_t seed;
     const uint64_t* seed_dev;
     int flags;
+    const uint32_t* needed;         // optional, one bit per row: gout is zero outside these rows (the last stage of a scored batch), so Gn and t
+                                   // are zero there and an edge whose two ends are both outside contributes exactly nothing
+    const int* rows;               // with needed: the same rows as a list (duplicates allowed, -1 = skip)
+    int nrows;
+    int short_max;                 // with needed: degree bound of the plan's short rows
 };
 
 template <typename T, int D, int HEADS>
@@ -93,15 +98,21 @@ __global__ __launch_bounds__(256) void prop_bwd_node_kernel(const PropBwdArgs a)
     using SH = BShape<T, D, HEADS>;
     constexpr int LPR = SH::LPR, HW = SH::HW, VEC = SH::VEC;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t li = gid / LPR;                              // index inside the row windows
+    const size_t li = gid / LPR;                              // index inside the row windows (with a.needed: inside the batch's row list)
     const int q = (int)(gid % LPR);
-    const bool ok = li < (size_t)(a.nu_n + a.ni_n);
+    bool ok = li < (size_t)(a.needed ? a.nrows : a.nu_n + a.ni_n);
     const size_t lj = ok ? li : 0;
-    const size_t n = lj < (size_t)a.nu_n ? a.nu_lo + lj : (size_t)a.U + a.ni_lo + (lj - a.nu_n);
+    size_t n = lj < (size_t)a.nu_n ? a.nu_lo + lj : (size_t)a.U + a.ni_lo + (lj - a.nu_n);
+    if (a.needed) {                                          // only the batch's rows: nothing outside them is read by step 2
+        const int r = a.rows[lj];
+        ok = ok && r >= 0;
+        n = r >= 0 ? r : 0;
+    }
     const size_t nn = n;
     const int head = (q * VEC) / HW;
     float g[VEC], o[VEC], ag[VEC];
-    Slice<T>::load(static_cast<const T*>(a.gout) + (a.gout_local ? lj : nn) * D + q * VEC, g);
+    if (a.flags & NGACF_GOUT_F32) load_f32<VEC>(static_cast<const float*>(a.gout) + nn * D + q * VEC, g);
+    else Slice<T>::load(static_cast<const T*>(a.gout) + (a.gout_local ? lj : nn) * D + q * VEC, g);
     load_f32<VEC>(a.agg + nn * D + q * VEC, ag);
     if (a.flags & NGACF_ELU) {
         Slice<T>::load(static_cast<const T*>(a.out) + nn * D + q * VEC, o);
@@ -129,16 +140,23 @@ struct RowCtx {
     float s_dst, t_own;
     uint32_t row_key, salt_h;
     bool dst_is_user;
+    bool in_batch;                 // a.needed == NULL, or this dst row is one of the batch's rows
 };
 
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE>
 __device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, int head, RowCtx<Slice<T>::VEC>& x) {
     constexpr int VEC = Slice<T>::VEC;
     x.dst_is_user = row < a.U;
+    x.in_batch = !SPARSE || flagged(a.needed, row);
     load_row<T, D, HEADS>(a.H, row, q, x.h_own);
     load_row<T, D, HEADS>(a.Gn, row, q, x.gn_own);
     x.s_dst = a.S_dst[(size_t)row * HEADS + head];
     x.t_own = a.Tn[(size_t)row * HEADS + head];
+    if (SPARSE && !x.in_batch) {                              // Gn / t exist for the batch's rows only: zero elsewhere
+#pragma unroll
+        for (int j = 0; j < Slice<T>::VEC; ++j) x.gn_own[j] = 0.f;
+        x.t_own = 0.f;
+    }
     if (FROM_ROW) {
         const float* ap = a.avec + (x.dst_is_user ? D : 0) + q * VEC;
 #pragma unroll
@@ -180,13 +198,113 @@ __device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<S
     for (int j = 0; j < VEC; ++j) acc[j] = fmaf(wgt, gv[j], acc[j]);
 }
 
+// The gathers of one edge: H row, Gn row, t entry (S entry without NGACF_SCORE_ROW).  SPARSE (a row walking ALL its edges):
+// Gn / t of a neighbour outside the batch were never written -- they are zero, and the two loads are pointed at the row's
+// own entries instead (one cached line for all such lanes; the value is discarded), so only H[c] is really gathered there.
+template <typename T, int D, int HEADS, bool FROM_ROW, bool SPARSE>
+__device__ __forceinline__ void load_edge_b(const PropBwdArgs& a, int c, int row, int q, int head, float (&hv)[Slice<T>::VEC],
+                                            float (&gv)[Slice<T>::VEC], float& ss, float& tc) {
+    load_row<T, D, HEADS>(a.H, c, q, hv);
+    const bool in = !SPARSE || flagged(a.needed, c);
+    const int cg = in ? c : row;
+    load_row<T, D, HEADS>(a.Gn, cg, q, gv);
+    tc = a.Tn[(size_t)cg * HEADS + head];
+    ss = FROM_ROW ? 0.f : a.S_src[(size_t)c * HEADS + head];
+    if (SPARSE) {
+#pragma unroll
+        for (int j = 0; j < Slice<T>::VEC; ++j) gv[j] = in ? gv[j] : 0.f;
+        tc = in ? tc : 0.f;
+    }
+}
+
+// SPARSE traversal of one lane group's edges (positions ebase + k * estride, k < count): per chunk of QCAP edges,
+// (1) every lane of the group tests ONE edge -- it takes part when the own row is in the batch or the other end is (one
+//     flag byte) -- and the columns that take part are appended, in order, to the group's queue in LDS;
+// (2) the queue is walked exactly like the dense loop (UNROLL edges of gathers in flight).
+// Outside the batch ~|batch| / N of a row's edges survive, so the three row gathers of the others are never issued, and
+// the surviving ones are still issued in full batches.  The order of the additions is the dense kernel's, minus terms that
+// are exactly zero there: same bits.
+constexpr int QCAP = 64;
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
+__device__ __forceinline__ void sparse_edges_b(const PropBwdArgs& a, const RowCtx<Slice<T>::VEC>& x, int* __restrict__ qbuf, int row,
+                                               int ebase, int estride, int count, int slot, int q, int head,
+                                               float (&acc)[Slice<T>::VEC], float& dsum) {
+    constexpr int LPR = BShape<T, D, HEADS>::LPR, VEC = Slice<T>::VEC;
+    int mc = count;
+#pragma unroll
+    for (int m = LPR; m < WAVE; m <<= 1) mc = max(mc, __shfl_xor(mc, m, WAVE));
+    const int maxcount = uniform(mc);
+    const unsigned long long below = (1ull << q) - 1ull, group = (LPR == 64) ? ~0ull : ((1ull << LPR) - 1ull);
+    for (int k0 = 0; k0 < maxcount; k0 += QCAP) {
+        // all the chunk's column loads first, then all the flag loads: two round trips, not two per LPR edges
+        constexpr int NS = QCAP / LPR;
+        int c[NS];
+        bool act[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int k = k0 + i * LPR + q;
+            act[i] = k < count;
+            c[i] = a.col[act[i] ? ebase + k * estride : 0];
+        }
+        if (!x.in_batch) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) act[i] = act[i] && flagged(a.needed, c[i]);
+        }
+        int n = 0;                                              // queued so far (the same in every lane of the group)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const unsigned long long mine = (__ballot(act[i]) >> (slot * LPR)) & group;
+            if (act[i]) qbuf[n + __popcll(mine & below)] = c[i];
+            n += __popcll(mine);
+        }
+        int mn = n;
+#pragma unroll
+        for (int m = LPR; m < WAVE; m <<= 1) mn = max(mn, __shfl_xor(mn, m, WAVE));
+        const int maxn = uniform(mn);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int b = 0; b < maxn; b += UNROLL) {
+            int c[UNROLL];
+            bool ok[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                ok[u] = b + u < n;
+                c[u] = ok[u] ? qbuf[b + u] : row;               // (idle: the own row, a cached line)
+            }
+            float hv[UNROLL][VEC], gv[UNROLL][VEC];
+            float ss[UNROLL], tc[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                load_row<T, D, HEADS>(a.H, c[u], q, hv[u]);
+                load_row<T, D, HEADS>(a.Gn, c[u], q, gv[u]);
+                tc[u] = a.Tn[(size_t)c[u] * HEADS + head];
+                ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[u] * HEADS + head];
+                if (!ok[u]) {                                   // idle: Gn / t of the own row (outside the batch) were never written
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) gv[u][j] = 0.f;
+                    tc[u] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], ok[u], c[u], acc, dsum);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <typename T, int D, int HEADS, int VEC>
 __device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum) {
     constexpr int HW = D / HEADS;
     float g[VEC], o[VEC];
     if ((a.flags & NGACF_RESIDUAL) && a.G) load_f32<VEC>(a.G + (size_t)row * D + q * VEC, g);
-    else if (a.flags & NGACF_RESIDUAL) {           // g = gout * ELU'(out), exactly as step 1 computed it (no 4-byte G table)
-        Slice<T>::load(static_cast<const T*>(a.gout) + (size_t)row * D + q * VEC, g);
+    else if ((a.flags & NGACF_RESIDUAL) && a.needed && !flagged(a.needed, row)) {          // outside the batch: g = 0, out is not valid
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) g[j] = 0.f;
+    } else if (a.flags & NGACF_RESIDUAL) {         // g = gout * ELU'(out), exactly as step 1 computed it (no 4-byte G table)
+        if (a.flags & NGACF_GOUT_F32) load_f32<VEC>(static_cast<const float*>(a.gout) + (size_t)row * D + q * VEC, g);
+        else Slice<T>::load(static_cast<const T*>(a.gout) + (size_t)row * D + q * VEC, g);
         if (a.flags & NGACF_ELU) {
             Slice<T>::load(static_cast<const T*>(a.out) + (size_t)row * D + q * VEC, o);
 #pragma unroll
@@ -203,7 +321,7 @@ __device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int 
     if ((q * VEC) % HW == 0) a.dS[(size_t)row * HEADS + head] = dsum;
 }
 
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE>
 __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
     using SH = BShape<T, D, HEADS>;
     constexpr int LPR = SH::LPR, EPI = SH::EPI, HW = SH::HW, VEC = SH::VEC;
@@ -218,6 +336,8 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
 
     int kind, widx, wend;
     locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, kind, widx, wend);
+    __shared__ int qmem[SPARSE ? 4 * EPI * (QCAP + 1) : 1];                // SPARSE: a column queue per lane group (odd stride: no bank clash)
+    int* qbuf = qmem + (SPARSE ? ((threadIdx.x >> 6) * EPI + slot) * (QCAP + 1) : 0);
     if (kind == WORK_HUB) {
         // ------------------------------------------------------------------ hub rows: workgroup per row (as in the forward)
         __shared__ float hub_acc[3][D];
@@ -225,7 +345,7 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
         const int wv = threadIdx.x >> 6;
         const int row = uniform(a.hrow[widx]);
         const int beg = uniform(a.rowptr[row]), end = uniform(a.rowptr[row + 1]);
-        load_ctx<T, D, HEADS, FROM_ROW, DROP>(a, row, q, head, x);
+        load_ctx<T, D, HEADS, FROM_ROW, DROP, SPARSE>(a, row, q, head, x);
         for (int base = beg + wv * EPI * UNROLL; base < end; base += 4 * EPI * UNROLL) {
             int c[UNROLL];
             bool ok[UNROLL];
@@ -238,11 +358,8 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
             float hv[UNROLL][VEC], gv[UNROLL][VEC];
             float ss[UNROLL], tc[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                load_row<T, D, HEADS>(a.H, c[u], q, hv[u]);
-                load_row<T, D, HEADS>(a.Gn, c[u], q, gv[u]);
-                tc[u] = a.Tn[(size_t)c[u] * HEADS + head];
-                ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[u] * HEADS + head];
+            for (int u = 0; u < UNROLL; ++u) {              // (SPARSE: every edge is gathered; the ones outside the batch add exact zeros)
+                load_edge_b<T, D, HEADS, FROM_ROW, SPARSE>(a, c[u], row, q, head, hv[u], gv[u], ss[u], tc[u]);
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
@@ -273,12 +390,18 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
         // ------------------------------------------------------------------ short rows: slot per row
         const int ridx = widx + slot;
         const int rraw = a.srow[ridx < wend ? ridx : wend - 1];
-        const bool live = ridx < wend && rraw >= 0;          // -1 = padding between the user and item lists
+        bool live = ridx < wend && rraw >= 0;                // -1 = padding between the user and item lists
         const int row = live ? rraw : 0;
         const int beg = a.rowptr[row];
-        const int deg = live ? a.rowptr[row + 1] - beg : 0;
-        const int maxdeg = uniform(deg);
-        load_ctx<T, D, HEADS, FROM_ROW, DROP>(a, row, q, head, x);
+        int deg = live ? a.rowptr[row + 1] - beg : 0;
+        if (SPARSE && flagged(a.needed, row)) { live = false; deg = 0; }      // a row of the batch: the row list carries it (long path)
+        const int maxdeg = uniform(deg);                     // rows are sorted: slot 0 holds the longest
+        load_ctx<T, D, HEADS, FROM_ROW, DROP, SPARSE>(a, row, q, head, x);
+        if (SPARSE) {                                        // outside the batch: only the edges into the batch take part (the queue)
+            sparse_edges_b<T, D, HEADS, FROM_ROW, DROP>(a, x, qbuf, row, beg, 1, deg, slot, q, head, acc, dsum);
+            if (live) finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
+            return;
+        }
         const int last = deg > 0 ? beg + deg - 1 : 0;
         int colv = a.col[min(beg + (q & 7), last)];
         for (int k0 = 0; k0 < maxdeg; k0 += 8) {
@@ -295,10 +418,7 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
                 float ss[UNROLL], tc[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    load_row<T, D, HEADS>(a.H, c[h0 + u], q, hv[u]);
-                    load_row<T, D, HEADS>(a.Gn, c[h0 + u], q, gv[u]);
-                    tc[u] = a.Tn[(size_t)c[h0 + u] * HEADS + head];
-                    ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[h0 + u] * HEADS + head];
+                    load_edge_b<T, D, HEADS, FROM_ROW, SPARSE>(a, c[h0 + u], row, q, head, hv[u], gv[u], ss[u], tc[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
@@ -312,30 +432,41 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
 
     // ---------------------------------------------------------------------- long rows: wave per segment
     const int w = uniform(widx);
-    const int4 sg = a.segs[w];
-    const int row = uniform(sg.x), beg = uniform(sg.y), end = uniform(sg.z), part = uniform(sg.w);
-    load_ctx<T, D, HEADS, FROM_ROW, DROP>(a, row, q, head, x);
-    for (int base = beg; base < end; base += EPI * UNROLL) {
-        int c[UNROLL];
-        bool ok[UNROLL];
+    int row, beg, end, part;
+    if (SPARSE && w < a.order.nseg_u) {
+        // SPARSE, first group: the batch's own row list, a WAVE per short row; all its edges take part (the dense loop below)
+        row = uniform(a.rows[w]);
+        if (row < 0) return;
+        beg = uniform(a.rowptr[row]); end = uniform(a.rowptr[row + 1]); part = -1;
+        if (end - beg > a.short_max) return;                 // a long row: its segments carry it
+    } else {
+        const int4 sg = a.segs[SPARSE ? w - a.order.nseg_u : w];
+        row = uniform(sg.x); beg = uniform(sg.y); end = uniform(sg.z); part = uniform(sg.w);
+    }
+    load_ctx<T, D, HEADS, FROM_ROW, DROP, SPARSE>(a, row, q, head, x);
+    if (SPARSE && !x.in_batch) {                    // the lane group's edges: beg + slot, + EPI, ... (the dense loop's assignment)
+        const int mine = end - beg - slot;
+        sparse_edges_b<T, D, HEADS, FROM_ROW, DROP>(a, x, qbuf, row, beg + slot, EPI, mine > 0 ? (mine + EPI - 1) / EPI : 0, slot, q, head, acc, dsum);
+    } else {
+        for (int base = beg; base < end; base += EPI * UNROLL) {
+            int c[UNROLL];
+            bool ok[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int e = base + u * EPI + slot;
-            ok[u] = e < end;
-            c[u] = a.col[ok[u] ? e : end - 1];
+            for (int u = 0; u < UNROLL; ++u) {
+                const int e = base + u * EPI + slot;
+                ok[u] = e < end;
+                c[u] = a.col[ok[u] ? e : end - 1];
+            }
+            float hv[UNROLL][VEC], gv[UNROLL][VEC];
+            float ss[UNROLL], tc[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                load_edge_b<T, D, HEADS, FROM_ROW, SPARSE>(a, c[u], row, q, head, hv[u], gv[u], ss[u], tc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], ok[u], c[u], acc, dsum);
         }
-        float hv[UNROLL][VEC], gv[UNROLL][VEC];
-        float ss[UNROLL], tc[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            load_row<T, D, HEADS>(a.H, c[u], q, hv[u]);
-            load_row<T, D, HEADS>(a.Gn, c[u], q, gv[u]);
-            tc[u] = a.Tn[(size_t)c[u] * HEADS + head];
-            ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[u] * HEADS + head];
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], ok[u], c[u], acc, dsum);
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
@@ -380,8 +511,8 @@ template <typename T, int D, int HEADS>
 static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st,
                       bool do_node, bool do_edges) {
     constexpr int EPI = BShape<T, D, HEADS>::EPI;
-    if (do_node && a.nu_n + a.ni_n > 0) {
-        const size_t threads = (size_t)(a.nu_n + a.ni_n) * BShape<T, D, HEADS>::LPR;
+    if (do_node && (a.needed ? a.nrows : a.nu_n + a.ni_n) > 0) {
+        const size_t threads = (size_t)(a.needed ? a.nrows : a.nu_n + a.ni_n) * BShape<T, D, HEADS>::LPR;
         hipLaunchKernelGGL((prop_bwd_node_kernel<T, D, HEADS>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
         NGACF_CHECK_LAUNCH();
     }
@@ -390,12 +521,15 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
     a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, a.order.nhub, a.order.nhub_u, EPI, &nb);
     if (nb > 0) {
         const dim3 grid(nb), block(256);
-        if (from_row) {
-            if (drop) hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, true>), grid, block, 0, st, a);
-            else      hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, false>), grid, block, 0, st, a);
+        if (a.needed) {                 // (only with NGACF_SCORE_ROW: checked by the caller)
+            if (drop) hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, true, true>), grid, block, 0, st, a);
+            else      hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, false, true>), grid, block, 0, st, a);
+        } else if (from_row) {
+            if (drop) hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, true, false>), grid, block, 0, st, a);
+            else      hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, false, false>), grid, block, 0, st, a);
         } else {
-            if (drop) hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, false, true>), grid, block, 0, st, a);
-            else      hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, false, false>), grid, block, 0, st, a);
+            if (drop) hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, false, true, false>), grid, block, 0, st, a);
+            else      hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, false, false, false>), grid, block, 0, st, a);
         }
         NGACF_CHECK_LAUNCH();
     }
@@ -420,7 +554,8 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
                          float* part_acc, float* part_r,
                          int U, int N, int d, int heads, float alpha,
                          float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
-                         int nu_lo, int nu_n, int ni_lo, int ni_n, int gout_local, bool do_node, bool do_edges, void* stream) {
+                         int nu_lo, int nu_n, int ni_lo, int ni_n, int gout_local, bool do_node, bool do_edges,
+                         const uint32_t* needed, const int32_t* rows, int nrows, int short_max, void* stream) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
     if (nseg_user < 0 || nseg_user > nseg || nshort_user < 0 || nshort_user > nshort || (nshort_user % 16 != 0 && nshort_user != nshort))
         return NGACF_E_ARG;
@@ -446,6 +581,12 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     a.U = U; a.N = N; a.nu_lo = nu_lo; a.nu_n = nu_n; a.ni_lo = ni_lo; a.ni_n = ni_n; a.gout_local = gout_local;
     a.order.nseg_u = nseg_user; a.order.nshort_u = nshort_user; a.alpha = alpha;
     a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.seed_dev = seed_dev; a.flags = flags;
+    if (needed && (!from_row || nrows < 0 || (nrows > 0 && !rows))) return NGACF_E_ARG;          // row flags: the SPUIGACF stages only
+    a.needed = needed; a.rows = rows; a.nrows = nrows; a.short_max = short_max;
+    if (needed && G) return NGACF_E_ARG;                       // (the G table is a node-partitioned run's; not with row flags)
+    if (needed) {              // groups: [the batch's row list, a wave per short row][-][all segments][all short rows minus the batch's]
+        a.order.nshort_u = 0; a.nseg = nrows + nseg; a.order.nseg_u = nrows;
+    }
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define NGACF_CASE(T, D, HD) return launch_bwd<T, D, HD>(a, split, nsplit, from_row, drop, st, do_node, do_edges)
@@ -472,12 +613,13 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
                               const void* out, const float* agg, const float* R, const void* gout,
                               float* G, void* Gn, float* ST, float* dH, float* dS,
                               float* part_acc, float* part_r,
+                              const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                               int U, int N, int d, int heads, float alpha,
                               float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
     const bool skip_node = (flags & NGACF_SKIP_NODE) != 0;
     return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, nseg_user, nshort_user, hrow, nhub, nhub_user, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
                          G, Gn, ST, dH, dS, part_acc, part_r, U, N, d, heads, alpha, drop_p, seed, seed_dev, flags,
-                         0, U, 0, N - U, 0, !skip_node, true, stream);
+                         0, U, 0, N - U, 0, !skip_node, true, needed, rows, nrows, short_max, stream);
 }
 
 extern "C" int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg, const float* R, const void* gout,
@@ -486,5 +628,5 @@ extern "C" int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg,
                                    int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream) {
     return prop_bwd_impl(nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, dtype, nullptr, S_src, nullptr,
                          out, agg, R, gout, G, Gn, ST, nullptr, nullptr, nullptr, nullptr, U, N, d, heads, 0.2f, 0.f, 0, nullptr, flags,
-                         u_lo, u_n, i_lo, i_n, gout_local, true, false, stream);
+                         u_lo, u_n, i_lo, i_n, gout_local, true, false, nullptr, nullptr, 0, 0, stream);
 }

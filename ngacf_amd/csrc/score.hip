@@ -68,6 +68,37 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const T* __restrict__ F,
     }
 }
 
+// bit u[b] and bit U + it[b] of `needed` set for the pairs of a batch, and the same rows as a list (rows[b] = u[b], rows[B + b] =
+// U + it[b]; -1 for an id out of range: the scoring kernels report those).  u == NULL: items only (rows[b] = U + it[b]).
+// gzero != NULL: rows u[b] and U + it[b] of that float [N][d] table are zeroed (where ngacf_score_bwd will add the batch's
+// gradient).  d / 4 threads per pair.
+__global__ __launch_bounds__(256) void mark_rows_kernel(const int64_t* __restrict__ u, const int64_t* __restrict__ it,
+                                                        uint32_t* __restrict__ needed, int* __restrict__ rows, float* __restrict__ gzero,
+                                                        int B, int U, int I, int d) {
+    const int tpp = d >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = t / tpp, piece = t - b * tpp;
+    if (b >= B) return;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u) {
+        const int64_t ub = u[b];
+        const bool ok = ub >= 0 && ub < U;
+        if (piece == 0) {
+            if (ok) atomicOr(needed + (ub >> 5), 1u << (ub & 31));
+            rows[b] = ok ? (int)ub : -1;
+        }
+        if (ok && gzero) reinterpret_cast<float4*>(gzero + (size_t)ub * d)[piece] = z;
+        rows += B;
+    }
+    const int64_t ib = it[b];
+    const bool ok = ib >= 0 && ib < I;
+    if (piece == 0) {
+        if (ok) atomicOr(needed + ((U + ib) >> 5), 1u << ((U + ib) & 31));
+        rows[b] = ok ? U + (int)ib : -1;
+    }
+    if (ok && gzero) reinterpret_cast<float4*>(gzero + (size_t)(U + ib) * d)[piece] = z;
+}
+
 __device__ __forceinline__ float log_sigmoid(float x) {       // log(1/(1+exp(-x))), stable for both signs
     return fminf(x, 0.f) - log1pf(__expf(-fabsf(x)));
 }
@@ -154,6 +185,22 @@ extern "C" int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const
     if (dtype == NGACF_BF16 && d == 128) NGACF_CASE(bf16_t, 128)
 #undef NGACF_CASE
     return NGACF_E_SHAPE;
+}
+
+extern "C" int ngacf_mark_rows(const int64_t* u, const int64_t* i, uint32_t* needed, int32_t* rows, float* gzero, int B, int U, int I,
+                               int d, int clear, void* stream) {
+    if (B < 0 || U <= 0 || I <= 0 || !needed || !rows || d < 4 || d % 4 != 0) return NGACF_E_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (clear) {
+        const hipError_t e = hipMemsetAsync(needed, 0, 4 * (((size_t)U + (size_t)I + 31) / 32), st);
+        if (e != hipSuccess) return static_cast<int>(e);
+    }
+    if (B == 0) return 0;
+    if (!i) return NGACF_E_ARG;
+    const size_t threads = (size_t)B * (d / 4);
+    hipLaunchKernelGGL(mark_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, u, i, needed, rows, gzero, B, U, I, d);
+    NGACF_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int ngacf_bpr_fwd(const float* pos, const float* neg, float* loss, int B, void* stream) {

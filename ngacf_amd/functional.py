@@ -13,7 +13,8 @@ class _Stage(torch.autograd.Function):
     SpUIGraphAttentionLayer heads computes in SPUIGACF.py:212 (or the out_att call :214)."""
 
     @staticmethod
-    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev=None, residual=True, grad_mode=True):
+    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev=None, residual=True, grad_mode=True,
+                needed=None):
         X = X.contiguous()
         W = W.contiguous().float()
         avec = avec.contiguous().float()
@@ -23,27 +24,72 @@ class _Stage(torch.autograd.Function):
         need = grad_mode and any(ctx.needs_input_grad[:3])
         if need:
             out, agg, R = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, save=True,
-                                       seed_dev=seed_dev)
+                                       seed_dev=seed_dev, needed=needed)
             ctx.save_for_backward(X, W, avec, H, S, out, agg, R)
-            ctx.cfg = (plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual)
+            ctx.cfg = (plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual, needed)
         else:
-            out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, seed_dev=seed_dev)
+            out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, seed_dev=seed_dev, needed=needed)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         X, W, avec, H, S, out, agg, R = ctx.saved_tensors
-        plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual = ctx.cfg
+        plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual, needed = ctx.cfg
         gout = gout.contiguous().to(H.dtype)              # already H's type under autograd: no cast kernel
-        dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, alpha, elu, residual, None, drop_p, seed, seed_dev)
+        # (needed: the rows of this stage's output the caller read -- gout is zero elsewhere and `out` is not valid there)
+        dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, alpha, elu, residual, None, drop_p, seed, seed_dev, needed)
         dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
-        return (dX, dW, da) + (None,) * 11
+        return (dX, dW, da) + (None,) * 12
+
+
+class _StageScore(torch.autograd.Function):
+    """The LAST stage of a scored batch and its scores as one node: SPUIGACF.py:212-214 + :49-52.  Only the batch's rows of
+    the stage exist (ops.BatchRows), forward and backward; the gradient of the scores goes into the rows of `rows.g32`
+    (zeroed when the batch was marked) and the traversal's backward reads it there in fp32 -- no [N, d] zero fill, no cast."""
+
+    @staticmethod
+    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev, residual, grad_mode, rows, u, *items):
+        U, I = plan.U, plan.I
+        H, S = ops.transform_fwd(X, W, avec, U, I, heads, h_dtype, feat_drop_p, seed, seed_dev)
+        u = u.contiguous().long()
+        items = [it.contiguous().long() for it in items]
+        if grad_mode and (X.requires_grad or W.requires_grad or avec.requires_grad):
+            if rows.g32 is None:
+                raise ValueError("stage_score under autograd needs ops.mark_rows(..., grad_d=d)")
+            out, agg, R = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, save=True,
+                                       seed_dev=seed_dev, needed=rows)
+            ctx.save_for_backward(X, W, avec, H, S, out, agg, R, u, *items)
+            ctx.cfg = (plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual, rows)
+        else:
+            out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, seed_dev=seed_dev, needed=rows)
+        return tuple(ops.score_fwd(out, u, it, U) for it in items)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        X, W, avec, H, S, out, agg, R, u, *items = ctx.saved_tensors
+        plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual, rows = ctx.cfg
+        for it, g in zip(items, gs):
+            if g is not None:
+                ops.score_bwd(out, u, it, g.contiguous().float(), plan.U, into=rows.g32)
+        dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, rows.g32, heads, alpha, elu, residual, None, drop_p, seed, seed_dev,
+                              rows, gout_f32=True)
+        dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
+        return (dX, dW, da) + (None,) * (13 + len(items))
+
+
+def stage_score(X, W, avec, plan, heads, rows, u, items, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=0.0, seed=0, h_dtype=None,
+                seed_dev=None, residual=True):
+    """scores[k][b] = out[u[b]] . out[U + items[k][b]] of the stage's output, computed for the rows of `rows` only."""
+    return _StageScore.apply(X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, X.dtype if h_dtype is None else h_dtype,
+                             seed_dev, residual, torch.is_grad_enabled(), rows, u, *items)
 
 
 def stage(X, W, avec, plan, heads, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=0.0, seed=0, h_dtype=None, seed_dev=None,
-          residual=True):
+          residual=True, needed=None):
+    """needed: ops.BatchRows (ops.mark_rows) -- ONLY those rows of the result are computed and may be read; the
+    gradient flowing back must be zero elsewhere (true for a result that is only read through those rows)."""
     return _Stage.apply(X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed,
-                        X.dtype if h_dtype is None else h_dtype, seed_dev, residual, torch.is_grad_enabled())
+                        X.dtype if h_dtype is None else h_dtype, seed_dev, residual, torch.is_grad_enabled(), needed)
 
 
 def stage_seed(base, s):

@@ -147,8 +147,51 @@ def _hub(plan, dev):
             _chk(plan.tickets, "plan.tickets", torch.int32, plan.nsplit, dev))
 
 
+class BatchRows:
+    """The rows of the propagated table a scored batch reads (SPUIGACF.py:49-52): one flag bit per row (int32 words) and the
+    same rows as an int32 list (first `n` entries; duplicates allowed), both written by ngacf_mark_rows."""
+    __slots__ = ("needed", "rows", "n", "U", "I", "g32")
+
+    def __init__(self, needed, rows, n, U, I, g32=None):
+        self.needed, self.rows, self.n, self.U, self.I = needed, rows, n, U, I
+        self.g32 = g32          # float [U+I, d], ZERO at the batch's rows (the rest is never read): where the scores' gradient lands
+
+    def mask(self):
+        """bool [U+I] (tests, debug asserts)"""
+        r = torch.arange(self.U + self.I, device=self.needed.device)
+        return ((self.needed[r >> 5] >> (r & 31)) & 1).bool()
+
+
+def mark_rows(u, i, U, I, into=None, grad_d=0):
+    """BatchRows of the pairs (u[b], i[b]).  `into` given: ADD the items i to it (u is ignored: forward_pairs marks
+    (user, positive) first, then the negatives of the same users).  grad_d = d: also a float [U+I, d] table whose batch
+    rows are zeroed (BatchRows.g32), for the backward of the scores."""
+    dev, B = i.device, i.numel()
+    if into is None:
+        into = BatchRows(torch.empty((U + I + 31) // 32, dtype=torch.int32, device=dev), torch.empty(max(3 * B, 1), dtype=torch.int32, device=dev), 0, U, I,
+                         torch.empty(U + I, grad_d, dtype=torch.float32, device=dev) if grad_d else None)
+        up, clear, add = (_idx(u, "userIdx", B, dev) if B else 0), 1, 2 * B
+    else:
+        if into.n + B > into.rows.numel() or (into.U, into.I) != (U, I):
+            raise ValueError("mark_rows: the row list has no room for %d more rows" % B)
+        up, clear, add = 0, 0, B
+    _lib.check(lib.ngacf_mark_rows(up, _idx(i, "itemIdx", B, dev) if B else 0, _chk(into.needed, "needed", torch.int32, (U + I + 31) // 32, dev, align=4),
+                                   into.rows.data_ptr() + 4 * into.n, into.g32.data_ptr() if into.g32 is not None else 0, B, U, I,
+                                   into.g32.shape[1] if into.g32 is not None else 4, clear, _stream()), "ngacf_mark_rows")
+    into.n += add
+    return into
+
+
+def _needed_args(needed, plan, N, dev):
+    if needed is None:
+        return 0, 0, 0, 0
+    if needed.U + needed.I != N:
+        raise ValueError("needed: row flags of a %d-row table for a table of %d rows" % (needed.U + needed.I, N))
+    return _chk(needed.needed, "needed", torch.int32, (N + 31) // 32, dev, align=4), needed.rows.data_ptr(), needed.n, int(plan.short_max)
+
+
 def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
-             drop_p=0.0, seed=0, save=False, out=None, seed_dev=None, half=None, agg=None, R=None):
+             drop_p=0.0, seed=0, save=False, out=None, seed_dev=None, half=None, agg=None, R=None, needed=None):
     """One propagation stage over plan's dst rows.  Returns out (and agg, R when save=True).
     half = "user" / "item": only the user / item dst rows (two calls with the same out / agg / R cover the stage)."""
     dev, N, d = H.device, plan.N, H.shape[1]
@@ -177,13 +220,14 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
     _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, *pp, hp,
                       _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
-                      pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev), plan.U, N, d, heads, float(alpha),
+                      pa.data_ptr(), pr.data_ptr(), *(_hub(plan, dev) if needed is None else (0, 0)), *_needed_args(needed, plan, N, dev),
+                      plan.U, N, d, heads, float(alpha),
                       float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_fwd")
     return (out, agg, R) if save else out
 
 
 def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, elu=True, residual=True,
-             score_from_row=None, drop_p=0.0, seed=0, seed_dev=None):
+             score_from_row=None, drop_p=0.0, seed=0, seed_dev=None, needed=None, gout_f32=False):
     """Returns dH [N,d] fp32 (with the dS*avec term) and dS [N,heads]."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
@@ -196,7 +240,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     op = _chk(out, "out", H.dtype, N * d, dev)
     gp = _chk(agg, "agg", torch.float32, N * d, dev)
     rp = _chk(R, "R", torch.float32, N * heads, dev)
-    go = _chk(gout, "gout", H.dtype, N * d, dev)
+    go = _chk(gout, "gout", torch.float32 if gout_f32 else H.dtype, N * d, dev)
     pp = _plan_ptrs(plan, dev)
     f32 = dict(dtype=torch.float32, device=dev)
     dH = torch.empty(N, d, **f32)                 # (no G table: one call runs both steps, step 2 recomputes g = gout * ELU'(out))
@@ -207,10 +251,11 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     if plan.n_rows != N:
         dH.zero_()
         dS.zero_()
-    flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
+    flags = ((FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) |
+             (_lib.FLAG_GOUT_F32 if gout_f32 else 0))
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, ss, ap,
                                   op, gp, rp, go, 0, Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
-                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
+                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *_needed_args(needed, plan, N, dev), plan.U, N, d, heads, float(alpha),
                                   float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_bwd")
     return dH, dS
 
@@ -298,13 +343,16 @@ def score_fwd(F, u, i, U):
     return score
 
 
-def score_bwd(F, u, i, gscore, U):
+def score_bwd(F, u, i, gscore, U, into=None):
+    """gF float [N, d] of sum(F[u] * F[U + i], 1).  into: ADD to that table instead of a fresh zero one (BatchRows.g32)."""
     dev, d, B = F.device, F.shape[1], u.numel()
     I = F.shape[0] - U
     if not 0 < U < F.shape[0]:
         raise ValueError("F has %d rows, U=%d" % (F.shape[0], U))
     fp = _chk(F, "F", None, F.shape[0] * d, dev)
-    gF = torch.zeros(F.shape[0], d, dtype=torch.float32, device=dev)
+    gF = torch.zeros(F.shape[0], d, dtype=torch.float32, device=dev) if into is None else into
+    if into is not None:
+        _chk(into, "into", torch.float32, F.shape[0] * d, dev)
     if B:
         gp = _chk(gscore, "gscore", torch.float32, B, dev)
         _lib.check(lib.ngacf_score_bwd(fp, _DT[F.dtype], _idx(u, "userIdx", B, dev), _idx(i, "itemIdx", B, dev),
@@ -498,7 +546,7 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     pr = torch.empty(max(plan.nparts, 1), heads, **f32)
     flags = (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) | _lib.FLAG_SKIP_NODE
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, sd, ap, hp, gp, sd, gp, gp, gn, st, dH.data_ptr(),
-                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), plan.U, N, d, heads, float(alpha),
+                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), 0, 0, 0, 0, plan.U, N, d, heads, float(alpha),
                                   float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_bwd")
     return dH, dS
 

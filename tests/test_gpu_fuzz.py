@@ -138,3 +138,45 @@ def test_random_eval_topk_and_sampler_vs_host(seed):
         pos, ng, un = rng.sample_pairs_host(bu.cpu().numpy(), ptr.cpu().numpy(), ki.to(torch.int32).cpu().numpy(), pool_items.cpu().numpy(), sd)
         assert int(unres) == un, tag
         assert np.array_equal(upn[1].cpu().numpy(), pos) and np.array_equal(upn[2].cpu().numpy(), ng), tag
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NGACF_FUZZ_ITERS", "12"))))
+def test_flagged_rows_stage_equals_full_stage_on_those_rows(seed, dtype):
+    """`needed` rows (the last stage of a scored batch, SPUIGACF.py:49-52 reads 2B rows of it): the batch's rows of the output
+    match the full stage's, and with a gradient that is zero outside them every input gradient matches the full stage's --
+    same terms, summed in another order (a wave per batch row instead of a lane group): rounding differences only."""
+    from ngacf_amd import functional as NF, ops
+    from ngacf_amd.plan import build_plan
+    dev = torch.device("cuda:0")
+    U, I, edge, heads, short_max, seg_len, rs = _case(5000 + seed)
+    N, d = U + I, 64
+    dt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    plan = build_plan(torch.as_tensor(edge, device=dev), U, I, seg_len=seg_len, short_max=short_max,
+                      hub_cap=int(rs.choice([0, 0, 2 * seg_len])))
+    X0 = torch.as_tensor(rs.randn(N, d) * 0.7, dtype=torch.float32, device=dev)
+    W0 = torch.as_tensor(rs.randn(2, d, d) * 0.3, dtype=torch.float32, device=dev)
+    a0 = torch.as_tensor(rs.randn(2, d) * 0.4, dtype=torch.float32, device=dev)
+    B = int(rs.randint(1, 40))
+    ub = torch.as_tensor(rs.randint(0, U, B), device=dev)
+    ib = torch.as_tensor(rs.randint(0, I, B), device=dev)
+    needed = ops.mark_rows(ub, ib, U, I)
+    want_flags = np.zeros(N, np.uint8); want_flags[ub.cpu().numpy()] = 1; want_flags[U + ib.cpu().numpy()] = 1
+    assert np.array_equal(needed.mask().cpu().numpy(), want_flags.astype(bool)) and needed.n == 2 * B
+    assert np.array_equal(needed.rows[:2 * B].cpu().numpy(), np.concatenate([ub.cpu().numpy(), U + ib.cpu().numpy()]))
+    nb = needed.mask()
+    wgt = torch.as_tensor(rs.randn(N, d), dtype=torch.float32, device=dev) * nb[:, None]
+    p_drop = float(rs.choice([0.0, 0.3]))
+    res = []
+    for flags in (None, needed):
+        X, W, a = (t.clone().requires_grad_() for t in (X0, W0, a0))
+        out = NF.stage(X, W, a, plan, heads, 0.2, True, p_drop, p_drop, 77 + seed, dt, needed=flags)
+        (out.float() * wgt).sum().backward()
+        res.append((out.detach(), X.grad, W.grad, a.grad))
+    (o_f, *g_f), (o_n, *g_n) = res
+    otol = (1e-5 if dtype == "fp32" else 1e-2) * float(o_f[nb].float().abs().max()) + 1e-12
+    assert float((o_f[nb].float() - o_n[nb].float()).abs().max()) <= otol
+    for name, x, y in zip(("dX", "dW", "da"), g_f, g_n):
+        assert torch.isfinite(y).all(), name
+        tol = (2e-5 if dtype == "fp32" else 2e-2) * float(x.abs().max()) + 1e-12
+        assert float((x - y).abs().max()) <= tol, (name, float((x - y).abs().max()), float(x.abs().max()))

@@ -73,10 +73,10 @@ def test_library_loaded_and_rejects_bad_shapes(dev):
     from ngacf_amd import _lib
     assert "gfx950" in ngacf_amd.version()
     # unsupported row width is refused before any launch
-    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 2, 48, 1, 0.2, 0.0, 0, 0, 3, 0)
+    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 48, 1, 0.2, 0.0, 0, 0, 3, 0)
     assert rc == -2
     # a table of 2^32 bytes or more does not fit the 32-bit row offsets: refused, not wrapped
-    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1 << 24, 64, 8, 0.2, 0.0, 0, 0, 3, 0)
+    rc = _lib.lib.ngacf_prop_fwd(1, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1 << 24, 64, 8, 0.2, 0.0, 0, 0, 3, 0)
     assert rc == -2
     assert _lib.lib.ngacf_score_fwd(0, 0, 0, 0, 0, 0, 5, 1, 1, 64, 0) == -1
 
@@ -624,6 +624,49 @@ def test_inkernel_hub_finish_is_bitwise_equal_to_two_kernel_path(dev):
                     torch.randn(4_000_000, device=dev).sum()
         finally:
             ops.INKERNEL_HUB_FINISH = False
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_sparse_last_stage_equals_full_propagation(dev, multi):
+    """model.forward / forward_pairs compute the LAST stage only for the rows of the batch (SPUIGACF.py:49-52 reads nothing
+    else): scores and gradients equal to the full propagation's up to the order of the fp32 additions."""
+    from ngacf_amd.SPUIGACF import SPUIGACF, SPUIMultiGACF
+    from ngacf_amd.BPRLoss import BPRLoss
+    U, I = 700, 500
+    edge = _random_graph(U, I, 9000, 3, hub=600)
+    adj = _t(edge, dev)
+    torch.manual_seed(5)
+    m = (SPUIMultiGACF if multi else SPUIGACF)(U, I, 64, [64, 64], 0.3).to(dev)
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30.0); m.iEmbd.weight.mul_(30.0)
+    for mod in m.modules():
+        if hasattr(mod, "seg_len"):
+            mod.seg_len = 64                                              # long and split rows too
+    gen = torch.Generator(device=dev).manual_seed(1)
+    u = torch.randint(0, U, (96,), device=dev, generator=gen)
+    pi = torch.randint(0, I, (96,), device=dev, generator=gen)
+    ni = torch.randint(0, I, (96,), device=dev, generator=gen)
+    out = {}
+    for sparse in (False, True):
+        m.sparse_last_stage = sparse
+        m.zero_grad(set_to_none=True)
+        m.eval()
+        with torch.no_grad():
+            s_eval = m(u, pi, adj)
+        m.train(); torch.manual_seed(11)                                  # dropout seeds come from torch's CPU generator
+        pos, neg = m.forward_pairs(u, pi, ni, adj)
+        loss = BPRLoss()(pos, neg)
+        loss.backward()
+        out[sparse] = (s_eval, pos.detach(), neg.detach(), [p.grad.clone() for p in m.parameters()])
+    for a, b in zip(out[False][:3], out[True][:3]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+    for (n, _), a, b in zip(m.named_parameters(), out[False][3], out[True][3]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12, n
+    # the full table stays available: propagate() ignores the batch
+    m.eval()
+    with torch.no_grad():
+        full = m.propagate(adj)
+    assert torch.isfinite(full).all() and full.shape[0] == U + I
 
 
 def test_integration_md_stub_runs(dev):
