@@ -226,8 +226,8 @@ def worker(args):
     if not args.no_train:
         model.train()
         lossfn = ng.BPRLoss()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=not args.eager,
-                               fused=not args.eager)    # one multi-tensor kernel instead of ~100 per step
+        from ngacf_amd.optim import Adam                 # torch.optim.Adam's arithmetic and state, one ngacf_adam_step launch per step
+        opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
         g = torch.Generator(device=dev)
         g.manual_seed(7)
         B = args.batch
@@ -269,7 +269,7 @@ def worker(args):
         if not args.eager and not big:
             # reported SEPARATELY: the opt-in mode that shares one propagation between the
             # positive and the negative scoring of a step -- not reference semantics, never the headline number
-            opt2 = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True, fused=True)
+            opt2 = Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
             gshared = GraphedBPRStep(model, lossfn, opt2, edge, B, shared_propagation=True)
             t_sh, n_sh, _ = time_train(lambda: gshared(upn))
             train["shared_propagation_optin"] = {"bpr_pairs_per_s": round(B * n_sh / t_sh, 1),

@@ -196,6 +196,17 @@ int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const int64_t* i
 int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
                     const float* gscore, float* gF, int32_t* bad_index, int B, int U, int I, int d, void* stream);
 
+/* optim.step() of the train loop (train_eval_Gowalla.py:137-138; torch.optim.Adam with L2 weight decay, run_Gowalla.py:121)
+ * for up to NGACF_ADAM_MAX_TENSORS fp32 tensors in ONE launch.  The five pointer tables and numel are HOST arrays of `count`
+ * entries (copied into the kernel's arguments); steps[t] points at the DEVICE float holding tensor t's step count AFTER this
+ * update (the caller increments it first, as torch does): bias corrections are computed from it on the device, so the call
+ * can sit in a hipGraph.  Arithmetic of torch's fused Adam: g += wd p; m += (1-b1)(g-m); v = b2 v + (1-b2) g^2;
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  All tensors 16-byte aligned. */
+#define NGACF_ADAM_MAX_TENSORS 24
+int ngacf_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const float* const* steps, const int64_t* numel, int count,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 /* BPR loss  -mean(log(sigmoid(pos - neg)))  (graphattention/BPRLoss.py:8-9).
  * loss is a single float; the function overwrites it (no pre-zeroing needed). */
 int ngacf_bpr_fwd(const float* pos, const float* neg, float* loss, int B, void* stream);

@@ -11,3 +11,4 @@ from .SPUIGACF import (SPUIGACF, SPUIGAGPCF, SPUIMultiGACF, SPUIStackedGACF, GPL
                        SpUIGraphAttentionLayer, set_compute_dtype)
 from . import SPGA                                             # noqa: F401,E402  (SPGA.SpGraphAttentionLayer, SPGA.SpGAT)
 from . import modules                                          # noqa: F401,E402  (dense multi-head attention: MultiHeadAttention, ATTLayer, GACFV1, GACFMask)
+from . import optim                                            # noqa: F401,E402  (optim.Adam: torch.optim.Adam's arithmetic and state, one launch per step)

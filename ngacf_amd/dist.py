@@ -764,7 +764,8 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
     if not args.no_train:
         model.train()
         lossfn = ng.BPRLoss()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        from .optim import Adam as _Adam
+        opt = _Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
         g = torch.Generator(device=dev)
         g.manual_seed(7)                                                  # same batch on every rank
         B = args.batch
@@ -885,7 +886,7 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
         try:
             from .graphs import GraphedBPRStep
             model.train()
-            opt_g = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True, fused=True)
+            opt_g = _Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
             gs = GraphedBPRStep(model, lossfn, opt_g, edge, B, concurrent_forwards=False, after_backward=model.reduce_grads)
             upn = torch.stack([ub, pb, nb])
             for _ in range(3):

@@ -595,3 +595,24 @@ def sample_pairs(train_u, offset, B, train_ptr, train_items32, pool_items32, see
                                           out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
                                           _chk(unresolved, "unresolved", torch.int32, 1, dev), B, _stream()), "ngacf_sample_pairs")
     return out, unresolved
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, weight_decay):
+    """ngacf_adam_step over up to _lib.ADAM_MAX_TENSORS fp32 tensors (one launch); steps[t]: 0-dim device float, already incremented."""
+    n = len(params)
+    if not (n == len(grads) == len(exp_avg) == len(exp_avg_sq) == len(steps)) or n > _lib.ADAM_MAX_TENSORS:
+        raise ValueError("adam_step: %d tensors (lists of equal length, at most %d)" % (n, _lib.ADAM_MAX_TENSORS))
+    if n == 0:
+        return
+    dev = params[0].device
+    import ctypes
+    P = ctypes.c_void_p * n
+
+    def table(ts, name, numels=None):
+        return P(*[_chk(t, name, torch.float32, t.numel() if numels is None else numels[k], dev) for k, t in enumerate(ts)])
+    numel = [p.numel() for p in params]
+    tp, tg, tm, tv = table(params, "param"), table(grads, "grad", numel), table(exp_avg, "exp_avg", numel), table(exp_avg_sq, "exp_avg_sq", numel)
+    ts = P(*[_chk(s_, "step", torch.float32, 1, dev, align=4) for s_ in steps])
+    nn = (ctypes.c_int64 * n)(*numel)
+    _lib.check(lib.ngacf_adam_step(tp, tg, tm, tv, ts, nn, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                   _stream()), "ngacf_adam_step")

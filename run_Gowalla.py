@@ -77,9 +77,9 @@ def main(args):
     print("adj.shape", tuple(adj.shape))
     model = create_model(args, data.U, data.I, dev)
     lossfn = ngacf_amd.BPRLoss()
-    # capturable + fused: the optimizer step is part of the replayed hipGraph of a batch (train_bpr(graph=True))
-    optim = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay,
-                             capturable=not args.eager, fused=not args.eager)
+    # torch.optim.Adam's arithmetic and state_dict; its step() is one ngacf_adam_step launch with the step counters on the
+    # device, so the optimizer step is part of the replayed hipGraph of a batch (train_bpr(graph=True))
+    optim = ngacf_amd.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
     os.makedirs("ckpts", exist_ok=True)
     if args.resume_from:
         # a checkpoint of the reference (run_Gowalla.py:143) or of this runner: both halves in the reference's layout;

@@ -497,3 +497,63 @@ def test_run_gowalla_csv_branch_and_refused_flags(tmp_path, monkeypatch):
         RG.parse(["--parallel", "True"])
     with pytest.raises(SystemExit):
         RG.parse(["--adj_type", "mean_adj"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_adam_step_matches_torch_adam(wd):
+    """ngacf_amd.optim.Adam (one ngacf_adam_step launch) against torch.optim.Adam on the same gradients, 6 steps: tensors of
+    ragged sizes (not multiples of 4, more tensors than one table holds), state_dict interchange both ways."""
+    from ngacf_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(3)
+    shapes = [(1000, 64), (2, 64, 64), (2, 64), (7,), (1,), (333, 5)] + [(9,)] * 27
+    pa = [torch.nn.Parameter(torch.randn(*s, device=dev, generator=gen)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = Adam(pa, lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=wd)
+    ob = torch.optim.Adam(pb, lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=wd)
+    for it in range(6):
+        if it == 3:                                   # hand the state over through state_dict, both directions
+            sa, sb = oa.state_dict(), ob.state_dict()
+            oa.load_state_dict(sb); ob.load_state_dict(sa)
+        for x, y in zip(pa, pb):
+            g = torch.randn(x.shape, device=dev, generator=gen) * (10.0 ** float(torch.randint(-3, 2, (1,)).item()))
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+        for k, (x, y) in enumerate(zip(pa, pb)):
+            assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max()) + 1e-7, (it, k)
+    assert float(oa.state[pa[0]]["step"]) == 6.0
+    for k in ("exp_avg", "exp_avg_sq"):
+        a_, b_ = oa.state[pa[0]][k], ob.state[pb[0]][k]
+        assert float((a_ - b_).abs().max()) <= 1e-6 * float(b_.abs().max())
+    with pytest.raises(ValueError):
+        Adam(pa, amsgrad=True)
+
+
+@pytest.mark.gpu
+def test_graphed_step_with_library_adam_matches_torch_adam():
+    """GraphedBPRStep with ngacf_amd.optim.Adam: same parameters after 4 replayed steps as with torch.optim.Adam(capturable)."""
+    import ngacf_amd
+    from ngacf_amd.graphs import GraphedBPRStep
+    from ngacf_amd.optim import Adam
+    from ngacf_amd import data as D
+    dev = torch.device("cuda:0")
+    U, I = 600, 400
+    edge = D.synthetic_bipartite(U, I, 8000, seed=3, device=dev)
+    res = []
+    for cls in (Adam, torch.optim.Adam):
+        torch.manual_seed(11)
+        m = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev).train()
+        kw = {} if cls is Adam else dict(capturable=True)
+        opt = cls(m.parameters(), lr=1e-2, weight_decay=1e-4, **kw)
+        step = GraphedBPRStep(m, ngacf_amd.BPRLoss(), opt, edge, 64, preserve_state=True)
+        g = torch.Generator(device=dev).manual_seed(2)
+        for _ in range(4):
+            upn = torch.stack([torch.randint(0, U, (64,), device=dev, generator=g), torch.randint(0, I, (64,), device=dev, generator=g),
+                               torch.randint(0, I, (64,), device=dev, generator=g)])
+            step(upn)
+        res.append([p.detach().clone() for p in m.parameters()])
+    # Adam's update is ~lr * g / |g| in its first steps: where a gradient is near zero, the rounding-level differences of the
+    # atomic score gradient decide its sign, so the bound is a fraction of the 4 steps of lr = 1e-2, not of the parameter
+    for a_, b_ in zip(*res):
+        assert float((a_ - b_).abs().max()) <= 0.02 * 4 * 1e-2

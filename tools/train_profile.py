@@ -28,7 +28,9 @@ def run(args):
     edge = D.workload_graph(wl, dev)
     model = bench.make_model(ng, torch, U, I, 64, args.stages, 0.1, args.dtype, dev)
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True, fused=True)
+    from ngacf_amd.optim import Adam
+    opt = (torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True, fused=True) if args.torch_adam
+           else Adam(model.parameters(), lr=1e-3, weight_decay=1e-5))
     g = torch.Generator(device=dev).manual_seed(7)
     B = args.batch
     upn = torch.stack([torch.randint(0, U, (B,), device=dev, generator=g), torch.randint(0, I, (B,), device=dev, generator=g),
@@ -81,5 +83,6 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--shared", action="store_true")
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true")
     a = ap.parse_args()
     profile(a) if a.profile else run(a)
