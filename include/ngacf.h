@@ -123,7 +123,7 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  *                           dS[n,h] = sum_src -e * lrelu'(s) * (m (Gn[n].H[src] + Gn[src].H[n])_h - t[n] - t[src])
  *   gout [N,d] dtype (the gradient arrives in the storage type of `out`)   out [N,d] dtype (forward output)
  *   agg, R: as saved by the forward
- *   G float[N][d], Gn [N][d] dtype, ST float[N][heads] (the t table): workspace    dH float[N][d], dS float[N][heads]: results
+ *   G float[N][d], Gn [N][d] dtype, ST float[N][heads] (the t table): workspace    dH [N][d] dtype (H's storage type), dS float[N][heads]: results
  *   G may be NULL when this call runs both steps (no NGACF_SKIP_NODE): step 2 then recomputes g from gout and out, bit for bit,
  *   and the 4-byte-per-element table is neither written nor read back
  *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows
@@ -140,7 +140,7 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
                    const void* out, const float* agg, const float* R, const void* gout,
-                   float* G, void* Gn, float* ST, float* dH, float* dS,
+                   float* G, void* Gn, float* ST, void* dH, float* dS,
                    float* part_acc, float* part_r,
                    const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                    int U, int N, int d, int heads, float alpha,
@@ -161,11 +161,12 @@ int ngacf_mark_rows(const int64_t* u, const int64_t* i, uint32_t* needed, int32_
  *   davec float[2][dout]        = sum_n dS[n,head(c)] * H[n,c]
  *   work  float[NGACF_TBWD_BLOCKS][din*dout + dout]: per-workgroup partial sums, reduced in
  *         workgroup order (no atomics: results are bitwise reproducible)
- * dH already contains the dS*avec term (ngacf_prop_bwd adds it).
+ * dH [N][dout] is in H's storage type h_dtype, as ngacf_prop_bwd writes it (a bf16 stage's dH was rounded to bf16 on its way
+ * into the matrix cores anyway: storing it that way halves two 18 MB streams); it already contains the dS*avec term.
  * Either half may be skipped: dX == NULL computes only dW/davec, dW == NULL (davec, work ignored) only dX, so a caller
  * can put the two independent halves on different streams. */
 int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
-                        const float* dH, const float* dS,
+                        const void* dH, const float* dS,
                         void* dX, float* dW, float* davec, float* work,
                         int U, int I, int din, int dout, int heads,
                         float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
@@ -173,7 +174,7 @@ int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* 
 /* Row-window form (see ngacf_transform_fwd_rows): X and dX local when x_local != 0; dW and davec are the
  * sums over the window rows only (all-reduce them across ranks). */
 int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
-                             const float* dH, const float* dS,
+                             const void* dH, const float* dS,
                              void* dX, float* dW, float* davec, float* work,
                              int U, int I, int din, int dout, int heads,
                              int u_lo, int u_n, int i_lo, int i_n, int x_local,

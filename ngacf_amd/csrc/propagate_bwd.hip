@@ -36,7 +36,7 @@ struct PropBwdArgs {
     float* G;
     void* Gn;
     float* Tn;                     // t[N][heads]
-    float* dH;
+    void* dH;                      // [N][d] in H's storage type: its consumer (transform_bwd.hip) rounds a bf16 stage's dH to bf16 anyway
     float* dS;
     float* part_acc;
     float* part_r;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int 
     const float* ao = a.avec + (row < a.U ? 0 : D) + q * VEC;      // the node's own type
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o[j] = g[j] + acc[j] + dsum * ao[j];
-    store_f32<VEC>(a.dH + (size_t)row * D + q * VEC, o);
+    Slice<T>::store(static_cast<T*>(a.dH) + (size_t)row * D + q * VEC, o);
     if ((q * VEC) % HW == 0) a.dS[(size_t)row * HEADS + head] = dsum;
 }
 
@@ -550,7 +550,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
                          const int32_t* col, const void* H, int dtype,
                          const float* S_dst, const float* S_src, const float* avec,
                          const void* out, const float* agg, const float* R, const void* gout,
-                         float* G, void* Gn, float* ST, float* dH, float* dS,
+                         float* G, void* Gn, float* ST, void* dH, float* dS,
                          float* part_acc, float* part_r,
                          int U, int N, int d, int heads, float alpha,
                          float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
@@ -611,7 +611,7 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
                               const int32_t* col, const void* H, int dtype,
                               const float* S_dst, const float* S_src, const float* avec,
                               const void* out, const float* agg, const float* R, const void* gout,
-                              float* G, void* Gn, float* ST, float* dH, float* dS,
+                              float* G, void* Gn, float* ST, void* dH, float* dS,
                               float* part_acc, float* part_r,
                               const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                               int U, int N, int d, int heads, float alpha,

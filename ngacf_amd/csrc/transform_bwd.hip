@@ -13,7 +13,7 @@ struct TransBwdArgs {
     const void* X;
     const float* W;
     const void* H;
-    const float* dH;
+    const void* dH;                // [N][dout] in H's storage type
     const float* dS;
     void* dX;                      // [rows][din] of X's type
     float* work;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArg
         for (int i = tid; i < TM * PER_ROW; i += 256) {
             const int r = i / PER_ROW, cv = i % PER_ROW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + r < row_end) v = *reinterpret_cast<const float4*>(a.dH + (size_t)(row0 + r) * DOUT + 4 * cv);
+            if (row0 + r < row_end) v = *reinterpret_cast<const float4*>(static_cast<const float*>(a.dH) + (size_t)(row0 + r) * DOUT + 4 * cv);
             *reinterpret_cast<float4*>(Gs + r * GS + 4 * cv) = v;
         }
     }
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void transform_bwd_dw_kernel(const TransBwdArg
             for (int i = tid; i < TM * GPR; i += 256) {
                 const int r = i / GPR, cv = i % GPR;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row0 + r < rend) v = *reinterpret_cast<const float4*>(a.dH + (size_t)(row0 + r) * DOUT + 4 * cv);
+                if (row0 + r < rend) v = *reinterpret_cast<const float4*>(static_cast<const float*>(a.dH) + (size_t)(row0 + r) * DOUT + 4 * cv);
                 *reinterpret_cast<float4*>(Gs + r * GS + 4 * cv) = v;
             }
         }
@@ -328,10 +328,7 @@ __global__ __launch_bounds__(256) void transform_dw_mfma_kernel(const TransBwdAr
             const int i = tid + 256 * j, r = i / (DOUT / 8), q = i % (DOUT / 8);
             const int row = row0 + r;
             if (row < rend) {
-                const float4 v0 = *reinterpret_cast<const float4*>(a.dH + (size_t)row * DOUT + 8 * q);
-                const float4 v1 = *reinterpret_cast<const float4*>(a.dH + (size_t)row * DOUT + 8 * q + 4);
-                const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                gr[j] = pack_bf16x8(f);
+                gr[j] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(a.dH) + (size_t)row * DOUT + 8 * q);   // bf16 as stored
                 // davec: this thread's 8 columns of row `row` (the column group q is the same for every item)
                 const uint4 hv = *reinterpret_cast<const uint4*>(Hg + (size_t)row * DOUT + 8 * q);
                 const float s = a.dS[(size_t)row * HEADS + (8 * q) / HW];
@@ -504,7 +501,7 @@ __global__ __launch_bounds__(256) void transform_bwd_reduce_kernel(const float* 
     else davec[(size_t)type * (wsz - dwsz) + (k - dwsz)] = s;
 }
 
-int transform_dx_mfma(const float* dH, const float* W, void* dX, int dx_dtype, int U, int I, int din, int dout, int heads,
+int transform_dx_mfma(const void* dH, int dh_dtype, const float* W, void* dX, int dx_dtype, int U, int I, int din, int dout, int heads,
                       int u_lo, int u_n, int i_lo, int i_n, int x_local,
                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st);   // transform_mfma.hip
 
@@ -519,7 +516,7 @@ static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool dr
     if (a.dX == nullptr || fuse_dx) {
         // nothing here: weight gradients only, or dX fused below
     } else if constexpr (sizeof(TH) == 2) {   // bf16 storage: dX on the matrix cores
-        const int rc = transform_dx_mfma(a.dH, a.W, a.dX, sizeof(TX) == 2 ? NGACF_BF16 : NGACF_F32, a.U, a.I, DIN, DOUT, HEADS, a.u_lo, a.u_n, a.i_lo, a.i_n, a.x_local,
+        const int rc = transform_dx_mfma(a.dH, NGACF_BF16, a.W, a.dX, sizeof(TX) == 2 ? NGACF_BF16 : NGACF_F32, a.U, a.I, DIN, DOUT, HEADS, a.u_lo, a.u_n, a.i_lo, a.i_n, a.x_local,
                                          a.drop_p, a.seed, a.seed_dev, st);
         if (rc != 0) return rc;
     } else {   // dX
@@ -595,7 +592,7 @@ static int dispatch_transform_bwd(const TransBwdArgs& a, float* dW, float* davec
 using namespace ngacf;
 
 extern "C" int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
-                                        const float* dH, const float* dS,
+                                        const void* dH, const float* dS,
                                         void* dX, float* dW, float* davec, float* work,
                                         int U, int I, int din, int dout, int heads,
                                         int u_lo, int u_n, int i_lo, int i_n, int x_local,
@@ -626,7 +623,7 @@ extern "C" int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float*
 }
 
 extern "C" int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,
-                                   const float* dH, const float* dS,
+                                   const void* dH, const float* dS,
                                    void* dX, float* dW, float* davec, float* work,
                                    int U, int I, int din, int dout, int heads,
                                    float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {

@@ -266,15 +266,20 @@ int transform_fwd_mfma(const void* X, int x_dtype, const float* W, const float* 
     return dispatch_mfma<float, bf16_t, true>(a, din, dout, heads, drop, st);
 }
 
-int transform_dx_mfma(const float* dH, const float* W, void* dX, int dx_dtype, int U, int I, int din, int dout, int heads,
+int transform_dx_mfma(const void* dH, int dh_dtype, const float* W, void* dX, int dx_dtype, int U, int I, int din, int dout, int heads,
                       int u_lo, int u_n, int i_lo, int i_n, int x_local,
                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st) {
     MfmaArgs a;
     a.B = dH; a.M = W; a.avec = nullptr; a.out = dX; a.S = nullptr; a.U = U; a.I = I;
     a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.b_local = 0; a.out_local = x_local;
     a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p); a.seed = seed; a.seed_dev = seed_dev; a.tpw = 1;
-    if (dx_dtype == NGACF_BF16) return dispatch_mfma<float, bf16_t, false>(a, din, dout, heads, feat_drop_p > 0.f, st);
-    return dispatch_mfma<float, float, false>(a, din, dout, heads, feat_drop_p > 0.f, st);
+    const bool drop = feat_drop_p > 0.f;
+    if (dh_dtype == NGACF_BF16) {
+        if (dx_dtype == NGACF_BF16) return dispatch_mfma<bf16_t, bf16_t, false>(a, din, dout, heads, drop, st);
+        return dispatch_mfma<bf16_t, float, false>(a, din, dout, heads, drop, st);
+    }
+    if (dx_dtype == NGACF_BF16) return dispatch_mfma<float, bf16_t, false>(a, din, dout, heads, drop, st);
+    return dispatch_mfma<float, float, false>(a, din, dout, heads, drop, st);
 }
 
 }  // namespace ngacf

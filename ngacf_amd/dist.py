@@ -293,7 +293,7 @@ class _ShardedStack(torch.autograd.Function):
                 d, heads = H.shape[1], cfg["heads"][s]
                 tabs[s] = (torch.empty(N, d, dtype=torch.float32, device=dev), torch.empty(N, d, dtype=H.dtype, device=dev),
                            torch.empty(N, heads, dtype=torch.float32, device=dev),
-                           torch.zeros(N, d, dtype=torch.float32, device=dev), torch.zeros(N, heads, dtype=torch.float32, device=dev))
+                           torch.zeros(N, d, dtype=H.dtype, device=dev), torch.zeros(N, heads, dtype=torch.float32, device=dev))
             G, Gn, ST, _, _ = tabs[s]
             be.prop_bwd_node(out, agg, R, g[t], S, G, Gn, ST, part.Up, cfg["heads"][s], part.half_win(t), True, True)
             pending[(s, t)] = comm.start_gather(t, Gn, ST)          # one grouped launch

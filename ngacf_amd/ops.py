@@ -228,7 +228,7 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
 
 def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, elu=True, residual=True,
              score_from_row=None, drop_p=0.0, seed=0, seed_dev=None, needed=None, gout_f32=False):
-    """Returns dH [N,d] fp32 (with the dS*avec term) and dS [N,heads]."""
+    """Returns dH [N,d] in H's dtype (with the dS*avec term) and dS [N,heads] fp32."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
     if score_from_row is None:
@@ -243,7 +243,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     go = _chk(gout, "gout", torch.float32 if gout_f32 else H.dtype, N * d, dev)
     pp = _plan_ptrs(plan, dev)
     f32 = dict(dtype=torch.float32, device=dev)
-    dH = torch.empty(N, d, **f32)                 # (no G table: one call runs both steps, step 2 recomputes g = gout * ELU'(out))
+    dH = torch.empty(N, d, dtype=H.dtype, device=dev)      # (no G table: one call runs both steps, step 2 recomputes g = gout * ELU'(out))
     Gn = torch.empty(N, d, dtype=H.dtype, device=dev)
     t, dS = torch.empty(N, heads, **f32), torch.empty(N, heads, **f32)
     pa = torch.empty(max(plan.nparts, 1), d, **f32)
@@ -269,7 +269,7 @@ def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0, seed_de
     xp = _chk(X, "X", None, N * din, dev)
     wp = _chk(W, "W", torch.float32, 2 * din * dout, dev)
     hp = _chk(H, "H", None, N * dout, dev)
-    gp = _chk(dH, "dH", torch.float32, N * dout, dev)
+    gp = _chk(dH, "dH", H.dtype, N * dout, dev)
     sp = _chk(dS, "dS", torch.float32, N * heads, dev)
     f32 = dict(dtype=torch.float32, device=dev)
     dX = dW = da = None
@@ -492,7 +492,7 @@ def transform_bwd_rows(X, W, H, dH, dS, U, I, heads, win, x_local, feat_drop_p=0
     xp = _chk(X, "X", None, nx * din, dev)
     wp = _chk(W, "W", torch.float32, 2 * din * dout, dev)
     hp = _chk(H, "H", None, N * dout, dev)
-    gp = _chk(dH, "dH", torch.float32, N * dout, dev)
+    gp = _chk(dH, "dH", H.dtype, N * dout, dev)
     sp = _chk(dS, "dS", torch.float32, N * heads, dev)
     f32 = dict(dtype=torch.float32, device=dev)
     dX = torch.empty(nx, din, dtype=X.dtype, device=dev)
@@ -538,9 +538,9 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     st = _chk(ST, "ST", torch.float32, N * heads, dev)
     pp = _plan_ptrs(plan, dev, half)
     f32 = dict(dtype=torch.float32, device=dev)
-    dH = torch.zeros(N, d, **f32) if dH is None else dH
+    dH = torch.zeros(N, d, dtype=H.dtype, device=dev) if dH is None else dH
     dS = torch.zeros(N, heads, **f32) if dS is None else dS
-    _chk(dH, "dH", torch.float32, N * d, dev)
+    _chk(dH, "dH", H.dtype, N * d, dev)
     _chk(dS, "dS", torch.float32, N * heads, dev)
     pa = torch.empty(max(plan.nparts, 1), d, **f32)
     pr = torch.empty(max(plan.nparts, 1), heads, **f32)

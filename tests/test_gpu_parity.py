@@ -355,7 +355,7 @@ def test_bf16_transform_backward_on_matrix_cores(dev, din, dout, heads, xdt):
         W = torch.randn(2, din, dout, device=dev, generator=g) * 0.2
         avec = torch.randn(2, dout, device=dev, generator=g)
         H, _ = ops.transform_fwd(X, W, avec, U, I, heads, torch.bfloat16, feat_drop_p=p, seed=11)
-        dH = torch.randn(N, dout, device=dev, generator=g)
+        dH = torch.randn(N, dout, device=dev, generator=g).to(torch.bfloat16)        # in H's storage type, as ngacf_prop_bwd writes it
         dS = torch.randn(N, heads, device=dev, generator=g)
         dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=p, seed=11)
         Xm = X.float()

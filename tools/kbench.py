@@ -71,7 +71,7 @@ def main():
                             med, mn = timeit(lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, go, heads, score_from_row=fr, drop_p=p, seed=3))
                             print("  prop_bwd  %s heads=%d from_row=%d drop=%.1f: med %.1f us min %.1f" % (tag, heads, fr, p, med, mn))
                     if "transform" in what:
-                        dH = torch.randn(N, 64, device=dev, generator=g); dS = torch.randn(N, heads, device=dev, generator=g)
+                        dH = torch.randn(N, 64, device=dev, generator=g).to(dt); dS = torch.randn(N, heads, device=dev, generator=g)
                         Xin = X.to(dt)
                         print("  transform_bwd heads=%d: med %.1f us min %.1f" %
                               ((heads,) + timeit(lambda: ops.transform_bwd(Xin, W, H, dH, dS, U, I, heads))))
