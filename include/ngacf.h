@@ -202,9 +202,12 @@ int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const int64_t* i
  * entries (copied into the kernel's arguments); steps[t] points at the DEVICE float holding tensor t's step count AFTER this
  * update (the caller increments it first, as torch does): bias corrections are computed from it on the device, so the call
  * can sit in a hipGraph.  Arithmetic of torch's fused Adam: g += wd p; m += (1-b1)(g-m); v = b2 v + (1-b2) g^2;
- * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  All tensors 16-byte aligned. */
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  grads2 (NULL, or a table with NULL entries allowed): a second gradient
+ * of the same tensor, g = grads[t] + grads2[t] -- the two propagations of a BPR step (train_eval_Gowalla.py:128-129) produce
+ * their parameter gradients separately, and summing them here saves autograd's eight accumulation kernels.  All tensors
+ * 16-byte aligned. */
 #define NGACF_ADAM_MAX_TENSORS 24
-int ngacf_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+int ngacf_adam_step(float* const* params, const float* const* grads, const float* const* grads2, float* const* exp_avg, float* const* exp_avg_sq,
                     const float* const* steps, const int64_t* numel, int count,
                     float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 

@@ -216,6 +216,11 @@ class _GATBase(nn.Module):
     def stage_params(self, s):
         return getattr(self, "stage%d_W" % s), getattr(self, "stage%d_a" % s)
 
+    def _stage_operands(self, s):
+        """stage_params for the forward: behind the gradient sink of the caller, if there is one (functional.grad_sink)"""
+        W, a = self.stage_params(s)
+        return NF.through_sink(W), NF.through_sink(a)
+
     def stage_shapes(self):
         """[(din, dout, heads)] per stage"""
         return [(l[0].in_dim, l[0].out_dim * len(l), len(l)) for l in self._stages()]
@@ -303,7 +308,7 @@ class _GATBase(nn.Module):
         x = features
         stages = self._stages()
         for s, layers in enumerate(stages):
-            W, avec = self.stage_params(s)
+            W, avec = self._stage_operands(s)
             # feature dropout in front of every stage (:208,:213) and the ELU behind it (:397 inside
             # the concat layers, :214 around out_att) are fused into the stage
             if score is not None and needed is not None and s == len(stages) - 1:
@@ -447,7 +452,7 @@ class _CFBase(nn.Module):
                 or wi.data_ptr() != flat.data_ptr() + wu.numel() * wu.element_size():
             self._link_tables()                                       # somebody re-assigned .data: alias again
             flat = self._flat
-        return _Table.apply(wu, wi, flat)
+        return _Table.apply(NF.through_sink(wu), NF.through_sink(wi), flat)
 
     def getFeatureMat(self):
         """SPUIGACF.py:30-39 without the per-call Python index lists."""

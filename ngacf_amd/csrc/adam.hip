@@ -4,7 +4,7 @@
 // of the four streams, four such groups in flight.
 //
 // Arithmetic = torch's fused Adam (fp32 opmath, bias corrections in double from the per-tensor step counter):
-//     g += wd * p;  m += (1 - b1) (g - m);  v = b2 v + (1 - b2) g g
+//     g (+= g2) += wd * p;  m += (1 - b1) (g - m);  v = b2 v + (1 - b2) g g
 //     p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 #include "ngacf_common.hpp"
 
@@ -13,6 +13,7 @@ namespace ngacf {
 struct AdamTable {
     float* p[NGACF_ADAM_MAX_TENSORS];
     const float* g[NGACF_ADAM_MAX_TENSORS];
+    const float* g2[NGACF_ADAM_MAX_TENSORS];       // optional second gradient of the tensor (NULL: none): g = g + g2
     float* m[NGACF_ADAM_MAX_TENSORS];
     float* v[NGACF_ADAM_MAX_TENSORS];
     const float* step[NGACF_ADAM_MAX_TENSORS];     // the step count t AFTER this update (the caller increments first)
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable a) {
     const float step_size = corr[0], bc2_sqrt = corr[1];
     float* __restrict__ P = a.p[t];
     const float* __restrict__ G = a.g[t];
+    const float* __restrict__ G2 = a.g2[t];
     float* __restrict__ M = a.m[t];
     float* __restrict__ V = a.v[t];
     const long long n = a.n[t];
@@ -53,6 +55,14 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable a) {
         if (full[k]) {
             p[k] = *reinterpret_cast<const float4*>(P + e); g[k] = *reinterpret_cast<const float4*>(G + e);
             m[k] = *reinterpret_cast<const float4*>(M + e); v[k] = *reinterpret_cast<const float4*>(V + e);
+        }
+    }
+    if (G2) {                                      // the two propagations of a BPR step hand in their gradients separately
+#pragma unroll
+        for (int k = 0; k < ADAM_ILP; ++k) {
+            if (!full[k]) continue;
+            const float4 h = *reinterpret_cast<const float4*>(G2 + base + (long long)k * 1024);
+            g[k].x += h.x; g[k].y += h.y; g[k].z += h.z; g[k].w += h.w;
         }
     }
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable a) {
         } else {
             for (long long j = e; j < n && j < e + 4; ++j) {       // ragged tail of a tensor whose size is not a multiple of 4
                 float pp = P[j], mm = M[j], vv = V[j];
-                upd(pp, G[j], mm, vv);
+                upd(pp, G2 ? G[j] + G2[j] : G[j], mm, vv);
                 P[j] = pp; M[j] = mm; V[j] = vv;
             }
         }
@@ -82,7 +92,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable a) {
 
 using namespace ngacf;
 
-extern "C" int ngacf_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+extern "C" int ngacf_adam_step(float* const* params, const float* const* grads, const float* const* grads2, float* const* exp_avg, float* const* exp_avg_sq,
                                const float* const* steps, const int64_t* numel, int count,
                                float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
     if (count < 0 || count > NGACF_ADAM_MAX_TENSORS) return NGACF_E_ARG;
@@ -95,6 +105,8 @@ extern "C" int ngacf_adam_step(float* const* params, const float* const* grads, 
         if (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t] || !steps[t] || numel[t] < 0) return NGACF_E_ARG;
         if ((reinterpret_cast<uintptr_t>(params[t]) | reinterpret_cast<uintptr_t>(grads[t]) | reinterpret_cast<uintptr_t>(exp_avg[t]) |
              reinterpret_cast<uintptr_t>(exp_avg_sq[t])) & 15) return NGACF_E_ARG;                      // 16-byte row slices
+        a.g2[t] = grads2 ? grads2[t] : nullptr;
+        if (reinterpret_cast<uintptr_t>(a.g2[t]) & 15) return NGACF_E_ARG;
         a.p[t] = params[t]; a.g[t] = grads[t]; a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t]; a.step[t] = steps[t]; a.n[t] = numel[t];
         a.first_block[t] = (int)blocks;
         blocks += (numel[t] + ADAM_CHUNK - 1) / ADAM_CHUNK;

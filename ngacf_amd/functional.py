@@ -1,5 +1,7 @@
 """autograd glue: one torch.autograd.Function per C-ABI forward/backward pair.  The math
 lives in the HIP library; these classes only route tensors and saved state."""
+import threading
+
 import torch
 
 from . import ops
@@ -94,6 +96,49 @@ def stage(X, W, avec, plan, heads, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=
 
 def stage_seed(base, s):
     return (base + (s + 1) * _STAGE_SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF
+
+
+class _Sink(torch.autograd.Function):
+    """Identity on a parameter whose backward parks the gradient in sink[key] instead of sending it on: autograd then never
+    accumulates into .grad, and the owner of the sink decides how the pieces are summed (ngacf_adam_step takes two)."""
+
+    @staticmethod
+    def forward(ctx, p, sink, key):
+        ctx.sink, ctx.key = sink, key
+        return p.view_as(p)
+
+    @staticmethod
+    def backward(ctx, g):
+        prev = ctx.sink.get(ctx.key)
+        ctx.sink[ctx.key] = g if prev is None else prev + g
+        return None, None, None
+
+
+_SINKS = threading.local()
+
+
+class grad_sink:
+    """with grad_sink(d): parameters read by the modules of this package inside the block (stage weights, embedding tables)
+    deliver their gradient to d[parameter] in the backward, not to parameter.grad."""
+
+    def __init__(self, sink):
+        self.sink = sink
+
+    def __enter__(self):                     # (sink None: an explicit "no sink here" -- parameters get .grad as usual)
+        stack = _SINKS.__dict__.setdefault("stack", [])
+        stack.append(self.sink)
+        return self.sink
+
+    def __exit__(self, *exc):
+        _SINKS.stack.pop()
+
+
+def through_sink(p):
+    """p itself, or (inside a grad_sink block, for a parameter that wants a gradient) p behind the sink"""
+    stack = _SINKS.__dict__.get("stack")
+    if not stack or stack[-1] is None or not p.requires_grad or not torch.is_grad_enabled():
+        return p
+    return _Sink.apply(p, stack[-1], p)
 
 
 class _Score(torch.autograd.Function):

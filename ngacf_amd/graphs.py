@@ -35,7 +35,7 @@ class GraphedBPRStep:
     optim must be capturable (torch.optim.Adam(..., capturable=True)); batch size is fixed at capture."""
 
     def __init__(self, model, lossfn, optim, adj, batch_size, warmup=3, shared_propagation=False, data=None,
-                 preserve_state=False, concurrent_forwards=True, fuse_loss_node=False, after_backward=None):
+                 preserve_state=False, concurrent_forwards=True, fuse_loss_node=False, after_backward=None, split_grads=True):
         """data: a train_eval.Interactions -> the graph also SAMPLES its batch (ngacf_sample_pairs over the rows
         train_u[offset : offset+B], offset and sampler seed advanced by captured adds): use begin_epoch()/replay().
         preserve_state: put parameters and optimizer state back after the warm-up steps (a training loop must not
@@ -73,6 +73,10 @@ class GraphedBPRStep:
         # natural skew of two separate score nodes lets one branch's small kernels hide under the other's traversal.
         fused_loss = (fuse_loss_node and isinstance(lossfn, BPRLoss) and isinstance(model, _CFBase)
                       and type(model).forward is _CFBase.forward)
+        # after a step of this kind .grad of the sunk parameters is None (the pieces went straight to the optimizer)
+        split_grads = (split_grads and concurrent_forwards and not shared_propagation and not fused_loss
+                       and getattr(optim, "supports_grad_pairs", False) and after_backward is None)
+        sinks = ({}, {})
 
         def step():
             for g in gats:
@@ -102,9 +106,12 @@ class GraphedBPRStep:
                     cur.wait_stream(sb)
                     loss = NF.score_pair_bpr(fa, fb, self.u, self.p, self.n, model.userNum)   # = lossfn(model(u,p), model(u,n))
                 else:
-                    with torch.cuda.stream(sa):
+                    # split_grads: every branch parks its parameter gradients in its own sink and the optimizer's kernel adds
+                    # the two (ngacf_adam_step's grads2) -- autograd would run one accumulation kernel per parameter, eight
+                    # launch-bound kernels at the very end of the slower branch
+                    with torch.cuda.stream(sa), NF.grad_sink(sinks[0] if split_grads else None):
                         ps = model(self.u, self.p, adj)
-                    with torch.cuda.stream(sb):
+                    with torch.cuda.stream(sb), NF.grad_sink(sinks[1] if split_grads else None):
                         ns = model(self.u, self.n, adj)
                     cur.wait_stream(sa)
                     cur.wait_stream(sb)
@@ -114,7 +121,16 @@ class GraphedBPRStep:
             loss.backward()
             if after_backward is not None:                  # e.g. the sharded model's grouped weight-gradient all-reduce
                 after_backward()
-            optim.step()
+            if sinks[0] or sinks[1]:
+                cur = torch.cuda.current_stream()           # the sinks were filled on the branch streams; no AccumulateGrad
+                cur.wait_stream(sa)                         # node synchronised them with this one
+                cur.wait_stream(sb)
+                keys = list(dict.fromkeys(list(sinks[0]) + list(sinks[1])))
+                optim.step(grad_pairs={k: (sinks[0].get(k), sinks[1].get(k)) for k in keys})
+                sinks[0].clear()
+                sinks[1].clear()
+            else:
+                optim.step()
             if data is not None:
                 self.total.add_(loss.detach())
             return loss

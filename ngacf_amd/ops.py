@@ -597,8 +597,9 @@ def sample_pairs(train_u, offset, B, train_ptr, train_items32, pool_items32, see
     return out, unresolved
 
 
-def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, weight_decay):
-    """ngacf_adam_step over up to _lib.ADAM_MAX_TENSORS fp32 tensors (one launch); steps[t]: 0-dim device float, already incremented."""
+def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, weight_decay, grads2=None):
+    """ngacf_adam_step over up to _lib.ADAM_MAX_TENSORS fp32 tensors (one launch); steps[t]: 0-dim device float, already
+    incremented.  grads2: optional list (entries may be None) of second gradients, g = grads[t] + grads2[t]."""
     n = len(params)
     if not (n == len(grads) == len(exp_avg) == len(exp_avg_sq) == len(steps)) or n > _lib.ADAM_MAX_TENSORS:
         raise ValueError("adam_step: %d tensors (lists of equal length, at most %d)" % (n, _lib.ADAM_MAX_TENSORS))
@@ -607,12 +608,15 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, 
     dev = params[0].device
     import ctypes
     P = ctypes.c_void_p * n
-
-    def table(ts, name, numels=None):
-        return P(*[_chk(t, name, torch.float32, t.numel() if numels is None else numels[k], dev) for k, t in enumerate(ts)])
     numel = [p.numel() for p in params]
-    tp, tg, tm, tv = table(params, "param"), table(grads, "grad", numel), table(exp_avg, "exp_avg", numel), table(exp_avg_sq, "exp_avg_sq", numel)
+
+    def table(ts, name, optional=False):
+        return P(*[(None if optional and t is None else _chk(t, name, torch.float32, numel[k], dev)) for k, t in enumerate(ts)])
+    tp, tg, tm, tv = table(params, "param"), table(grads, "grad"), table(exp_avg, "exp_avg"), table(exp_avg_sq, "exp_avg_sq")
+    if grads2 is not None and len(grads2) != n:
+        raise ValueError("adam_step: %d second gradients for %d tensors" % (len(grads2), n))
+    t2 = table(grads2, "grad2", True) if grads2 is not None and any(g is not None for g in grads2) else None
     ts = P(*[_chk(s_, "step", torch.float32, 1, dev, align=4) for s_ in steps])
     nn = (ctypes.c_int64 * n)(*numel)
-    _lib.check(lib.ngacf_adam_step(tp, tg, tm, tv, ts, nn, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+    _lib.check(lib.ngacf_adam_step(tp, tg, t2, tm, tv, ts, nn, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                    _stream()), "ngacf_adam_step")

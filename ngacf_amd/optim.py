@@ -37,18 +37,27 @@ class Adam(torch.optim.Adam):
             if "step" in st and torch.is_tensor(st["step"]):
                 st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
 
+    supports_grad_pairs = True
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_pairs=None):
+        """grad_pairs: {parameter: (g_a, g_b)} -- the parameter's gradient is g_a + g_b (g_b may be None), summed inside the
+        step's kernel; parameters not in it use .grad as usual.  (GraphedBPRStep hands in the gradients of its two
+        propagations this way instead of letting autograd accumulate them.)"""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         for group in self.param_groups:
             ps, gs, ms, vs, steps = [], [], [], [], []
+            g2s = []
             for p in group["params"]:
-                if p.grad is None:
+                ga, gb = grad_pairs[p] if grad_pairs is not None and p in grad_pairs else (p.grad, None)
+                if ga is None and gb is not None:
+                    ga, gb = gb, None
+                if ga is None:
                     continue
-                if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                if ga.is_sparse or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
                     raise ValueError("ngacf_amd.optim.Adam: contiguous fp32 CUDA parameters with dense gradients only")
                 st = self.state[p]
                 if len(st) == 0:
@@ -57,12 +66,14 @@ class Adam(torch.optim.Adam):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 if st["step"].device != p.device or st["step"].dtype != torch.float32:      # a state loaded from a host-step Adam
                     st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
-                ps.append(p); gs.append(p.grad.contiguous()); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"]); steps.append(st["step"])
+                ps.append(p); gs.append(ga.contiguous()); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"]); steps.append(st["step"])
+                g2s.append(None if gb is None else gb.contiguous())
             if not ps:
                 continue
             torch._foreach_add_(steps, 1.0)
             b1, b2 = group["betas"]
             for lo in range(0, len(ps), _lib.ADAM_MAX_TENSORS):
                 hi = lo + _lib.ADAM_MAX_TENSORS
-                ops.adam_step(ps[lo:hi], gs[lo:hi], ms[lo:hi], vs[lo:hi], steps[lo:hi], group["lr"], b1, b2, group["eps"], group["weight_decay"])
+                ops.adam_step(ps[lo:hi], gs[lo:hi], ms[lo:hi], vs[lo:hi], steps[lo:hi], group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                              grads2=g2s[lo:hi])
         return loss

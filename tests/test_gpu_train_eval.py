@@ -519,7 +519,16 @@ def test_adam_step_matches_torch_adam(wd):
         for x, y in zip(pa, pb):
             g = torch.randn(x.shape, device=dev, generator=gen) * (10.0 ** float(torch.randint(-3, 2, (1,)).item()))
             x.grad, y.grad = g.clone(), g.clone()
-        oa.step(); ob.step()
+        if it >= 4:                                   # the gradient handed in as two pieces: summed inside the kernel
+            pairs = {}
+            for k, x in enumerate(pa):
+                piece = torch.randn(x.shape, device=dev, generator=gen)
+                pairs[x] = (x.grad - piece, piece if k % 3 else None) if k % 3 else (x.grad, None)
+                x.grad = None
+            oa.step(grad_pairs=pairs)
+        else:
+            oa.step()
+        ob.step()
         for k, (x, y) in enumerate(zip(pa, pb)):
             assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max()) + 1e-7, (it, k)
     assert float(oa.state[pa[0]]["step"]) == 6.0
