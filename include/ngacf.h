@@ -197,7 +197,7 @@ int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const int64_t* i
 int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
                     const float* gscore, float* gF, int32_t* bad_index, int B, int U, int I, int d, void* stream);
 
-/* optim.step() of the train loop (train_eval_Gowalla.py:137-138; torch.optim.Adam with L2 weight decay, run_Gowalla.py:121)
+/* optim.step() of the train loop (train_eval_Gowalla.py:137-138; torch.optim.Adam with L2 weight decay, run_Gowalla.py:114)
  * for up to NGACF_ADAM_MAX_TENSORS fp32 tensors in ONE launch.  The five pointer tables and numel are HOST arrays of `count`
  * entries (copied into the kernel's arguments); steps[t] points at the DEVICE float holding tensor t's step count AFTER this
  * update (the caller increments it first, as torch does): bias corrections are computed from it on the device, so the call

@@ -1,5 +1,5 @@
 // Adam step of the BPR train loop (train_eval_Gowalla.py:137-138: optim.step() of torch.optim.Adam with L2 weight decay,
-// run_Gowalla.py:121) for ALL parameter tensors in one launch.  Pure streaming: per element it reads p, g, m, v and writes
+// run_Gowalla.py:114) for ALL parameter tensors in one launch.  Pure streaming: per element it reads p, g, m, v and writes
 // p, m, v (28 B) -- 126 MB per step at Gowalla scale, i.e. bound by the HBM/fabric copy rate; a lane moves 16 bytes of each
 // of the four streams, four such groups in flight.
 //

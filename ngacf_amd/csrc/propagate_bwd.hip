@@ -240,19 +240,26 @@ __device__ __forceinline__ void sparse_edges_b(const PropBwdArgs& a, const RowCt
         constexpr int NS = QCAP / LPR;
         int c[NS];
         bool act[NS];
+        const int rem = maxcount - k0;                          // (uniform) edges left in the longest group: rounds beyond it are skipped
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
+            act[i] = false; c[i] = 0;
+            if (i * LPR >= rem) continue;
             const int k = k0 + i * LPR + q;
             act[i] = k < count;
             c[i] = a.col[act[i] ? ebase + k * estride : 0];
         }
         if (!x.in_batch) {
 #pragma unroll
-            for (int i = 0; i < NS; ++i) act[i] = act[i] && flagged(a.needed, c[i]);
+            for (int i = 0; i < NS; ++i) {
+                if (i * LPR >= rem) continue;
+                act[i] = act[i] && flagged(a.needed, c[i]);
+            }
         }
         int n = 0;                                              // queued so far (the same in every lane of the group)
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
+            if (i * LPR >= rem) continue;
             const unsigned long long mine = (__ballot(act[i]) >> (slot * LPR)) & group;
             if (act[i]) qbuf[n + __popcll(mine & below)] = c[i];
             n += __popcll(mine);

@@ -2,7 +2,7 @@
 `step`, `exp_avg`, `exp_avg_sq` per parameter, so ngacf_amd/checkpoint.py and the reference's .pkl files interchange) whose
 step() is ONE ngacf_adam_step launch over all parameters instead of torch's multi-tensor kernels (49 us -> see DESIGN.md
 section 3.6 at Gowalla scale).  Reference: `optim = Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)`
-run_Gowalla.py:121, `optim.step()` train_eval_Gowalla.py:138."""
+run_Gowalla.py:114, `optim.step()` train_eval_Gowalla.py:138."""
 import ctypes
 
 import torch

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--user-batch", type=int, default=1 << 20)
+    ap.add_argument("--epochs", type=int, default=0, help="also time this many training epochs (train_bpr(graph=True), B = 2048)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     U, I, E = D.SHAPES[a.workload]
@@ -35,6 +36,19 @@ def main():
     torch.manual_seed(0)
     m = ng.SPUIMultiGACF(U, I, 64, [64, 64], 0.1).to(dev)
     ng.set_compute_dtype(m, torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    if a.epochs:
+        from ngacf_amd.optim import Adam
+        from ngacf_amd.train_eval import train_bpr
+        opt = Adam(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        gen = torch.Generator(device=dev).manual_seed(3)
+        loss = train_bpr(m, 2048, data, adj, opt, ng.BPRLoss(), gen, graph=True)      # capture + first epoch
+        torch.cuda.synchronize()
+        for _ in range(a.epochs):
+            t0 = time.perf_counter()
+            loss = train_bpr(m, 2048, data, adj, opt, ng.BPRLoss(), gen, graph=True)
+            torch.cuda.synchronize()
+            print("train epoch %s: %d pairs, %d steps of 2048: %.3f s  loss %.6f" % (a.workload, data.train_u.numel(), data.train_u.numel() // 2048,
+                                                                                  time.perf_counter() - t0, float(loss)), flush=True)
     res = eval_neg_all(m, 2048, data, adj, user_batch=a.user_batch)
     torch.cuda.synchronize()
     ts = []
