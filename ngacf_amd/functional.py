@@ -70,6 +70,10 @@ class _StageScore(torch.autograd.Function):
     def backward(ctx, *gs):
         X, W, avec, H, S, out, agg, R, u, *items = ctx.saved_tensors
         plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual, rows = ctx.cfg
+        if rows.consumed:
+            raise RuntimeError("second backward through the same scored batch: its gradient rows were zeroed once, by the forward "
+                               "(run the forward again, or set sparse_last_stage = False for retain_graph use)")
+        rows.consumed = True
         for it, g in zip(items, gs):
             if g is not None:
                 ops.score_bwd(out, u, it, g.contiguous().float(), plan.U, into=rows.g32)

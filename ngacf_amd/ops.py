@@ -150,11 +150,12 @@ def _hub(plan, dev):
 class BatchRows:
     """The rows of the propagated table a scored batch reads (SPUIGACF.py:49-52): one flag bit per row (int32 words) and the
     same rows as an int32 list (first `n` entries; duplicates allowed), both written by ngacf_mark_rows."""
-    __slots__ = ("needed", "rows", "n", "U", "I", "g32")
+    __slots__ = ("needed", "rows", "n", "U", "I", "g32", "consumed")
 
     def __init__(self, needed, rows, n, U, I, g32=None):
         self.needed, self.rows, self.n, self.U, self.I = needed, rows, n, U, I
         self.g32 = g32          # float [U+I, d], ZERO at the batch's rows (the rest is never read): where the scores' gradient lands
+        self.consumed = False   # one backward per marking: a second one would add to the first one's gradient rows
 
     def mask(self):
         """bool [U+I] (tests, debug asserts)"""

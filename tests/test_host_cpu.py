@@ -378,3 +378,41 @@ def test_runner_makes_the_references_seeded_split():
     assert np.array_equal(data.train_u.numpy(), u[g["train_rows"]]) and np.array_equal(data.train_i.numpy(), i[g["train_rows"]])
     assert np.array_equal(data.test_u.numpy(), u[g["test_rows"]]) and np.array_equal(data.test_i.numpy(), i[g["test_rows"]])
     assert int(data.train_users.numel()) == int(g["n_train_users"])
+
+
+def test_grad_sink_parks_parameter_gradients_and_adam_refuses_what_it_cannot_step():
+    """functional.grad_sink: inside the block a parameter read through through_sink() delivers its gradient to the sink, not
+    to .grad (GraphedBPRStep hands the two propagations' pieces to ngacf_adam_step separately); outside the block, with a
+    None sink, without grad mode or for a frozen parameter it is the parameter itself.  ngacf_amd.optim.Adam keeps
+    torch.optim.Adam's constructor / state layout and refuses the modes its kernel does not implement."""
+    from ngacf_amd import functional as NF
+    from ngacf_amd.optim import Adam
+    p = torch.nn.Parameter(torch.arange(6.0).reshape(2, 3))
+    frozen = torch.nn.Parameter(torch.ones(3), requires_grad=False)
+    assert NF.through_sink(p) is p
+    sink_a, sink_b = {}, {}
+    with NF.grad_sink(sink_a):
+        ya = (NF.through_sink(p) * 2.0).sum()
+        assert NF.through_sink(frozen) is frozen
+        with torch.no_grad():
+            assert NF.through_sink(p) is p
+        with NF.grad_sink(None):                       # an explicit "no sink here"
+            assert NF.through_sink(p) is p
+    with NF.grad_sink(sink_b):
+        q = NF.through_sink(p)
+        yb = (q * 3.0).sum() + (NF.through_sink(p) * 1.0).sum()      # read twice inside one block: the pieces add up
+    (ya + yb).backward()
+    assert p.grad is None
+    assert torch.equal(sink_a[p], torch.full((2, 3), 2.0)) and torch.equal(sink_b[p], torch.full((2, 3), 4.0))
+    # the optimizer: same defaults and state_dict keys as torch's, loud on what the kernel does not do
+    opt = Adam([p], lr=1e-2, weight_decay=1e-4)
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone())], lr=1e-2, weight_decay=1e-4)
+    for k in ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize"):
+        assert opt.param_groups[0][k] == ref.param_groups[0][k]
+    assert isinstance(opt, torch.optim.Adam) and opt.supports_grad_pairs
+    for bad in (dict(amsgrad=True), dict(maximize=True), dict(lr=torch.tensor(1e-3)), dict(unknown=1)):
+        with pytest.raises(ValueError):
+            Adam([p], **bad)
+    p.grad = torch.ones_like(p)
+    with pytest.raises(ValueError, match="CUDA"):      # a host parameter never reaches the library (no CPU fallback)
+        opt.step()
