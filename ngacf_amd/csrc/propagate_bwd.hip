@@ -16,6 +16,7 @@
 namespace ngacf {
 
 constexpr int UNROLL = 4;
+constexpr int UNROLL_Q = 2;          // edges in flight per lane group while a row outside the batch walks its queue (2-5 entries, typically)
 
 struct PropBwdArgs {
     const int4* segs;
@@ -270,18 +271,18 @@ __device__ __forceinline__ void sparse_edges_b(const PropBwdArgs& a, const RowCt
         const int maxn = uniform(mn);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int b = 0; b < maxn; b += UNROLL) {
-            int c[UNROLL];
-            bool ok[UNROLL];
+        for (int b = 0; b < maxn; b += UNROLL_Q) {
+            int c[UNROLL_Q];
+            bool ok[UNROLL_Q];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
+            for (int u = 0; u < UNROLL_Q; ++u) {
                 ok[u] = b + u < n;
                 c[u] = ok[u] ? qbuf[b + u] : row;               // (idle: the own row, a cached line)
             }
-            float hv[UNROLL][VEC], gv[UNROLL][VEC];
-            float ss[UNROLL], tc[UNROLL];
+            float hv[UNROLL_Q][VEC], gv[UNROLL_Q][VEC];
+            float ss[UNROLL_Q], tc[UNROLL_Q];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
+            for (int u = 0; u < UNROLL_Q; ++u) {
                 load_row<T, D, HEADS>(a.H, c[u], q, hv[u]);
                 load_row<T, D, HEADS>(a.Gn, c[u], q, gv[u]);
                 tc[u] = a.Tn[(size_t)c[u] * HEADS + head];
@@ -293,7 +294,7 @@ __device__ __forceinline__ void sparse_edges_b(const PropBwdArgs& a, const RowCt
                 }
             }
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
+            for (int u = 0; u < UNROLL_Q; ++u)
                 edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], ok[u], c[u], acc, dsum);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -329,8 +330,9 @@ __device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int 
 }
 
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE>
-__global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
+__global__ __launch_bounds__(256, (SPARSE && DROP) ? 5 : 1) void prop_bwd_kernel(const PropBwdArgs a) {
     using SH = BShape<T, D, HEADS>;
+    constexpr int UNR = SPARSE ? 2 : UNROLL;      // SPARSE: the dense loops serve the few rows of the batch only -- fewer registers, more waves
     constexpr int LPR = SH::LPR, EPI = SH::EPI, HW = SH::HW, VEC = SH::VEC;
     const int lane = threadIdx.x & 63;
     const int slot = lane / LPR, q = lane % LPR;
@@ -353,23 +355,23 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
         const int row = uniform(a.hrow[widx]);
         const int beg = uniform(a.rowptr[row]), end = uniform(a.rowptr[row + 1]);
         load_ctx<T, D, HEADS, FROM_ROW, DROP, SPARSE>(a, row, q, head, x);
-        for (int base = beg + wv * EPI * UNROLL; base < end; base += 4 * EPI * UNROLL) {
-            int c[UNROLL];
-            bool ok[UNROLL];
+        for (int base = beg + wv * EPI * UNR; base < end; base += 4 * EPI * UNR) {
+            int c[UNR];
+            bool ok[UNR];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const int e = base + u * EPI + slot;
                 ok[u] = e < end;
                 c[u] = a.col[ok[u] ? e : end - 1];
             }
-            float hv[UNROLL][VEC], gv[UNROLL][VEC];
-            float ss[UNROLL], tc[UNROLL];
+            float hv[UNR][VEC], gv[UNR][VEC];
+            float ss[UNR], tc[UNR];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {              // (SPARSE: every edge is gathered; the ones outside the batch add exact zeros)
+            for (int u = 0; u < UNR; ++u) {              // (SPARSE: every edge is gathered; the ones outside the batch add exact zeros)
                 load_edge_b<T, D, HEADS, FROM_ROW, SPARSE>(a, c[u], row, q, head, hv[u], gv[u], ss[u], tc[u]);
             }
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
+            for (int u = 0; u < UNR; ++u)
                 edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], ok[u], c[u], acc, dsum);
         }
 #pragma unroll
@@ -419,16 +421,16 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
             c[4] = slot_bcast_b<LPR, 4>(colv); c[5] = slot_bcast_b<LPR, 5>(colv);
             c[6] = slot_bcast_b<LPR, 6>(colv); c[7] = slot_bcast_b<LPR, 7>(colv);
 #pragma unroll
-            for (int h0 = 0; h0 < 8; h0 += UNROLL) {
+            for (int h0 = 0; h0 < 8; h0 += UNR) {
                 if (h0 > 0 && k0 + h0 >= maxdeg) break;
-                float hv[UNROLL][VEC], gv[UNROLL][VEC];
-                float ss[UNROLL], tc[UNROLL];
+                float hv[UNR][VEC], gv[UNR][VEC];
+                float ss[UNR], tc[UNR];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
+                for (int u = 0; u < UNR; ++u) {
                     load_edge_b<T, D, HEADS, FROM_ROW, SPARSE>(a, c[h0 + u], row, q, head, hv[u], gv[u], ss[u], tc[u]);
                 }
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u)
+                for (int u = 0; u < UNR; ++u)
                     edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], k0 + h0 + u < deg, c[h0 + u], acc, dsum);
             }
             colv = coln;
@@ -455,23 +457,23 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropBwdArgs a) {
         const int mine = end - beg - slot;
         sparse_edges_b<T, D, HEADS, FROM_ROW, DROP>(a, x, qbuf, row, beg + slot, EPI, mine > 0 ? (mine + EPI - 1) / EPI : 0, slot, q, head, acc, dsum);
     } else {
-        for (int base = beg; base < end; base += EPI * UNROLL) {
-            int c[UNROLL];
-            bool ok[UNROLL];
+        for (int base = beg; base < end; base += EPI * UNR) {
+            int c[UNR];
+            bool ok[UNR];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const int e = base + u * EPI + slot;
                 ok[u] = e < end;
                 c[u] = a.col[ok[u] ? e : end - 1];
             }
-            float hv[UNROLL][VEC], gv[UNROLL][VEC];
-            float ss[UNROLL], tc[UNROLL];
+            float hv[UNR][VEC], gv[UNR][VEC];
+            float ss[UNR], tc[UNR];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 load_edge_b<T, D, HEADS, FROM_ROW, SPARSE>(a, c[u], row, q, head, hv[u], gv[u], ss[u], tc[u]);
             }
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
+            for (int u = 0; u < UNR; ++u)
                 edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], ok[u], c[u], acc, dsum);
         }
     }
