@@ -330,7 +330,7 @@ __device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int 
 }
 
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE>
-__global__ __launch_bounds__(256, (SPARSE && DROP) ? 5 : 1) void prop_bwd_kernel(const PropBwdArgs a) {
+__global__ __launch_bounds__(256, SPARSE ? (DROP ? 5 : 4) : 1) void prop_bwd_kernel(const PropBwdArgs a) {
     using SH = BShape<T, D, HEADS>;
     constexpr int UNR = SPARSE ? 2 : UNROLL;      // SPARSE: the dense loops serve the few rows of the batch only -- fewer registers, more waves
     constexpr int LPR = SH::LPR, EPI = SH::EPI, HW = SH::HW, VEC = SH::VEC;
