@@ -90,8 +90,8 @@ int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float* W, const f
  * the two numerator sparse.mm, div, NaN->0, residual) plus the ELU of :397/:214.
  *   H      [N,d] dtype     S_dst,S_src float[N][heads] (may alias; S_src unused with NGACF_SCORE_ROW)
  *   avec   float[2][d]     (as in ngacf_transform_fwd; used only with NGACF_SCORE_ROW)
- *   out    [N,d] dtype     agg float[N][d] / R float[N][heads]: normalised aggregate and
- *                          denominators, saved for the backward (both may be NULL)
+ *   out    [N,d] dtype     agg [N,d] dtype / R float[N][heads]: normalised aggregate (in the storage type, like
+ *                          every other table of the stage) and denominators, saved for the backward (both may be NULL)
  *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows
  *   part_split int32[nparts] (hub row of every slot), tickets int32[nsplit] (all zero on entry, left all zero):
  *       with both given, the last-arriving slice of a hub row finishes it inside the launch (agent-scope
@@ -111,7 +111,7 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
-                   void* out, float* agg, float* R, float* part_acc, float* part_r,
+                   void* out, void* agg, float* R, float* part_acc, float* part_r,
                    const int32_t* part_split, int32_t* tickets,
                    const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                    int U, int N, int d, int heads, float alpha,
@@ -139,7 +139,7 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
                    const int32_t* col, const void* H, int dtype,
                    const float* S_dst, const float* S_src, const float* avec,
-                   const void* out, const float* agg, const float* R, const void* gout,
+                   const void* out, const void* agg, const float* R, const void* gout,
                    float* G, void* Gn, float* ST, void* dH, float* dS,
                    float* part_acc, float* part_r,
                    const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
@@ -182,7 +182,7 @@ int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float* W, const v
 
 /* Step 1 of ngacf_prop_bwd alone, over row windows; gout holds only the window rows when gout_local != 0.
  * Lets a node-partitioned run all-gather Gn/ST between the two steps (then ngacf_prop_bwd with NGACF_SKIP_NODE). */
-int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg, const float* R, const void* gout,
+int ngacf_prop_bwd_node(const void* out, int dtype, const void* agg, const float* R, const void* gout,
                         const float* S_src, float* G, void* Gn, float* ST,
                         int U, int N, int d, int heads, int flags,
                         int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream);

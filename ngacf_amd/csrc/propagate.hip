@@ -31,7 +31,7 @@ struct PropArgs {
     const float* S_src;
     const float* avec;     // [2][d]
     void* out;
-    float* agg;
+    void* agg;             // optional [N][d] in the storage type: the normalised aggregate, for the backward
     float* R;
     float* part_acc;
     float* part_r;
@@ -100,11 +100,7 @@ __device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, in
         o[j] = (a.flags & NGACF_ELU) ? elu_fast(pre) : pre;
     }
     Slice<T>::store(static_cast<T*>(a.out) + (size_t)row * D + q * VEC, o);
-    if (a.agg) {
-        float* ga = a.agg + (size_t)row * D + q * VEC;
-#pragma unroll
-        for (int j = 0; j < VEC; j += 4) *reinterpret_cast<float4*>(ga + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
-    }
+    if (a.agg) Slice<T>::store(static_cast<T*>(a.agg) + (size_t)row * D + q * VEC, acc);    // (bf16 storage: 128 B per row instead of 256)
     if (a.R && (q * VEC) % SH::HW == 0) a.R[(size_t)row * HEADS + head] = rsum;
 }
 
@@ -437,7 +433,7 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
                               const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
                               const int32_t* col, const void* H, int dtype,
                               const float* S_dst, const float* S_src, const float* avec,
-                              void* out, float* agg, float* R, float* part_acc, float* part_r,
+                              void* out, void* agg, float* R, float* part_acc, float* part_r,
                               const int32_t* part_split, int32_t* tickets,
                               const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                               int U, int N, int d, int heads, float alpha,

@@ -31,7 +31,7 @@ struct PropBwdArgs {
     const float* S_src;
     const float* avec;
     const void* out;
-    const float* agg;
+    const void* agg;               // [N][d] in the storage type (as ngacf_prop_fwd saved it)
     const float* R;
     const void* gout;              // [rows][d] of the stage's storage type (the dtype autograd hands back)
     float* G;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void prop_bwd_node_kernel(const PropBwdArgs a)
     float g[VEC], o[VEC], ag[VEC];
     if (a.flags & NGACF_GOUT_F32) load_f32<VEC>(static_cast<const float*>(a.gout) + nn * D + q * VEC, g);
     else Slice<T>::load(static_cast<const T*>(a.gout) + (a.gout_local ? lj : nn) * D + q * VEC, g);
-    load_f32<VEC>(a.agg + nn * D + q * VEC, ag);
+    Slice<T>::load(static_cast<const T*>(a.agg) + nn * D + q * VEC, ag);
     if (a.flags & NGACF_ELU) {
         Slice<T>::load(static_cast<const T*>(a.out) + nn * D + q * VEC, o);
 #pragma unroll
@@ -558,7 +558,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
                          const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
                          const int32_t* col, const void* H, int dtype,
                          const float* S_dst, const float* S_src, const float* avec,
-                         const void* out, const float* agg, const float* R, const void* gout,
+                         const void* out, const void* agg, const float* R, const void* gout,
                          float* G, void* Gn, float* ST, void* dH, float* dS,
                          float* part_acc, float* part_r,
                          int U, int N, int d, int heads, float alpha,
@@ -619,7 +619,7 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
                               const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
                               const int32_t* col, const void* H, int dtype,
                               const float* S_dst, const float* S_src, const float* avec,
-                              const void* out, const float* agg, const float* R, const void* gout,
+                              const void* out, const void* agg, const float* R, const void* gout,
                               float* G, void* Gn, float* ST, void* dH, float* dS,
                               float* part_acc, float* part_r,
                               const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
@@ -631,7 +631,7 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
                          0, U, 0, N - U, 0, !skip_node, true, needed, rows, nrows, short_max, stream);
 }
 
-extern "C" int ngacf_prop_bwd_node(const void* out, int dtype, const float* agg, const float* R, const void* gout,
+extern "C" int ngacf_prop_bwd_node(const void* out, int dtype, const void* agg, const float* R, const void* gout,
                                    const float* S_src, float* G, void* Gn, float* ST,
                                    int U, int N, int d, int heads, int flags,
                                    int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream) {

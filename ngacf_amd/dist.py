@@ -257,7 +257,7 @@ class _ShardedStack(torch.autograd.Function):
             H, S, heads = Hs[s], Ss[s], cfg["heads"][s]
             dout = H.shape[1]
             out = torch.empty(N, dout, dtype=H.dtype, device=dev)
-            agg = torch.empty(N, dout, dtype=torch.float32, device=dev) if need else None
+            agg = torch.empty(N, dout, dtype=H.dtype, device=dev) if need else None
             R = torch.empty(N, heads, dtype=torch.float32, device=dev) if need else None
             Xs = dict(X)
             for t in (A, B):

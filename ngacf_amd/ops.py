@@ -210,9 +210,9 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
         out = torch.empty(N, d, dtype=H.dtype, device=dev)
     op = _chk(out, "out", H.dtype, N * d, dev)
     if save:
-        agg = torch.empty(N, d, dtype=torch.float32, device=dev) if agg is None else agg
+        agg = torch.empty(N, d, dtype=H.dtype, device=dev) if agg is None else agg       # (storage type: bf16 tables halve it)
         R = torch.empty(N, heads, dtype=torch.float32, device=dev) if R is None else R
-        _chk(agg, "agg", torch.float32, N * d, dev)
+        _chk(agg, "agg", H.dtype, N * d, dev)
         _chk(R, "R", torch.float32, N * heads, dev)
     else:
         agg = R = None
@@ -239,7 +239,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
     ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
     op = _chk(out, "out", H.dtype, N * d, dev)
-    gp = _chk(agg, "agg", torch.float32, N * d, dev)
+    gp = _chk(agg, "agg", H.dtype, N * d, dev)
     rp = _chk(R, "R", torch.float32, N * heads, dev)
     go = _chk(gout, "gout", torch.float32 if gout_f32 else H.dtype, N * d, dev)
     pp = _plan_ptrs(plan, dev)
@@ -513,7 +513,7 @@ def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local
     _heads_ok(d, heads)
     u_lo, u_n, i_lo, i_n = win
     op = _chk(out, "out", None, N * d, dev)
-    ap = _chk(agg, "agg", torch.float32, N * d, dev)
+    ap = _chk(agg, "agg", out.dtype, N * d, dev)
     rp = _chk(R, "R", torch.float32, N * heads, dev)
     go = _chk(gout, "gout", out.dtype, ((u_n + i_n) if gout_local else N) * d, dev)
     ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
