@@ -467,6 +467,7 @@ class _CFBase(nn.Module):
     # rows only (ngacf_prop_fwd / _bwd `needed`), forward and backward -- same numbers, ~1/17 of the last stage's edges at
     # B = 2048 on a Gowalla-size graph.  False: every stage in full (A/B timing, tests).
     sparse_last_stage = os.environ.get("NGACF_SPARSE_LAST", "1") != "0"
+    sparse_max_fraction = float(os.environ.get("NGACF_SPARSE_MAX_FRACTION", "0.2"))
 
     def propagate(self, mask, needed=None, score=None):
         _refuse_replica(self)
@@ -476,6 +477,10 @@ class _CFBase(nn.Module):
     def _batch_rows(self, userIdx, *itemIdxs):
         _refuse_replica(self)
         if not self.sparse_last_stage or NF.ops.INKERNEL_HUB_FINISH:
+            return None
+        # worth it while the batch touches a small part of the table: measured crossover with the full stage at ~23 % of the
+        # rows (B = 8192 of a 70 839-row graph, profiles/r02_sparse_probe_gowalla.log); beyond 1/5 the full stage runs
+        if (1 + len(itemIdxs)) * userIdx.numel() > self.sparse_max_fraction * (self.userNum + self.itemNum):
             return None
         rows = None
         d = self.gat.stage_shapes()[-1][1] if torch.is_grad_enabled() else 0          # width of the last stage's output

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The modules compute the last stage for the batch's rows only while the batch lists at most a fifth of the table's rows (a
+# profitability cut-off); the test graphs are small next to their batches, so the tests lift the cut-off to keep exercising
+# that path (test_sparse_last_stage_cutoff checks the default).
+os.environ.setdefault("NGACF_SPARSE_MAX_FRACTION", "1e9")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -669,6 +669,18 @@ def test_sparse_last_stage_equals_full_propagation(dev, multi):
     assert torch.isfinite(full).all() and full.shape[0] == U + I
 
 
+def test_sparse_last_stage_cutoff(dev):
+    """Beyond sparse_max_fraction (default 0.2 of the rows, the measured crossover is ~0.23) the modules run the full stage."""
+    from ngacf_amd.SPUIGACF import SPUIGACF
+    m = SPUIGACF(100, 80, 64, [64, 64], 0.1).to(dev)
+    u = torch.zeros(10, dtype=torch.long, device=dev)
+    m.sparse_max_fraction = 0.2
+    assert m._batch_rows(u, u) is not None and m._batch_rows(u, u, u).n == 30          # 20 and 30 of 180 rows
+    assert m._batch_rows(torch.zeros(19, dtype=torch.long, device=dev), torch.zeros(19, dtype=torch.long, device=dev)) is None   # 38 > 36
+    m.sparse_last_stage = False
+    assert m._batch_rows(u, u) is None
+
+
 def test_integration_md_stub_runs(dev):
     """The ctypes binding shown in INTEGRATION.md is executed verbatim (library path redirected to the in-tree .so)
     and must reproduce the packaged stage."""
