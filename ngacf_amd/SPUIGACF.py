@@ -476,7 +476,7 @@ class _CFBase(nn.Module):
 
     def _batch_rows(self, userIdx, *itemIdxs):
         _refuse_replica(self)
-        if not self.sparse_last_stage or NF.ops.INKERNEL_HUB_FINISH:
+        if not self.sparse_last_stage:
             return None
         # worth it while the batch touches a small part of the table: measured crossover with the full stage at ~23 % of the
         # rows (B = 8192 of a 70 839-row graph, profiles/r02_sparse_probe_gowalla.log); beyond 1/5 the full stage runs

@@ -120,8 +120,6 @@ def _plan_ptrs(plan, dev, half=None):
     if half is None:
         return (segs, plan.nseg, split, plan.nsplit, srow, plan.nshort, plan.nseg_user, plan.nshort_user,
                 hrow, plan.nhub, plan.nhub_user, rowptr, col)
-    if INKERNEL_HUB_FINISH:
-        raise ValueError("half launches use the two-kernel path for sliced rows (unset NGACF_INKERNEL_HUB)")
     if half == "user":
         return (segs, plan.nseg_user, split, plan.nsplit_user, srow, plan.nshort_user, plan.nseg_user, plan.nshort_user,
                 hrow, plan.nhub_user, plan.nhub_user, rowptr, col)
@@ -133,18 +131,20 @@ def _plan_ptrs(plan, dev, half=None):
     raise ValueError("half must be None, 'user' or 'item'")
 
 
-# Hub rows can be finished by their last-arriving slice inside the launch (sc1 stores + agent-scope ticket/acquire,
-# bitwise equal to the two-kernel path: tests/test_gpu_parity.py).  Measured 31.5 us against 27 + 4.9 us for the
-# two kernels (a release-fence form: 75 us) -- a 2 us gain that does not pay for an inter-workgroup protocol on
-# the default path, so the plain second kernel stays the default.
-INKERNEL_HUB_FINISH = __import__("os").environ.get("NGACF_INKERNEL_HUB") == "1"
+# Hub rows are finished by their last-arriving slice INSIDE the launch (write-through stores of the partial sums, an
+# agent-scope ticket per row, agent-scope atomic loads by the last arriver -- no fence, no waiting; bitwise equal to the
+# two-kernel path, tests/test_gpu_parity.py): the forward's serial chain loses one 5 us kernel per stage (0.126 -> 0.115 ms
+# per 3-stage pass).  An earlier form with an acquire FENCE in the last arriver invalidated the XCD's L2 under a kernel
+# that lives on its cache hits and cost what it saved (31.5 us against 27 + 4.9).  NGACF_INKERNEL_HUB=0: the plain second
+# kernel (also used by half launches and by the batch-rows-only stage, which count arrivals differently).
+INKERNEL_HUB_FINISH = __import__("os").environ.get("NGACF_INKERNEL_HUB", "1") != "0"
 
 
-def _hub(plan, dev):
-    if not INKERNEL_HUB_FINISH or plan.nsplit == 0:
+def _hub(plan, dev, half=None):
+    if not INKERNEL_HUB_FINISH or plan.nsplit == 0 or half is not None:
         return 0, 0
     return (_chk(plan.part_split, "plan.part_split", torch.int32, plan.nparts, dev),
-            _chk(plan.tickets, "plan.tickets", torch.int32, plan.nsplit, dev))
+            _chk(plan.tickets_for(_stream()), "plan.tickets", torch.int32, plan.nsplit, dev, align=4))
 
 
 class BatchRows:
@@ -221,7 +221,7 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
     _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, *pp, hp,
                       _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
-                      pa.data_ptr(), pr.data_ptr(), *(_hub(plan, dev) if needed is None else (0, 0)), *_needed_args(needed, plan, N, dev),
+                      pa.data_ptr(), pr.data_ptr(), *(_hub(plan, dev, half) if needed is None else (0, 0)), *_needed_args(needed, plan, N, dev),
                       plan.U, N, d, heads, float(alpha),
                       float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_fwd")
     return (out, agg, R) if save else out

@@ -16,6 +16,9 @@ invariants the kernels rely on, because a bad index is a GPU fault, not an excep
 import torch
 
 
+_TICKET_SETS = 16        # arrival-counter sets per plan: one per stream that launches it
+
+
 class GraphPlan:
     def __init__(self, U, I, E, rowptr, col, segs, split, nparts, seg_len, row_lo=0, row_hi=None,
                  srow=None, short_max=0, row_ranges=None, hrow=None, nhub_user=0):
@@ -44,7 +47,24 @@ class GraphPlan:
             self.part_split = torch.repeat_interleave(torch.arange(self.nsplit, device=col.device), split[:, 2].long()).to(torch.int32)
         else:
             self.part_split = torch.empty(0, dtype=torch.int32, device=col.device)
-        self.tickets = torch.zeros(max(self.nsplit, 1), dtype=torch.int32, device=col.device)[:self.nsplit]
+        # (a pool allocated HERE: a buffer created during a hipGraph capture would put its zero fill into the graph)
+        self._ticket_pool = torch.zeros(_TICKET_SETS, max(self.nsplit, 1), dtype=torch.int32, device=col.device)
+        self.tickets = self._ticket_pool[0, :self.nsplit]
+        self._tickets = {}
+
+    def tickets_for(self, stream_handle):
+        """The arrival counters for launches on ONE stream (zero between launches: the last slice resets its row's counter).
+        Launches on different streams may overlap (the two propagations of a train step), so each stream has its own."""
+        t = self._tickets.get(stream_handle)
+        if t is None:
+            k = len(self._tickets)
+            if k < _TICKET_SETS:
+                t = self._ticket_pool[k, :self.nsplit]
+            else:                                   # more streams than sets: a fresh one (its zero fill is a launch)
+                with torch.cuda.device(self.device):
+                    t = torch.zeros(max(self.nsplit, 1), dtype=torch.int32, device=self.device)[:self.nsplit]
+            self._tickets[stream_handle] = t
+        return t
 
     @property
     def degrees(self):

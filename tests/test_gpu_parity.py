@@ -612,18 +612,31 @@ def test_inkernel_hub_finish_is_bitwise_equal_to_two_kernel_path(dev):
         plan = build_plan(edge, U, I, seg_len=seg)
         assert plan.nsplit > 400
         H, S = ops.transform_fwd(X.to(dt), W, avec, U, I, 8, dt)
-        ref = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)          # default: second kernel finishes the hub rows
-        ops.INKERNEL_HUB_FINISH = True
+        was = ops.INKERNEL_HUB_FINISH
+        ops.INKERNEL_HUB_FINISH = False
         try:
-            for it in range(25):
-                out = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)
-                for a_, b_ in zip(out, ref):
-                    assert torch.equal(a_, b_), (seg, dt, it)
-                assert int(plan.tickets.abs().sum()) == 0              # counters are left clean
-                if it % 5 == 0:                                        # unrelated traffic between launches
-                    torch.randn(4_000_000, device=dev).sum()
+            ref = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)      # a second kernel finishes the hub rows
         finally:
-            ops.INKERNEL_HUB_FINISH = False
+            ops.INKERNEL_HUB_FINISH = was
+        assert ops.INKERNEL_HUB_FINISH                                 # the default
+        side = torch.cuda.Stream()
+        for it in range(25):
+            out = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)
+            for a_, b_ in zip(out, ref):
+                assert torch.equal(a_, b_), (seg, dt, it)
+            if it % 5 == 0:                                            # unrelated traffic between launches
+                torch.randn(4_000_000, device=dev).sum()
+            if it % 7 == 0:                                            # an overlapping launch of the same plan on another stream
+                side.wait_stream(torch.cuda.current_stream())         # (its own arrival counters)
+                with torch.cuda.stream(side):
+                    o2 = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)
+                o1 = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)
+                torch.cuda.current_stream().wait_stream(side)
+                for a_, b_, c_ in zip(o1, o2, ref):
+                    assert torch.equal(a_, c_) and torch.equal(b_, c_), (seg, dt, it)
+        torch.cuda.synchronize()
+        for t in plan._tickets.values():
+            assert int(t.abs().sum()) == 0                             # counters are left clean
 
 
 @pytest.mark.parametrize("multi", [False, True])
