@@ -94,8 +94,9 @@ int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float* W, const f
  *                          every other table of the stage) and denominators, saved for the backward (both may be NULL)
  *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows
  *   part_split int32[nparts] (hub row of every slot), tickets int32[nsplit] (all zero on entry, left all zero):
- *       with both given, the last-arriving slice of a hub row finishes it inside the launch (agent-scope
- *       release/acquire, no waiting); with NULL a small second kernel does (same sums, same order)
+ *       with both given, the last-arriving slice of a hub row finishes it inside the launch (write-through stores,
+ *       an agent-scope ticket, agent-scope atomic loads; no fence, no waiting); with NULL a small second kernel does (same
+ *       sums, same order, same bits).  Overlapping launches (different streams) need their own tickets.
  * drop_p > 0 applies the edge dropout of :375 (numerators only), mask keyed by
  * (seed, head, user, item) so both directions see the same mask.
  * needed (uint32[ceil(N/32)], bit `row` of the table, or NULL) + rows (int32[nrows]) + short_max: compute only the flagged rows and leave the
@@ -126,7 +127,8 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  *   G float[N][d], Gn [N][d] dtype, ST float[N][heads] (the t table): workspace    dH [N][d] dtype (H's storage type), dS float[N][heads]: results
  *   G may be NULL when this call runs both steps (no NGACF_SKIP_NODE): step 2 then recomputes g from gout and out, bit for bit,
  *   and the 4-byte-per-element table is neither written nor read back
- *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows
+ *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows; part_split / tickets: as in ngacf_prop_fwd
+ *   (both given: the last-arriving slice of a hub row finishes it inside the launch; NULL: a second kernel does)
  *   needed / rows / nrows / short_max (NULL / NULL / 0 / 0, or the forward's): the forward ran with these flags, i.e. gout is
  *   zero outside the flagged rows (and out / agg / R are not valid there).  Then Gn and t vanish outside, and an edge with
  *   both ends outside contributes exactly zero.  Step 1 runs over the list only (Gn / t exist for the batch's rows).  The
@@ -141,7 +143,7 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    const float* S_dst, const float* S_src, const float* avec,
                    const void* out, const void* agg, const float* R, const void* gout,
                    float* G, void* Gn, float* ST, void* dH, float* dS,
-                   float* part_acc, float* part_r,
+                   float* part_acc, float* part_r, const int32_t* part_split, int32_t* tickets,
                    const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);

@@ -41,6 +41,9 @@ struct PropBwdArgs {
     float* dS;
     float* part_acc;
     float* part_r;
+    const int* split;              // {row, first slot, slots} of the hub rows
+    const int* part_split;         // hub row (index into split) of every partial-sum slot
+    int* tickets;                  // arrival counter per hub row (zero between launches); NULL = a second kernel finishes the hub rows
     int U, N;
     int nu_lo, nu_n, ni_lo, ni_n;  // step-1 row windows: users [nu_lo, +nu_n), items [ni_lo, +ni_n) (global row = U + i)
     int gout_local;                // gout holds only the window rows, users first (node-partitioned runs)
@@ -480,13 +483,57 @@ __global__ __launch_bounds__(256, SPARSE ? (DROP ? 5 : 4) : 1) void prop_bwd_ker
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     dsum = group_sum<LPR, WAVE>(dsum);
-    if (slot != 0) return;
-    if (part >= 0) {
-        store_f32<VEC>(a.part_acc + (size_t)part * D + q * VEC, acc);
-        if ((q * VEC) % HW == 0) a.part_r[(size_t)part * HEADS + head] = dsum;
+    if (part < 0) {
+        if (slot == 0) finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
         return;
     }
-    finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
+    // slice of a hub row: leave the partial sums in slot `part`
+    if (a.tickets == nullptr) {                            // prop_bwd_split_kernel finishes the row
+        if (slot == 0) {
+            store_f32<VEC>(a.part_acc + (size_t)part * D + q * VEC, acc);
+            if ((q * VEC) % HW == 0) a.part_r[(size_t)part * HEADS + head] = dsum;
+        }
+        return;
+    }
+    // The slice that arrives LAST finishes the row in this launch -- the forward's protocol (propagate.hip): write-through stores
+    // of the partial sums, drain, relaxed agent-scope ticket; the last arriver reads all partials with agent-scope atomic
+    // loads (no acquire fence: it would invalidate this XCD's L2) and adds them in slot order.  Nobody waits for anybody.
+    if (slot == 0) {
+        unsigned long long* pa = reinterpret_cast<unsigned long long*>(a.part_acc + (size_t)part * D + q * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; j += 2) {
+            const unsigned long long bits = (unsigned long long)__float_as_uint(acc[j]) | ((unsigned long long)__float_as_uint(acc[j + 1]) << 32);
+            __hip_atomic_store(pa + j / 2, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if ((q * VEC) % HW == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned*>(a.part_r + (size_t)part * HEADS + head), __float_as_uint(dsum),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int si = uniform(a.part_split[part]);
+    const int p0 = uniform(a.split[3 * si + 1]), np = uniform(a.split[3 * si + 2]);
+    int tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add(a.tickets + si, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (uniform(tk) != np - 1) return;
+    if (lane == 0) __hip_atomic_store(a.tickets + si, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    dsum = 0.f;
+#pragma unroll 4
+    for (int p = p0 + slot; p < p0 + np; p += EPI) {
+        unsigned long long* pa = reinterpret_cast<unsigned long long*>(a.part_acc + (size_t)p * D + q * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; j += 2) {
+            const unsigned long long bits = __hip_atomic_load(pa + j / 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc[j] += __uint_as_float((unsigned)bits); acc[j + 1] += __uint_as_float((unsigned)(bits >> 32));
+        }
+        dsum += __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(a.part_r + (size_t)p * HEADS + head), __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT));
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
+    dsum = group_sum<LPR, WAVE>(dsum);
+    if (slot == 0) finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
 }
 
 template <typename T, int D, int HEADS>
@@ -542,7 +589,7 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
         }
         NGACF_CHECK_LAUNCH();
     }
-    if (nsplit > 0) {
+    if (nsplit > 0 && a.tickets == nullptr) {
         hipLaunchKernelGGL((prop_bwd_split_kernel<T, D, HEADS>), dim3((nsplit + 3) / 4), dim3(256), 0, st, a, split, nsplit);
         NGACF_CHECK_LAUNCH();
     }
@@ -560,7 +607,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
                          const float* S_dst, const float* S_src, const float* avec,
                          const void* out, const void* agg, const float* R, const void* gout,
                          float* G, void* Gn, float* ST, void* dH, float* dS,
-                         float* part_acc, float* part_r,
+                         float* part_acc, float* part_r, const int32_t* part_split, int32_t* tickets,
                          int U, int N, int d, int heads, float alpha,
                          float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
                          int nu_lo, int nu_n, int ni_lo, int ni_n, int gout_local, bool do_node, bool do_edges,
@@ -587,6 +634,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     a.hrow = hrow; a.order.nhub = nhub; a.order.nhub_u = nhub_user;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R; a.gout = gout;
     a.G = G; a.Gn = Gn; a.Tn = ST; a.dH = dH; a.dS = dS; a.part_acc = part_acc; a.part_r = part_r;
+    a.split = split; a.part_split = part_split; a.tickets = (part_split && nsplit > 0) ? tickets : nullptr;
     a.U = U; a.N = N; a.nu_lo = nu_lo; a.nu_n = nu_n; a.ni_lo = ni_lo; a.ni_n = ni_n; a.gout_local = gout_local;
     a.order.nseg_u = nseg_user; a.order.nshort_u = nshort_user; a.alpha = alpha;
     a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.seed_dev = seed_dev; a.flags = flags;
@@ -621,13 +669,13 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
                               const float* S_dst, const float* S_src, const float* avec,
                               const void* out, const void* agg, const float* R, const void* gout,
                               float* G, void* Gn, float* ST, void* dH, float* dS,
-                              float* part_acc, float* part_r,
+                              float* part_acc, float* part_r, const int32_t* part_split, int32_t* tickets,
                               const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                               int U, int N, int d, int heads, float alpha,
                               float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
     const bool skip_node = (flags & NGACF_SKIP_NODE) != 0;
     return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, nseg_user, nshort_user, hrow, nhub, nhub_user, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
-                         G, Gn, ST, dH, dS, part_acc, part_r, U, N, d, heads, alpha, drop_p, seed, seed_dev, flags,
+                         G, Gn, ST, dH, dS, part_acc, part_r, part_split, tickets, U, N, d, heads, alpha, drop_p, seed, seed_dev, flags,
                          0, U, 0, N - U, 0, !skip_node, true, needed, rows, nrows, short_max, stream);
 }
 
@@ -636,6 +684,6 @@ extern "C" int ngacf_prop_bwd_node(const void* out, int dtype, const void* agg, 
                                    int U, int N, int d, int heads, int flags,
                                    int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream) {
     return prop_bwd_impl(nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, dtype, nullptr, S_src, nullptr,
-                         out, agg, R, gout, G, Gn, ST, nullptr, nullptr, nullptr, nullptr, U, N, d, heads, 0.2f, 0.f, 0, nullptr, flags,
+                         out, agg, R, gout, G, Gn, ST, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, U, N, d, heads, 0.2f, 0.f, 0, nullptr, flags,
                          u_lo, u_n, i_lo, i_n, gout_local, true, false, nullptr, nullptr, 0, 0, stream);
 }

@@ -256,7 +256,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
              (_lib.FLAG_GOUT_F32 if gout_f32 else 0))
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, ss, ap,
                                   op, gp, rp, go, 0, Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
-                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *_needed_args(needed, plan, N, dev), plan.U, N, d, heads, float(alpha),
+                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev), *_needed_args(needed, plan, N, dev), plan.U, N, d, heads, float(alpha),
                                   float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_bwd")
     return dH, dS
 
@@ -547,7 +547,7 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     pr = torch.empty(max(plan.nparts, 1), heads, **f32)
     flags = (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) | _lib.FLAG_SKIP_NODE
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, sd, ap, hp, gp, sd, gp, gp, gn, st, dH.data_ptr(),
-                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), 0, 0, 0, 0, plan.U, N, d, heads, float(alpha),
+                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), 0, 0, 0, 0, 0, 0, plan.U, N, d, heads, float(alpha),
                                   float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_bwd")
     return dH, dS
 

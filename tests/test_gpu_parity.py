@@ -612,10 +612,12 @@ def test_inkernel_hub_finish_is_bitwise_equal_to_two_kernel_path(dev):
         plan = build_plan(edge, U, I, seg_len=seg)
         assert plan.nsplit > 400
         H, S = ops.transform_fwd(X.to(dt), W, avec, U, I, 8, dt)
+        gout = torch.randn(N, 64, device=dev, generator=g).to(dt)
         was = ops.INKERNEL_HUB_FINISH
         ops.INKERNEL_HUB_FINISH = False
         try:
             ref = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)      # a second kernel finishes the hub rows
+            ref_b = ops.prop_bwd(plan, H, S, S, avec, *ref, gout, 8, drop_p=0.1, seed=9)
         finally:
             ops.INKERNEL_HUB_FINISH = was
         assert ops.INKERNEL_HUB_FINISH                                 # the default
@@ -624,6 +626,9 @@ def test_inkernel_hub_finish_is_bitwise_equal_to_two_kernel_path(dev):
             out = ops.prop_fwd(plan, H, S, S, avec, 8, save=True)
             for a_, b_ in zip(out, ref):
                 assert torch.equal(a_, b_), (seg, dt, it)
+            if it % 3 == 0:                                            # the backward's hub rows, the same protocol
+                for a_, b_ in zip(ops.prop_bwd(plan, H, S, S, avec, *ref, gout, 8, drop_p=0.1, seed=9), ref_b):
+                    assert torch.equal(a_, b_), (seg, dt, it, "backward")
             if it % 5 == 0:                                            # unrelated traffic between launches
                 torch.randn(4_000_000, device=dev).sum()
             if it % 7 == 0:                                            # an overlapping launch of the same plan on another stream
