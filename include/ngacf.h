@@ -106,7 +106,8 @@ int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float* W, const f
  *   plan's short_max) are taken from the list, a WAVE each (their few edges are gathered in one or two rounds); longer rows
  *   from the plan's segments, by flag.  The same terms as the full launch, added in another order for the short rows
  *   (deterministic; equal to rounding).  srow / nshort are not read.
- *   Needs NGACF_SCORE_ROW; not combinable with the in-kernel hub finish (part_split / tickets). */
+ *   Needs NGACF_SCORE_ROW.  (In-kernel hub finish: all slices of a flagged hub row run, none of an unflagged one, so the
+ *   arrival counters work unchanged.) */
 int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                    const int32_t* srow, int nshort, int nseg_user, int nshort_user,
                    const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,

@@ -441,7 +441,6 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
                               int U, int N, int d, int heads, float alpha,
                               float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
-    if (needed && part_split && nsplit > 0 && tickets) return NGACF_E_ARG;     // in-kernel hub finish counts arrivals of ALL slices
     if (needed && !(flags & NGACF_SCORE_ROW)) return NGACF_E_ARG;              // row flags: the SPUIGACF stages only
     if (needed && (nrows < 0 || (nrows > 0 && !rows))) return NGACF_E_ARG;
     if (nseg_user < 0 || nseg_user > nseg || nshort_user < 0 || nshort_user > nshort || (nshort_user % 16 != 0 && nshort_user != nshort))

@@ -140,8 +140,12 @@ def _plan_ptrs(plan, dev, half=None):
 INKERNEL_HUB_FINISH = __import__("os").environ.get("NGACF_INKERNEL_HUB", "1") != "0"
 
 
+INKERNEL_MAX_PARTS = 1 << 18      # beyond this many slices the second kernel wins: the 10^9-edge graph (1.27 M hub rows, 11 M
+                                  # segments) runs a stage in 35.6 ms with it, 36.8 ms with write-through stores + tickets
+
+
 def _hub(plan, dev, half=None):
-    if not INKERNEL_HUB_FINISH or plan.nsplit == 0 or half is not None:
+    if not INKERNEL_HUB_FINISH or plan.nsplit == 0 or half is not None or plan.nparts > INKERNEL_MAX_PARTS:
         return 0, 0
     return (_chk(plan.part_split, "plan.part_split", torch.int32, plan.nparts, dev),
             _chk(plan.tickets_for(_stream()), "plan.tickets", torch.int32, plan.nsplit, dev, align=4))
@@ -221,7 +225,7 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
     _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, *pp, hp,
                       _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
-                      pa.data_ptr(), pr.data_ptr(), *(_hub(plan, dev, half) if needed is None else (0, 0)), *_needed_args(needed, plan, N, dev),
+                      pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev, half), *_needed_args(needed, plan, N, dev),
                       plan.U, N, d, heads, float(alpha),
                       float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_fwd")
     return (out, agg, R) if save else out
