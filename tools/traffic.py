@@ -19,7 +19,7 @@ def one_pass(counter, workload, dtype, tag):
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--passes-per-step", "4",
-           "--no-cpu-baseline", "--no-train", "--workload", workload, "--dtype", dtype]
+           "--no-cpu-baseline", "--no-train", "--no-probe", "--workload", workload, "--dtype", dtype]
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     tot, n = collections.defaultdict(float), collections.defaultdict(int)
     for root, _, files in os.walk(out):
@@ -43,7 +43,7 @@ def main():
     dtypes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["bf16", "fp32"]
     res = {"workload": wl, "stages": 3,
            "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --steps 3 --warmup 1 "
-                      "--passes-per-step 4 --no-cpu-baseline --no-train --workload %s [--dtype fp32]  (tools/traffic.py)" % wl,
+                      "--passes-per-step 4 --no-cpu-baseline --no-train --no-probe --workload %s [--dtype fp32]  (tools/traffic.py)" % wl,
            "by_dtype": {}}
     for dt in dtypes:
         fetch = one_pass("FETCH_SIZE", wl, dt, wl)
