@@ -104,7 +104,7 @@ def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.
     return H, S
 
 
-def _plan_ptrs(plan, dev, half=None):
+def _plan_ptrs(plan, dev, half=None, inkernel=False):
     """The plan arguments of ngacf_prop_fwd / ngacf_prop_bwd.  half = "user" / "item": only that half of the launch's
     work order ([user long segments][user short rows] / [item long segments][item short rows]) -- the lists are
     contiguous per half, so a half is a pointer offset and a count; partial-sum slots keep their global numbers.
@@ -120,13 +120,19 @@ def _plan_ptrs(plan, dev, half=None):
     if half is None:
         return (segs, plan.nseg, split, plan.nsplit, srow, plan.nshort, plan.nseg_user, plan.nshort_user,
                 hrow, plan.nhub, plan.nhub_user, rowptr, col)
+    if inkernel:        # hub rows finished by their last slice: the kernel looks rows up in the WHOLE split table (slot -> row
+        su = si = (split, plan.nsplit)              # indices are global) and no second kernel walks a half's share of it
+    else:
+        su = (split, plan.nsplit_user)
+        nsp = plan.nsplit - plan.nsplit_user
+        si = (split + 12 * plan.nsplit_user if nsp else 0, nsp)
     if half == "user":
-        return (segs, plan.nseg_user, split, plan.nsplit_user, srow, plan.nshort_user, plan.nseg_user, plan.nshort_user,
+        return (segs, plan.nseg_user, su[0], su[1], srow, plan.nshort_user, plan.nseg_user, plan.nshort_user,
                 hrow, plan.nhub_user, plan.nhub_user, rowptr, col)
     if half == "item":
-        ns, nsh, nsp = plan.nseg - plan.nseg_user, plan.nshort - plan.nshort_user, plan.nsplit - plan.nsplit_user
+        ns, nsh = plan.nseg - plan.nseg_user, plan.nshort - plan.nshort_user
         nh = plan.nhub - plan.nhub_user
-        return (segs + 16 * plan.nseg_user if ns else 0, ns, split + 12 * plan.nsplit_user if nsp else 0, nsp,
+        return (segs + 16 * plan.nseg_user if ns else 0, ns, si[0], si[1],
                 srow + 4 * plan.nshort_user if nsh else 0, nsh, 0, 0, hrow + 4 * plan.nhub_user if nh else 0, nh, 0, rowptr, col)
     raise ValueError("half must be None, 'user' or 'item'")
 
@@ -136,7 +142,7 @@ def _plan_ptrs(plan, dev, half=None):
 # two-kernel path, tests/test_gpu_parity.py): the forward's serial chain loses one 5 us kernel per stage (0.126 -> 0.115 ms
 # per 3-stage pass).  An earlier form with an acquire FENCE in the last arriver invalidated the XCD's L2 under a kernel
 # that lives on its cache hits and cost what it saved (31.5 us against 27 + 4.9).  NGACF_INKERNEL_HUB=0: the plain second
-# kernel (also used by half launches and by the batch-rows-only stage, which count arrivals differently).
+# kernel (also used for plans with very many slices, INKERNEL_MAX_PARTS).
 INKERNEL_HUB_FINISH = __import__("os").environ.get("NGACF_INKERNEL_HUB", "1") != "0"
 
 
@@ -145,7 +151,7 @@ INKERNEL_MAX_PARTS = 1 << 18      # beyond this many slices the second kernel wi
 
 
 def _hub(plan, dev, half=None):
-    if not INKERNEL_HUB_FINISH or plan.nsplit == 0 or half is not None or plan.nparts > INKERNEL_MAX_PARTS:
+    if not INKERNEL_HUB_FINISH or plan.nsplit == 0 or plan.nparts > INKERNEL_MAX_PARTS:
         return 0, 0
     return (_chk(plan.part_split, "plan.part_split", torch.int32, plan.nparts, dev),
             _chk(plan.tickets_for(_stream()), "plan.tickets", torch.int32, plan.nsplit, dev, align=4))
@@ -209,7 +215,8 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     sd = _chk(S_dst, "S_dst", torch.float32, N * heads, dev)
     ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
     ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
-    pp = _plan_ptrs(plan, dev, half)
+    hub = _hub(plan, dev, half)
+    pp = _plan_ptrs(plan, dev, half, inkernel=hub[1] != 0)
     if out is None:
         out = torch.empty(N, d, dtype=H.dtype, device=dev)
     op = _chk(out, "out", H.dtype, N * d, dev)
@@ -225,7 +232,7 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
     _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, *pp, hp,
                       _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
-                      pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev, half), *_needed_args(needed, plan, N, dev),
+                      pa.data_ptr(), pr.data_ptr(), *hub, *_needed_args(needed, plan, N, dev),
                       plan.U, N, d, heads, float(alpha),
                       float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_fwd")
     return (out, agg, R) if save else out
@@ -541,7 +548,8 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     gp = _chk(G, "G", torch.float32, N * d, dev)
     gn = _chk(Gn, "Gn", H.dtype, N * d, dev)
     st = _chk(ST, "ST", torch.float32, N * heads, dev)
-    pp = _plan_ptrs(plan, dev, half)
+    hub = _hub(plan, dev, half)
+    pp = _plan_ptrs(plan, dev, half, inkernel=hub[1] != 0)
     f32 = dict(dtype=torch.float32, device=dev)
     dH = torch.zeros(N, d, dtype=H.dtype, device=dev) if dH is None else dH
     dS = torch.zeros(N, heads, **f32) if dS is None else dS
@@ -551,7 +559,7 @@ def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=T
     pr = torch.empty(max(plan.nparts, 1), heads, **f32)
     flags = (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) | _lib.FLAG_SKIP_NODE
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, sd, ap, hp, gp, sd, gp, gp, gn, st, dH.data_ptr(),
-                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), 0, 0, 0, 0, 0, 0, plan.U, N, d, heads, float(alpha),
+                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *hub, 0, 0, 0, 0, plan.U, N, d, heads, float(alpha),
                                   float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_bwd")
     return dH, dS
 
