@@ -214,6 +214,13 @@ int ngacf_adam_step(float* const* params, const float* const* grads, const float
                     const float* const* steps, const int64_t* numel, int count,
                     float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* The scalar bookkeeping of one train step in one launch: *int_counters[k] += int_strides[k] (device int64: dropout seed
+ * counters, the pair sampler's row offset and seed) and *float_counters[k] += 1 (device float: Adam's step counts, which
+ * ngacf_adam_step reads).  Host arrays of n_int / n_float (<= NGACF_TICK_MAX) entries. */
+#define NGACF_TICK_MAX 48
+int ngacf_tick(int64_t* const* int_counters, const int64_t* int_strides, int n_int, float* const* float_counters, int n_float,
+               void* stream);
+
 /* BPR loss  -mean(log(sigmoid(pos - neg)))  (graphattention/BPRLoss.py:8-9).
  * loss is a single float; the function overwrites it (no pre-zeroing needed). */
 int ngacf_bpr_fwd(const float* pos, const float* neg, float* loss, int B, void* stream);

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libngacf_hip.so")
 F32, BF16 = 0, 1
 FLAG_ELU, FLAG_RESIDUAL, FLAG_SCORE_ROW, FLAG_SKIP_NODE, FLAG_GOUT_F32 = 1, 2, 4, 8, 16
 ADAM_MAX_TENSORS = 24            # NGACF_ADAM_MAX_TENSORS
+TICK_MAX = 48                      # NGACF_TICK_MAX
 TBWD_BLOCKS = 1024
 
 _p = ctypes.c_void_p
@@ -30,6 +31,7 @@ SIGNATURES = {
     "ngacf_prop_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
                        _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p],
     "ngacf_adam_step": [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p],
+    "ngacf_tick": [_p, _p, _i, _p, _i, _p],
     "ngacf_mark_rows": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ngacf_transform_bwd": [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _p],
     "ngacf_transform_fwd_rows": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _p, _p],

@@ -88,6 +88,21 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable a) {
     }
 }
 
+// The per-step scalar bookkeeping of a train step in ONE launch: int64 counters += their strides (dropout seed counters,
+// the sampler's row offset and seed) and float counters += 1 (Adam's step counts) -- each a one-element torch add otherwise,
+// 4-5 us apiece on the serial part of the step.
+struct TickTable {
+    long long* ic[NGACF_TICK_MAX];
+    long long istride[NGACF_TICK_MAX];
+    float* fc[NGACF_TICK_MAX];
+    int ni, nf;
+};
+__global__ void tick_kernel(const TickTable t) {
+    const int k = threadIdx.x;
+    if (k < t.ni) *reinterpret_cast<unsigned long long*>(t.ic[k]) += (unsigned long long)t.istride[k];   // (wraps, like torch's add_)
+    if (k < t.nf) *t.fc[k] += 1.f;
+}
+
 }  // namespace ngacf
 
 using namespace ngacf;
@@ -116,6 +131,26 @@ extern "C" int ngacf_adam_step(float* const* params, const float* const* grads, 
     a.count = count; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay;
     if (blocks == 0) return 0;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    NGACF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ngacf_tick(int64_t* const* int_counters, const int64_t* int_strides, int n_int, float* const* float_counters, int n_float,
+                          void* stream) {
+    if (n_int < 0 || n_float < 0 || n_int > NGACF_TICK_MAX || n_float > NGACF_TICK_MAX) return NGACF_E_ARG;
+    if (n_int + n_float == 0) return 0;
+    if ((n_int && (!int_counters || !int_strides)) || (n_float && !float_counters)) return NGACF_E_ARG;
+    TickTable t;
+    t.ni = n_int; t.nf = n_float;
+    for (int k = 0; k < n_int; ++k) {
+        if (!int_counters[k]) return NGACF_E_ARG;
+        t.ic[k] = reinterpret_cast<long long*>(int_counters[k]); t.istride[k] = int_strides[k];
+    }
+    for (int k = 0; k < n_float; ++k) {
+        if (!float_counters[k]) return NGACF_E_ARG;
+        t.fc[k] = float_counters[k];
+    }
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), t);
     NGACF_CHECK_LAUNCH();
     return 0;
 }

@@ -77,16 +77,20 @@ class GraphedBPRStep:
         split_grads = (split_grads and concurrent_forwards and not shared_propagation and not fused_loss
                        and getattr(optim, "supports_grad_pairs", False) and after_backward is None)
         sinks = ({}, {})
+        own_steps = hasattr(optim, "step_counters")        # ngacf_amd.optim.Adam: its step counts join the step's one tick launch
+        from .SPUIGACF import _CTR_STRIDE as CTR_STRIDE
 
         def step():
-            for g in gats:
-                g.advance_device_seed()                     # one captured add per step: fresh masks every replay
             if data is not None:                            # the batch itself: rows offset .. offset+B of train_u
                 ops.sample_pairs(data.train_u, 0, batch_size, data.train_ptr, data.train_items32, data.pool_items32,
                                  0, out=self.upn, unresolved=self.unresolved, offset_dev=self.offset,
                                  seed_dev=self.sample_seed)
-                self.offset.add_(batch_size)
-                self.sample_seed.add_(SAMPLE_STRIDE)
+            # the scalar bookkeeping of the step -- fresh dropout masks every replay, the sampler's next rows, Adam's step
+            # counts -- as ONE launch (each was a one-element add kernel on the serial part of the step)
+            ints = [(g._seed_ctr, CTR_STRIDE) for g in gats if getattr(g, "_seed_ctr", None) is not None]
+            if data is not None:
+                ints += [(self.offset, batch_size), (self.sample_seed, SAMPLE_STRIDE)]
+            NF.ops.tick([t for t, _ in ints], [k for _, k in ints], optim.step_counters() if own_steps else [])
             optim.zero_grad(set_to_none=True)
             if shared_propagation:                          # opt-in: one propagation per step (model.forward_pairs)
                 loss = lossfn(*model.forward_pairs(self.u, self.p, self.n, adj))
@@ -126,9 +130,11 @@ class GraphedBPRStep:
                 cur.wait_stream(sa)                         # node synchronised them with this one
                 cur.wait_stream(sb)
                 keys = list(dict.fromkeys(list(sinks[0]) + list(sinks[1])))
-                optim.step(grad_pairs={k: (sinks[0].get(k), sinks[1].get(k)) for k in keys})
+                optim.step(grad_pairs={k: (sinks[0].get(k), sinks[1].get(k)) for k in keys}, steps_incremented=own_steps)
                 sinks[0].clear()
                 sinks[1].clear()
+            elif own_steps:
+                optim.step(steps_incremented=True)
             else:
                 optim.step()
             if data is not None:

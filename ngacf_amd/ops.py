@@ -633,3 +633,19 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, 
     nn = (ctypes.c_int64 * n)(*numel)
     _lib.check(lib.ngacf_adam_step(tp, tg, t2, tm, tv, ts, nn, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                    _stream()), "ngacf_adam_step")
+
+
+def tick(int_counters=(), int_strides=(), float_counters=()):
+    """One launch for the scalar bookkeeping of a train step: int64 device counters += strides, float device counters += 1."""
+    import ctypes
+    ni, nf = len(int_counters), len(float_counters)
+    if ni != len(int_strides) or ni > _lib.TICK_MAX or nf > _lib.TICK_MAX:
+        raise ValueError("tick: %d int counters / %d strides / %d float counters (at most %d each)" % (ni, len(int_strides), nf, _lib.TICK_MAX))
+    if ni + nf == 0:
+        return
+    dev = (int_counters[0] if ni else float_counters[0]).device
+    P = ctypes.c_void_p
+    ic = (P * max(ni, 1))(*[_chk(t, "int counter", torch.int64, 1, dev, align=8) for t in int_counters])
+    st = (ctypes.c_int64 * max(ni, 1))(*[int(x) for x in int_strides])
+    fc = (P * max(nf, 1))(*[_chk(t, "float counter", torch.float32, 1, dev, align=4) for t in float_counters])
+    _lib.check(lib.ngacf_tick(ic, st, ni, fc, nf, _stream()), "ngacf_tick")

@@ -39,8 +39,28 @@ class Adam(torch.optim.Adam):
 
     supports_grad_pairs = True
 
+    def step_counters(self):
+        """The device step counters of every parameter that takes gradients (state created if need be): a caller that
+        increments them itself -- ops.tick, together with its other per-step counters -- passes steps_incremented=True to step()."""
+        out = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.requires_grad:
+                    out.append(self._state_of(p)["step"])
+        return out
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if st["step"].device != p.device or st["step"].dtype != torch.float32:      # a state loaded from a host-step Adam
+            st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+        return st
+
     @torch.no_grad()
-    def step(self, closure=None, grad_pairs=None):
+    def step(self, closure=None, grad_pairs=None, steps_incremented=False):
         """grad_pairs: {parameter: (g_a, g_b)} -- the parameter's gradient is g_a + g_b (g_b may be None), summed inside the
         step's kernel; parameters not in it use .grad as usual.  (GraphedBPRStep hands in the gradients of its two
         propagations this way instead of letting autograd accumulate them.)"""
@@ -56,21 +76,18 @@ class Adam(torch.optim.Adam):
                 if ga is None and gb is not None:
                     ga, gb = gb, None
                 if ga is None:
+                    if steps_incremented and p.requires_grad:
+                        raise RuntimeError("a parameter whose step counter was incremented up front got no gradient")
                     continue
                 if ga.is_sparse or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
                     raise ValueError("ngacf_amd.optim.Adam: contiguous fp32 CUDA parameters with dense gradients only")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if st["step"].device != p.device or st["step"].dtype != torch.float32:      # a state loaded from a host-step Adam
-                    st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+                st = self._state_of(p)
                 ps.append(p); gs.append(ga.contiguous()); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"]); steps.append(st["step"])
                 g2s.append(None if gb is None else gb.contiguous())
             if not ps:
                 continue
-            torch._foreach_add_(steps, 1.0)
+            if not steps_incremented:
+                torch._foreach_add_(steps, 1.0)
             b1, b2 = group["betas"]
             for lo in range(0, len(ps), _lib.ADAM_MAX_TENSORS):
                 hi = lo + _lib.ADAM_MAX_TENSORS

@@ -566,3 +566,25 @@ def test_graphed_step_with_library_adam_matches_torch_adam():
     # atomic score gradient decide its sign, so the bound is a fraction of the 4 steps of lr = 1e-2, not of the parameter
     for a_, b_ in zip(*res):
         assert float((a_ - b_).abs().max()) <= 0.02 * 4 * 1e-2
+
+
+@pytest.mark.gpu
+def test_tick_is_the_per_step_adds_in_one_launch():
+    """ops.tick: int64 counters += their strides (wrapping like torch's add_), float counters += 1 -- the dropout seed counter,
+    the sampler's offsets and Adam's step counts of a graphed train step."""
+    from ngacf_amd import ops
+    dev = torch.device("cuda:0")
+    big = 0x2545F4914F6CDD1D
+    ints = [torch.tensor([5], dtype=torch.int64, device=dev), torch.tensor([2 ** 62], dtype=torch.int64, device=dev),
+            torch.tensor([-7], dtype=torch.int64, device=dev)]
+    want = [t.clone() for t in ints]
+    floats = [torch.zeros((), device=dev), torch.full((), 41.0, device=dev)]
+    for _ in range(5):
+        ops.tick(ints, [3, big, 2048], floats)
+        for w, k in zip(want, (3, big, 2048)):
+            w.add_(k)
+    assert all(torch.equal(a, b) for a, b in zip(ints, want))
+    assert float(floats[0]) == 5.0 and float(floats[1]) == 46.0
+    ops.tick()                                                    # nothing to do: no launch, no error
+    with pytest.raises(ValueError):
+        ops.tick(ints, [1], floats)
