@@ -227,6 +227,10 @@ int ngacf_bpr_fwd(const float* pos, const float* neg, float* loss, int B, void* 
 /* gpos[b] = -gloss * sigmoid(neg-pos) / B ; gneg = -gpos */
 int ngacf_bpr_bwd(const float* pos, const float* neg, const float* gloss,
                   float* gpos, float* gneg, int B, void* stream);
+/* The loss and its gradients for d loss = 1 in ONE launch (what loss.backward() of train_eval_Gowalla.py:136-137 starts from):
+ * loss as ngacf_bpr_fwd, gpos[b] = -sigmoid(neg[b] - pos[b]) / B, gneg = -gpos.  A train step that owns its backward
+ * (GraphedBPRStep) feeds these straight to the score nodes: no loss node, no ones-like fill, no second BPR kernel. */
+int ngacf_bpr_fwd_bwd(const float* pos, const float* neg, float* loss, float* gpos, float* gneg, int B, void* stream);
 
 /* Static-weight propagation  out[n] = (self_loop ? X[n] : 0) + sum_e val[e] * X[col[e]]
  * (GPLayer.forward, SPUIGACF.py:178-185: torch.sparse.mm(L + I, features)). */

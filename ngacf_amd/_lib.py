@@ -31,6 +31,7 @@ SIGNATURES = {
     "ngacf_prop_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
                        _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p],
     "ngacf_adam_step": [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p],
+    "ngacf_bpr_fwd_bwd": [_p, _p, _p, _p, _p, _i, _p],
     "ngacf_tick": [_p, _p, _i, _p, _i, _p],
     "ngacf_mark_rows": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ngacf_transform_bwd": [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _p],

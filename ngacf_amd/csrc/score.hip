@@ -118,6 +118,28 @@ __global__ __launch_bounds__(256) void bpr_fwd_kernel(const float* __restrict__ 
     }
 }
 
+// loss AND its gradients (for d loss = 1) in one pass: gpos[b] = -sigmoid(neg - pos) / B = -gneg[b]
+__global__ __launch_bounds__(256) void bpr_fwd_bwd_kernel(const float* __restrict__ pos, const float* __restrict__ neg, float* __restrict__ loss,
+                                                          float* __restrict__ gpos, float* __restrict__ gneg, int B) {
+    float s = 0.f;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        const float x = pos[b] - neg[b];
+        s -= log_sigmoid(x);
+        const float g = -(1.f / (1.f + __expf(x))) / (float)B;             // (bpr_bwd_kernel's, for d loss = 1)
+        gpos[b] = g;
+        gneg[b] = -g;
+    }
+    s = group_sum<1, WAVE>(s);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (ws[0] + ws[1] + ws[2] + ws[3]) / (float)B;      // (bpr_fwd_kernel's expression: the same bits)
+        if (gridDim.x == 1) *loss = v;
+        else atomicAdd(loss, v);
+    }
+}
+
 __global__ __launch_bounds__(256) void bpr_bwd_kernel(const float* __restrict__ pos, const float* __restrict__ neg,
                                                       const float* __restrict__ gloss, float* __restrict__ gpos,
                                                       float* __restrict__ gneg, int B) {
@@ -211,6 +233,18 @@ extern "C" int ngacf_bpr_fwd(const float* pos, const float* neg, float* loss, in
         if (e != hipSuccess) return static_cast<int>(e);
     }
     hipLaunchKernelGGL(bpr_fwd_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), pos, neg, loss, B);
+    NGACF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int ngacf_bpr_fwd_bwd(const float* pos, const float* neg, float* loss, float* gpos, float* gneg, int B, void* stream) {
+    if (B <= 0 || !pos || !neg || !loss || !gpos || !gneg) return NGACF_E_ARG;
+    const int nb = B <= (1 << 16) ? 1 : 64;
+    if (nb > 1) {
+        const hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return static_cast<int>(e);
+    }
+    hipLaunchKernelGGL(bpr_fwd_bwd_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), pos, neg, loss, gpos, gneg, B);
     NGACF_CHECK_LAUNCH();
     return 0;
 }

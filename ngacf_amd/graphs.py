@@ -77,6 +77,7 @@ class GraphedBPRStep:
         split_grads = (split_grads and concurrent_forwards and not shared_propagation and not fused_loss
                        and getattr(optim, "supports_grad_pairs", False) and after_backward is None)
         sinks = ({}, {})
+        direct_bpr = type(lossfn) is BPRLoss and split_grads           # this step owns its backward: see the join below
         own_steps = hasattr(optim, "step_counters")        # ngacf_amd.optim.Adam: its step counts join the step's one tick launch
         from .SPUIGACF import _CTR_STRIDE as CTR_STRIDE
 
@@ -119,10 +120,17 @@ class GraphedBPRStep:
                         ns = model(self.u, self.n, adj)
                     cur.wait_stream(sa)
                     cur.wait_stream(sb)
-                    loss = lossfn(ps, ns)
+                    if direct_bpr:
+                        # BPRLoss and the start of its backward as ONE launch: the scores' gradients go straight into the two
+                        # branches (the loss node, autograd's ones-like fill and the second BPR kernel sat on the serial join)
+                        loss, gp, gn = NF.ops.bpr_fwd_bwd(ps.detach().float().contiguous(), ns.detach().float().contiguous())
+                        torch.autograd.backward([ps, ns], [gp.to(ps.dtype), gn.to(ns.dtype)])
+                    else:
+                        loss = lossfn(ps, ns)
             else:                                           # reference semantics: two forwards, two propagations
                 loss = lossfn(model(self.u, self.p, adj), model(self.u, self.n, adj))
-            loss.backward()
+            if not (direct_bpr and concurrent_forwards and not shared_propagation and not fused_loss):
+                loss.backward()
             if after_backward is not None:                  # e.g. the sharded model's grouped weight-gradient all-reduce
                 after_backward()
             if sinks[0] or sinks[1]:

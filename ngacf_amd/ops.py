@@ -380,6 +380,16 @@ def bpr_fwd(pos, neg):
     return loss
 
 
+def bpr_fwd_bwd(pos, neg):
+    """loss, d loss / d pos, d loss / d neg (for a unit gradient of the loss) in one launch"""
+    dev, B = pos.device, pos.numel()
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    gpos, gneg = torch.empty_like(pos), torch.empty_like(neg)
+    _lib.check(lib.ngacf_bpr_fwd_bwd(_chk(pos, "pos", torch.float32, B, dev), _chk(neg, "neg", torch.float32, B, dev), loss.data_ptr(),
+                                     gpos.data_ptr(), gneg.data_ptr(), B, _stream()), "ngacf_bpr_fwd_bwd")
+    return loss, gpos, gneg
+
+
 def bpr_bwd(pos, neg, gloss):
     dev, B = pos.device, pos.numel()
     gpos, gneg = torch.empty_like(pos), torch.empty_like(neg)

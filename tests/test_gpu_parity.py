@@ -409,6 +409,8 @@ def test_score_and_bpr_kernels(dev):
     gp, gn = ops.bpr_bwd(_t(pos, dev), _t(neg, dev), torch.tensor(1.0, device=dev))
     want_g = -(1.0 / (1.0 + np.exp(pos.astype(np.float64) - neg))) / B
     assert _maxabs(gp, want_g) < 1e-7 and _maxabs(gn, -want_g) < 1e-7
+    l2, gp2, gn2 = ops.bpr_fwd_bwd(_t(pos, dev), _t(neg, dev))        # loss + unit-gradient in one launch
+    assert abs(float(l2) - float(loss)) < 1e-7 and _maxabs(gp2, want_g) < 1e-7 and _maxabs(gn2, -want_g) < 1e-7
     # empty batch
     assert ops.score_fwd(_t(F, dev), _t(u[:0], dev), _t(it[:0], dev), U).numel() == 0
 
