@@ -149,7 +149,8 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
 
-/* Sets bit u[b] and bit U + i[b] of needed (uint32[ceil((U+I)/32)]) for b < B (after zeroing the table when clear != 0): the rows a scored batch reads
+/* Sets bit u[b] and bit U + i[b] of needed (uint32[ceil((U+I)/32)], ALLOCATED up to the next multiple of 16 words: the clear
+ * writes whole 64-byte units) for b < B (after zeroing the table when clear != 0): the rows a scored batch reads
  * from the last stage (SPUIGACF.py:49-52), for the `needed` argument of ngacf_prop_fwd / ngacf_prop_bwd; and the same rows as
  * a list: rows[b] = u[b], rows[B + b] = U + i[b] (2B entries; -1 for an id out of range).  u == NULL: items only, rows[b] = U +
  * i[b] (B entries) -- the negatives of a (user, positive, negative) batch, appended to the list of the first call.

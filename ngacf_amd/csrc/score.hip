@@ -214,7 +214,8 @@ extern "C" int ngacf_mark_rows(const int64_t* u, const int64_t* i, uint32_t* nee
     if (B < 0 || U <= 0 || I <= 0 || !needed || !rows || d < 4 || d % 4 != 0) return NGACF_E_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (clear) {
-        const hipError_t e = hipMemsetAsync(needed, 0, 4 * (((size_t)U + (size_t)I + 31) / 32), st);
+        // (whole 64-byte units: the runtime splits a fill with a ragged tail into two kernels -- the table is allocated padded)
+        const hipError_t e = hipMemsetAsync(needed, 0, 64 * ((4 * (((size_t)U + (size_t)I + 31) / 32) + 63) / 64), st);
         if (e != hipSuccess) return static_cast<int>(e);
     }
     if (B == 0) return 0;

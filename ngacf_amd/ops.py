@@ -179,7 +179,7 @@ def mark_rows(u, i, U, I, into=None, grad_d=0):
     rows are zeroed (BatchRows.g32), for the backward of the scores."""
     dev, B = i.device, i.numel()
     if into is None:
-        into = BatchRows(torch.empty((U + I + 31) // 32, dtype=torch.int32, device=dev), torch.empty(max(3 * B, 1), dtype=torch.int32, device=dev), 0, U, I,
+        into = BatchRows(torch.empty(((U + I + 31) // 32 + 15) // 16 * 16, dtype=torch.int32, device=dev)[:(U + I + 31) // 32], torch.empty(max(3 * B, 1), dtype=torch.int32, device=dev), 0, U, I,
                          torch.empty(U + I, grad_d, dtype=torch.float32, device=dev) if grad_d else None)
         up, clear, add = (_idx(u, "userIdx", B, dev) if B else 0), 1, 2 * B
     else:
