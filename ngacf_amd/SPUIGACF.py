@@ -287,7 +287,7 @@ class _GATBase(nn.Module):
                 p_._version                                            # (copy_ above already bumped the versions)
 
     def _run(self, uidx, iidx, features, adj, needed=None, score=None):
-        """needed: ops.BatchRows for the LAST stage (the rows the caller will read); earlier stages run in full.
+        """needed: ops.BatchRows (or a closure returning one) for the LAST stage (the rows the caller will read); earlier stages run in full.
         score = (userIdx, [itemIdx, ...]) with needed: return the tuple of score vectors (SPUIGACF.py:49-52) instead of the table
         -- the last stage and the scoring are one autograd node."""
         _refuse_replica(self)
@@ -311,6 +311,8 @@ class _GATBase(nn.Module):
             W, avec = self._stage_operands(s)
             # feature dropout in front of every stage (:208,:213) and the ELU behind it (:397 inside
             # the concat layers, :214 around out_att) are fused into the stage
+            if callable(needed) and s == len(stages) - 1:
+                needed = needed()                           # the batch's rows are marked HERE, in front of the stage that wants them
             if score is not None and needed is not None and s == len(stages) - 1:
                 return NF.stage_score(x, W, avec, plan, len(layers), needed, score[0], score[1], layers[0].alpha, True, p, p,
                                       NF.stage_seed(base, s), self.compute_dtype, seed_dev)
@@ -474,13 +476,19 @@ class _CFBase(nn.Module):
         uidx, iidx, features = self.getFeatureMat()
         return self.gat(uidx, iidx, features, squeeze_mask(mask), needed, score)        # :42-46
 
-    def _batch_rows(self, userIdx, *itemIdxs):
+    def _sparse_batch(self, userIdx, n_item_lists):
+        """Does the batch list few enough rows for the rows-only last stage to pay?  (a host-side decision)"""
         _refuse_replica(self)
-        if not self.sparse_last_stage:
-            return None
-        # worth it while the batch touches a small part of the table: measured crossover with the full stage at ~23 % of the
-        # rows (B = 8192 of a 70 839-row graph, profiles/r02_sparse_probe_gowalla.log); beyond 1/5 the full stage runs
-        if (1 + len(itemIdxs)) * userIdx.numel() > self.sparse_max_fraction * (self.userNum + self.itemNum):
+        # measured crossover with the full stage at ~23 % of the rows (B = 8192 of a 70 839-row graph,
+        # profiles/r02_sparse_probe_gowalla.log); beyond 1/5 the full stage runs
+        return (self.sparse_last_stage
+                and (1 + n_item_lists) * userIdx.numel() <= self.sparse_max_fraction * (self.userNum + self.itemNum))
+
+    def _batch_rows(self, userIdx, *itemIdxs):
+        """ops.BatchRows of the batch (None when the full stage runs).  The modules call it through a closure, right in front
+        of the last stage: its two small launches then sit next to the other chain's big kernels of a two-chain train step,
+        not at the head of both chains at once."""
+        if not self._sparse_batch(userIdx, len(itemIdxs)):
             return None
         rows = None
         d = self.gat.stage_shapes()[-1][1] if torch.is_grad_enabled() else 0          # width of the last stage's output
@@ -489,18 +497,16 @@ class _CFBase(nn.Module):
         return rows
 
     def forward(self, userIdx, itemIdx, mask):
-        rows = self._batch_rows(userIdx, itemIdx)
-        if rows is not None:
-            return self.propagate(mask, rows, (userIdx, [itemIdx]))[0]
+        if self._sparse_batch(userIdx, 1):
+            return self.propagate(mask, lambda: self._batch_rows(userIdx, itemIdx), (userIdx, [itemIdx]))[0]
         return NF.score(self.propagate(mask), userIdx, itemIdx, self.userNum)    # :49-52
 
     def forward_pairs(self, userIdx, posIdx, negIdx, mask):
         """OPT-IN, not reference semantics: one propagation shared by the positive and the negative scoring of a
         BPR step (the reference calls forward() twice, train_eval_Gowalla.py:128-129, i.e. two propagations with
         independent dropout masks).  Identical to two forward() calls when droprate == 0 or in eval mode."""
-        rows = self._batch_rows(userIdx, posIdx, negIdx)
-        if rows is not None:
-            return self.propagate(mask, rows, (userIdx, [posIdx, negIdx]))
+        if self._sparse_batch(userIdx, 2):
+            return self.propagate(mask, lambda: self._batch_rows(userIdx, posIdx, negIdx), (userIdx, [posIdx, negIdx]))
         features = self.propagate(mask)
         return (NF.score(features, userIdx, posIdx, self.userNum), NF.score(features, userIdx, negIdx, self.userNum))
 
