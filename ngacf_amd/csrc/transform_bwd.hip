@@ -535,7 +535,8 @@ static int launch_transform_bwd(TransBwdArgs a, float* dW, float* davec, bool dr
     if (dW != nullptr) {   // dW, davec
         int nb = NGACF_TBWD_BLOCKS;
         if constexpr (sizeof(TH) == 2) {
-            nb = 256;          // one workgroup per CU: 256 / 512 / 1024 measured 10.2+4.4 / 9.4+5.5 / 10.1+9.9 us (kernel + reduce)
+            nb = 384;          // alone, 256 / 512 / 1024 workgroups measured 10.2+4.4 / 9.4+5.5 / 10.1+9.9 us (kernel + reduce); inside the
+                               // train step (two chains sharing the CUs) 256 / 384 / 512 / 768 / 1024 -> 0.680 / 0.670 / 0.674 / 0.695 / 0.704 ms per step
         }
         if (tu + ti < nb) { a.nbu = tu; a.nbi = ti; }
         else {
