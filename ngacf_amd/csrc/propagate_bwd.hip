@@ -15,7 +15,8 @@
 
 namespace ngacf {
 
-constexpr int UNROLL = 4;
+constexpr int UNROLL = 2;            // edges of gathers in flight per lane group (3 rows each).  4: 102-122 VGPRs, 4 waves/SIMD; 2: 92 VGPRs, 5 waves/SIMD --
+                                     // alone 66 -> 65 us with dropout (72 -> 73 without), inside the train step 0.668 -> 0.662 ms
 constexpr int UNROLL_Q = 2;          // edges in flight per lane group while a row outside the batch walks its queue (2-5 entries, typically)
 
 struct PropBwdArgs {
@@ -335,7 +336,7 @@ __device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int 
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE>
 __global__ __launch_bounds__(256, SPARSE ? (DROP ? 5 : 4) : 1) void prop_bwd_kernel(const PropBwdArgs a) {
     using SH = BShape<T, D, HEADS>;
-    constexpr int UNR = SPARSE ? 2 : UNROLL;      // SPARSE: the dense loops serve the few rows of the batch only -- fewer registers, more waves
+    constexpr int UNR = UNROLL;
     constexpr int LPR = SH::LPR, EPI = SH::EPI, HW = SH::HW, VEC = SH::VEC;
     const int lane = threadIdx.x & 63;
     const int slot = lane / LPR, q = lane % LPR;
