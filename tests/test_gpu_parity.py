@@ -644,6 +644,16 @@ def test_inkernel_hub_finish_is_bitwise_equal_to_two_kernel_path(dev):
         torch.cuda.synchronize()
         for t in plan._tickets.values():
             assert int(t.abs().sum()) == 0                             # counters are left clean
+    # more launch streams than the plan's pool of counter sets: further sets are allocated on demand
+    streams = [torch.cuda.Stream() for _ in range(20)]
+    outs = []
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            outs.append(ops.prop_fwd(plan, H, S, S, avec, 8))
+    for st in streams:
+        torch.cuda.current_stream().wait_stream(st)
+    assert len(plan._tickets) >= 20 and all(torch.equal(o, ref[0]) for o in outs)
 
 
 @pytest.mark.parametrize("multi", [False, True])
