@@ -416,3 +416,19 @@ def test_grad_sink_parks_parameter_gradients_and_adam_refuses_what_it_cannot_ste
     p.grad = torch.ones_like(p)
     with pytest.raises(ValueError, match="CUDA"):      # a host parameter never reaches the library (no CPU fallback)
         opt.step()
+
+
+def test_header_constants_match_the_python_side():
+    """The flag bits and table sizes of include/ngacf.h are restated in ngacf_amd/_lib.py (ctypes cannot read a header)."""
+    import re
+    from conftest import ROOT
+    from ngacf_amd import _lib
+    h = open(os.path.join(ROOT, "include", "ngacf.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+NGACF_(\w+)\s+(-?\d+|\(-\d+\))", h.replace("(-", "-").replace(")", ""))}
+    want = {"ELU": _lib.FLAG_ELU, "RESIDUAL": _lib.FLAG_RESIDUAL, "SCORE_ROW": _lib.FLAG_SCORE_ROW, "SKIP_NODE": _lib.FLAG_SKIP_NODE,
+            "GOUT_F32": _lib.FLAG_GOUT_F32, "TBWD_BLOCKS": _lib.TBWD_BLOCKS, "ADAM_MAX_TENSORS": _lib.ADAM_MAX_TENSORS,
+            "TICK_MAX": _lib.TICK_MAX, "F32": _lib.F32, "BF16": _lib.BF16}
+    for k, v in want.items():
+        assert defs.get(k) == v, (k, defs.get(k), v)
+    flags = [defs[k] for k in ("ELU", "RESIDUAL", "SCORE_ROW", "SKIP_NODE", "GOUT_F32")]
+    assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)          # distinct single bits
