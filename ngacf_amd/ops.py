@@ -3,6 +3,8 @@ dtype, contiguity and element counts of every tensor before a raw pointer crosse
 boundary -- a wrong size would be an out-of-bounds access on the GPU, not a Python error --
 then launches on the caller's current stream.  No torch math happens here.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -629,7 +631,6 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, 
     if n == 0:
         return
     dev = params[0].device
-    import ctypes
     P = ctypes.c_void_p * n
     numel = [p.numel() for p in params]
 
@@ -647,7 +648,6 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, 
 
 def tick(int_counters=(), int_strides=(), float_counters=()):
     """One launch for the scalar bookkeeping of a train step: int64 device counters += strides, float device counters += 1."""
-    import ctypes
     ni, nf = len(int_counters), len(float_counters)
     if ni != len(int_strides) or ni > _lib.TICK_MAX or nf > _lib.TICK_MAX:
         raise ValueError("tick: %d int counters / %d strides / %d float counters (at most %d each)" % (ni, len(int_strides), nf, _lib.TICK_MAX))
