@@ -44,7 +44,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="gowalla", choices=WORKLOADS)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--stages", type=int, default=3, help="propagation stages L (2 = SPUIGACF, 3 = SPUIMultiGACF)")
+    ap.add_argument("--stages", type=int, default=0, help="propagation stages L (2 = SPUIGACF, 3 = SPUIMultiGACF; default 3, "
+                    "4 for --workload gowalla128 = BASELINE config 4's d=128 L=4)")
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--droprate", type=float, default=0.1)
     ap.add_argument("--seg-len", type=int, default=256)
@@ -56,7 +57,10 @@ def parse(argv=None):
     ap.add_argument("--passes-per-step", type=int, default=0, help="R (0 = sized from --target-seconds)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: serial all-gather -> traversal schedule")
     ap.add_argument("--no-probe", action="store_true", help="skip the 10^9-edge scaling probe of the default (gowalla) line")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if not a.stages:
+        a.stages = 4 if a.workload == "gowalla128" else 3
+    return a
 
 
 _RESULT_FD = None

@@ -58,6 +58,16 @@ def optim_state_to_reference(model, optim_sd):
         state[j] = {k: (take(v).detach().clone().contiguous() if _is_param_shaped(v, params[pi])
                         else (v.detach().clone() if torch.is_tensor(v) else v)) for k, v in st.items()}
     group = dict(optim_sd["param_groups"][0], params=list(range(len(layout))))
+    # The reference's own layout (torch.optim.Adam defaults, run_Gowalla.py:114): default implementation flags and `step` as a
+    # CPU float32 0-dim tensor.  ngacf_amd.optim.Adam runs with capturable=True and device-side steps; a reference Adam that
+    # inherited those would take the slow capturable path and assert on CPU parameters.  (load_checkpoint re-applies the
+    # RUNNING optimizer's flags and torch moves `step` where that optimizer wants it.)
+    for k, v in (("capturable", False), ("foreach", None), ("fused", None)):
+        if k in group:
+            group[k] = v
+    for st in state.values():
+        if torch.is_tensor(st.get("step")):
+            st["step"] = st["step"].detach().to("cpu", torch.float32).reshape(())
     return {"state": state, "param_groups": [group]}
 
 

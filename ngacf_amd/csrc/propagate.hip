@@ -7,10 +7,13 @@
 //   short rows (degree <= plan.short_max, the bulk): one slot per destination row, EPI rows
 //     per wave, rows pre-sorted by degree so the slots of a wave finish together.  No
 //     cross-lane reduction at all; prologue/epilogue amortised over EPI rows.
-//   long rows (degree <= seg_len): one wave per row, slots stride over the edges, one cross-slot fold at the end.
-//   hub rows (degree > seg_len): one WORKGROUP per row -- the four waves stride over the edges and fold through LDS;
-//     dispatched first in their half.  (A second kernel summing per-slice partials cost 5 us per stage, 12 % of a
-//     forward pass, for a few hundred rows.)  Rows beyond plan.hub_cap keep the slice + partial-sum path.
+//   long rows (short_max < degree <= seg_len): one wave per row, slots stride over the edges, one cross-slot fold at the end.
+//   hub rows (degree > seg_len): cut into seg_len-edge slices, one wave each; every slice leaves (sum m e H, sum e) partials in
+//     its slot and the row's LAST-ARRIVING slice adds them in slot order and finishes the row inside this launch (ticket per row,
+//     write-through stores, agent-scope atomic loads: DESIGN.md section 3.3).  Plans beyond 2^18 slices (or tickets == NULL) leave
+//     the sums to prop_fwd_split_kernel.  This is the DEFAULT layout.
+//   OPTIONAL, off by default (build_plan(hub_cap=None), measured slower: plan.py default_hub_cap): rows of 4*seg_len < degree
+//     <= hub_cap as one WORKGROUP per row (WORK_HUB below), the four waves fold through LDS.
 //
 // The first version (wave per row everywhere) was VALU-issue bound at 540 instructions per
 // 28-edge row (rocprof: profiles/r01_v0_*); this layout needs ~4 VALU per edge.

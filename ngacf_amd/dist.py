@@ -41,7 +41,7 @@ import torch.nn as nn
 from . import functional as NF
 from . import ops as _hip_ops
 from .plan import build_plan, build_plan_from_keys, squeeze_mask
-from .SPUIGACF import SpUIGAT, SPUIMultiGAT, StackedSpUIGAT, _fresh_seed, _SEED_STRIDE, _CTR_STRIDE
+from .SPUIGACF import SpUIGAT, SPUIMultiGAT, StackedSpUIGAT, _PlanCache, _fresh_seed, _SEED_STRIDE, _CTR_STRIDE
 
 OTHER = {"user": "item", "item": "user"}
 
@@ -399,7 +399,7 @@ class ShardedSPUIGACF(nn.Module):
                 self.iEmbd.weight.normal_(std=0.01, generator=g)
                 self.uEmbd.weight[ou < 0] = 0                                 # padding slots: isolated zero nodes
                 self.iEmbd.weight[oi < 0] = 0
-        self._plans = {}
+        self._plans = _PlanCache()
         self._attached = None
         self.compute_dtype = torch.float32
         self.seg_len = 256
@@ -453,16 +453,16 @@ class ShardedSPUIGACF(nn.Module):
         self._attached = plan
 
     def _plan(self, mask):
+        """The sharded plan of `mask` through SPUIGACF._PlanCache: keyed by (address, shape, device, version) of the tensor
+        AND holding a reference to it, so a different adjacency can never be allocated at a cached address (the reference's
+        loop re-uploads `adj` every epoch, train_eval_Gowalla.py:106)."""
         if self._attached is not None:
             return self._attached
         mask = squeeze_mask(mask)
-        key = (mask.data_ptr(), tuple(mask.shape), mask._version, self.seg_len)
-        if key not in self._plans:
-            p = self.part
-            self._plans.clear()
-            self._plans[key] = build_plan(p.map_edges(mask.long()), p.Up, p.Ip, seg_len=self.seg_len, require_user_edges=False,
-                                          row_range=p.row_ranges)
-        return self._plans[key]
+        p = self.part
+        return self._plans.get(mask, p.Up, p.Ip, self.seg_len,
+                               builder=lambda: build_plan(p.map_edges(mask.long()), p.Up, p.Ip, seg_len=self.seg_len,
+                                                          require_user_edges=False, row_range=p.row_ranges))
 
     def use_device_seed(self, device, on=True):
         """Dropout seeds = per-call host constant + a device counter (advance_device_seed): what a captured hipGraph needs
@@ -657,6 +657,16 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
     torch.manual_seed(2019)
     U, I, E_target = D.SHAPES[wl]
     big = wl in D.BIG_WORKLOADS
+
+    def no_line():
+        # nothing complete to report: a NON-ZERO status (the rc-0 exit further down is only for a stalled optional re-run
+        # behind a complete eager line)
+        print("[bench] rank %d: stalled before any complete measurement (a collective or a kernel never finished)" % rank,
+              file=sys.stderr, flush=True)
+        os._exit(3)
+    dog0 = threading.Timer(float(os.environ.get("NGACF_DIST_EAGER_TIMEOUT", "900")), no_line)
+    dog0.daemon = True
+    dog0.start()
     if big:
         part, plan, E, sample_edge = sharded_graph(wl, world, rank, dev, seg_len=args.seg_len)
         model = ShardedSPUIGACF(U, I, d, [64, 64], args.droprate, world, rank, stages=args.stages, partition=part).to(dev)
@@ -822,6 +832,7 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
         dist.barrier()
 
     eager_line = line(t_eager, win_eager, "eager", extra)
+    dog0.cancel()
     if getattr(args, "eager", False) or os.environ.get("NGACF_DIST_GRAPH") == "0":
         if rank == 0:
             emit(eager_line)

@@ -321,16 +321,28 @@ def _bad_counter(dev):
     return c
 
 
+def _same_device(key, dev):
+    """Does the counter's device `key` (always indexed: cuda:0) match `dev`?  An index-less device ("cuda", what
+    Interactions(device="cuda") stores) means the current device."""
+    if dev is None:
+        return True
+    dev = torch.device(dev)
+    if key.type != dev.type:
+        return False
+    want = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else None)
+    return key.index == want
+
+
 def bad_index_count(dev=None):
     """Out-of-range indices seen by the scoring / ranking kernels since the last reset (synchronises)."""
-    return sum(int(c.item()) for d, c in _BAD.items() if dev is None or d == torch.device(dev))
+    return sum(int(c.item()) for d, c in _BAD.items() if _same_device(d, dev))
 
 
 def raise_if_bad_indices(dev=None):
     n = bad_index_count(dev)
     if n:
         for d, c in _BAD.items():
-            if dev is None or d == torch.device(dev):
+            if _same_device(d, dev):
                 c.zero_()
         raise IndexError("%d user/item index value(s) out of range reached the scoring kernels (their scores are NaN, "
                          "their gradients were dropped)" % n)

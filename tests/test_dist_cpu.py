@@ -12,6 +12,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
@@ -206,3 +208,24 @@ def test_chunk_generated_shards_assemble_the_whole_graph():
         assert torch.equal(first, whole[:, :first.shape[1]])                    # the CPU baseline's sample: the first user chunk
     nnz = [pl.n_edges_directed for _, pl, _, _ in shards]
     assert max(nnz) - min(nnz) < 0.05 * (2 * E / world)                        # degree-balanced shards
+
+
+def test_sharded_plan_cache_never_reuses_a_plan_for_another_tensor():
+    """ShardedSPUIGACF._plan keys on the mask tensor AND holds it (SPUIGACF._PlanCache), like the single-GPU
+    modules: same tensor -> same plan, equal shape + new tensor -> its own plan, in-place edit -> new plan."""
+    from ngacf_amd.dist import ShardedSPUIGACF
+    import fake_backend
+    a = torch.tensor([[0, 1, 2, 3], [0, 1, 0, 2]])
+    m = ShardedSPUIGACF(4, 3, 64, [64, 64], 0.0, world=2, rank=0, backend=fake_backend)
+    p1 = m._plan(a)
+    assert m._plan(a) is p1
+    b = torch.tensor([[0, 1, 2, 3], [1, 0, 1, 2]])                        # same shape, other edges
+    p2 = m._plan(b)
+    assert p2 is not p1 and not torch.equal(p2.col, p1.col)
+    held = [t for _, t, _ in m._plans._d.values()]
+    assert any(t is a for t in held) and any(t is b for t in held)        # the keyed storage stays allocated while cached
+    before = p1.col.clone()
+    a[1, 0] = 2                                                           # in-place edit bumps the version
+    p3 = m._plan(a)
+    assert p3 is not p1 and torch.equal(p1.col, before) and not torch.equal(p3.col, before)
+    assert p1.n_edges_directed < 2 * 4                                    # a rank's plan holds its shard only

@@ -82,8 +82,10 @@ def test_eval_neg_all_matches_the_references_own_eval_on_a_fixed_score_table(tag
         assert np.allclose(got[k], g["%s.%s" % (tag, k)], rtol=0, atol=1e-12), (k, got[k], g["%s.%s" % (tag, k)])
 
 
-def test_ml100k_two_epochs_reach_reference_metrics():
-    """The README smoke run (README.md:13-15: ml100k, lr 0.002, wd 1e-6, droprate 0.2, 2 epochs) on the REFERENCE'S split
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_ml100k_two_epochs_reach_reference_metrics(dt):
+    """(fp32 storage, and bf16 storage -- the headline bench configuration -- against the same reference band.)
+    The README smoke run (README.md:13-15: ml100k, lr 0.002, wd 1e-6, droprate 0.2, 2 epochs) on the REFERENCE'S split
     (g11: train_test_split under seed 2019), five sampler seeds, against the reference's own runs of the same command on
     the same split (tests/golden/g12: oracle/ref_train_probe.py, three seeds of the `random` module the reference never
     seeds).  The reference's run-to-run spread is large (Recall@20 0.234 .. 0.272), so the statement is distributional:
@@ -103,13 +105,15 @@ def test_ml100k_two_epochs_reach_reference_metrics():
     for seed in range(5):
         torch.manual_seed(2019)                                        # the model init of run_Gowalla.py:191
         model = ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.2).to(dev)
+        if dt == "bf16":
+            ngacf_amd.set_compute_dtype(model, torch.bfloat16)
         optim = torch.optim.Adam(model.parameters(), lr=0.002, weight_decay=1e-6)      # README.md:15
         gen = torch.Generator(device=dev); gen.manual_seed(1000 + seed)               # the sampler: the free variable
         torch.manual_seed(77 + seed)                                   # dropout seeds
         losses = [train_bpr(model, 2048, data, adj, optim, ngacf_amd.BPRLoss(), gen) for _ in range(2)]
         m = eval_neg_all(model, 2048, data, adj)
         runs.append((losses, m))
-        print("ml100k seed %d: loss %s" % (seed, np.round(losses, 7).tolist()), {k: np.round(v, 4).tolist() for k, v in m.items() if k != "auc"})
+        print("ml100k %s seed %d: loss %s" % (dt, seed, np.round(losses, 7).tolist()), {k: np.round(v, 4).tolist() for k, v in m.items() if k != "auc"})
     ref_loss = np.array([ref["loss.%d" % j] for j in range(nref)])
     print("reference losses", ref_loss.tolist())
     for key in ("recall", "precision", "ndcg", "hit_ratio"):
@@ -588,3 +592,47 @@ def test_tick_is_the_per_step_adds_in_one_launch():
     ops.tick()                                                    # nothing to do: no launch, no error
     with pytest.raises(ValueError):
         ops.tick(ints, [1], floats)
+
+
+def test_checkpoint_written_from_the_library_adam_is_the_references_layout(tmp_path):
+    """save_checkpoint from ngacf_amd.optim.Adam (capturable, device-side float32 `step`) writes the reference's
+    own optimizer layout -- default flags, CPU 0-dim float32 `step` -- so a plain 53-parameter torch.optim.Adam on CPU
+    parameters (the reference's, run_Gowalla.py:114) loads it and STEPS with it; and it loads back here unchanged."""
+    import ngacf_amd
+    from ngacf_amd import checkpoint as CK
+    from ngacf_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    U, I = 60, 50
+    rs = np.random.RandomState(0)
+    uu = np.concatenate([np.arange(U), rs.randint(0, U, 500)]); ii = np.concatenate([rs.randint(0, I, U), rs.randint(0, I, 500)])
+    key = np.unique(uu.astype(np.int64) * I + ii)
+    edge = torch.from_numpy(np.stack([key // I, key % I])).to(dev)
+    torch.manual_seed(3)
+    m = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev).train()
+    opt = Adam(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    u, p, n = (torch.from_numpy(rs.randint(0, k, 32)).to(dev) for k in (U, I, I))
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        ngacf_amd.BPRLoss()(m(u, p, edge), m(u, n, edge)).backward()
+        opt.step()
+    path = str(tmp_path / "ck.pkl")
+    CK.save_checkpoint(path, m, opt)
+    ck = torch.load(path, map_location="cpu")
+    grp = ck["optim"]["param_groups"][0]
+    assert grp["capturable"] is False and grp["foreach"] is None and grp["fused"] is None and len(grp["params"]) == 53
+    for st in ck["optim"]["state"].values():
+        assert st["step"].device.type == "cpu" and st["step"].dtype == torch.float32 and st["step"].dim() == 0 and float(st["step"]) == 2.0
+    ref_params = [torch.nn.Parameter(v.clone()) for v in ck["model"].values()]
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-3, weight_decay=1e-5)
+    ref_opt.load_state_dict(ck["optim"])
+    for q in ref_params:
+        q.grad = torch.ones_like(q)
+    ref_opt.step()                                                        # (capturable=True would assert on CPU parameters)
+    assert float(ref_opt.state[ref_params[0]]["step"]) == 3.0
+    m2 = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev)
+    opt2 = Adam(m2.parameters(), lr=1e-3, weight_decay=1e-5)
+    CK.load_checkpoint(path, m2, opt2, map_location=dev)
+    for (a, sa), (b, sb) in zip(opt.state.items(), opt2.state.items()):
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+        assert sb["step"].is_cuda and float(sb["step"]) == 2.0
+    assert opt2.param_groups[0]["capturable"] is True
