@@ -203,10 +203,22 @@ def _needed_args(needed, plan, N, dev):
     return _chk(needed.needed, "needed", torch.int32, (N + 31) // 32, dev, align=4), needed.rows.data_ptr(), needed.n, int(plan.short_max)
 
 
+def _scratch(scratch, plan, d, heads, dev):
+    if scratch is None:
+        return (torch.empty(max(plan.nparts, 1), d, dtype=torch.float32, device=dev),
+                torch.empty(max(plan.nparts, 1), heads, dtype=torch.float32, device=dev))
+    pa, pr = scratch
+    _chk(pa, "scratch[0]", torch.float32, max(plan.nparts, 1) * d, dev)
+    _chk(pr, "scratch[1]", torch.float32, max(plan.nparts, 1) * heads, dev, align=4)
+    return pa, pr
+
+
 def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
-             drop_p=0.0, seed=0, save=False, out=None, seed_dev=None, half=None, agg=None, R=None, needed=None):
+             drop_p=0.0, seed=0, save=False, out=None, seed_dev=None, half=None, agg=None, R=None, needed=None, scratch=None):
     """One propagation stage over plan's dst rows.  Returns out (and agg, R when save=True).
-    half = "user" / "item": only the user / item dst rows (two calls with the same out / agg / R cover the stage)."""
+    half = "user" / "item": only the user / item dst rows (two calls with the same out / agg / R cover the stage).
+    scratch = (float [nparts, d], float [nparts, heads]): the hub rows' partial-sum slots (default: fresh buffers; the soak
+    test hands in buffers it has poisoned)."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
     if score_from_row is None:
@@ -229,8 +241,7 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
         _chk(R, "R", torch.float32, N * heads, dev)
     else:
         agg = R = None
-    pa = torch.empty(max(plan.nparts, 1), d, dtype=torch.float32, device=dev)
-    pr = torch.empty(max(plan.nparts, 1), heads, dtype=torch.float32, device=dev)
+    pa, pr = _scratch(scratch, plan, d, heads, dev)
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
     _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, *pp, hp,
                       _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
@@ -241,8 +252,8 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
 
 
 def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, elu=True, residual=True,
-             score_from_row=None, drop_p=0.0, seed=0, seed_dev=None, needed=None, gout_f32=False):
-    """Returns dH [N,d] in H's dtype (with the dS*avec term) and dS [N,heads] fp32."""
+             score_from_row=None, drop_p=0.0, seed=0, seed_dev=None, needed=None, gout_f32=False, scratch=None):
+    """Returns dH [N,d] in H's dtype (with the dS*avec term) and dS [N,heads] fp32.  scratch: as in prop_fwd."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
     if score_from_row is None:
@@ -260,8 +271,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     dH = torch.empty(N, d, dtype=H.dtype, device=dev)      # (no G table: one call runs both steps, step 2 recomputes g = gout * ELU'(out))
     Gn = torch.empty(N, d, dtype=H.dtype, device=dev)
     t, dS = torch.empty(N, heads, **f32), torch.empty(N, heads, **f32)
-    pa = torch.empty(max(plan.nparts, 1), d, **f32)
-    pr = torch.empty(max(plan.nparts, 1), heads, **f32)
+    pa, pr = _scratch(scratch, plan, d, heads, dev)
     if plan.n_rows != N:
         dH.zero_()
         dS.zero_()

@@ -656,6 +656,18 @@ def test_inkernel_hub_finish_is_bitwise_equal_to_two_kernel_path(dev):
     assert len(plan._tickets) >= 20 and all(torch.equal(o, ref[0]) for o in outs)
 
 
+def test_inkernel_hub_finish_soak_with_poisoned_partial_sums(dev, capsys):
+    """tools/hub_soak.py, short form (the 120 000-launch run is profiles/r03_hub_soak.json): rotating input tables, the
+    partial-sum slots NaN-filled before every launch, forward and backward launches overlapped on two streams, every output
+    word compared bitwise with the two-kernel path.  A stale read of another slice's sums -- from a previous launch or from
+    the NaN fill sitting in an L2 -- would show as a mismatching launch."""
+    import json
+    from tools import hub_soak
+    rc = hub_soak.main(["--launches", os.environ.get("NGACF_SOAK_LAUNCHES", "4000")])
+    rep = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rc == 0 and rep["mismatches"] == 0 and rep["launches"] >= 4000, rep
+
+
 @pytest.mark.parametrize("multi", [False, True])
 def test_sparse_last_stage_equals_full_propagation(dev, multi):
     """model.forward / forward_pairs compute the LAST stage only for the rows of the batch (SPUIGACF.py:49-52 reads nothing
