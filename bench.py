@@ -90,19 +90,31 @@ def stage_layer_names(model):
 
 
 def cpu_baseline_leg(torch, p_cpu, names, edge_c, Us, Is, L, budget_s, sample):
-    """`cpu_baseline`: oracle/cpu_baseline.py (the reference's operator order, torch CPU ops) on this box's host cores.
+    """`cpu_baseline`: oracle/cpu_baseline.py (the reference's operator order, torch CPU ops) on this box's host cores, TWICE:
+    on a GPU's share of the host (16 threads: the figure in `value`) and on every core (torch.set_num_threads(os.cpu_count()),
+    BASELINE.md section 3) -- both in the line, half the budget each.
     p_cpu: reference-keyed CPU state_dict of the (sub)graph's Us users / Is items; edge_c: its [2,E] CPU edge list."""
     from oracle import cpu_baseline as CB
-    ncores = min(os.cpu_count() or 1, 16)            # a GPU's share of the host (more threads only oversubscribe)
-    torch.set_num_threads(ncores)
-    x_cpu = torch.cat([p_cpu["uEmbd.weight"], p_cpu["iEmbd.weight"]])
-    sec, iters = CB.time_forward(p_cpu, x_cpu, edge_c, Us, Is, names, budget_s=budget_s)
-    trav = L * 2 * int(edge_c.shape[1])
     bk = _benchkit()
-    return {"value": round(trav / sec, 1), "unit": "edges/s", "cores": ncores, "kind": "port",
-            "cpu_model": bk.cpu_model_name(), "host_cpus": os.cpu_count(),
-            "sample": "%d eval forward(s) over %s, same weights (L=%d, fp32), %.2f s each, torch CPU ops in the reference's "
-                      "operator order (oracle/cpu_baseline.py)" % (iters, sample, L, sec)}
+    x_cpu = torch.cat([p_cpu["uEmbd.weight"], p_cpu["iEmbd.weight"]])
+    trav = L * 2 * int(edge_c.shape[1])
+    host = os.cpu_count() or 1
+
+    def run(nthreads, budget):
+        torch.set_num_threads(nthreads)
+        sec, iters = CB.time_forward(p_cpu, x_cpu, edge_c, Us, Is, names, budget_s=budget)
+        return sec, iters
+    share = min(host, 16)
+    sec, iters = run(share, budget_s / 2 if host > share else budget_s)
+    out = {"value": round(trav / sec, 1), "unit": "edges/s", "cores": share, "kind": "port",
+           "cpu_model": bk.cpu_model_name(), "host_cpus": host,
+           "sample": "%d eval forward(s) over %s, same weights (L=%d, fp32), %.2f s each, torch CPU ops in the reference's "
+                     "operator order (oracle/cpu_baseline.py)" % (iters, sample, L, sec)}
+    if host > share:
+        sec_a, it_a = run(host, budget_s / 2)
+        out["all_cores"] = {"value": round(trav / sec_a, 1), "unit": "edges/s", "cores": host,
+                            "sample": "%d forward(s), %.2f s each, torch.set_num_threads(%d)" % (it_a, sec_a, host)}
+    return out
 
 
 def cpu_sample(torch, model, edge, U, I, wl):
@@ -121,6 +133,107 @@ def cpu_sample(torch, model, edge, U, I, wl):
     p_cpu["iEmbd.weight"] = p_cpu["iEmbd.weight"][items.cpu()]
     return (p_cpu, torch.stack([sub[0], inv]).cpu(), u_hi, int(items.numel()),
             "the subgraph of the first %d users of the %s graph (%d edges, %d items touched)" % (u_hi, wl, n_e, int(items.numel())))
+
+
+def measure_forward(torch, BK, ops, model, edge, steps, warmup, target_s, passes_per_step, eager, n_timed):
+    """The eval-mode forward propagation of `model`: K steps of R passes (hipGraph replay unless eager) between synchronize()
+    pairs, then `n_timed` eager passes whose traversal / transform launches carry dispatch-timestamp events (ops.KernelTimer).
+    Returns a dict (seconds of the timed region, windows, R, per-launch kernel durations by stage)."""
+    def sync():
+        torch.cuda.synchronize()
+    model.eval()
+    with torch.no_grad():
+        if eager:
+            run = lambda: model.propagate(edge)
+        else:                                   # the same launches, captured once into a hipGraph and replayed
+            from ngacf_amd.graphs import GraphedPropagate
+            run = GraphedPropagate(model, edge)
+        run()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            run()
+        sync()
+        t_pass = (time.perf_counter() - t0) / 5
+        R = passes_per_step or BK.passes_per_step(t_pass, steps, target_s)
+        for _ in range(warmup):
+            for _ in range(R):
+                run()
+        t_fwd, windows = BK.timed_steps(run, steps, R, sync, torch)
+        # duration of every kernel of the pass from its dispatch packet's own timestamps (hipExtLaunchKernel start / stop
+        # events): eager launches of the same kernels on the same data -- no host launch gap inside the figure, it is what a
+        # rocprofv3 kernel trace reports for the replayed graph (profiles/README.md)
+        for _ in range(3):
+            model.propagate(edge)
+        sync()
+        with ops.KernelTimer() as kt:
+            for _ in range(n_timed):
+                model.propagate(edge)
+            sync()
+    return {"t": t_fwd, "windows": windows, "R": R, "prop_ms": kt.durations_ms(), "transform_ms": kt.durations_ms(kt.TAG_TRANSFORM_FWD),
+            "n_timed": n_timed}
+
+
+def roofline_of(BK, D, wl, dtype, U, I, E, dims, elem, prop_ms, n_timed, fused):
+    """`roofline` of the dominant kernel (attention propagation) from its algorithmic bytes per launch (SURVEY.md 8(d):
+    2E (4 + d T) + N (2 d T + 8)) and its average duration.  The roof depends on where the gathered rows come from:
+      * table far beyond the 256 MiB Infinity Cache: HBM, peak 8 TB/s -- `frac` is the fraction of the HBM roofline;
+      * table inside L2 + Infinity Cache (Gowalla / Yelp): the gather never reaches HBM; the roof is the blend of the measured
+        L2-hit and Infinity-Cache row-gather rates (MI355X_MICROARCH.md, "Indexed rows") at the kernel's measured L2 hit
+        rate, 1 / (hit / 17.8 + miss / 8.6) TB/s; the algorithmic rate over the HBM peak is reported separately as
+        `frac_hbm_algorithmic` (it may exceed 1 there and is NOT an HBM statement)."""
+    L = len(dims)
+    N, d = U + I, dims[0][1]
+    per_launch_bytes = [D.algorithmic_bytes_stage(U, I, E, din, dout, elem)[0] for din, dout, _ in dims]
+    assert len(prop_ms) == L * n_timed, (len(prop_ms), L, n_timed)
+    avg_ms = sum(prop_ms) / len(prop_ms)
+    avg_bytes = sum(per_launch_bytes) / L
+    achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+    per_stage_ms = [sum(prop_ms[s::L]) / n_timed for s in range(L)]
+    regime = BK.gather_regime(N * d * elem, max(U, I) * d * elem)
+    traffic, traffic_src = BK.traffic_from_profile(ROOT, wl, dtype, L, d)
+    hit, hit_src = BK.l2_hit_from_profile(ROOT, wl, dtype)
+    if regime["regime"] == "HBM":
+        bound, peak, peak_note = "hbm", BK.HBM_PEAK_GBS, "HBM3E spec peak"
+    else:
+        bound = "l2+mall gather"
+        if hit is not None:
+            peak = 1.0 / (hit / BK.ROOF_L2_GATHER_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
+            peak_note = ("1 / (hit / %.0f + miss / %.0f) GB/s at the kernel's L2 hit rate %.3f (%s)"
+                         % (BK.ROOF_L2_GATHER_GBS, BK.ROOF_MALL_GATHER_GBS, hit, hit_src))
+        else:
+            peak, peak_note = regime["roof_GBps"], "no request-counter profile for this workload: the regime's row-gather rate"
+    out = {"bound": bound, "kernel": "prop_fwd_kernel (ngacf_prop_fwd%s)" % (": with the next stage's transform in its epilogue on all but the last stage" if fused else ""),
+           "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s", "frac": round(achieved / peak, 4),
+           "peak_note": peak_note, "traffic": traffic, "traffic_source": traffic_src,
+           "frac_hbm_algorithmic": round(achieved / BK.HBM_PEAK_GBS, 4),
+           "counter_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
+           "regime": regime["regime"], "regime_note": regime["note"], "l2_hit_rate": hit,
+           "bytes_per_launch": int(avg_bytes), "avg_launch_us": round(avg_ms * 1e3, 2),
+           "per_stage_us": [round(x * 1e3, 2) for x in per_stage_ms], "launches_timed": len(prop_ms),
+           "timing": "dispatch-packet timestamps (hipExtLaunchKernel start/stop events) of eager launches of the replayed graph's kernels",
+           "edges_per_s_in_kernel": round(2 * E / (avg_ms * 1e-3), 1)}
+    return out
+
+
+def performed_train_traversals(torch, model, plan, ub, pb, nb_, L, E):
+    """Directed-edge gathers one reference-semantics train step really performs (the last stage of a scored batch touches the
+    batch's rows only): dense stages 2E each, forward and backward, for both propagations; the last stage: the edges of the
+    batch's rows (forward), and in the backward those plus every other row's edges INTO the batch."""
+    U = model.userNum
+    N = U + model.itemNum
+    if not model._sparse_batch(ub, 1):
+        return 4 * L * 2 * E
+    deg = (plan.rowptr[1:] - plan.rowptr[:-1]).long()
+    tot = 0
+    for items in (pb, nb_):
+        m = torch.zeros(N, dtype=torch.bool, device=ub.device)
+        m[ub] = True
+        m[U + items] = True
+        own = int(deg[m].sum())                      # forward: every edge of a batch row; backward: the same rows again
+        into = int(m[plan.col.long()].sum()) - int((m[plan.col.long()] & torch.repeat_interleave(m, deg)).sum())
+        tot += 2 * (L - 1) * 2 * E + own + (own + into)
+    return tot
 
 
 def worker(args):
@@ -142,7 +255,7 @@ def worker(args):
         dist.init_process_group("nccl", device_id=dev)
 
     import ngacf_amd as ng
-    from ngacf_amd import benchkit as BK, data as D, ops
+    from ngacf_amd import benchkit as BK, data as D, functional as NF, ops
 
     wl = "gowalla" if args.workload == "gowalla128" else args.workload
     d = 128 if args.workload == "gowalla128" else 64
@@ -164,65 +277,25 @@ def worker(args):
     dims = model.gat.stage_shapes()
     L = len(dims)
     big = wl in D.BIG_WORKLOADS
+    fused = NF.FUSE_NEXT and args.dtype == "bf16"
 
     def sync():
         torch.cuda.synchronize()
 
     # ---------------- headline: forward propagation, eval mode ----------------
-    model.eval()
-    with torch.no_grad():
-        if args.eager:
-            run = lambda: model.propagate(edge)
-        else:                                   # the same launches, captured once into a hipGraph and replayed
-            from ngacf_amd.graphs import GraphedPropagate
-            run = GraphedPropagate(model, edge)
-        run()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            run()
-        sync()
-        t_pass = (time.perf_counter() - t0) / 5
-        R = args.passes_per_step or BK.passes_per_step(t_pass, args.steps, args.target_seconds)
-        for _ in range(args.warmup):
-            for _ in range(R):
-                run()
-        t_fwd, windows = BK.timed_steps(run, args.steps, R, sync, torch)
-        # per-launch duration of the dominant kernel: events on the launch stream around every ngacf_prop_fwd
-        # call of eager passes (events cannot be placed inside a replayed graph; same kernels, same data)
-        n_eager = max(args.steps, 20 if big else 100)
-        with ops.KernelTimer("ngacf_prop_fwd") as kt:
-            for _ in range(n_eager):
-                model.propagate(edge)
-            sync()
-        durs = kt.durations_ms()
+    fm = measure_forward(torch, BK, ops, model, edge, args.steps, args.warmup, args.target_seconds, args.passes_per_step, args.eager,
+                         max(args.steps, 20 if big else 100))
+    t_fwd, windows, R = fm["t"], fm["windows"], fm["R"]
     trav_per_pass = L * 2 * E
     trav_per_step = trav_per_pass * R
     value = trav_per_step * args.steps / t_fwd
     ms_per_step = 1e3 * t_fwd / args.steps
     med_ms = BK.median(windows)
-
-    # roofline of the dominant kernel (attention propagation): algorithmic bytes per launch / avg launch time
-    per_launch_bytes = [D.algorithmic_bytes_stage(U, I, E, din, dout, elem)[0] for din, dout, _ in dims]
-    assert len(durs) == L * n_eager
-    avg_ms = sum(durs) / len(durs)
-    avg_bytes = sum(per_launch_bytes) / L
-    achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
-    per_stage_ms = [sum(durs[s::L]) / n_eager for s in range(L)]
-    regime = BK.gather_regime(N * d * elem, max(U, I) * d * elem)
-    traffic, traffic_src = BK.traffic_from_profile(ROOT, wl, args.dtype, args.stages, d)
-    roofline = {"bound": "hbm", "kernel": "prop_fwd_kernel (ngacf_prop_fwd: main kernel + hub-row pass)",
-                "achieved": round(achieved, 1), "peak": BK.HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / BK.HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": traffic_src,
-                "counter_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
-                "counter_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / BK.HBM_PEAK_GBS, 4) if traffic else None,
-                "regime": regime["regime"], "regime_note": regime["note"],
-                "applicable_roof_GBps": regime["roof_GBps"], "frac_of_applicable_roof": round(achieved / regime["roof_GBps"], 4),
-                "bytes_per_launch": int(avg_bytes), "avg_launch_us": round(avg_ms * 1e3, 2),
-                "per_stage_us": [round(x * 1e3, 2) for x in per_stage_ms], "launches_timed": len(durs),
-                "edges_per_s_in_kernel": round(2 * E / (avg_ms * 1e-3), 1),
-                "measured_copy_GBps": BK.copy_rate_GBps(torch, dev)}
+    roofline = roofline_of(BK, D, wl, args.dtype, U, I, E, dims, elem, fm["prop_ms"], fm["n_timed"], fused)
+    roofline["measured_copy_GBps"] = BK.copy_rate_GBps(torch, dev)
+    if fm["transform_ms"]:
+        roofline["transform_launch_us"] = round(1e3 * sum(fm["transform_ms"]) / len(fm["transform_ms"]), 2)
+        roofline["transform_launches_per_pass"] = len(fm["transform_ms"]) // fm["n_timed"]
     fwd_bytes = sum(sum(D.algorithmic_bytes_stage(U, I, E, din, dout, elem)) for din, dout, _ in dims)
 
     # ---------------- BPR train steps (reference semantics: 2 propagations per step) ----------------
@@ -267,9 +340,14 @@ def worker(args):
             sync()
             return time.perf_counter() - t0, n, out
         t_tr, ksteps, loss = time_train(step)
+        plan = model.gat._plans.get(edge, U, I, args.seg_len)
+        performed = performed_train_traversals(torch, model, plan, ub, pb, nb, L, E)
         train = {"bpr_pairs_per_s": round(B * ksteps / t_tr, 1), "train_ms_per_step": round(1e3 * t_tr / ksteps, 3),
                  "train_steps": ksteps, "batch": B, "droprate": args.droprate, "final_loss": round(float(loss.detach()), 6),
-                 "fwd_bwd_traversals_per_s": round(4 * trav_per_pass * ksteps / t_tr, 1)}
+                 "train_traversals_per_step": {"performed": performed, "if_every_stage_ran_in_full": 4 * trav_per_pass,
+                                               "note": "directed-edge gathers of one step (2 propagations, forward + backward); the last "
+                                                       "stage of a scored batch walks the batch's rows only"},
+                 "train_traversals_per_s": round(performed * ksteps / t_tr, 1)}
         if not args.eager and not big:
             # reported SEPARATELY: the opt-in mode that shares one propagation between the
             # positive and the negative scoring of a step -- not reference semantics, never the headline number
@@ -292,7 +370,9 @@ def worker(args):
                                   % (wl, U, I, E, d, L, type(model).__name__, d),
                       "passes_per_step": R, "edges_directed_per_pass": trav_per_pass, "edges_directed_per_step": trav_per_step,
                       "seg_len": args.seg_len, "parallelism": "1 GPU",
-                      "launch": "eager" if args.eager else "hipGraph replay"},
+                      "launch": "eager" if args.eager else "hipGraph replay",
+                      "launches_per_pass": (L + 1 if fused else 2 * L),
+                      "fused_next_stage_transform": bool(fused)},
            "ms_per_pass": round(ms_per_step / R, 5), "timed_region_s": round(t_fwd, 4),
            "value_median_window": round(trav_per_step / (med_ms * 1e-3), 1) if med_ms > 0 else None,
            "window_ms": {"median": round(med_ms, 4), "min": round(min(windows), 4), "max": round(max(windows), 4)},
@@ -301,6 +381,14 @@ def worker(args):
     if train:
         out.update(train)
     if wl == "gowalla" and d == 64 and not args.no_probe:
+        del model, edge
+        torch.cuda.empty_cache()
+        # north_star's roofline target is stated at Yelp scale: the same forward on the Yelp-scale graph, a short second region
+        try:
+            out["yelp_probe"] = yelp_probe(args, torch, ng, BK, D, NF, ops, dev)
+        except Exception as e:
+            print("[bench] yelp probe failed: %r" % (e,), file=sys.stderr, flush=True)
+            out["yelp_probe"] = {"error": repr(e)}
         # the same forward on the 10^9-edge graph (BASELINE config 5) at this GPU count: the regime where the node partition
         # can pay; lets one `bench.py --gpus N` sweep yield a second strong-scaling curve (ngacf_amd.dist.scaling_probe)
         try:
@@ -310,6 +398,26 @@ def worker(args):
             print("[bench] scaling probe failed: %r" % (e,), file=sys.stderr, flush=True)
             out["scaling_probe"] = {"error": repr(e)}
     emit(json.dumps(out))
+
+
+def yelp_probe(args, torch, ng, BK, D, NF, ops, dev):
+    """The headline measurement repeated at Yelp scale (BASELINE config 2's graph; north_star: ">= 50 % of the HBM roofline on
+    the attention-propagation kernel at Yelp scale on 1 GPU"): forward only, ~0.3 s timed region, its own roofline."""
+    wl = "yelp"
+    U, I, _ = D.SHAPES[wl]
+    torch.manual_seed(2019)
+    edge = D.workload_graph(wl, dev)
+    E = int(edge.shape[1])
+    elem = 2 if args.dtype == "bf16" else 4
+    model = make_model(ng, torch, U, I, 64, 3, args.droprate, args.dtype, dev)
+    dims = model.gat.stage_shapes()
+    K = max(5, min(args.steps, 10))
+    fm = measure_forward(torch, BK, ops, model, edge, K, 2, 0.3, 0, args.eager, 50)
+    trav = len(dims) * 2 * E
+    rl = roofline_of(BK, D, wl, args.dtype, U, I, E, dims, elem, fm["prop_ms"], fm["n_timed"], NF.FUSE_NEXT and args.dtype == "bf16")
+    return {"workload": "%s-scale bipartite graph U=%d I=%d E=%d, d=64, L=3, eval forward" % (wl, U, I, E),
+            "value": round(trav * fm["R"] * K / fm["t"], 1), "unit": "edges/s", "ms_per_pass": round(1e3 * fm["t"] / K / fm["R"], 5),
+            "steps": K, "passes_per_step": fm["R"], "dtype": args.dtype, "roofline": rl}
 
 
 def main(argv=None):

@@ -76,6 +76,20 @@ int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, const float*
                         int U, int I, int din, int dout, int heads,
                         float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
+/* ngacf_transform_fwd on the matrix-core path (h_dtype must be NGACF_BF16) whose launch ALSO packs the weight panels of up to
+ * NGACF_MAX_PACK later stages for ngacf_prop_fwd_next (side workgroups of the same launch: the first launch of a forward
+ * refreshes the fragments from the live fp32 weights, so a captured hipGraph never replays a stale copy after an optimizer
+ * step).  Host arrays of n_pack entries: pack_W[k] float[2][din_k][dout_k] (device), pack_panel[k] device buffer of
+ * 2 * din_k * dout_k * 2 bytes, din_k == 64, dout_k in {64, 128}.  Fragment layout (16 bytes = 8 bf16 each):
+ *   index ((y * (din/32) + s) * (dout/16) + t) * 64 + l  holds  W[y][32 s + 8 (l >> 4) + j][16 t + (l & 15)], j = 0..7. */
+#define NGACF_MAX_PACK 4
+int ngacf_transform_fwd_pack(const void* X, int x_dtype, const float* W, const float* avec,
+                             void* H, int h_dtype, float* S,
+                             int U, int I, int din, int dout, int heads,
+                             float feat_drop_p, uint64_t seed, const uint64_t* seed_dev,
+                             int n_pack, const float* const* pack_W, void* const* pack_panel,
+                             const int* pack_din, const int* pack_dout, void* stream);
+
 /* The same over row windows (node-partitioned runs, ngacf_amd/dist.py): users [u_lo, u_lo+u_n) and items
  * [i_lo, i_lo+i_n) (global row = U + i).  H and S are indexed by global row; with x_local != 0, X holds only
  * the window rows (the u_n user rows first, then the i_n item rows). */
@@ -118,6 +132,42 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
+
+/* The NEXT stage's row transform fused into the traversal: SpUIGAT.forward chains the stages (SPUIGACF.py:207-215: the heads'
+ * outputs are concatenated, dropped out and fed to the next layer's torch.mm(features, W) :356-357), so a finished output
+ * row of stage s is the input row of stage s+1's transform.  ngacf_prop_fwd_next = ngacf_prop_fwd + that transform in the
+ * epilogue: every wave turns the rows it has just finished (still in registers) into
+ *     H'[n, :] = dropout'(out[n, :]) @ W'[type(n)],   S'[n, h] = sum_{c in head h} H'[n, c] * avec'[type(n)][c]
+ * on the matrix cores (v_mfma_f32_16x16x32_bf16; operands = the bf16 values that `out` stores, fp32 accumulate, H' rounded
+ * to bf16 and S' formed from the rounded values: what ngacf_transform_fwd computes from the stored table).  One dependent
+ * launch and one write + read of the [N][d] table less per stage.
+ *   next->panel   the next stage's W as bf16 matrix-core fragments, written by ngacf_transform_fwd_pack (2 * din * dout * 2 bytes)
+ *   next->avec    float[2][dout']        next->H  [N][dout'] bf16        next->S  float[N][heads']
+ *   next->dout in {64, 128}, next->heads in {1, dout' / 8}; next->feat_drop_p / next->seed: the next stage's feature dropout
+ *   (mask keyed by (seed', n, c) exactly as in ngacf_transform_fwd; the device addend seed_dev is shared with this stage).
+ * Restrictions: dtype NGACF_BF16, d == 64, heads == 8, NGACF_SCORE_ROW, no `needed`, no workgroup-per-row hubs (nhub == 0), and
+ * hub rows finished in-kernel (part_split + tickets given) or absent.  `out` may be NULL (an evaluation forward needs only
+ * H' and S'); agg / R as in ngacf_prop_fwd.  next == NULL: exactly ngacf_prop_fwd. */
+typedef struct ngacf_next_stage {
+    const void* panel;
+    const float* avec;
+    void* H;
+    float* S;
+    int32_t dout, heads;
+    float feat_drop_p;
+    uint64_t seed;
+} ngacf_next_stage;
+int ngacf_prop_fwd_next(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                        const int32_t* srow, int nshort, int nseg_user, int nshort_user,
+                        const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
+                        const int32_t* col, const void* H, int dtype,
+                        const float* S_dst, const float* S_src, const float* avec,
+                        void* out, void* agg, float* R, float* part_acc, float* part_r,
+                        const int32_t* part_split, int32_t* tickets,
+                        const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
+                        int U, int N, int d, int heads, float alpha,
+                        float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
+                        const ngacf_next_stage* next, void* stream);
 
 /* Backward of ngacf_prop_fwd (autograd of SPUIGACF.py:359-397; formulas SURVEY.md §8(a) A4b).
  * Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  t[n,h] = (g . agg)_h / R   (ST below = this t table)
@@ -281,6 +331,18 @@ int ngacf_mha_bwd(const float* Q, const float* K, const float* V, const uint32_t
                   const float* LSE, const float* dO, float* dQ, float* dK, float* dV, float* delta,
                   int Nq, int Nk, int dim, int heads, float drop_p, uint64_t seed, const uint64_t* seed_dev,
                   int bf16_operands, void* stream);
+
+/* Opt-in kernel timing for measurements (bench.py's roofline leg): between ngacf_timing_begin() and ngacf_timing_end() on the
+ * SAME host thread, the launches of the traversal and transform kernels carry start / stop events of their dispatch packets
+ * (hipExtLaunchKernel): the kernel's own duration, without the host's launch gaps -- the number a kernel trace reports.
+ * ngacf_timing_end synchronises, writes up to cap (duration in ms, NGACF_TAG_*) pairs in launch order and returns their count
+ * (negative on error).  Not for use inside a stream capture.  Per-thread state; nothing happens unless a thread asks. */
+#define NGACF_TAG_PROP_FWD        1   /* prop_fwd_kernel (also with the fused next-stage transform) */
+#define NGACF_TAG_PROP_FWD_SPLIT  2   /* prop_fwd_split_kernel (hub rows' partial sums, second kernel) */
+#define NGACF_TAG_TRANSFORM_FWD   3   /* transform_mfma_kernel / transform_fwd_kernel, forward */
+#define NGACF_TAG_PROP_BWD        4   /* prop_bwd_kernel */
+int ngacf_timing_begin(void);
+int ngacf_timing_end(float* ms, int32_t* tags, int cap);
 
 /* Counter-hash dropout mask bits, exposed so tests can pin the device RNG against the
  * host restatement: bits[k] = the 32-bit hash the kernels compare against drop_p * 2^32.

@@ -73,6 +73,17 @@ class _PlanCache:
         return hit[0]
 
 
+class _PanelRef:
+    """The packed weight panel of stage s, available once the stack's first transform has run (functional.StageLink.panels)."""
+    __slots__ = ("link", "s")
+
+    def __init__(self, link, s):
+        self.link, self.s = link, s
+
+    def get(self):
+        return self.link.panels[self.s]
+
+
 def _refuse_replica(module):
     """nn.DataParallel (the reference's --parallel path, parallel.py:94-130) shallow-copies the module per device and
     runs the replicas on threads: every replica would redo the whole propagation (that is what the reference does) and
@@ -307,21 +318,39 @@ class _GATBase(nn.Module):
             base = _fresh_seed() if p > 0 else 0
         x = features
         stages = self._stages()
+        L = len(stages)
+        ops_ = [self._stage_operands(s) for s in range(L)]
+        # Which stage transforms ride in the previous stage's traversal (ngacf_prop_fwd_next)?  Stage s+1's can when stage s is a
+        # bf16 8-head stage of 64 columns whose hub rows finish in-kernel, and stage s+1 maps 64 -> 64 | 128 columns.  Their
+        # weight panels are packed by the FIRST transform's launch (functional.StageLink).
+        shapes = self.stage_shapes()
+        fuse = [False] * L                                   # fuse[s]: stage s's transform is done by stage s-1's traversal
+        if NF.FUSE_NEXT and self.compute_dtype == torch.bfloat16 and features.is_cuda:
+            for s in range(1, L):
+                fuse[s] = (NF.ops.can_fuse_next(plan, self.compute_dtype, shapes[s - 1][1], shapes[s - 1][2])
+                           and shapes[s][0] == 64 and shapes[s][1] in (64, 128))
+        link = NF.StageLink() if any(fuse) else None
+        if link is not None:
+            link.pack = {s: ops_[s][0].detach() for s in range(1, L) if fuse[s]}
         for s, layers in enumerate(stages):
-            W, avec = self._stage_operands(s)
+            W, avec = ops_[s]
             # feature dropout in front of every stage (:208,:213) and the ELU behind it (:397 inside
             # the concat layers, :214 around out_att) are fused into the stage
-            if callable(needed) and s == len(stages) - 1:
+            if callable(needed) and s == L - 1:
                 needed = needed()                           # the batch's rows are marked HERE, in front of the stage that wants them
-            if score is not None and needed is not None and s == len(stages) - 1:
+            if score is not None and needed is not None and s == L - 1:
                 return NF.stage_score(x, W, avec, plan, len(layers), needed, score[0], score[1], layers[0].alpha, True, p, p,
-                                      NF.stage_seed(base, s), self.compute_dtype, seed_dev)
+                                      NF.stage_seed(base, s), self.compute_dtype, seed_dev, link=link)
+            nxt = None
+            if s + 1 < L and fuse[s + 1]:
+                nxt = NF.ops.NextStage(None, ops_[s + 1][1].detach().contiguous().float(), len(stages[s + 1]), p, NF.stage_seed(base, s + 1))
+                nxt.panel = _PanelRef(link, s + 1)           # resolved at launch: the stack's first transform packs the panels
             x = NF.stage(x, W, avec, plan, len(layers), layers[0].alpha, True, p, p,
                          NF.stage_seed(base, s), self.compute_dtype, seed_dev,
-                         needed=needed if s == len(stages) - 1 else None)
-            if getattr(self, "debug_asserts", False) and needed is not None and s == len(stages) - 1:
+                         needed=needed if s == L - 1 else None, link=link, nxt=nxt)
+            if getattr(self, "debug_asserts", False) and needed is not None and s == L - 1:
                 assert not bool(torch.isnan(x[needed.mask()]).any()), "NaN after propagation stage %d" % s
-            elif getattr(self, "debug_asserts", False):
+            elif getattr(self, "debug_asserts", False) and x is not None:
                 # the reference's per-layer checks (SPUIGACF.py:384,391); a device sync each, so off by default.
                 # (:368, "every user has an edge", is enforced once at plan build.)
                 assert not bool(torch.isnan(x).any()), "NaN after propagation stage %d" % s

@@ -17,6 +17,7 @@ FLAG_ELU, FLAG_RESIDUAL, FLAG_SCORE_ROW, FLAG_SKIP_NODE, FLAG_GOUT_F32 = 1, 2, 4
 ADAM_MAX_TENSORS = 24            # NGACF_ADAM_MAX_TENSORS
 TICK_MAX = 48                      # NGACF_TICK_MAX
 TBWD_BLOCKS = 1024
+MAX_PACK = 4                       # NGACF_MAX_PACK
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -28,6 +29,9 @@ SIGNATURES = {
     "ngacf_transform_fwd": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _p],
     "ngacf_prop_fwd": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                        _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p],
+    "ngacf_prop_fwd_next": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                            _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p, _p],
+    "ngacf_transform_fwd_pack": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _i, _p, _p, _p, _p, _p],
     "ngacf_prop_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
                        _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p],
     "ngacf_adam_step": [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p],
@@ -47,9 +51,16 @@ SIGNATURES = {
     "ngacf_sample_pairs": [_p, ctypes.c_longlong, ctypes.c_longlong, _p, _p, _i, _p, _p, _i, _u64, _p, _p, _p, _p, _p, _i, _p],
     "ngacf_eval_topk": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
     "ngacf_dropout_bits": [_i, _u64, _p, _p, _p, _p, _i, _p],
+    "ngacf_timing_end": [_p, _p, _i],
     "ngacf_mha_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _i, _p],
     "ngacf_mha_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _i, _p],
 }
+
+
+class NextStage(ctypes.Structure):
+    """ngacf_next_stage of include/ngacf.h"""
+    _fields_ = [("panel", _p), ("avec", _p), ("H", _p), ("S", _p), ("dout", ctypes.c_int32), ("heads", ctypes.c_int32),
+                ("feat_drop_p", _f), ("seed", _u64)]
 
 
 class NgacfError(RuntimeError):
@@ -64,6 +75,8 @@ def _load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.ngacf_version.restype = ctypes.c_char_p
     lib.ngacf_version.argtypes = []
+    lib.ngacf_timing_begin.restype = ctypes.c_int
+    lib.ngacf_timing_begin.argtypes = []
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
         fn.restype = ctypes.c_int

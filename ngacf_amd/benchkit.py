@@ -147,13 +147,16 @@ def cpu_model_name():
     return "unknown"
 
 
+_ROUNDS = ("r03", "r02", "r01")
+
+
 def traffic_from_profile(root, workload, dtype, stages, d):
     """(bytes per launch, source) from the committed PMC passes of this command (tools/traffic.py: separate --pmc
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 on gfx950), newest round first; (None, None) when there is none.
     The counters are NOT collected by this run -- the line says where they come from."""
     if stages != 3 or d != 64:
         return None, None
-    for rnd in ("r02", "r01"):
+    for rnd in _ROUNDS:
         rel = os.path.join("profiles", "%s_traffic_%s.json" % (rnd, workload))
         p = os.path.join(root, rel)
         if os.path.exists(p):
@@ -161,4 +164,26 @@ def traffic_from_profile(root, workload, dtype, stages, d):
             if by:
                 return by.get("traffic_bytes"), "from_profile: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
                                                 "FETCH_SIZE x2 per the gfx950 correction; not collected in this run)" % rel
+    return None, None
+
+
+def l2_hit_from_profile(root, workload, dtype):
+    """(L2 hit rate of the forward traversal kernel, source): TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) of the prop_fwd_kernel
+    launches of this bench command (tools/traffic.py's third pass), or -- older rounds -- of tools/reqcount.py's kbench passes;
+    newest round first; (None, None) without one."""
+    for rnd in _ROUNDS:
+        rel = os.path.join("profiles", "%s_traffic_%s.json" % (rnd, workload))
+        p = os.path.join(root, rel)
+        if os.path.exists(p):
+            by = json.load(open(p)).get("by_dtype", {}).get(dtype) or {}
+            if by.get("l2_hit_rate") is not None:
+                return by["l2_hit_rate"], "from_profile: %s (rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum pass of this command)" % rel
+        rel = os.path.join("profiles", "%s_reqcount_%s_%s.json" % (rnd, workload, dtype))
+        p = os.path.join(root, rel)
+        if os.path.exists(p):
+            ks = json.load(open(p)).get("kernels", {})
+            rates = [v["per_directed_edge"]["L2_hit_rate"] for k, v in sorted(ks.items())
+                     if k.startswith("prop_fwd_kernel") and ", true, false, false" in k and "L2_hit_rate" in v.get("per_directed_edge", {})]
+            if rates:
+                return round(sum(rates) / len(rates), 4), "from_profile: %s (rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum over tools/kbench.py)" % rel
     return None, None

@@ -2,6 +2,7 @@
 // bf16 storage, wave64 cross-lane moves, the counter-hash dropout RNG.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/ngacf.h"
@@ -154,6 +155,18 @@ __device__ __forceinline__ void locate(const WorkOrder& o, int block, int wave, 
 
 // row flags of a scored batch: one bit per row (N / 8 bytes: the table of a 10^5-row graph sits in a CU's vector L1)
 __device__ __forceinline__ bool flagged(const uint32_t* __restrict__ bits, int row) { return (bits[row >> 5] >> (row & 31)) & 1u; }
+
+// Kernel launch with optional dispatch-timestamp timing (timing.hip; tags: NGACF_TAG_* of include/ngacf.h).
+bool timing_on();
+int timing_events(int tag, hipEvent_t* a, hipEvent_t* b);
+template <typename K, typename... Args>
+inline void launch_k(int tag, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    hipEvent_t ea, eb;
+    if (timing_on() && timing_events(tag, &ea, &eb) == 0)
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, ea, eb, 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
 
 #define NGACF_CHECK_LAUNCH()                                   \
     do {                                                       \

@@ -18,6 +18,7 @@
 // The first version (wave per row everywhere) was VALU-issue bound at 540 instructions per
 // 28-edge row (rocprof: profiles/r01_v0_*); this layout needs ~4 VALU per edge.
 #include "ngacf_common.hpp"
+#include "mfma_rows.hpp"
 
 namespace ngacf {
 
@@ -52,7 +53,17 @@ struct PropArgs {
     uint64_t seed;
     const uint64_t* seed_dev;   // optional device-side addend (hipGraph replays advance it)
     int flags;
+    // the NEXT stage's row transform in the epilogue (ngacf_prop_fwd_next; next_H == nullptr: none)
+    const uint4* next_panel;    // [2][D/16][NEXT/32][64] bf16x8 A fragments of W' (ngacf_transform_fwd_pack, mfma_rows.hpp)
+    const float* next_avec;     // [2][NEXT]
+    void* next_H;               // [N][NEXT] bf16
+    float* next_S;              // [N][next heads]
+    uint32_t next_drop_thr;     // the next stage's feature dropout (0 = none)
+    float next_drop_scale;
+    uint64_t next_seed;
 };
+
+constexpr int XROW_U4 = 9;      // a staged row: 128 B of bf16 + 16 B pad (36-dword stride: the fragment reads of 16 rows hit 64 distinct banks)
 
 template <typename T, int D, int HEADS>
 struct Shape {
@@ -90,10 +101,11 @@ __device__ __forceinline__ int slot_bcast(int v) {
 }
 
 template <typename T, int D, int HEADS>
-__device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum) {
+__device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum,
+                                           float (&o)[Slice<T>::VEC]) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC;
-    float own[VEC], o[VEC];
+    float own[VEC];
     load_slice<T, SH::ROW_SHIFT>(a.H, row, q, own);
     const float inv = rsum > 0.f ? 1.f / rsum : 0.f;   // isolated node: aggregate is 0 (SPUIGACF.py:389)
 #pragma unroll
@@ -102,9 +114,73 @@ __device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, in
         const float pre = (a.flags & NGACF_RESIDUAL) ? own[j] + acc[j] : acc[j];
         o[j] = (a.flags & NGACF_ELU) ? elu_fast(pre) : pre;
     }
-    Slice<T>::store(static_cast<T*>(a.out) + (size_t)row * D + q * VEC, o);
+    if (a.out) Slice<T>::store(static_cast<T*>(a.out) + (size_t)row * D + q * VEC, o);     // (NULL: only the next stage's operands are wanted)
     if (a.agg) Slice<T>::store(static_cast<T*>(a.agg) + (size_t)row * D + q * VEC, acc);    // (bf16 storage: 128 B per row instead of 256)
     if (a.R && (q * VEC) % SH::HW == 0) a.R[(size_t)row * HEADS + head] = rsum;
+}
+
+template <typename T, int D, int HEADS>
+__device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum) {
+    float o[Slice<T>::VEC];
+    finish_row<T, D, HEADS>(a, row, q, head, acc, rsum, o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The next stage's transform of the rows THIS WORKGROUP has just finished (ngacf_prop_fwd_next): the tail of the fused kernel.
+// Lane (slot, q) holds columns 8q..8q+7 of the row its lane group finished in `o` (valid: it did finish one: every group of a
+// short-row wave, group 0 of a long-row wave).
+//   1. every wave writes its rows as the next stage's bf16 operand (the values `out` stores, after the next stage's feature
+//      dropout) into the workgroup's 32-row LDS tile (row 8 * wave + slot) -- and has meanwhile received its share of the
+//      weight panel by LDS-DMA (issued at kernel start);
+//   2. ONE barrier publishes tile and panel; waves 1..3 leave;
+//   3. wave 0 runs exactly the tile step of transform_mfma.hip on it: B fragments = 16 bytes of a node's row per k-step, KS x OT
+//      v_mfma_f32_32x32x16_bf16, mfma_fwd_epilogue (H' rows as 16-byte stores, S' from the rounded H').  Same arithmetic, same
+//      order, same bits as the stand-alone launch on the stored table.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int D, int NEXT, bool NONE>
+__device__ __forceinline__ void next_transform_tail(const PropArgs& a, uint4* xtile, int* xmeta, const uint4* panel, const float* av,
+                                                    bool valid, int row, int slot, int q, const float (&o)[8]) {
+    constexpr int KS = D / 16, OT = NEXT / 32, NH = NONE ? 1 : NEXT / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tr = 8 * wave + slot;
+    if (valid) {
+        uint32_t w[4];
+        if (a.next_drop_thr) {
+            const uint32_t salt = salt_of(a.next_seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u);
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                x[j] = Slice<bf16_t>::round(o[j]);            // the stored value, then the mask: what the stand-alone launch reads and does
+                x[j] = feat_bits(salt, row, 8 * q + j) >= a.next_drop_thr ? x[j] * a.next_drop_scale : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = f32_to_bf16(x[2 * j]) | (f32_to_bf16(x[2 * j + 1]) << 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = f32_to_bf16(o[2 * j]) | (f32_to_bf16(o[2 * j + 1]) << 16);
+        }
+        xtile[tr * XROW_U4 + q] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (q == 0) xmeta[tr] = valid ? row : -1;
+    __syncthreads();                                          // (the compiler drains the LDS-DMA of the panel in front of it)
+    if (wave != 0) return;
+    const int r = lane & 31, h = lane >> 5;
+    const int nrow = xmeta[r];
+    const bool ok = nrow >= 0;
+    bf16x8 bf[KS];
+#pragma unroll
+    for (int sk = 0; sk < KS; ++sk) bf[sk] = __builtin_bit_cast(bf16x8, xtile[r * XROW_U4 + 2 * sk + h]);
+    f32x16 acc[OT];
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+    for (int sk = 0; sk < KS; ++sk)
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, panel[(sk * OT + t) * 64 + lane]), bf[sk], acc[t], 0, 0, 0);
+    mfma_fwd_epilogue<OT, NH, NEXT>(acc, ok ? nrow : 0, ok, h, av, a.next_H, a.next_S);
 }
 
 // one edge: score, exp(-leakyrelu), optional dropout, accumulate
@@ -135,8 +211,11 @@ __device__ __forceinline__ void edge_step(const PropArgs& a, const float (&hv)[S
     for (int j = 0; j < VEC; ++j) acc[j] = fmaf(ev, hv[j], acc[j]);
 }
 
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE>
-__global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
+// The traversal of one wave's work item(s).  NEXT (the fused form, ngacf_prop_fwd_next): the finished row of this lane's group
+// is also handed back (rvalid, rrow, ro) for the workgroup's transform tail, and no path leaves before it.
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, bool NEXT>
+__device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int widx, int wend, bool& rvalid, int& rrow,
+                                              float (&ro)[Slice<T>::VEC]) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC, LPR = SH::LPR, EPI = SH::EPI, SHIFT = SH::ROW_SHIFT;
     const int lane = threadIdx.x & 63;
@@ -147,9 +226,6 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     float rsum = 0.f;
     float av[VEC];
-
-    int kind, widx, wend;
-    locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, kind, widx, wend);
     if (kind == WORK_HUB) {
         // ------------------------------------------------------------------ hub rows: workgroup per row
         // The four waves stride over the row's edges (EPI * UNROLL per wave and step); slots fold inside each wave,
@@ -259,7 +335,10 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
             }
             colv = coln;
         }
-        if (live) finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+        if (live) {
+            if constexpr (NEXT) { finish_row<T, D, HEADS>(a, row, q, head, acc, rsum, ro); rvalid = true; rrow = row; }
+            else finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+        }
         return;
     }
 
@@ -313,7 +392,10 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     rsum = group_sum<LPR, WAVE>(rsum);
     if (part < 0) {
-        if (slot == 0) finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+        if (slot == 0) {                                      // one finished row per wave, in lane group 0
+            if constexpr (NEXT) { finish_row<T, D, HEADS>(a, row, q, head, acc, rsum, ro); rvalid = true; rrow = row; }
+            else finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+        }
         return;
     }
     // slice of a hub row: leave the partial sums in slot `part`
@@ -368,7 +450,49 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     rsum = group_sum<LPR, WAVE>(rsum);
-    if (slot == 0) finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+    if (slot == 0) {
+        if constexpr (NEXT) { finish_row<T, D, HEADS>(a, row, q, head, acc, rsum, ro); rvalid = true; rrow = row; }
+        else finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+    }
+}
+
+// NEXT > 0 (= the next stage's output width; NONE: that stage has ONE head): the fused form of ngacf_prop_fwd_next.
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int NEXT = 0, bool NONE = false>
+__global__ __launch_bounds__(256, NEXT == 64 ? 5 : NEXT == 128 ? 4 : (sizeof(T) == 2 && D == 64 && !SPARSE ? 6 : 1)) void prop_fwd_kernel(const PropArgs a) {
+    using SH = Shape<T, D, HEADS>;
+    constexpr int VEC = SH::VEC, EPI = SH::EPI;
+    static_assert(NEXT == 0 || (sizeof(T) == 2 && D == 64 && !SPARSE), "fused next-stage transform: bf16 rows of 64 columns");
+    int kind, widx, wend;
+    locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, kind, widx, wend);
+    bool rvalid = false;
+    int rrow = 0;
+    float ro[VEC];
+    if constexpr (NEXT > 0) {
+        // the workgroup's weight panel (its rows are all users or all items) goes global -> LDS by LDS-DMA right here and lands
+        // while the waves traverse; the barrier of the tail publishes it together with the finished rows
+        constexpr int PANEL_U4 = (D / 16) * (NEXT / 32) * 64;
+        __shared__ __attribute__((aligned(16))) uint4 panel_lds[PANEL_U4];
+        __shared__ __attribute__((aligned(16))) uint4 xtile_lds[32 * XROW_U4];
+        __shared__ int xmeta_lds[32];
+        __shared__ __attribute__((aligned(16))) float4 avec_lds[NEXT / 4];
+        const bool users = (int)blockIdx.x < a.order.b2;
+        const uint4* src = a.next_panel + (users ? 0 : PANEL_U4);
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int piece = threadIdx.x >> 6; piece < PANEL_U4 / 64; piece += 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(panel_lds + piece * 64), 16, 0, 0);
+        if (threadIdx.x < NEXT / 4)                             // the next stage's attention vector of this node type, the same way
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.next_avec + (users ? 0 : NEXT) + 4 * lane),
+                                             (__attribute__((address_space(3))) void*)avec_lds, 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) ro[j] = 0.f;
+        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true>(a, kind, widx, wend, rvalid, rrow, ro);
+        next_transform_tail<D, NEXT, NONE>(a, xtile_lds, xmeta_lds, panel_lds, reinterpret_cast<const float*>(avec_lds), rvalid, rrow,
+                                           lane / SH::LPR, lane % SH::LPR, ro);
+    } else {
+        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, false>(a, kind, widx, wend, rvalid, rrow, ro);
+    }
 }
 
 // Hub rows: add the partial sums of the row's slices (slots take interleaved slices, fixed order) and finish.
@@ -404,26 +528,47 @@ __global__ __launch_bounds__(256) void prop_fwd_split_kernel(const PropArgs a, c
 }
 
 template <typename T, int D, int HEADS>
-static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st) {
+static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st, int next_dout = 0, bool next_one = false) {
     constexpr int EPI = Shape<T, D, HEADS>::EPI;
     int nb = 0;
     a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, a.order.nhub, a.order.nhub_u, EPI, &nb);
+    if (next_dout) {
+        if constexpr (sizeof(T) == 2 && D == 64 && HEADS == 8) {
+            if (nb == 0) return 0;
+            const dim3 grid(nb), block(256);
+#define NGACF_NEXT(ND, ONE)                                                                                              \
+            do {                                                                                                         \
+                if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, true, false, ND, ONE>, grid, block, 0, st, a);   \
+                else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, false, ND, ONE>, grid, block, 0, st, a);  \
+            } while (0)
+            if (next_dout == 64 && !next_one) NGACF_NEXT(64, false);
+            else if (next_dout == 64) NGACF_NEXT(64, true);
+            else if (next_dout == 128 && !next_one) NGACF_NEXT(128, false);
+            else if (next_dout == 128) NGACF_NEXT(128, true);
+            else return NGACF_E_SHAPE;
+#undef NGACF_NEXT
+            NGACF_CHECK_LAUNCH();
+            return 0;
+        } else {
+            return NGACF_E_SHAPE;
+        }
+    }
     if (nb > 0) {
         const dim3 grid(nb), block(256);
         if (a.needed) {                 // (only with NGACF_SCORE_ROW: checked by the caller)
-            if (drop) hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, true, true, true>), grid, block, 0, st, a);
-            else      hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, true, false, true>), grid, block, 0, st, a);
+            if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, true, true>, grid, block, 0, st, a);
+            else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, true>, grid, block, 0, st, a);
         } else if (from_row) {
-            if (drop) hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, true, true, false>), grid, block, 0, st, a);
-            else      hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, true, false, false>), grid, block, 0, st, a);
+            if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, true, false>, grid, block, 0, st, a);
+            else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, false>, grid, block, 0, st, a);
         } else {
-            if (drop) hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, false, true, false>), grid, block, 0, st, a);
-            else      hipLaunchKernelGGL((prop_fwd_kernel<T, D, HEADS, false, false, false>), grid, block, 0, st, a);
+            if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, false, true, false>, grid, block, 0, st, a);
+            else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, false, false, false>, grid, block, 0, st, a);
         }
         NGACF_CHECK_LAUNCH();
     }
     if (nsplit > 0 && a.tickets == nullptr) {
-        hipLaunchKernelGGL((prop_fwd_split_kernel<T, D, HEADS>), dim3((nsplit + 3) / 4), dim3(256), 0, st, a, split, nsplit);
+        launch_k(NGACF_TAG_PROP_FWD_SPLIT, prop_fwd_split_kernel<T, D, HEADS>, dim3((nsplit + 3) / 4), dim3(256), 0, st, a, split, nsplit);
         NGACF_CHECK_LAUNCH();
     }
     return 0;
@@ -433,16 +578,17 @@ static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, b
 
 using namespace ngacf;
 
-extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
-                              const int32_t* srow, int nshort, int nseg_user, int nshort_user,
-                              const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
-                              const int32_t* col, const void* H, int dtype,
-                              const float* S_dst, const float* S_src, const float* avec,
-                              void* out, void* agg, float* R, float* part_acc, float* part_r,
-                              const int32_t* part_split, int32_t* tickets,
-                              const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
-                              int U, int N, int d, int heads, float alpha,
-                              float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
+extern "C" int ngacf_prop_fwd_next(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                                   const int32_t* srow, int nshort, int nseg_user, int nshort_user,
+                                   const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
+                                   const int32_t* col, const void* H, int dtype,
+                                   const float* S_dst, const float* S_src, const float* avec,
+                                   void* out, void* agg, float* R, float* part_acc, float* part_r,
+                                   const int32_t* part_split, int32_t* tickets,
+                                   const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
+                                   int U, int N, int d, int heads, float alpha,
+                                   float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
+                                   const ngacf_next_stage* next, void* stream) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
     if (needed && !(flags & NGACF_SCORE_ROW)) return NGACF_E_ARG;              // row flags: the SPUIGACF stages only
     if (needed && (nrows < 0 || (nrows > 0 && !rows))) return NGACF_E_ARG;
@@ -450,7 +596,8 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
         return NGACF_E_ARG;
     if (nhub < 0 || nhub_user < 0 || nhub_user > nhub) return NGACF_E_ARG;
     if (nseg + nshort + nhub == 0) return 0;
-    if (!col || !H || !S_dst || !out || !rowptr) return NGACF_E_ARG;
+    if (!col || !H || !S_dst || !rowptr) return NGACF_E_ARG;
+    if (!out && !next) return NGACF_E_ARG;                                      // (out may be NULL only when the next stage's operands are the result)
     if ((nseg > 0 && !segs) || (nshort > 0 && !srow) || (nhub > 0 && !hrow)) return NGACF_E_ARG;
     const bool from_row = (flags & NGACF_SCORE_ROW) != 0;
     if (from_row ? !avec : !S_src) return NGACF_E_ARG;
@@ -468,9 +615,25 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
     }
     a.tickets = (part_split && nsplit > 0) ? tickets : nullptr; a.U = U; a.N = N; a.order.nseg_u = nseg_user; a.order.nshort_u = nshort_user; a.alpha = alpha;
     a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.seed_dev = seed_dev; a.flags = flags;
+    a.next_panel = nullptr; a.next_avec = nullptr; a.next_H = nullptr; a.next_S = nullptr; a.next_drop_thr = 0; a.next_drop_scale = 1.f; a.next_seed = 0;
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define NGACF_CASE(T, D, HD) return launch_fwd<T, D, HD>(a, split, nsplit, from_row, drop, st)
+    int next_dout = 0;
+    bool next_one = false;
+    if (next) {
+        if (!next->panel || !next->avec || !next->H || !next->S) return NGACF_E_ARG;
+        if (dtype != NGACF_BF16 || d != 64 || heads != 8 || !from_row || needed || nhub > 0) return NGACF_E_SHAPE;
+        if (nsplit > 0 && a.tickets == nullptr) return NGACF_E_ARG;             // hub rows must be finished inside the launch
+        if ((next->dout != 64 && next->dout != 128) || (next->heads != 1 && next->heads != next->dout / 8)) return NGACF_E_SHAPE;
+        if (!(next->feat_drop_p >= 0.f && next->feat_drop_p < 1.f)) return NGACF_E_ARG;
+        if ((uint64_t)N * (uint64_t)next->dout * 2 >= (1ull << 32)) return NGACF_E_SHAPE;
+        a.next_panel = static_cast<const uint4*>(next->panel); a.next_avec = next->avec; a.next_H = next->H; a.next_S = next->S;
+        a.next_drop_thr = next->feat_drop_p > 0.f ? drop_threshold(next->feat_drop_p) : 0u;
+        if (next->feat_drop_p > 0.f && a.next_drop_thr == 0) a.next_drop_thr = 1;     // (p below 2^-32: keep the branch, drop nothing measurable)
+        a.next_drop_scale = 1.f / (1.f - next->feat_drop_p); a.next_seed = next->seed;
+        next_dout = next->dout; next_one = next->heads == 1;
+    }
+#define NGACF_CASE(T, D, HD) return launch_fwd<T, D, HD>(a, split, nsplit, from_row, drop, st, next_dout, next_one)
     if (dtype == NGACF_F32) {
         if (d == 64 && heads == 8) NGACF_CASE(float, 64, 8);
         if (d == 64 && heads == 1) NGACF_CASE(float, 64, 1);
@@ -484,4 +647,19 @@ extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* spli
     }
 #undef NGACF_CASE
     return NGACF_E_SHAPE;
+}
+
+extern "C" int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                              const int32_t* srow, int nshort, int nseg_user, int nshort_user,
+                              const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
+                              const int32_t* col, const void* H, int dtype,
+                              const float* S_dst, const float* S_src, const float* avec,
+                              void* out, void* agg, float* R, float* part_acc, float* part_r,
+                              const int32_t* part_split, int32_t* tickets,
+                              const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
+                              int U, int N, int d, int heads, float alpha,
+                              float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
+    return ngacf_prop_fwd_next(segs, nseg, split, nsplit, srow, nshort, nseg_user, nshort_user, hrow, nhub, nhub_user, rowptr, col, H, dtype,
+                               S_dst, S_src, avec, out, agg, R, part_acc, part_r, part_split, tickets, needed, rows, nrows, short_max,
+                               U, N, d, heads, alpha, drop_p, seed, seed_dev, flags, nullptr, stream);
 }

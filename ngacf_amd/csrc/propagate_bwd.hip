@@ -579,14 +579,14 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
     if (nb > 0) {
         const dim3 grid(nb), block(256);
         if (a.needed) {                 // (only with NGACF_SCORE_ROW: checked by the caller)
-            if (drop) hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, true, true>), grid, block, 0, st, a);
-            else      hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, false, true>), grid, block, 0, st, a);
+            if (drop) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, true, true>, grid, block, 0, st, a);
+            else      launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, false, true>, grid, block, 0, st, a);
         } else if (from_row) {
-            if (drop) hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, true, false>), grid, block, 0, st, a);
-            else      hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, true, false, false>), grid, block, 0, st, a);
+            if (drop) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, true, false>, grid, block, 0, st, a);
+            else      launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, false, false>, grid, block, 0, st, a);
         } else {
-            if (drop) hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, false, true, false>), grid, block, 0, st, a);
-            else      hipLaunchKernelGGL((prop_bwd_kernel<T, D, HEADS, false, false, false>), grid, block, 0, st, a);
+            if (drop) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, false, true, false>, grid, block, 0, st, a);
+            else      launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, false, false, false>, grid, block, 0, st, a);
         }
         NGACF_CHECK_LAUNCH();
     }

@@ -1,0 +1,62 @@
+// Opt-in per-kernel timing from the dispatch packets' own timestamps (hipExtLaunchKernel start / stop events): the duration of
+// the KERNEL, without the host's launch gaps that an event pair around a launch call includes -- the number rocprofv3
+// --kernel-trace reports.  bench.py's roofline leg brackets eager passes with ngacf_timing_begin / ngacf_timing_end.
+// State is per host thread (thread_local); nothing is recorded, created or synchronised unless a thread asked for it.
+#include <hip/hip_runtime.h>
+#include <vector>
+
+#include "ngacf_common.hpp"
+
+namespace ngacf {
+
+struct TimedLaunch { hipEvent_t a, b; int tag; };
+struct Timing {
+    bool on = false;
+    std::vector<TimedLaunch> v;
+};
+static Timing& timing() {
+    static thread_local Timing t;
+    return t;
+}
+
+bool timing_on() { return timing().on; }
+
+int timing_events(int tag, hipEvent_t* a, hipEvent_t* b) {
+    hipError_t e = hipEventCreate(a);
+    if (e != hipSuccess) return static_cast<int>(e);
+    e = hipEventCreate(b);
+    if (e != hipSuccess) { (void)hipEventDestroy(*a); return static_cast<int>(e); }
+    timing().v.push_back({*a, *b, tag});
+    return 0;
+}
+
+}  // namespace ngacf
+
+using namespace ngacf;
+
+extern "C" int ngacf_timing_begin(void) {
+    Timing& t = timing();
+    for (auto& l : t.v) { (void)hipEventDestroy(l.a); (void)hipEventDestroy(l.b); }
+    t.v.clear();
+    t.on = true;
+    return 0;
+}
+
+extern "C" int ngacf_timing_end(float* ms, int32_t* tags, int cap) {
+    Timing& t = timing();
+    t.on = false;
+    int n = 0, rc = 0;
+    for (auto& l : t.v) {
+        if (rc == 0) {
+            hipError_t e = hipEventSynchronize(l.b);
+            float d = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&d, l.a, l.b);
+            if (e != hipSuccess) rc = static_cast<int>(e);
+            else if (n < cap && ms && tags) { ms[n] = d; tags[n] = l.tag; ++n; }
+        }
+        (void)hipEventDestroy(l.a);
+        (void)hipEventDestroy(l.b);
+    }
+    t.v.clear();
+    return rc != 0 ? -1000 - rc : n;
+}

@@ -168,11 +168,11 @@ static int launch_transform_rpt(const TransArgs& a, bool drop, hipStream_t st) {
     if (drop) {
         auto k = transform_fwd_kernel<TX, TH, DIN, DOUT, HEADS, true, RPT>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(nb), dim3(256), lds, st, a);
+        launch_k(NGACF_TAG_TRANSFORM_FWD, k, dim3(nb), dim3(256), lds, st, a);
     } else {
         auto k = transform_fwd_kernel<TX, TH, DIN, DOUT, HEADS, false, RPT>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3(nb), dim3(256), lds, st, a);
+        launch_k(NGACF_TAG_TRANSFORM_FWD, k, dim3(nb), dim3(256), lds, st, a);
     }
     NGACF_CHECK_LAUNCH();
     return 0;
@@ -206,7 +206,8 @@ static int dispatch_transform(const TransArgs& a, int din, int dout, int heads, 
 // transform_mfma.hip: the bf16-storage path on the matrix cores
 int transform_fwd_mfma(const void* X, int x_dtype, const float* W, const float* avec, void* H, float* S,
                        int U, int I, int din, int dout, int heads, int u_lo, int u_n, int i_lo, int i_n, int x_local,
-                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st);
+                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st,
+                       int n_pack, const float* const* pack_W, void* const* pack_panel, const int* pack_din, const int* pack_dout);
 
 }  // namespace ngacf
 
@@ -231,7 +232,7 @@ extern "C" int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float*
     if ((x_dtype != NGACF_F32 && x_dtype != NGACF_BF16) || (h_dtype != NGACF_F32 && h_dtype != NGACF_BF16)) return NGACF_E_SHAPE;
     if (h_dtype == NGACF_BF16)                     // bf16 storage: bf16 MFMA, fp32 accumulate
         return transform_fwd_mfma(X, x_dtype, W, avec, H, S, U, I, din, dout, heads, u_lo, u_n, i_lo, i_n, x_local,
-                                  feat_drop_p, seed, seed_dev, st);
+                                  feat_drop_p, seed, seed_dev, st, 0, nullptr, nullptr, nullptr, nullptr);
     if (x_dtype == NGACF_F32) return dispatch_transform<float, float>(a, din, dout, heads, drop, st);
     return dispatch_transform<bf16_t, float>(a, din, dout, heads, drop, st);
 }

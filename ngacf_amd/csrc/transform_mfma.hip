@@ -11,11 +11,9 @@
 // A-fragments once per workgroup (LDS, 8..32 KB).  fp32 accumulate; operands rounded to bf16 (this path
 // runs only when H is stored as bf16 -- the fp32 path keeps the exact FMA kernels of transform.hip).
 #include "ngacf_common.hpp"
+#include "mfma_rows.hpp"
 
 namespace ngacf {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int MF_MAX_BLOCKS = 4096;  // ~16 workgroups per CU: beyond that a wave takes several 32-row tiles, so the
                                     // per-workgroup weight-panel prologue stays amortised on 10^7-row tables
@@ -35,6 +33,12 @@ struct MfmaArgs {
     uint64_t seed;
     const uint64_t* seed_dev;
     int tpw;                       // 32-row tiles per wave
+    // side jobs (forward only): workgroups nb_main .. nb_main + 2*npack - 1 pack LATER stages' weight panels into the bf16
+    // A fragments of v_mfma_f32_16x16x32_bf16 that the fused traversal epilogue reads (propagate.hip, NextArgs)
+    int nb_main, npack;
+    const float* pack_W[NGACF_MAX_PACK];
+    void* pack_F[NGACF_MAX_PACK];
+    int pack_din[NGACF_MAX_PACK], pack_dout[NGACF_MAX_PACK];
 };
 
 __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
@@ -54,6 +58,13 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
     bf16x8* Af = reinterpret_cast<bf16x8*>(lds_raw);           // [KS][OT][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (FWD) {
+        if ((int)blockIdx.x >= a.nb_main) {                  // a side job: one (stage, node type) weight panel
+            const int job = blockIdx.x - a.nb_main;
+            pack_panel_job(a.pack_W[job >> 1], a.pack_F[job >> 1], a.pack_din[job >> 1], a.pack_dout[job >> 1], job & 1, tid);
+            return;
+        }
+    }
     const int tiles_u = (a.u_n + 31) / 32, tiles_i = (a.i_n + 31) / 32;
     const int nbu = (tiles_u + 4 * a.tpw - 1) / (4 * a.tpw);
     const bool users = (int)blockIdx.x < nbu;
@@ -134,59 +145,7 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
         if (it + 1 < a.tpw) load_tile(it + 1, bf, nd, ok);     // next tile's rows fly under this tile's epilogue
         // lane: node r (+ half h); acc[t][4g + j] = output column 32t + 8g + 4h + j
         if constexpr (FWD) {
-            const float* av = a.avec + type * DOUT;
-            float head_part[OT * 4];
-            float total = 0.f;
-            char* Hrow = reinterpret_cast<char*>(a.out) + (size_t)nd_cur * DOUT * 2;
-#pragma unroll
-            for (int t = 0; t < OT; ++t)
-#pragma unroll
-                for (int gp = 0; gp < 4; gp += 2) {
-                    uint2 pk[2];
-#pragma unroll
-                    for (int gg = 0; gg < 2; ++gg) {
-                        const int g = gp + gg;
-                        const int c = 32 * t + 8 * g + 4 * h;
-                        const float4 a4 = *reinterpret_cast<const float4*>(av + c);
-                        uint32_t b[4];
-                        float v[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            b[j] = f32_to_bf16(acc[t][4 * g + j]);
-                            v[j] = bf16_to_f32(b[j]);
-                        }
-                        float p = v[0] * a4.x;
-                        p = fmaf(v[1], a4.y, p); p = fmaf(v[2], a4.z, p); p = fmaf(v[3], a4.w, p);
-                        head_part[t * 4 + g] = p;
-                        total += p;
-                        pk[gg] = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
-                    }
-                    // the two half-waves hold columns 8g..8g+3 / 8g+4..8g+7 of the node: one v_permlane32_swap per dword
-                    // turns two 8-byte stores per lane into one 16-byte store (lower half: group gp, upper half: group gp+1)
-                    const auto rx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
-                    const auto ry = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-                    if (ok_cur)
-                        *reinterpret_cast<uint4*>(Hrow + 64 * t + 16 * gp + 16 * h) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
-                }
-            if (HEADS == 1) {
-                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(total), __float_as_uint(total), false, false);
-                total += __uint_as_float(h ? r[0] : r[1]);
-                if (ok_cur && h == 0) a.S[nd_cur] = total;
-            } else {                                   // 8-wide heads: head 4t+g = this lane's 4 columns + the other half's
-                float p[OT * 4];
-#pragma unroll
-                for (int q = 0; q < OT * 4; ++q) {
-                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(head_part[q]), __float_as_uint(head_part[q]), false, false);
-                    p[q] = head_part[q] + __uint_as_float(h ? r[0] : r[1]);
-                }
-                // half 0 stores heads 0..3 (+8..11), half 1 heads 4..7 (+12..15): one 16-byte store per lane and group
-#pragma unroll
-                for (int q0 = 0; q0 < OT * 4; q0 += 8) {
-                    const float4 v = h == 0 ? make_float4(p[q0], p[q0 + 1], p[q0 + 2], p[q0 + 3])
-                                            : make_float4(p[q0 + 4], p[q0 + 5], p[q0 + 6], p[q0 + 7]);
-                    if (ok_cur) *reinterpret_cast<float4*>(a.S + (size_t)nd_cur * HEADS + q0 + 4 * h) = v;
-                }
-            }
+            mfma_fwd_epilogue<OT, HEADS, DOUT>(acc, nd_cur, ok_cur, h, a.avec + type * DOUT, a.out, a.S);
         } else {
             const size_t orow = (size_t)(a.out_local ? nd_cur - loc_off : nd_cur);
 #pragma unroll
@@ -231,11 +190,18 @@ static int launch_mfma(MfmaArgs a, bool drop, hipStream_t st) {
     const int tiles_u = (a.u_n + 31) / 32, tiles_i = (a.i_n + 31) / 32;
     a.tpw = (tiles_u + tiles_i + 4 * MF_MAX_BLOCKS - 1) / (4 * MF_MAX_BLOCKS);
     if (a.tpw < 1) a.tpw = 1;
-    const int nb = (tiles_u + 4 * a.tpw - 1) / (4 * a.tpw) + (tiles_i + 4 * a.tpw - 1) / (4 * a.tpw);
+    a.nb_main = (tiles_u + 4 * a.tpw - 1) / (4 * a.tpw) + (tiles_i + 4 * a.tpw - 1) / (4 * a.tpw);
+    if (!FWD) a.npack = 0;
+    const int nb = a.nb_main + 2 * a.npack;
     if (nb == 0) return 0;
     constexpr size_t lds = (size_t)(KD / 16) * (OD / 32) * 64 * 16;
-    if (drop) hipLaunchKernelGGL((transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, true>), dim3(nb), dim3(256), lds, st, a);
-    else      hipLaunchKernelGGL((transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, false>), dim3(nb), dim3(256), lds, st, a);
+    if (!FWD) {
+        if (drop) hipLaunchKernelGGL((transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, true>), dim3(nb), dim3(256), lds, st, a);
+        else      hipLaunchKernelGGL((transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, false>), dim3(nb), dim3(256), lds, st, a);
+    } else {
+        if (drop) launch_k(NGACF_TAG_TRANSFORM_FWD, transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, true>, dim3(nb), dim3(256), lds, st, a);
+        else      launch_k(NGACF_TAG_TRANSFORM_FWD, transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, false>, dim3(nb), dim3(256), lds, st, a);
+    }
     NGACF_CHECK_LAUNCH();
     return 0;
 }
@@ -256,8 +222,11 @@ static int dispatch_mfma(const MfmaArgs& a, int din, int dout, int heads, bool d
 // entry points used by transform.hip / transform_bwd.hip when H is stored as bf16
 int transform_fwd_mfma(const void* X, int x_dtype, const float* W, const float* avec, void* H, float* S,
                        int U, int I, int din, int dout, int heads, int u_lo, int u_n, int i_lo, int i_n, int x_local,
-                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st) {
+                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st,
+                       int n_pack, const float* const* pack_W, void* const* pack_panel, const int* pack_din, const int* pack_dout) {
     MfmaArgs a;
+    a.npack = n_pack;
+    for (int k = 0; k < n_pack; ++k) { a.pack_W[k] = pack_W[k]; a.pack_F[k] = pack_panel[k]; a.pack_din[k] = pack_din[k]; a.pack_dout[k] = pack_dout[k]; }
     a.B = X; a.M = W; a.avec = avec; a.out = H; a.S = S; a.U = U; a.I = I;
     a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.b_local = x_local; a.out_local = 0;
     a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p); a.seed = seed; a.seed_dev = seed_dev; a.tpw = 1;
@@ -270,6 +239,7 @@ int transform_dx_mfma(const void* dH, int dh_dtype, const float* W, void* dX, in
                       int u_lo, int u_n, int i_lo, int i_n, int x_local,
                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st) {
     MfmaArgs a;
+    a.npack = 0; a.nb_main = 0;
     a.B = dH; a.M = W; a.avec = nullptr; a.out = dX; a.S = nullptr; a.U = U; a.I = I;
     a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.b_local = 0; a.out_local = x_local;
     a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p); a.seed = seed; a.seed_dev = seed_dev; a.tpw = 1;
@@ -283,3 +253,23 @@ int transform_dx_mfma(const void* dH, int dh_dtype, const float* W, void* dX, in
 }
 
 }  // namespace ngacf
+
+using namespace ngacf;
+
+extern "C" int ngacf_transform_fwd_pack(const void* X, int x_dtype, const float* W, const float* avec, void* H, int h_dtype, float* S,
+                                        int U, int I, int din, int dout, int heads,
+                                        float feat_drop_p, uint64_t seed, const uint64_t* seed_dev,
+                                        int n_pack, const float* const* pack_W, void* const* pack_panel, const int* pack_din,
+                                        const int* pack_dout, void* stream) {
+    if (U < 0 || I < 0 || n_pack < 0 || n_pack > NGACF_MAX_PACK) return NGACF_E_ARG;
+    if (!X || !W || !avec || !H || !S) return NGACF_E_ARG;
+    if (!(feat_drop_p >= 0.f && feat_drop_p < 1.f)) return NGACF_E_ARG;
+    if (h_dtype != NGACF_BF16 || (x_dtype != NGACF_F32 && x_dtype != NGACF_BF16)) return NGACF_E_SHAPE;   // the matrix-core path only
+    if (n_pack > 0 && (!pack_W || !pack_panel || !pack_din || !pack_dout)) return NGACF_E_ARG;
+    for (int k = 0; k < n_pack; ++k) {
+        if (!pack_W[k] || !pack_panel[k]) return NGACF_E_ARG;
+        if (pack_din[k] != 64 || (pack_dout[k] != 64 && pack_dout[k] != 128)) return NGACF_E_SHAPE;      // what ngacf_prop_fwd_next takes
+    }
+    return transform_fwd_mfma(X, x_dtype, W, avec, H, S, U, I, din, dout, heads, 0, U, 0, I, 0, feat_drop_p, seed, seed_dev,
+                              static_cast<hipStream_t>(stream), n_pack, pack_W, pack_panel, pack_din, pack_dout);
+}

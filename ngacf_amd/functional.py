@@ -9,28 +9,61 @@ from . import ops
 _STAGE_SEED_STRIDE = 0x9E3779B97F4A7C15
 
 
+FUSE_NEXT = __import__("os").environ.get("NGACF_FUSE_NEXT", "1") != "0"     # A/B switch: "0" = every transform as its own launch
+
+
+class StageLink:
+    """What travels from one stage of a stack to the next when the next stage's transform rides in this stage's traversal
+    (ngacf_prop_fwd_next): `pack` (stage 0 only) = the later stages' weights to pack in the first transform's launch, `panels` =
+    the packed panels by stage index, `pre` = (H, S) of the coming stage, produced by the previous traversal."""
+    __slots__ = ("pack", "panels", "pre")
+
+    def __init__(self):
+        self.pack, self.panels, self.pre = None, {}, None
+
+
+def _transform_or_pre(X, W, avec, plan, heads, h_dtype, feat_drop_p, seed, seed_dev, link):
+    """(H, S) of the stage: handed over by the previous traversal (link.pre), or computed here -- the first transform of a stack
+    also packs the later stages' weight panels (link.pack = {stage: W})."""
+    if link is not None and link.pre is not None:
+        pre, link.pre = link.pre, None
+        return pre
+    if link is not None and link.pack:
+        idx = sorted(link.pack)
+        H, S, panels = ops.transform_fwd(X, W, avec, plan.U, plan.I, heads, h_dtype, feat_drop_p, seed, seed_dev,
+                                         pack=[link.pack[k].contiguous().float() for k in idx])
+        link.panels.update(zip(idx, panels))
+        link.pack = None
+        return H, S
+    return ops.transform_fwd(X, W, avec, plan.U, plan.I, heads, h_dtype, feat_drop_p, seed, seed_dev)
+
+
 class _Stage(torch.autograd.Function):
     """One propagation stage: transform (X @ W per node type, scores) + attention
     propagation over both directions.  Mirrors what one list-comprehension over
-    SpUIGraphAttentionLayer heads computes in SPUIGACF.py:212 (or the out_att call :214)."""
+    SpUIGraphAttentionLayer heads computes in SPUIGACF.py:212 (or the out_att call :214).
+    link / nxt (StageLink, ops.NextStage): the stage's own transform may have been done by the previous stage's traversal, and
+    this stage's traversal may do the next one's (nxt.H / nxt.S are filled and handed on through link.pre)."""
 
     @staticmethod
     def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev=None, residual=True, grad_mode=True,
-                needed=None):
+                needed=None, link=None, nxt=None):
         X = X.contiguous()
         W = W.contiguous().float()
         avec = avec.contiguous().float()
-        H, S = ops.transform_fwd(X, W, avec, plan.U, plan.I, heads, h_dtype, feat_drop_p, seed, seed_dev)
+        H, S = _transform_or_pre(X, W, avec, plan, heads, h_dtype, feat_drop_p, seed, seed_dev, link)
         # needs_input_grad ignores torch.no_grad() and grad mode is always off inside forward(): the caller's mode comes in as
         # an argument, so an eval / no_grad forward does not allocate and write the backward's agg [N,d] fp32 + R tables
         need = grad_mode and any(ctx.needs_input_grad[:3])
         if need:
             out, agg, R = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, save=True,
-                                       seed_dev=seed_dev, needed=needed)
+                                       seed_dev=seed_dev, needed=needed, next=nxt)
             ctx.save_for_backward(X, W, avec, H, S, out, agg, R)
             ctx.cfg = (plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual, needed)
         else:
-            out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, seed_dev=seed_dev, needed=needed)
+            out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, seed_dev=seed_dev, needed=needed, next=nxt)
+        if nxt is not None:
+            link.pre = (nxt.H, nxt.S)
         return out
 
     @staticmethod
@@ -41,7 +74,7 @@ class _Stage(torch.autograd.Function):
         # (needed: the rows of this stage's output the caller read -- gout is zero elsewhere and `out` is not valid there)
         dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, alpha, elu, residual, None, drop_p, seed, seed_dev, needed)
         dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
-        return (dX, dW, da) + (None,) * 12
+        return (dX, dW, da) + (None,) * 14
 
 
 class _StageScore(torch.autograd.Function):
@@ -50,12 +83,13 @@ class _StageScore(torch.autograd.Function):
     (zeroed when the batch was marked) and the traversal's backward reads it there in fp32 -- no [N, d] zero fill, no cast."""
 
     @staticmethod
-    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev, residual, grad_mode, rows, u, *items):
+    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev, residual, grad_mode, rows, link, u, *items):
         U, I = plan.U, plan.I
-        H, S = ops.transform_fwd(X, W, avec, U, I, heads, h_dtype, feat_drop_p, seed, seed_dev)
+        X, W, avec = (X.contiguous() if X is not None else None), W.contiguous().float(), avec.contiguous().float()
+        H, S = _transform_or_pre(X, W, avec, plan, heads, h_dtype, feat_drop_p, seed, seed_dev, link)
         u = u.contiguous().long()
         items = [it.contiguous().long() for it in items]
-        if grad_mode and (X.requires_grad or W.requires_grad or avec.requires_grad):
+        if grad_mode and ((X is not None and X.requires_grad) or W.requires_grad or avec.requires_grad):
             if rows.g32 is None:
                 raise ValueError("stage_score under autograd needs ops.mark_rows(..., grad_d=d)")
             out, agg, R = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, save=True,
@@ -80,22 +114,35 @@ class _StageScore(torch.autograd.Function):
         dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, rows.g32, heads, alpha, elu, residual, None, drop_p, seed, seed_dev,
                               rows, gout_f32=True)
         dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
-        return (dX, dW, da) + (None,) * (13 + len(items))
+        return (dX, dW, da) + (None,) * (14 + len(items))
 
 
 def stage_score(X, W, avec, plan, heads, rows, u, items, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=0.0, seed=0, h_dtype=None,
-                seed_dev=None, residual=True):
+                seed_dev=None, residual=True, link=None):
     """scores[k][b] = out[u[b]] . out[U + items[k][b]] of the stage's output, computed for the rows of `rows` only."""
     return _StageScore.apply(X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, X.dtype if h_dtype is None else h_dtype,
-                             seed_dev, residual, torch.is_grad_enabled(), rows, u, *items)
+                             seed_dev, residual, torch.is_grad_enabled(), rows, link, u, *items)
 
 
 def stage(X, W, avec, plan, heads, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=0.0, seed=0, h_dtype=None, seed_dev=None,
-          residual=True, needed=None):
+          residual=True, needed=None, link=None, nxt=None):
     """needed: ops.BatchRows (ops.mark_rows) -- ONLY those rows of the result are computed and may be read; the
-    gradient flowing back must be zero elsewhere (true for a result that is only read through those rows)."""
-    return _Stage.apply(X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed,
-                        X.dtype if h_dtype is None else h_dtype, seed_dev, residual, torch.is_grad_enabled(), needed)
+    gradient flowing back must be zero elsewhere (true for a result that is only read through those rows).
+    link / nxt: see _Stage.  Without autograd (evaluation) and with nxt, the stage's own output table is never written: the
+    result is None and the next stage runs from link.pre alone."""
+    h_dtype = X.dtype if h_dtype is None else h_dtype
+    grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (X, W, avec))
+    if not grad and (nxt is not None or X is None):
+        # no autograd: X is None when the previous stage handed over (H, S) without ever writing its output table
+        Wc, ac = W.contiguous().float(), avec.contiguous().float()
+        H, S = _transform_or_pre(X.contiguous() if X is not None else None, Wc, ac, plan, heads, h_dtype, feat_drop_p, seed, seed_dev, link)
+        out = ops.prop_fwd(plan, H, S, S, ac, heads, alpha, elu, residual, None, drop_p, seed, seed_dev=seed_dev, needed=needed, next=nxt,
+                           want_out=nxt is None)
+        if nxt is not None:
+            link.pre = (nxt.H, nxt.S)
+        return out
+    return _Stage.apply(X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev, residual, torch.is_grad_enabled(),
+                        needed, link, nxt)
 
 
 def stage_seed(base, s):

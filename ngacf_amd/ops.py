@@ -27,35 +27,44 @@ def _stream():
 
 
 class KernelTimer:
-    """Opt-in per-launch timing of one entry point with events on the launch stream
-    (bench.py's roofline leg).  `with KernelTimer("ngacf_prop_fwd") as t: ...; t.durations_ms()`."""
-    active = None
+    """Opt-in per-KERNEL timing (bench.py's roofline leg): inside the block the traversal and transform launches of this host
+    thread carry start / stop events of their dispatch packets (ngacf_timing_begin / _end, hipExtLaunchKernel) -- the
+    kernel's own duration, without the host's launch gaps; it is the number a rocprofv3 kernel trace reports (an event pair
+    AROUND a launch call read 5-8 us longer in round 2).  Eager launches only (not inside a stream capture).
+      with KernelTimer() as t: ...;   t.durations_ms(TAG_PROP_FWD) -> [ms per launch, in launch order]"""
+    TAG_PROP_FWD, TAG_PROP_FWD_SPLIT, TAG_TRANSFORM_FWD, TAG_PROP_BWD = 1, 2, 3, 4
 
-    def __init__(self, name):
-        self.name, self.pairs = name, []
+    def __init__(self, name=None, cap=1 << 20):
+        self.cap, self._res = cap, None
 
     def __enter__(self):
-        KernelTimer.active = self
+        _lib.check(lib.ngacf_timing_begin(), "ngacf_timing_begin")
         return self
 
     def __exit__(self, *exc):
-        KernelTimer.active = None
+        ms = (ctypes.c_float * self.cap)()
+        tags = (ctypes.c_int32 * self.cap)()
+        n = lib.ngacf_timing_end(ms, tags, self.cap)
+        if n < 0:
+            raise _lib.NgacfError("ngacf_timing_end failed: %d" % n)
+        self._res = [(tags[k], ms[k]) for k in range(n)]
 
-    def durations_ms(self):
-        torch.cuda.synchronize()
-        return [a.elapsed_time(b) for a, b in self.pairs]
+    def durations_ms(self, tag=None):
+        """tag None: one entry per ngacf_prop_fwd CALL = its main kernel + the hub rows' second kernel where one ran (plans
+        beyond INKERNEL_MAX_PARTS); a tag: that kernel family alone."""
+        if tag is not None:
+            return [d for t, d in self._res if t == tag]
+        out = []
+        for t, d in self._res:
+            if t == self.TAG_PROP_FWD:
+                out.append(d)
+            elif t == self.TAG_PROP_FWD_SPLIT and out:
+                out[-1] += d
+        return out
 
 
 def _timed(name, fn, *args):
-    t = KernelTimer.active
-    if t is None or t.name != name:
-        return fn(*args)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    rc = fn(*args)
-    b.record()
-    t.pairs.append((a, b))
-    return rc
+    return fn(*args)
 
 
 def _chk(t, name, dtype, numel, dev, align=16):
@@ -86,8 +95,10 @@ def _sd(seed_dev, dev):
     return _chk(seed_dev, "seed_dev", torch.int64, 1, dev)
 
 
-def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.0, seed=0, seed_dev=None):
-    """H[N,dout], S[N,heads] = ngacf_transform_fwd(X[N,din], W[2,din,dout], avec[2,dout])."""
+def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.0, seed=0, seed_dev=None, pack=None):
+    """H[N,dout], S[N,heads] = ngacf_transform_fwd(X[N,din], W[2,din,dout], avec[2,dout]).
+    pack = [W_k float[2,64,dout_k], ...] (bf16 storage only): the same launch also writes those LATER stages' weight panels as
+    matrix-core fragments (ngacf_transform_fwd_pack); returns (H, S, [panel_k uint8 tensors]) then."""
     dev, N = X.device, U + I
     din, dout = W.shape[1], W.shape[2]
     _heads_ok(dout, heads)
@@ -100,10 +111,42 @@ def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.
     ap = _chk(avec, "avec", torch.float32, 2 * dout, dev)
     H = torch.empty(N, dout, dtype=h_dtype, device=dev)
     S = torch.empty(N, heads, dtype=torch.float32, device=dev)
+    if pack:
+        if h_dtype != torch.bfloat16 or len(pack) > _lib.MAX_PACK:
+            raise ValueError("transform_fwd(pack=...): bf16 storage, at most %d panels" % _lib.MAX_PACK)
+        n = len(pack)
+        for Wk in pack:
+            if Wk.dim() != 3 or Wk.shape[0] != 2 or Wk.shape[1] != 64 or Wk.shape[2] not in (64, 128):
+                raise ValueError("pack: W [2, 64, 64 | 128], got %s" % (tuple(Wk.shape),))
+        panels = [torch.empty(2 * Wk.shape[1] * Wk.shape[2] * 2, dtype=torch.uint8, device=dev) for Wk in pack]
+        P, Iarr = ctypes.c_void_p * n, ctypes.c_int * n
+        pw = P(*[_chk(Wk, "pack W", torch.float32, Wk.numel(), dev) for Wk in pack])
+        pf = P(*[t.data_ptr() for t in panels])
+        _lib.check(lib.ngacf_transform_fwd_pack(xp, _DT[X.dtype], wp, ap, H.data_ptr(), _DT[h_dtype], S.data_ptr(), U, I, din, dout, heads,
+                                                float(feat_drop_p), int(seed), _sd(seed_dev, dev), n, pw, pf,
+                                                Iarr(*[int(Wk.shape[1]) for Wk in pack]), Iarr(*[int(Wk.shape[2]) for Wk in pack]), _stream()),
+                   "ngacf_transform_fwd_pack")
+        return H, S, panels
     _lib.check(lib.ngacf_transform_fwd(xp, _DT[X.dtype], wp, ap, H.data_ptr(), _DT[h_dtype], S.data_ptr(),
                                        U, I, din, dout, heads, float(feat_drop_p), int(seed), _sd(seed_dev, dev),
                                        _stream()), "ngacf_transform_fwd")
     return H, S
+
+
+class NextStage:
+    """The next stage's transform riding in this stage's traversal epilogue (ngacf_prop_fwd_next): its weight panel (from
+    transform_fwd(pack=...)), avec [2, dout], heads, feature dropout and seed.  prop_fwd(next=...) fills .H / .S."""
+    __slots__ = ("panel", "avec", "dout", "heads", "feat_drop_p", "seed", "H", "S")
+
+    def __init__(self, panel, avec, heads, feat_drop_p=0.0, seed=0):
+        self.panel, self.avec, self.dout, self.heads = panel, avec, int(avec.shape[1]), int(heads)
+        self.feat_drop_p, self.seed, self.H, self.S = float(feat_drop_p), int(seed), None, None
+
+
+def can_fuse_next(plan, H_dtype, d, heads, needed=None):
+    """Can ngacf_prop_fwd_next serve this launch?  (bf16 rows of 64 columns in 8 heads, hub rows finished in-kernel or absent)"""
+    return (H_dtype == torch.bfloat16 and d == 64 and heads == 8 and needed is None and plan.nhub == 0
+            and (plan.nsplit == 0 or (INKERNEL_HUB_FINISH and plan.nparts <= INKERNEL_MAX_PARTS)))
 
 
 def _plan_ptrs(plan, dev, half=None, inkernel=False):
@@ -214,11 +257,14 @@ def _scratch(scratch, plan, d, heads, dev):
 
 
 def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
-             drop_p=0.0, seed=0, save=False, out=None, seed_dev=None, half=None, agg=None, R=None, needed=None, scratch=None):
+             drop_p=0.0, seed=0, save=False, out=None, seed_dev=None, half=None, agg=None, R=None, needed=None, scratch=None,
+             next=None, want_out=True):
     """One propagation stage over plan's dst rows.  Returns out (and agg, R when save=True).
     half = "user" / "item": only the user / item dst rows (two calls with the same out / agg / R cover the stage).
     scratch = (float [nparts, d], float [nparts, heads]): the hub rows' partial-sum slots (default: fresh buffers; the soak
-    test hands in buffers it has poisoned)."""
+    test hands in buffers it has poisoned).
+    next = NextStage: the launch also produces the next stage's H' [N, dout'] (bf16) and S' [N, heads'] in next.H / next.S; with
+    want_out=False (an evaluation forward) `out` is not written at all and None is returned in its place."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
     if score_from_row is None:
@@ -231,9 +277,14 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
     hub = _hub(plan, dev, half)
     pp = _plan_ptrs(plan, dev, half, inkernel=hub[1] != 0)
-    if out is None:
-        out = torch.empty(N, d, dtype=H.dtype, device=dev)
-    op = _chk(out, "out", H.dtype, N * d, dev)
+    if next is not None and (half is not None or not can_fuse_next(plan, H.dtype, d, heads, needed) or not score_from_row):
+        raise ValueError("prop_fwd(next=...): not available for this launch (ops.can_fuse_next)")
+    if next is None or want_out:
+        if out is None:
+            out = torch.empty(N, d, dtype=H.dtype, device=dev)
+        op = _chk(out, "out", H.dtype, N * d, dev)
+    else:
+        out, op = None, 0
     if save:
         agg = torch.empty(N, d, dtype=H.dtype, device=dev) if agg is None else agg       # (storage type: bf16 tables halve it)
         R = torch.empty(N, heads, dtype=torch.float32, device=dev) if R is None else R
@@ -243,6 +294,17 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
         agg = R = None
     pa, pr = _scratch(scratch, plan, d, heads, dev)
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
+    if next is not None:
+        next.H = torch.empty(N, next.dout, dtype=torch.bfloat16, device=dev)
+        next.S = torch.empty(N, next.heads, dtype=torch.float32, device=dev)
+        panel = next.panel.get() if hasattr(next.panel, "get") else next.panel
+        ns = _lib.NextStage(_chk(panel, "next.panel", torch.uint8, 2 * 64 * next.dout * 2, dev), _chk(next.avec, "next.avec", torch.float32, 2 * next.dout, dev),
+                            next.H.data_ptr(), next.S.data_ptr(), next.dout, next.heads, next.feat_drop_p, next.seed & 0xFFFFFFFFFFFFFFFF)
+        _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd_next, *pp, hp,
+                          _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
+                          pa.data_ptr(), pr.data_ptr(), *hub, 0, 0, 0, 0, plan.U, N, d, heads, float(alpha),
+                          float(drop_p), int(seed), _sd(seed_dev, dev), flags, ctypes.byref(ns), _stream()), "ngacf_prop_fwd_next")
+        return (out, agg, R) if save else out
     _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, *pp, hp,
                       _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
                       pa.data_ptr(), pr.data_ptr(), *hub, *_needed_args(needed, plan, N, dev),

@@ -813,3 +813,85 @@ def test_g15_spga_model_wrappers(dev):
         m.train()
         m(u, it, mask).sum().backward()
         assert float(m.uEmbd.weight.grad.abs().sum()) > 0 and bool(torch.isfinite(m.uEmbd.weight.grad).all())
+
+
+def test_next_stage_transform_in_the_traversal_epilogue(dev):
+    """ngacf_prop_fwd_next against the two-launch form it replaces (ngacf_prop_fwd, then ngacf_transform_fwd on the stored
+    table): same `out` / agg / R AND the same H' / S', bit for bit -- the epilogue runs the stand-alone launch's tile step
+    (csrc/mfma_rows.hpp) on rows that are still on chip.
+    Every row class (short rows, long rows, hub rows finished in-kernel, an isolated item), both next-stage widths, one head and
+    8-wide heads, with and without the next stage's feature dropout, with and without writing `out`."""
+    from ngacf_amd import ops
+    from ngacf_amd.plan import build_plan
+    rs = np.random.RandomState(5)
+    U, I = 700, 500
+    edge = _random_graph(U, I, 30000, 5, hub=450)
+    plan = build_plan(_t(edge, dev), U, I, seg_len=128)
+    assert plan.nsplit > 0 and plan.nseg > plan.nparts and plan.nshort > 0       # hub rows in slices, one-wave long rows, short rows
+    N = U + I
+    X = _t(rs.randn(N, 64).astype(np.float32), dev)
+    W = _t((rs.randn(2, 64, 64) * 0.2).astype(np.float32), dev)
+    avec = _t((rs.randn(2, 64) * 0.3).astype(np.float32), dev)
+    for dout, heads2, p2 in ((64, 8, 0.0), (64, 1, 0.0), (128, 16, 0.0), (128, 1, 0.3), (64, 8, 0.25)):
+        W2 = _t((rs.randn(2, 64, dout) * 0.2).astype(np.float32), dev)
+        a2 = _t((rs.randn(2, dout) * 0.3).astype(np.float32), dev)
+        H, S, panels = ops.transform_fwd(X, W, avec, U, I, 8, torch.bfloat16, pack=[W2])
+        H0, S0 = ops.transform_fwd(X, W, avec, U, I, 8, torch.bfloat16)
+        assert torch.equal(H, H0) and torch.equal(S, S0)                       # the side jobs leave the transform alone
+        for drop, save in ((0.0, False), (0.2, True)):
+            ref = ops.prop_fwd(plan, H, S, S, avec, 8, drop_p=drop, seed=11, save=save)
+            out_ref = ref[0] if save else ref
+            H2r, S2r = ops.transform_fwd(out_ref, W2, a2, U, I, heads2, torch.bfloat16, feat_drop_p=p2, seed=77)
+            for want_out in (True, False):
+                nxt = ops.NextStage(panels[0], a2, heads2, p2, 77)
+                got = ops.prop_fwd(plan, H, S, S, avec, 8, drop_p=drop, seed=11, save=save, next=nxt, want_out=want_out)
+                if want_out:
+                    for a_, b_ in zip(got if save else (got,), ref if save else (ref,)):
+                        assert torch.equal(a_, b_)
+                elif save:
+                    assert got[0] is None and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+                else:
+                    assert got is None
+                assert torch.equal(nxt.H, H2r) and torch.equal(nxt.S, S2r), (dout, heads2, p2, drop, save, want_out)
+
+
+@pytest.mark.parametrize("kind", ["spuigacf", "multi", "d128L4"])
+def test_fused_stack_equals_unfused_stack(dev, kind):
+    """The whole stack with NGACF_FUSE_NEXT on (default) and off: evaluation table, train-mode scores with dropout (same seeds =
+    same masks) and every gradient, bf16 storage.  (Both forms are checked against the reference's float64 numbers by the
+    golden tests; this is the A/B of the two launch plans.)"""
+    import ngacf_amd
+    from ngacf_amd import functional as NF
+    U, I = 900, 700
+    edge = _t(_random_graph(U, I, 40000, 3, hub=500), dev)
+    mk = {"spuigacf": lambda: ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.1),
+          "multi": lambda: ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.1),
+          "d128L4": lambda: ngacf_amd.SPUIStackedGACF(U, I, 128, [64, 64], 0.1, stages=4)}[kind]
+    torch.manual_seed(4)
+    m = mk().to(dev)
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30.0); m.iEmbd.weight.mul_(30.0)
+    ngacf_amd.set_compute_dtype(m, torch.bfloat16)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    u, pi, ni = (torch.randint(0, k, (256,), device=dev, generator=g) for k in (U, I, I))
+    res = {}
+    was = NF.FUSE_NEXT
+    try:
+        for fuse in (True, False):
+            NF.FUSE_NEXT = fuse
+            m.eval()
+            with torch.no_grad():
+                F = m.propagate(edge).float()
+            m.train()
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(9)
+            loss = ngacf_amd.BPRLoss()(m(u, pi, edge), m(u, ni, edge))
+            loss.backward()
+            res[fuse] = (F, float(loss.detach()), {n: p.grad.clone() for n, p in m.named_parameters()})
+    finally:
+        NF.FUSE_NEXT = was
+    assert torch.equal(res[True][0], res[False][0]) and res[True][1] == res[False][1]        # the same bits on both launch plans
+    for n in res[True][2]:
+        a_, b_ = res[True][2][n].double(), res[False][2][n].double()
+        # (the backward is the same code on the same saved tensors; float atomics in the score gradient reorder a few sums)
+        assert float((a_ - b_).norm() / b_.norm().clamp_min(1e-30)) < 1e-5, n

@@ -1,7 +1,8 @@
 """HBM-side traffic of the dominant kernel from PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
 WRITE_SIZE in SEPARATE rocprofv3 --pmc passes of the same bench command (kernel-trace only), units of KB, FETCH_SIZE
-doubled on gfx950.  Writes gpurun_out/r02_traffic_<workload>.json -- copy it to profiles/ (bench.py reads roofline.traffic
-from there and labels it from_profile).
+doubled on gfx950; a third pass collects TCC_HIT_sum / TCC_MISS_sum (the L2 hit rate bench.py's cache-gather roof is built
+from).  Writes gpurun_out/r03_traffic_<workload>.json -- copy it to profiles/ (bench.py reads roofline.traffic and
+roofline.l2_hit_rate from there and labels them from_profile).
 Run on the GPU box:  python tools/traffic.py gowalla   (this process never touches the GPU itself)."""
 import collections
 import csv
@@ -13,26 +14,33 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def one_pass(counter, workload, dtype, tag):
-    out = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s_%s" % (tag, dtype, counter))
+def one_pass(counters, workload, dtype, tag):
+    """{counter: {kernel family: (mean value per launch, launches)}} of one rocprofv3 --pmc pass (counters: a name or a list)."""
+    counters = [counters] if isinstance(counters, str) else list(counters)
+    out = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s_%s" % (tag, dtype, counters[0]))
     subprocess.run(["rm", "-rf", out])
     env = dict(os.environ, TMPDIR="/tmp")
-    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--passes-per-step", "4",
-           "--no-cpu-baseline", "--no-train", "--no-probe", "--workload", workload, "--dtype", dtype]
+    steps = ["--steps", "3", "--warmup", "1", "--passes-per-step", "4"] if workload not in ("synthetic1b", "synthetic200m") else \
+            ["--steps", "2", "--warmup", "1", "--passes-per-step", "1"]
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", "p", "--",
+           sys.executable, os.path.join(ROOT, "bench.py")] + steps + ["--no-cpu-baseline", "--no-train", "--no-probe", "--workload", workload, "--dtype", dtype]
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    tot, n = collections.defaultdict(float), collections.defaultdict(int)
+    tot = {c: collections.defaultdict(float) for c in counters}
+    n = {c: collections.defaultdict(int) for c in counters}
     for root, _, files in os.walk(out):
         for f in files:
             if f.endswith("counter_collection.csv"):
                 for r in csv.DictReader(open(os.path.join(root, f))):
-                    if r["Counter_Name"] != counter:
+                    c = r["Counter_Name"]
+                    if c not in tot:
                         continue
                     for k in KERNELS:
-                        if k in r["Kernel_Name"]:
-                            tot[k] += float(r["Counter_Value"])
-                            n[k] += 1
-    return {k: (tot[k] / max(n[k], 1), n[k]) for k in KERNELS}
+                        if k + "<" in r["Kernel_Name"] or k + "(" in r["Kernel_Name"]:
+                            tot[c][k] += float(r["Counter_Value"])
+                            n[c][k] += 1
+    subprocess.run(["rm", "-rf", out])
+    res = {c: {k: (tot[c][k] / max(n[c][k], 1), n[c][k]) for k in KERNELS} for c in counters}
+    return res[counters[0]] if len(counters) == 1 else res
 
 
 KERNELS = ("prop_fwd_kernel", "prop_fwd_split_kernel", "transform_mfma_kernel", "transform_fwd_kernel")
@@ -42,23 +50,27 @@ def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "gowalla"
     dtypes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["bf16", "fp32"]
     res = {"workload": wl, "stages": 3,
-           "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --steps 3 --warmup 1 "
-                      "--passes-per-step 4 --no-cpu-baseline --no-train --no-probe --workload %s [--dtype fp32]  (tools/traffic.py)" % wl,
+           "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum} -- python bench.py --steps 3 --warmup 1 "
+                      "--passes-per-step 4 --no-cpu-baseline --no-train --no-probe --workload %s [--dtype fp32]  (tools/traffic.py; "
+                      "three separate passes, the eval forward as benched: the fused traversals of a bf16 pass included)" % wl,
            "by_dtype": {}}
     for dt in dtypes:
         fetch = one_pass("FETCH_SIZE", wl, dt, wl)
         write = one_pass("WRITE_SIZE", wl, dt, wl)
+        hm = one_pass(["TCC_HIT_sum", "TCC_MISS_sum"], wl, dt, wl)
         f0, nf = fetch["prop_fwd_kernel"]
         w0, nw = write["prop_fwd_kernel"]
+        hit, miss = hm["TCC_HIT_sum"]["prop_fwd_kernel"][0], hm["TCC_MISS_sum"]["prop_fwd_kernel"][0]
         res["by_dtype"][dt] = {"kernel": "prop_fwd_kernel", "launches": [nf, nw], "fetch_size_kb": round(f0, 1),
                                "write_size_kb": round(w0, 1),
+                               "l2_hit_rate": round(hit / max(hit + miss, 1.0), 4), "tcc_hit_per_launch": round(hit, 1), "tcc_miss_per_launch": round(miss, 1),
                                "traffic_bytes": int(round((2.0 * f0 + w0) * 1024)),
                                "note": "bytes crossing the L2<->fabric boundary per launch (Infinity-Cache hits included), "
                                        "avg over the launches of all stages; FETCH_SIZE x2 = gfx950 correction",
                                "other_kernels": {k: {"fetch_size_kb": round(fetch[k][0], 1), "write_size_kb": round(write[k][0], 1),
                                                      "launches": fetch[k][1]} for k in KERNELS[1:] if fetch[k][1]}}
         print(wl, dt, res["by_dtype"][dt], flush=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r02_traffic_%s.json" % wl), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r03_traffic_%s.json" % wl), "w") as f:
         json.dump(res, f, indent=1)
 
 
