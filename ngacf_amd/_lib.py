@@ -51,6 +51,7 @@ SIGNATURES = {
     "ngacf_sample_pairs": [_p, ctypes.c_longlong, ctypes.c_longlong, _p, _p, _i, _p, _p, _i, _u64, _p, _p, _p, _p, _p, _i, _p],
     "ngacf_eval_topk": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
     "ngacf_dropout_bits": [_i, _u64, _p, _p, _p, _p, _i, _p],
+    "ngacf_timing_begin": [],
     "ngacf_timing_end": [_p, _p, _i],
     "ngacf_mha_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _i, _p],
     "ngacf_mha_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _i, _p],
@@ -75,8 +76,6 @@ def _load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.ngacf_version.restype = ctypes.c_char_p
     lib.ngacf_version.argtypes = []
-    lib.ngacf_timing_begin.restype = ctypes.c_int
-    lib.ngacf_timing_begin.argtypes = []
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
         fn.restype = ctypes.c_int

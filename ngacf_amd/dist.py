@@ -631,7 +631,18 @@ def scaling_probe(args, world, rank, dev, d=64):
     stage_ms = sum(durs) / 3 / L
     bytes_stage = local_edges * (4 + d * elem) + n_local * (2 * d * elem + 8)
     achieved = -allmax(-bytes_stage / (stage_ms * 1e-3) / 1e9)
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    traffic, traffic_src = BK.traffic_from_profile(root, wl, args.dtype, 3, d) if world == 1 else (None, None)
+    roofline = {"bound": "hbm", "kernel": "prop_fwd_kernel + the hub rows' second kernel (11 M slices: beyond the in-kernel finish)",
+                "achieved": round(achieved, 1), "peak": BK.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / BK.HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "counter_GBps": round(traffic / (stage_ms * 1e-3) / 1e9, 1) if traffic else None,
+                "bytes_per_launch": int(bytes_stage), "avg_launch_us": round(stage_ms * 1e3, 1),
+                "timing": "dispatch-packet timestamps of %d eager launches (slowest rank)" % len(durs),
+                "regime": "HBM", "regime_note": "%.2f GB table, far beyond the 256 MiB Infinity Cache" % (n_local * d * elem / 1e9)}
     return {"workload": "%s bipartite graph U=%d I=%d E=%d, d=%d, L=3, eval forward" % (wl, U, I, E, d), "n_gpus": world,
+            "roofline": roofline,
             "value": round(L * 2 * E * K / best, 1), "unit": "edges/s", "ms_per_pass": round(1e3 * best / K, 3), "passes": K,
             "launch": launch, "ms_per_pass_eager": round(1e3 * t_eager / K, 3), "dtype": args.dtype,
             "prop_fwd_GBps_slowest_rank": round(achieved, 1), "prop_fwd_frac_of_hbm_peak": round(achieved / BK.HBM_PEAK_GBS, 4),

@@ -414,9 +414,10 @@ def test_bench_prints_one_contract_line():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "edges/s" and d["vs_baseline"] is None
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    assert d["cpu_baseline"]["cores"] <= 16 and ("all_cores" not in d["cpu_baseline"] or d["cpu_baseline"]["all_cores"]["cores"] == os.cpu_count())
     assert "workload" in d["config"] and d["value"] > 1e9 and d["bpr_pairs_per_s"] > 1e5
     # the timed region: exactly `steps` steps of passes_per_step passes, sized to last about --target-seconds
     R = d["config"]["passes_per_step"]
@@ -424,10 +425,21 @@ def test_bench_prints_one_contract_line():
     assert abs(d["value"] - d["config"]["edges_directed_per_step"] * 3 / d["timed_region_s"]) < 0.01 * d["value"]
     assert 0.7 < d["value_median_window"] / d["value"] < 1.3
     rf = d["roofline"]
-    assert rf["regime"].startswith("cache-resident") and rf["applicable_roof_GBps"] == 8600.0 and rf["launches_timed"] >= 300
+    # Gowalla scale: the 9 MB table never leaves L2 + Infinity Cache -- the roof is the cache row-gather blend and the fraction
+    # of it stays at or below 1; the HBM figure is kept apart under its own name
+    assert rf["regime"].startswith("cache-resident") and rf["bound"] == "l2+mall gather" and rf["launches_timed"] >= 300
+    assert 8600.0 <= rf["peak"] <= 17800.0 and 0.3 < rf["frac"] <= 1.0 and rf["frac_hbm_algorithmic"] > rf["frac"]
     assert rf["traffic"] is None or "from_profile" in rf["traffic_source"]
+    # the kernels' own durations (dispatch timestamps): the pass cannot be shorter than its kernels
+    kern_us = sum(rf["per_stage_us"]) + rf.get("transform_launch_us", 0.0) * rf.get("transform_launches_per_pass", 0)
+    assert 0.8 * kern_us < 1e3 * d["ms_per_pass"] < 1.25 * kern_us, (kern_us, d["ms_per_pass"])
+    assert d["config"]["fused_next_stage_transform"] and d["config"]["launches_per_pass"] == 4
+    assert d["train_traversals_per_step"]["performed"] < d["train_traversals_per_step"]["if_every_stage_ran_in_full"]
+    yp = d["yelp_probe"]
+    assert "error" not in yp and yp["value"] > 3e10 and yp["roofline"]["bound"] == "l2+mall gather" and yp["roofline"]["frac"] <= 1.0, yp
     pr = d["scaling_probe"]                                              # the same forward on the 10^9-edge graph, one GPU
     assert "error" not in pr and pr["n_gpus"] == 1 and pr["value"] > 3e10 and pr["prop_fwd_frac_of_hbm_peak"] > 0.7, pr
+    assert pr["roofline"]["bound"] == "hbm" and pr["roofline"]["peak"] == 8000.0 and 0.5 < pr["roofline"]["frac"] <= 1.0, pr
 
 
 @pytest.mark.gpu
