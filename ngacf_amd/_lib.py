@@ -10,7 +10,9 @@ import torch  # noqa: F401  -- must come first: the library has to bind to the H
               # loaded (torch bundles its own libamdhip64); two runtimes in one process cannot share pointers
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libngacf_hip.so")
+# (NGACF_LIB_PATH: another build of the same library, e.g. an instrumented variant for an A/B measurement -- never a fallback:
+#  a missing file fails the import just the same)
+LIB_PATH = os.environ.get("NGACF_LIB_PATH") or os.path.join(_HERE, "lib", "libngacf_hip.so")
 
 F32, BF16 = 0, 1
 FLAG_ELU, FLAG_RESIDUAL, FLAG_SCORE_ROW, FLAG_SKIP_NODE, FLAG_GOUT_F32 = 1, 2, 4, 8, 16

@@ -105,5 +105,8 @@ extern "C" int ngacf_spmm_fwd(const int32_t* segs, int nseg, const int32_t* spli
     if (dtype == NGACF_F32 && d == 128) return launch_spmm<float, 128>(segs, nseg, split, nsplit, col, val, X, out, part_acc, self_loop, st);
     if (dtype == NGACF_BF16 && d == 64) return launch_spmm<bf16_t, 64>(segs, nseg, split, nsplit, col, val, X, out, part_acc, self_loop, st);
     if (dtype == NGACF_BF16 && d == 128) return launch_spmm<bf16_t, 128>(segs, nseg, split, nsplit, col, val, X, out, part_acc, self_loop, st);
+    // 256 columns: the reference's default embedSize of the dense-attention models (GACFmodel1.py:43, GACFmodel6.py:47): a row = a whole wave (fp32)
+    if (dtype == NGACF_F32 && d == 256) return launch_spmm<float, 256>(segs, nseg, split, nsplit, col, val, X, out, part_acc, self_loop, st);
+    if (dtype == NGACF_BF16 && d == 256) return launch_spmm<bf16_t, 256>(segs, nseg, split, nsplit, col, val, X, out, part_acc, self_loop, st);
     return NGACF_E_SHAPE;
 }

@@ -7,6 +7,7 @@ families built on it, backed by the HIP flash-style kernel ngacf_mha_fwd / ngacf
   ATTLayer_mask(dim, heads, dropout).forward(features, mask)            modules.py:20-30
   GALayer / GACFV1_layer / GACFV1 (and GACFV3, GACFV4, GACFV5)          GACFmodel{1,3,4,5}.py
   GACFV2                                                                GACFmodel2.py:34-135
+  GACFV3x, GACFV6 (three-layer MLP head on cat(user row, item row))     GACFmodel3.py:114-200, GACFmodel6.py:12-161
   GPLayer / GACFV2_layer / GACFMask                                     GACFMask.py:22-136
 
 What differs from the reference is how the attention core runs: the [heads, Nq, Nk] score and probability tensors are
@@ -132,8 +133,8 @@ class _Laplacian:
 
 
 def _check_width(d):
-    if d not in (64, 128):
-        raise ValueError("layer widths must be 64 or 128 on the accelerated path (got %d)" % d)
+    if d not in (64, 128, 256):
+        raise ValueError("layer widths must be 64, 128 or 256 on the accelerated path (got %d)" % d)
 
 
 class GALayer(nn.Module):
@@ -231,6 +232,103 @@ class GACFV4(GACFV1):
 
 class GACFV5(GACFV1):
     _layer = GACFV5_layer
+
+
+class GALayerV6(nn.Module):
+    """GACFmodel6.py:12-43: affine1((L + I) @ cat(users, items)) + affine2(ATTLayer(users, items)) -- the attention output goes
+    straight into the second Linear (no Laplacian product, no ReLU inside the layer)."""
+
+    def __init__(self, input_dim, out_dim, heads, dropout):
+        super().__init__()
+        _check_width(input_dim)
+        self.att = ATTLayer(input_dim, heads, dropout)
+        self.affine1 = nn.Linear(input_dim, out_dim)
+        self.affine2 = nn.Linear(input_dim, out_dim)
+        for lin in (self.affine1, self.affine2):
+            nn.init.xavier_uniform_(lin.weight)
+            lin.bias.data.zero_()
+
+    def forward(self, userFeatures, itemFeatures, propagation):
+        f1 = self.affine1(propagation(torch.cat([userFeatures, itemFeatures], dim=0), self_loop=True))
+        return f1 + self.affine2(self.att(userFeatures, itemFeatures))
+
+
+def rating_laplacian_coo(user_ids, item_ids, rating, U, I):
+    """GACFV6.buildLaplacianMat (GACFmodel6.py:139-161) as COO (rows, cols, vals): D^-1/2 A D^-1/2 over the (U+I) x (U+I) block
+    matrix whose entries are the RATINGS (duplicate pairs summed, as coo_matrix does) and whose degrees count a row's non-zero
+    entries ((A > 0).sum)."""
+    u, i = torch.as_tensor(user_ids).long(), torch.as_tensor(item_ids).long()
+    key, inv = torch.unique(u * I + i, return_inverse=True)
+    val = torch.zeros(key.numel(), dtype=torch.float64).index_add_(0, inv, torch.as_tensor(rating, dtype=torch.float64))
+    uu, ii = key // I, key % I + U
+    r, c, v = torch.cat([uu, ii]), torch.cat([ii, uu]), torch.cat([val, val])
+    deg = torch.bincount(r[v > 0], minlength=U + I).double()
+    dis = torch.where(deg > 0, deg.pow(-0.5), torch.full_like(deg, float("inf")))
+    return r, c, (dis[r] * v * dis[c]).float()
+
+
+class _GACFMlpHead(nn.Module):
+    """Shared body of GACFV6 and GACFV3x: embeddings -> GALayers (stage outputs concatenated) -> cat(user row, item row) ->
+    transForm1 (ReLU) -> transForm2 (ReLU) -> transForm3 -> flatten (GACFmodel6.py:96-122, GACFmodel3.py:170-194)."""
+
+    def __init__(self, userNum, itemNum, adj, embedSize, layers, droprate, useCuda, make_layer, relu_outside):
+        super().__init__()
+        layers = list(layers)
+        self.useCuda, self.userNum, self.itemNum, self.droprate = useCuda, userNum, itemNum, droprate
+        self.uEmbd = nn.Embedding(userNum, embedSize)
+        self.iEmbd = nn.Embedding(itemNum, embedSize)
+        self.GALayers = nn.ModuleList()
+        self.leakyRelu = nn.LeakyReLU()                                   # (held, never applied: GACFmodel6.py:62)
+        self.transForm1 = nn.Linear(sum(layers) * 2, 64)
+        self.transForm2 = nn.Linear(64, 32)
+        self.transForm3 = nn.Linear(32, 1)
+        for a, b in zip(layers[:-1], layers[1:]):
+            self.GALayers.append(make_layer(a, b, 8, droprate))
+        self._lap = _Laplacian(adj, userNum + itemNum)
+        self._relu_outside = relu_outside
+        nn.init.normal_(self.uEmbd.weight, std=0.01)
+        nn.init.normal_(self.iEmbd.weight, std=0.01)
+        for lin in (self.transForm1, self.transForm2, self.transForm3):
+            nn.init.xavier_uniform_(lin.weight)
+            lin.bias.data.zero_()
+
+    def forward(self, userIdx, itemIdx):
+        U = self.userNum
+        features = torch.cat([self.uEmbd.weight, self.iEmbd.weight], dim=0)
+        prop = self._lap.get(features.device)
+        final = [features]
+        for ga in self.GALayers:
+            features = ga(features[:U], features[U:], prop)
+            if self._relu_outside:
+                features = torch.relu(features)
+            final.append(features)
+        final = torch.cat(final, dim=1)
+        embd = torch.cat([final[userIdx], final[itemIdx + U]], dim=1)
+        embd = torch.relu(self.transForm1(embd))
+        embd = torch.relu(self.transForm2(embd))
+        return self.transForm3(embd).flatten()
+
+
+class GACFV6(_GACFMlpHead):
+    """GACFmodel6.py:45-161.  `rt`: the rating table -- a DataFrame / mapping with userId, itemId, rating columns (the reference
+    builds its Laplacian from it, :139-161), or a ready (rows, cols, vals) triple / torch sparse tensor."""
+
+    def __init__(self, userNum, itemNum, rt, embedSize=256, layers=(256, 128, 64), droprate=0.2, useCuda=True):
+        if hasattr(rt, "__getitem__") and not isinstance(rt, (tuple, list)) and not torch.is_tensor(rt):
+            import numpy as np
+            adj = rating_laplacian_coo(np.asarray(rt["userId"]), np.asarray(rt["itemId"]), np.asarray(rt["rating"], dtype=np.float64),
+                                       userNum, itemNum)
+        else:
+            adj = rt
+        super().__init__(userNum, itemNum, adj, embedSize, layers, droprate, useCuda, GALayerV6, relu_outside=False)
+
+
+class GACFV3x(_GACFMlpHead):
+    """GACFmodel3.py:114-200: GACFV3's layers (attention through both Laplacian products), a ReLU around each, the MLP head."""
+
+    def __init__(self, userNum, itemNum, adj, embedSize=256, layers=(256, 128, 64), droprate=0.2, useCuda=True):
+        super().__init__(userNum, itemNum, adj, embedSize, layers, droprate, useCuda,
+                         lambda a, b, h, p: GALayer(a, b, h, p, variant=3), relu_outside=True)
 
 
 class GPLayer(nn.Module):

@@ -487,7 +487,7 @@ def bpr_bwd(pos, neg, gloss):
 
 def spmm_fwd(plan, val, X, self_loop=True):
     dev, N, d = X.device, plan.N, X.shape[1]
-    if d not in SUPPORTED_D or X.dtype not in _DT:
+    if d not in SUPPORTED_D + (256,) or X.dtype not in _DT:          # (256: the dense-attention models' default width)
         raise ValueError("unsupported X: d=%d dtype=%s" % (d, X.dtype))
     xp = _chk(X, "X", None, N * d, dev)
     vp = _chk(val, "val", torch.float32, plan.n_edges_directed, dev)

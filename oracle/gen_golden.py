@@ -507,6 +507,48 @@ def g16_gacf_variants(edge, U, I):
     save("g16_gacf_variants", **out)
 
 
+def g17_gacf_mlp_heads(edge, U, I):
+    """GACFV6 (GACFmodel6.py:45-110: the Laplacian built from the rating table by the model itself, :139-161; attention fed
+    straight into affine2, no ReLU inside the layer) and GACFV3x (GACFmodel3.py:114-200: GACFV3's layers, ReLU around each, the
+    same three-layer MLP head on cat(user row, item row))."""
+    import pandas as pd
+    import graphattention.GACFmodel3 as G3
+    import graphattention.GACFmodel6 as G6
+    from data.loadGowalla import buildLaplacianMat, scipySP_torchSP
+    g14 = np.load(os.path.join(OUT, "g14_dense_mha.npz"))
+    e37, I37 = g14["edge"], int(g14["I"])
+    rs = np.random.RandomState(17)
+    rating = rs.randint(1, 6, e37.shape[1]).astype(np.float64)                     # ml100k-style ratings 1..5
+    rt = pd.DataFrame({"userId": e37[0], "itemId": e37[1], "rating": rating})
+    rt1 = pd.DataFrame({"userId": e37[0], "itemId": e37[1], "rating": np.ones(e37.shape[1])})
+    L = scipySP_torchSP(buildLaplacianMat(rt1, U, I37, "mean_adj")).coalesce()
+    u, it = torch.from_numpy(g14["u"]), torch.from_numpy(g14["item"])
+    out = {"rating": rating.astype(np.float32)}
+    real_cuda = (torch.Tensor.cuda, torch.nn.Module.cuda)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    try:
+        with CpuDevice():
+            for tag, make in (("v6", lambda: G6.GACFV6(U, I37, rt, 64, [64, 64, 64], 0.0, useCuda=False)),
+                              ("v3x", lambda: G3.GACFV3x(U, I37, L, 64, [64, 64, 64], 0.0, useCuda=False))):
+                torch.manual_seed(71)
+                m = make()
+                emb = m
+                emb.useCuda = False
+                with torch.no_grad():
+                    emb.uEmbd.weight.mul_(30.0); emb.iEmbd.weight.mul_(30.0)
+                m.eval()
+                out[tag + "_scores"] = m(u, it).detach().numpy()
+                for k_, v in m.state_dict().items():
+                    out[tag + ".p." + k_] = v.numpy().copy()
+                if tag == "v6":                                                   # the Laplacian the model built (GACFmodel6.py:139-161)
+                    Lm = m.LaplacianMat.coalesce()
+                    out["v6_L_row"], out["v6_L_col"], out["v6_L_val"] = Lm.indices()[0].numpy(), Lm.indices()[1].numpy(), Lm.values().numpy()
+    finally:
+        torch.Tensor.cuda, torch.nn.Module.cuda = real_cuda
+    save("g17_gacf_mlp_heads", **out)
+
+
 def g11_factors(U, I, seed=7):
     rs = np.random.RandomState(seed)
     cont = (rs.randn(U, 64).astype(np.float32).astype(np.float64), rs.randn(I, 64).astype(np.float32).astype(np.float64))
@@ -580,6 +622,8 @@ def main():
         return g15_spga_models(edge, U, I)
     if "--only-g16" in sys.argv:
         return g16_gacf_variants(edge, U, I)
+    if "--only-g17" in sys.argv:
+        return g17_gacf_mlp_heads(edge, U, I)
     if "--only-g7b" in sys.argv:                      # added after the first batch: leaves the other fixtures untouched
         return g7b_norm_adj(edge[:, edge[1] < 37], U, 37)
     g1_layers(edge, U, I)
@@ -597,6 +641,7 @@ def main():
     g14_dense_mha(edge, U, I)
     g15_spga_models(edge, U, I)
     g16_gacf_variants(edge, U, I)
+    g17_gacf_mlp_heads(edge, U, I)
 
 
 if __name__ == "__main__":

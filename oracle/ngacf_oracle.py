@@ -380,6 +380,44 @@ def gacfv1_scores(p, L, u, it, U, I, heads=8, variant=1):
     return np.sum(E[u] * E[it + U], 1)
 
 
+def rating_laplacian(u, it, rating, U, I):
+    """GACFV6.buildLaplacianMat (GACFmodel6.py:139-161): D^-1/2 A D^-1/2 over the (U+I) x (U+I) block matrix whose entries are the
+    RATINGS (duplicates summed by coo_matrix) and whose degrees count the non-zero entries of a row ((A > 0).sum)."""
+    N = U + I
+    R = sp.coo_matrix((np.asarray(rating, dtype=np.float64), (u, it)), shape=(U, I)).tocsr()
+    A = sp.bmat([[None, R], [R.T, None]], format="csr")
+    deg = np.asarray((A > 0).sum(1)).ravel().astype(np.float64)
+    with np.errstate(divide="ignore"):
+        d = np.power(deg, -0.5)
+    D = sp.diags(d)
+    return (D @ A @ D).tocsr()
+
+
+def gacf_mlp_scores(p, L, u, it, U, I, kind, heads=8):
+    """GACFV6.forward (GACFmodel6.py:96-122, GALayer :29-43) / GACFV3x.forward (GACFmodel3.py:170-194, GALayer :29-40):
+    stage outputs concatenated, the user row and the item row side by side through transForm1..3 (ReLU, ReLU, none)."""
+    F = np.concatenate([p["uEmbd.weight"], p["iEmbd.weight"]])
+    N = U + I
+    L1 = L + sp.eye(N, format="csr")
+    final, s = [F], 0
+    while "GALayers.%d.affine1.weight" % s in p:
+        pre = "GALayers.%d." % s
+        A = att_layer(p, F[:U], F[U:], heads, pre + "att.")
+        if kind == "v6":
+            F = (L1 @ F @ p[pre + "affine1.weight"].T + p[pre + "affine1.bias"]) + (A @ p[pre + "affine2.weight"].T + p[pre + "affine2.bias"])
+        else:
+            f1 = np.maximum(L1 @ A @ p[pre + "affine1.weight"].T + p[pre + "affine1.bias"], 0)
+            f2 = np.maximum(L @ A @ p[pre + "affine2.weight"].T + p[pre + "affine2.bias"], 0)
+            F = np.maximum(f1 + f2, 0)
+        final.append(F)
+        s += 1
+    E = np.concatenate(final, 1)
+    x = np.concatenate([E[u], E[it + U]], 1)
+    x = np.maximum(x @ p["transForm1.weight"].T + p["transForm1.bias"], 0)
+    x = np.maximum(x @ p["transForm2.weight"].T + p["transForm2.bias"], 0)
+    return (x @ p["transForm3.weight"].T + p["transForm3.bias"]).ravel()
+
+
 def gacfv2_scores(p, L, u, it, U, I, heads=8):
     """GACFV2.forward (GACFmodel2.py:88-135): ATTLayer -> (L + I) -> Linear -> ReLU per layer."""
     F = np.concatenate([p["gacf.uEmbd.weight"], p["gacf.iEmbd.weight"]])

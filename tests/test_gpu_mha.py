@@ -171,3 +171,60 @@ def test_g16_gacf_variants(dev):
         assert _rel(m(u, it), g["v%d_scores" % v]) < 1e-5, v
     m2 = _load(M.GACFV2(U, I, L, 64, [64, 64], 0.0), g, "v2.p.").to(dev).eval()
     assert _rel(m2(u, it), g["v2_scores"]) < 1e-5
+
+
+def test_g17_gacfv6_and_gacfv3x(dev):
+    """GACFV6 (its Laplacian built from the rating table, as the reference's constructor does) and GACFV3x against the
+    reference's scores; both load the reference's state_dict strictly."""
+    import pandas as pd
+    from ngacf_amd import modules as M
+    g14, g = load_golden("g14_dense_mha"), load_golden("g17_gacf_mlp_heads")
+    U, I = int(g14["U"]), int(g14["I"])
+    e = g14["edge"]
+    u, it = torch.from_numpy(g14["u"]).to(dev), torch.from_numpy(g14["item"]).to(dev)
+    rt = pd.DataFrame({"userId": e[0], "itemId": e[1], "rating": g["rating"].astype(np.float64)})
+    m6 = _load(M.GACFV6(U, I, rt, 64, [64, 64, 64], 0.0), g, "v6.p.").to(dev).eval()
+    r, c, v = M.rating_laplacian_coo(e[0], e[1], g["rating"], U, I)
+    ours = torch.sparse_coo_tensor(torch.stack([r, c]), v, (U + I, U + I)).coalesce().to_dense()
+    ref = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g["v6_L_row"], g["v6_L_col"]])), torch.from_numpy(g["v6_L_val"]), (U + I, U + I)).to_dense()
+    assert float((ours - ref).abs().max()) < 1e-6
+    assert _rel(m6(u, it), g["v6_scores"]) < 2e-5
+    L = (torch.from_numpy(g14["L_row"]), torch.from_numpy(g14["L_col"]), torch.from_numpy(g14["L_val"]))
+    m3 = _load(M.GACFV3x(U, I, L, 64, [64, 64, 64], 0.0), g, "v3x.p.").to(dev).eval()
+    assert _rel(m3(u, it), g["v3x_scores"]) < 2e-5
+    # gradients flow through the MLP head, the attention kernels and the Laplacian products
+    m3.train()
+    m3(u, it).sum().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m3.parameters())
+
+
+def test_default_width_256_models_vs_oracle(dev):
+    """The reference's DEFAULT configuration of the dense-attention models (embedSize 256, layers 256-128-64: GACFmodel1.py:43,
+    GACFmodel6.py:47) now constructs and runs (the first rounds refused width 256): GACFV1 and GACFV6 with default
+    arguments against the numpy oracle (itself pinned by g14 / g16 / g17 at width 64)."""
+    import scipy.sparse as sp
+    from oracle import ngacf_oracle as O
+    from ngacf_amd import modules as M
+    g14 = load_golden("g14_dense_mha")
+    U, I = int(g14["U"]), int(g14["I"])
+    N = U + I
+    L = (torch.from_numpy(g14["L_row"]), torch.from_numpy(g14["L_col"]), torch.from_numpy(g14["L_val"]))
+    Ls = sp.coo_matrix((g14["L_val"].astype(np.float64), (g14["L_row"], g14["L_col"])), shape=(N, N)).tocsr()
+    u, it = g14["u"], g14["item"]
+    torch.manual_seed(8)
+    m1 = M.GACFV1(U, I, L, 256, [256, 128, 64], 0.0)
+    assert m1.gacf.uEmbd.weight.shape[1] == 256 and len(m1.gacf.GALayers) == 2
+    with torch.no_grad():
+        m1.gacf.uEmbd.weight.mul_(30.0); m1.gacf.iEmbd.weight.mul_(30.0)
+    p1 = {k: v.detach().numpy().astype(np.float64) for k, v in m1.state_dict().items()}
+    got = m1.to(dev).eval()(torch.from_numpy(u).to(dev), torch.from_numpy(it).to(dev))
+    assert _rel(got, O.gacfv1_scores(p1, Ls, u, it, U, I)) < 5e-5
+    layer_default = M.GACFV1_layer(U, I, L)                               # default arguments: embedSize 256, layers (256, 128, 64)
+    assert layer_default.uEmbd.weight.shape[1] == 256
+    m6 = M.GACFV6(U, I, L)                                                # default widths, a ready Laplacian
+    with torch.no_grad():
+        m6.uEmbd.weight.mul_(30.0); m6.iEmbd.weight.mul_(30.0)
+    p6 = {k: v.detach().numpy().astype(np.float64) for k, v in m6.state_dict().items()}
+    got6 = m6.to(dev).eval()(torch.from_numpy(u).to(dev), torch.from_numpy(it).to(dev))
+    ref6 = O.gacf_mlp_scores(p6, Ls, u, it, U, I, "v6")
+    assert float((got6.detach().cpu().double() - torch.from_numpy(ref6)).abs().max()) < 5e-5 * max(float(np.abs(ref6).max()), 1.0)

@@ -267,3 +267,22 @@ def test_g11_eval_all_items_matches_the_references_eval_neg_all(tag):
     for k in ("precision", "recall", "ndcg", "hit_ratio"):
         assert np.allclose(got[k], g["%s.%s" % (tag, k)], rtol=0, atol=1e-12), (k, got[k], g["%s.%s" % (tag, k)])
     assert float(g[tag + ".auc"]) == 0.0
+
+
+def test_g17_gacfv6_and_gacfv3x():
+    """GACFV6 / GACFV3x (GACFmodel6.py, GACFmodel3.py:114-200): the numpy restatement -- incl. the Laplacian GACFV6 builds from
+    the rating table itself -- against the reference's scores and its Laplacian."""
+    import scipy.sparse as sp
+    g14, g = load_golden("g14_dense_mha"), load_golden("g17_gacf_mlp_heads")
+    U, I = int(g14["U"]), int(g14["I"])
+    N = U + I
+    e = g14["edge"]
+    L6 = O.rating_laplacian(e[0], e[1], g["rating"], U, I)
+    ref6 = sp.coo_matrix((g["v6_L_val"].astype(np.float64), (g["v6_L_row"], g["v6_L_col"])), shape=(N, N)).tocsr()
+    assert abs(L6 - ref6).max() < 1e-6
+    L = sp.coo_matrix((g14["L_val"].astype(np.float64), (g14["L_row"], g14["L_col"])), shape=(N, N)).tocsr()
+    for kind, Lk in (("v6", L6), ("v3x", L)):
+        p = {k[len(kind) + 3:]: v.astype(np.float64) for k, v in g.items() if k.startswith(kind + ".p.")}
+        got = O.gacf_mlp_scores(p, Lk, g14["u"], g14["item"], U, I, kind)
+        ref = g[kind + "_scores"]
+        assert np.abs(got - ref).max() < 2e-5 * max(np.abs(ref).max(), 1.0), (kind, np.abs(got - ref).max())
