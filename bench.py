@@ -167,12 +167,7 @@ def measure_forward(torch, BK, ops, model, edge, steps, warmup, target_s, passes
             from ngacf_amd.graphs import GraphedPropagate
             run = GraphedPropagate(model, edge)
         run()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            run()
-        sync()
-        t_pass = (time.perf_counter() - t0) / 5
+        t_pass = BK.pass_time(run, sync)
         R = passes_per_step or BK.passes_per_step(t_pass, steps, target_s)
         for _ in range(warmup):
             for _ in range(R):

@@ -83,6 +83,20 @@ def passes_per_step(t_pass_s, steps, target_s=0.6, cap=20000):
     return int(max(1, min(cap, math.ceil(target_s / (max(steps, 1) * t_pass_s)))))
 
 
+def pass_time(run, sync, groups=3, n=5):
+    """Seconds per call of run() for sizing the timed region: the FASTEST of `groups` groups of n calls -- the first calls on a
+    fresh box (pages still faulting in, a graph's first uploads) can run an order of magnitude slow and would shrink the region."""
+    best = float("inf")
+    for _ in range(groups):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            run()
+        sync()
+        best = min(best, (time.perf_counter() - t0) / n)
+    return best
+
+
 def timed_steps(run, steps, passes, sync, torch):
     """EXACTLY `steps` steps of `passes` calls of run() between sync()s.  Returns (seconds of the whole region, [ms per
     step] from one event per step on the current stream -- no host synchronisation inside the region)."""

@@ -377,17 +377,23 @@ class ShardedSPUIGACF(nn.Module):
         self.comm = Comm(self.part, group)
         self.be = backend if backend is not None else _hip_ops
         p = self.part
-        self.uEmbd = nn.Embedding(p.cu, embedSize)
-        self.iEmbd = nn.Embedding(p.ci, embedSize)
+        # Same values on every rank -- and at every world size -- as the unsharded model under the same torch seed: the random
+        # draws happen in the unsharded constructor's order (SPUIGACF.py:7-28: nn.Embedding's own N(0,1) init of both tables, the
+        # layers' xavier draws, then N(0, 0.01^2) over both tables), on full-size tables of which this rank keeps its rows.
+        # Tables beyond 1 GiB are drawn block-wise instead: every rank seeds its own block.
+        small = (userNum + itemNum) * embedSize * 4 <= (1 << 30)
+        if small:
+            torch.empty(userNum, embedSize).normal_()
+            torch.empty(itemNum, embedSize).normal_()
+        self.uEmbd = nn.Embedding(p.cu, embedSize, _weight=torch.zeros(p.cu, embedSize))
+        self.iEmbd = nn.Embedding(p.ci, embedSize, _weight=torch.zeros(p.ci, embedSize))
         if stages == 2:
             self.gat = SpUIGAT(embedSize, 8, embedSize, droprate, 0.2, 8)
         elif stages == 3 and embedSize == 64:
             self.gat = SPUIMultiGAT(embedSize, 8, embedSize, droprate, 0.2, 8)
         else:
             self.gat = StackedSpUIGAT(embedSize, 8, embedSize, droprate, 0.2, 8, stages - 1)
-        # same values on every rank as the unsharded model with the same seed: draw the full tables, keep this rank's
-        # rows (tables beyond 1 GiB are drawn block-wise instead: every rank seeds its own block)
-        if (userNum + itemNum) * embedSize * 4 <= (1 << 30):
+        if small:
             full_u = torch.empty(userNum, embedSize).normal_(std=0.01)       # SPUIGACF.py:26-28
             full_i = torch.empty(itemNum, embedSize).normal_(std=0.01)
             self.load_full_embeddings(full_u, full_i)
@@ -715,12 +721,7 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
         model.comm.launches = 0
         fwd()
         launches_fwd = model.comm.launches
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            fwd()
-        sync()
-        t_pass = allmax((time.perf_counter() - t0) / 5)
+        t_pass = allmax(BK.pass_time(fwd, sync))
         R = R_eager = args.passes_per_step or BK.passes_per_step(t_pass, args.steps, args.target_seconds)
         for _ in range(args.warmup):
             fwd()
@@ -885,12 +886,8 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
                 fwd()
             for _ in range(args.warmup):
                 graph.replay()
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                graph.replay()
-            sync()                                 # the replayed pass is shorter than the eager one: its own pass count
-            R_graph = args.passes_per_step or BK.passes_per_step(allmax((time.perf_counter() - t0) / 5), args.steps, args.target_seconds)
+            # the replayed pass is shorter than the eager one: its own pass count
+            R_graph = args.passes_per_step or BK.passes_per_step(allmax(BK.pass_time(graph.replay, sync)), args.steps, args.target_seconds)
             t_graph, win_graph = BK.timed_steps(graph.replay, args.steps, R_graph, sync, torch)
             t_graph = allmax(t_graph)
     except Exception as e:                         # capture refused here (maybe not on the peers): the eager numbers stand

@@ -219,12 +219,14 @@ class GraphedPropagate:
         return self.out
 
 
-def graphed_epoch_step(model, lossfn, optim, adj, batch_size, data):
+def graphed_epoch_step(model, lossfn, optim, adj, batch_size, data, after_backward=None):
     """The sampling GraphedBPRStep of (model, optimizer, adjacency, batch size, data), captured once and kept on the
-    model (train_bpr(graph=True) asks for it every epoch)."""
-    key = (id(optim), adj.data_ptr(), tuple(adj.shape), batch_size, id(data))
+    model (train_bpr(graph=True) asks for it every epoch).  after_backward (the node-partitioned model's gradient
+    all-reduce): captured between backward and optimizer; such a step runs its two forwards one after the other."""
+    key = (id(optim), adj.data_ptr(), tuple(adj.shape), batch_size, id(data), after_backward is not None)
     cache = model.__dict__.setdefault("_graphed_steps", {})
     if key not in cache:
         cache.clear()
-        cache[key] = GraphedBPRStep(model, lossfn, optim, adj, batch_size, data=data, preserve_state=True)
+        cache[key] = GraphedBPRStep(model, lossfn, optim, adj, batch_size, data=data, preserve_state=True,
+                                    concurrent_forwards=after_backward is None, after_backward=after_backward)
     return cache[key]

@@ -94,23 +94,25 @@ def _epoch_seed(generator, dev):
     return int(torch.randint(0, 2 ** 62, (1,), device=generator.device, generator=generator).item())
 
 
-def train_bpr(model, batch_size, data, adj, optim, lossfn, generator=None, log_every=0, graph=False):
+def train_bpr(model, batch_size, data, adj, optim, lossfn, generator=None, log_every=0, graph=False, after_backward=None):
     """One epoch (train_eval_Gowalla.py:90-144).  On the GPU the pairs come from ngacf_sample_pairs (one launch per
     batch, no host synchronisation); with graph=True every full batch is ONE hipGraph replay (sampler, 2 forwards,
     loss, backward, optimizer: ngacf_amd.graphs.GraphedBPRStep; the optimizer must be capturable) and only a ragged
-    last batch runs eagerly.  Both modes draw the same pairs for the same seed."""
+    last batch runs eagerly.  Both modes draw the same pairs for the same seed.
+    after_backward: called between loss.backward() and optim.step() (the node-partitioned model's grouped all-reduce of
+    the stage-weight gradients, ShardedSPUIGACF.reduce_grads)."""
     model.train()
     n = data.train_u.numel()
     B = batch_size
     if data.device.type != "cuda":
-        return _train_bpr_host_sampler(model, B, data, adj, optim, lossfn, generator, log_every)
+        return _train_bpr_host_sampler(model, B, data, adj, optim, lossfn, generator, log_every, after_backward)
     seed0 = _epoch_seed(generator, data.device)
     total = torch.zeros((), device=data.device)
     unres = torch.zeros(1, dtype=torch.int32, device=data.device)
     first_eager = 0
     if graph and n >= B:
         from .graphs import graphed_epoch_step
-        gs = graphed_epoch_step(model, lossfn, optim, adj, B, data)
+        gs = graphed_epoch_step(model, lossfn, optim, adj, B, data, after_backward=after_backward)
         gs.begin_epoch(seed0)
         for _ in range(n // B):
             gs.replay()
@@ -129,6 +131,8 @@ def train_bpr(model, batch_size, data, adj, optim, lossfn, generator=None, log_e
         neg_scores = model(upn[0], upn[2], adj)                       # dropout masks (:131-132)
         loss = lossfn(pos_scores, neg_scores)
         loss.backward()
+        if after_backward is not None:
+            after_backward()
         optim.step()
         total += loss.detach()
         if log_every and b % log_every == 0:
@@ -140,7 +144,7 @@ def train_bpr(model, batch_size, data, adj, optim, lossfn, generator=None, log_e
     return float(total) / n                                           # :144 (sum of batch means / rows)
 
 
-def _train_bpr_host_sampler(model, batch_size, data, adj, optim, lossfn, generator=None, log_every=0):
+def _train_bpr_host_sampler(model, batch_size, data, adj, optim, lossfn, generator=None, log_every=0, after_backward=None):
     """The same loop with the torch statement of the sampler (CPU tensors: host-logic tests)."""
     n = data.train_u.numel()
     total = torch.zeros((), device=data.device)
@@ -153,6 +157,8 @@ def _train_bpr_host_sampler(model, batch_size, data, adj, optim, lossfn, generat
         optim.zero_grad(set_to_none=True)
         loss = lossfn(model(users, pos, adj), model(users, neg, adj))
         loss.backward()
+        if after_backward is not None:
+            after_backward()
         optim.step()
         total += loss.detach()
     return float(total) / n
@@ -178,23 +184,29 @@ def metrics_from_hits(r, npos, n_norm):
 
 
 @torch.no_grad()
-def eval_neg_all(model, batch_size, data, adj, user_batch=1 << 20, return_scores=False):
+def eval_neg_all(model, batch_size, data, adj, user_batch=1 << 20, return_scores=False, shard=None, all_reduce=None, topk=None):
     """All-item evaluation.  Users = those with test positives that also appear in train (the merge at
-    train_eval_Gowalla.py:307); normaliser = number of train users (:283)."""
+    train_eval_Gowalla.py:307); normaliser = number of train users (:283).
+    shard = (rank, world) + all_reduce(tensor): every rank ranks its share of the users (users[rank::world]) on the
+    propagated table and the metric sums are added over the ranks (ngacf_amd/sharded_loop.py); topk: stand-in for
+    ops.eval_topk with the same signature (the CPU tests of the loop logic; the product never passes it)."""
     model.eval()
     F = model.propagate(adj).contiguous()                             # once: eval mode is deterministic
     U, I = data.U, data.I
     has_test = (data.test_ptr[1:] - data.test_ptr[:-1]) > 0
     has_train = (data.train_ptr[1:] - data.train_ptr[:-1]) > 0
     users = torch.nonzero(has_test & has_train).squeeze(1)
+    if shard is not None:
+        users = users[shard[0]::shard[1]].contiguous()
     n_norm = float(data.train_users.numel())
     res = {k: torch.zeros(len(KS), dtype=torch.double, device=data.device) for k in ("precision", "recall", "ndcg", "hit_ratio")}
     kept = []
+    rank_items = topk if topk is not None else ops.eval_topk
     for s in range(0, users.numel(), user_batch):
         ub = users[s:s + user_batch].contiguous()
         # scoring F_u . F_i^T on the matrix cores fused with the top-20 selection (ngacf_eval_topk): candidates =
         # pool - train positives, best first, ties to the lower item id (= the stable sort of heapq.nlargest's input)
-        top, top_s = ops.eval_topk(F, ub, U, I, data.pool_mask_u8, data.train_ptr, data.train_items32, 20)
+        top, top_s = rank_items(F, ub, U, I, data.pool_mask_u8, data.train_ptr, data.train_items32, 20)
         if return_scores:
             kept.append(F[ub].float() @ F[U:].float().t())
         valid = top >= 0                                              # fewer than 20 candidates
@@ -205,8 +217,12 @@ def eval_neg_all(model, batch_size, data, adj, user_batch=1 << 20, return_scores
         m = metrics_from_hits(r, npos, n_norm)
         for k in res:
             res[k] += m[k]
+    if all_reduce is not None:
+        for k in res:
+            all_reduce(res[k])
     out = {k: v.cpu().numpy() for k, v in res.items()}
-    ops.raise_if_bad_indices(data.device)
+    if data.device.type == "cuda":
+        ops.raise_if_bad_indices(data.device)
     out["auc"] = 0.0                                                  # the reference reports 0 (:385)
     if return_scores:
         return out, users, torch.cat(kept)

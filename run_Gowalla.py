@@ -4,6 +4,13 @@ eval / checkpoint cadence, same scalar names.  Additions: --dtype, --stages, --d
 
   python run_Gowalla.py --dataset ml100k --model SPUIGACF --adj_type ui_mat --train_mode PairSampling \
       --eval_mode AllNeg --epochs 2 --eval_every 1 --lr 0.002 --weight_decay 0.000001 --droprate 0.2
+
+Several GPUs (where the reference has --parallel True = nn.DataParallel replicas, :104-113): one process per GPU,
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 run_Gowalla.py <the same flags>
+
+runs the SAME loop on a node partition: embedding table, Adam state and edges sharded over the ranks, one RCCL all-gather per
+half-table per propagation stage, every rank ranking its share of the users in the evaluation (ngacf_amd/sharded_loop.py).
 """
 import argparse
 import ast
@@ -14,7 +21,7 @@ import numpy as np
 import torch
 
 import ngacf_amd
-from ngacf_amd import checkpoint as CK, data as D
+from ngacf_amd import checkpoint as CK, data as D, sharded_loop as SL
 from ngacf_amd.train_eval import Interactions, eval_neg_all, train_bpr
 
 
@@ -68,40 +75,61 @@ def create_model(args, U, I, dev):
 
 
 def main(args):
-    dev = torch.device("cuda", int(args.gpu_id.split(",")[0]))
-    torch.cuda.set_device(dev)
+    sharded = SL.in_torchrun()
+    if sharded:                                       # one process per GPU under torchrun: LOCAL_RANK picks the device
+        rank, world, dev = SL.init()
+    else:
+        rank, world = 0, 1
+        dev = torch.device("cuda", int(args.gpu_id.split(",")[0]))
+        torch.cuda.set_device(dev)
+    say = print if rank == 0 else (lambda *a, **k: None)
     data = prepare_data(args, dev)
     adj = data.adjacency()
-    print("userNum:{}, itemNum:{}".format(data.U, data.I))
-    print("lenth of traindf", data.train_u.numel(), "lenth of test_df", data.test_u.numel())
-    print("adj.shape", tuple(adj.shape))
-    model = create_model(args, data.U, data.I, dev)
+    say("userNum:{}, itemNum:{}".format(data.U, data.I))
+    say("lenth of traindf", data.train_u.numel(), "lenth of test_df", data.test_u.numel())
+    say("adj.shape", tuple(adj.shape))
+    if sharded:
+        model = SL.create_model(args.model, args.stages, data.U, data.I, args.embedSize, args.layers, args.droprate, adj, dev,
+                                torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+        say("node partition over %d ranks: %d user rows + %d item rows per rank, %d of %d directed edges on rank 0"
+            % (world, model.part.cu, model.part.ci, model._plan(adj).n_edges_directed, 2 * adj.shape[1]))
+        train_fn, eval_fn, save_fn, load_fn = SL.train_bpr, SL.eval_neg_all, SL.save_checkpoint, SL.load_checkpoint
+    else:
+        model = create_model(args, data.U, data.I, dev)
+        train_fn, eval_fn, save_fn, load_fn = train_bpr, eval_neg_all, CK.save_checkpoint, CK.load_checkpoint
     lossfn = ngacf_amd.BPRLoss()
     # torch.optim.Adam's arithmetic and state_dict; its step() is one ngacf_adam_step launch with the step counters on the
     # device, so the optimizer step is part of the replayed hipGraph of a batch (train_bpr(graph=True))
     optim = ngacf_amd.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
-    os.makedirs("ckpts", exist_ok=True)
+    if rank == 0:
+        os.makedirs("ckpts", exist_ok=True)
     if args.resume_from:
-        # a checkpoint of the reference (run_Gowalla.py:143) or of this runner: both halves in the reference's layout;
-        # the optimizer state is converted to the fused stage parameters (ngacf_amd/checkpoint.py)
-        CK.load_checkpoint("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, args.resume_from), model, optim, map_location=dev)
-        print("=> loaded checkpoint 'ckpts/{}_{:03d}.pkl'".format(args.model, args.resume_from))
+        # a checkpoint of the reference (run_Gowalla.py:143) or of this runner (any world size): both halves in the reference's
+        # layout; the optimizer state is converted to the fused stage parameters (ngacf_amd/checkpoint.py)
+        load_fn("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, args.resume_from), model, optim, map_location=dev)
+        say("=> loaded checkpoint 'ckpts/{}_{:03d}.pkl'".format(args.model, args.resume_from))
     gen = torch.Generator(device=dev)
-    gen.manual_seed(args.seed)
+    gen.manual_seed(args.seed)                        # (the same on every rank: every rank draws the same batches)
     history = []
+    # a sharded step replays as ONE hipGraph (kernels + RCCL launches) only on request: captured collectives are rehearsed on
+    # one rank only, the eager loop is the safe default there
+    graph = (not args.eager) if not sharded else args.sharded_graph
     for epoch in range(args.resume_from, args.epochs):
         t0 = time.time()
-        loss = train_bpr(model, args.batch_size, data, adj, optim, lossfn, gen, graph=not args.eager)
+        loss = train_fn(model, args.batch_size, data, adj, optim, lossfn, gen, graph=graph)
         torch.cuda.synchronize()
-        print("------epoch:{}, train_loss:{:5f}, time consuming:{:.2f}s".format(epoch, loss, time.time() - t0), flush=True)
+        say("------epoch:{}, train_loss:{:5f}, time consuming:{:.2f}s".format(epoch, loss, time.time() - t0), flush=True)
         if (epoch + 1) % args.save_every == 0:
-            CK.save_checkpoint("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, epoch + 1), model, optim)
+            save_fn("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, epoch + 1), model, optim)
         if (epoch + 1) % args.eval_every == 0:
             t0 = time.time()
-            m = eval_neg_all(model, args.batch_size, data, adj)
-            print("epoch:{} metrics:{}".format(epoch, {k: np.round(v, 5).tolist() if k != "auc" else v for k, v in m.items()}))
-            print("The time of evaluate epoch {:03d} is: {:.2f}s".format(epoch, time.time() - t0), flush=True)
+            m = eval_fn(model, args.batch_size, data, adj)
+            say("epoch:{} metrics:{}".format(epoch, {k: np.round(v, 5).tolist() if k != "auc" else v for k, v in m.items()}))
+            say("The time of evaluate epoch {:03d} is: {:.2f}s".format(epoch, time.time() - t0), flush=True)
             history.append((epoch, loss, m))
+    if sharded:
+        import torch.distributed as dist
+        dist.barrier()
     return history
 
 
@@ -129,14 +157,16 @@ def parse(argv=None):
     p.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"])
     p.add_argument("--stages", type=int, default=0, help="0 = the model's own depth; L>0 = SPUIStackedGACF with L stages")
     p.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of one hipGraph replay per batch")
+    p.add_argument("--sharded_graph", action="store_true", help="under torchrun: replay each batch as one hipGraph (kernels + RCCL launches)")
     p.add_argument("--data_root", type=str, default="")
     p.add_argument("--synthetic", type=str, default="", choices=["", "ml100k", "gowalla", "yelp"])
     a = p.parse_args(argv)
     if a.parallel:
         # the reference's --parallel True wraps the model in nn.DataParallel (parallel.py:94-130): every GPU redoes the whole
-        # propagation.  This package's modules refuse to run as replicas; the multi-GPU path is one process per GPU
-        raise SystemExit("--parallel True (nn.DataParallel replicas) is not supported: the multi-GPU path is "
-                         "ngacf_amd.dist.ShardedSPUIGACF under torchrun, e.g. `python bench.py --gpus 8`")
+        # propagation.  Here several GPUs mean one process per GPU on a node partition: the same script under torchrun
+        import sys
+        raise SystemExit("--parallel True (nn.DataParallel replicas, every GPU redoing the whole propagation) is replaced by a node "
+                         "partition with one process per GPU.  Run:\n  " + SL.torchrun_command(sys.argv[1:] if argv is None else argv))
     if a.adj_type != "ui_mat" or a.train_mode != "PairSampling" or a.eval_mode != "AllNeg":
         raise SystemExit("the accelerated path is --adj_type ui_mat --train_mode PairSampling --eval_mode AllNeg (README.md:13-29)")
     return a

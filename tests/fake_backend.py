@@ -137,3 +137,16 @@ def transform_bwd_rows(X, W, H, dH, dS, U, I, heads, win, x_local, feat_drop_p=0
 
 def score(Fm, u, i, U):
     return (Fm[u] * Fm[i + U]).sum(1)
+
+
+def eval_topk(Fm, users, U, I, pool_mask, train_ptr, train_items, K=20):
+    """Stand-in for ops.eval_topk (same signature, CPU tensors): candidates = pool minus the user's train positives, best first,
+    ties to the lower item id (a stable sort of the negated scores)."""
+    sc = Fm[users].double() @ Fm[U:U + I].double().t()
+    sc[:, pool_mask == 0] = -float("inf")
+    for b, u in enumerate(users.tolist()):
+        sc[b, train_items[int(train_ptr[u]):int(train_ptr[u + 1])].long()] = -float("inf")
+    order = torch.sort(-sc, dim=1, stable=True).indices[:, :K]
+    top_s = torch.gather(sc, 1, order)
+    top_i = torch.where(torch.isinf(top_s), torch.full_like(order, -1), order)
+    return top_i.to(torch.int32), top_s.float()

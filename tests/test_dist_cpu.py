@@ -229,3 +229,135 @@ def test_sharded_plan_cache_never_reuses_a_plan_for_another_tensor():
     p3 = m._plan(a)
     assert p3 is not p1 and torch.equal(p1.col, before) and not torch.equal(p3.col, before)
     assert p1.n_edges_directed < 2 * 4                                    # a rank's plan holds its shard only
+
+
+def _loop_data(seed=0, U=60, I=45, n=1400):
+    from ngacf_amd.train_eval import Interactions
+    rs = np.random.RandomState(seed)
+    u = np.concatenate([np.arange(U), rs.randint(0, U, n)])
+    i = np.concatenate([rs.randint(0, I, U), rs.randint(0, I, n)])
+    key = np.unique(u.astype(np.int64) * I + i)
+    u, i = key // I, key % I
+    perm = rs.permutation(len(u))
+    te = perm[:len(u) // 5]
+    tr = perm[len(u) // 5:]
+    tr = np.concatenate([tr, [np.nonzero(u == x)[0][0] for x in range(U) if x not in set(u[tr])]]).astype(np.int64)   # every user trains
+    return Interactions(u[tr], i[tr], u[te], i[te], U, I, "cpu")
+
+
+def _run_loop(world, rank, ckpt_dir, epochs=2):
+    """Two epochs + evaluation + checkpoint of the sharded runner's loop on CPU tensors (torch stand-in kernels, host sampler)."""
+    import fake_backend
+    from ngacf_amd import sharded_loop as SL
+    data = _loop_data()
+    adj = data.adjacency()
+    torch.manual_seed(2019)
+    m = SL.create_model("SPUIMultiGACF", 0, data.U, data.I, 64, [64, 64], 0.0, adj, torch.device("cpu"), backend=fake_backend,
+                        world=world, rank=rank)
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(20.0); m.iEmbd.weight.mul_(20.0)
+    opt = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-5)
+    lossfn = lambda p, n: -torch.log(torch.sigmoid(p - n)).mean()
+    gen = torch.Generator().manual_seed(5)
+    losses = [SL.train_bpr(m, 256, data, adj, opt, lossfn, gen) for _ in range(epochs)]
+    metrics = SL.eval_neg_all(m, 256, data, adj, topk=fake_backend.eval_topk)
+    path = os.path.join(ckpt_dir, "w%d.pkl" % world)
+    SL.save_checkpoint(path, m, opt)
+    return losses, metrics, m, opt, path
+
+
+def _loop_worker(rank, world, port, ckpt_dir, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, HERE)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        from ngacf_amd import sharded_loop as SL
+        r, w, dev = SL.init(device=torch.device("cpu"))
+        assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+        losses, metrics, m, opt, path = _run_loop(world, rank, ckpt_dir)
+        # resume on this world size from the checkpoint rank 0 wrote: same moments on the rows this rank owns
+        m2 = SL.create_model("SPUIMultiGACF", 0, m.userNum, m.itemNum, 64, [64, 64], 0.0, _loop_data().adjacency(), torch.device("cpu"),
+                             backend=__import__("fake_backend"), world=world, rank=rank)
+        opt2 = torch.optim.Adam(m2.parameters(), lr=0.01, weight_decay=1e-5)
+        SL.load_checkpoint(path, m2, opt2)
+        same = all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+        for (pa, sa), (pb, sb) in zip(opt.state.items(), opt2.state.items()):
+            same = same and torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]) and float(sa["step"]) == float(sb["step"])
+        q.put((rank, {"losses": losses, "metrics": {k: np.asarray(v).tolist() for k, v in metrics.items() if k != "auc"}, "resume_same": same}))
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, {"exception": "%s\n%s" % (e, traceback.format_exc())}))
+
+
+def test_sharded_runner_loop_under_gloo_equals_one_rank(tmp_path):
+    """ngacf_amd/sharded_loop.py (what `torchrun run_Gowalla.py` runs) at world size 2 under gloo against the same loop on one rank:
+    same batches on every rank, same epoch losses, same Recall/NDCG/precision/hit ratio (each rank ranks half of the users, the
+    sums are all-reduced), a checkpoint in the reference's layout that resumes at world size 2 AND at world size 1 with the same
+    weights and Adam moments."""
+    from ngacf_amd import sharded_loop as SL
+    import fake_backend
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert "exception" not in res[r], res[r].get("exception")
+    assert res[0]["losses"] == res[1]["losses"] and res[0]["metrics"] == res[1]["metrics"] and res[0]["resume_same"] and res[1]["resume_same"]
+    losses1, metrics1, m1, opt1, path1 = _run_loop(1, 0, str(tmp_path))
+    assert np.allclose(res[0]["losses"], losses1, rtol=1e-5, atol=1e-8), (res[0]["losses"], losses1)
+    assert res[0]["losses"][1] < res[0]["losses"][0]
+    for k in ("precision", "recall", "ndcg", "hit_ratio"):
+        assert np.allclose(res[0]["metrics"][k], metrics1[k], atol=1e-9), (k, res[0]["metrics"][k], metrics1[k])
+    assert metrics1["hit_ratio"][3] > 0
+    # the world-2 checkpoint (reference layout: 53 optimizer entries, full tables) resumes on ONE rank with the one-rank run's state
+    ck2, ck1 = torch.load(str(tmp_path / "w2.pkl")), torch.load(path1)
+    assert list(ck2["model"]) == list(ck1["model"]) and len(ck2["optim"]["param_groups"][0]["params"]) == 53
+    for k in ck1["model"]:
+        assert float((ck2["model"][k] - ck1["model"][k]).abs().max()) < 1e-5, k
+    for j in range(53):
+        for k in ("exp_avg", "exp_avg_sq"):
+            a, b = ck2["optim"]["state"][j][k], ck1["optim"]["state"][j][k]
+            assert a.shape == b.shape and float((a - b).abs().max()) < 1e-5 * max(float(b.abs().max()), 1e-6) + 1e-9, (j, k)
+    m3 = SL.create_model("SPUIMultiGACF", 0, m1.userNum, m1.itemNum, 64, [64, 64], 0.0, _loop_data().adjacency(), torch.device("cpu"),
+                         backend=fake_backend, world=1, rank=0)
+    opt3 = torch.optim.Adam(m3.parameters(), lr=0.01, weight_decay=1e-5)
+    SL.load_checkpoint(str(tmp_path / "w2.pkl"), m3, opt3)
+    assert float((m3.uEmbd.weight - m1.uEmbd.weight).abs().max()) < 1e-5
+
+
+def test_sharded_model_draws_the_unsharded_models_initial_values():
+    """Same torch seed -> the sharded model's full state_dict equals the unsharded model's, at any world size (the constructor
+    draws in the unsharded constructor's order on full-size tables and keeps its rows)."""
+    import ngacf_amd
+    import fake_backend
+    from ngacf_amd.dist import ShardedSPUIGACF
+    U, I = 37, 29
+    for stages, cls in ((2, ngacf_amd.SPUIGACF), (3, ngacf_amd.SPUIMultiGACF)):
+        torch.manual_seed(7)
+        ref = cls(U, I, 64, [64, 64], 0.1, useCuda=False).state_dict()
+        for world in (1, 3):
+            got = {}
+            for rank in range(world):
+                torch.manual_seed(7)
+                m = ShardedSPUIGACF(U, I, 64, [64, 64], 0.1, world=world, rank=rank, stages=stages, backend=fake_backend)
+                ou, oi = m.part.local_original_ids()
+                for k, v in m.gat.state_dict().items():
+                    assert torch.equal(v, ref["gat." + k]), (world, rank, k)
+                got.setdefault("u", torch.zeros(U, 64))[ou[ou >= 0]] = m.uEmbd.weight.detach()[ou >= 0]
+                got.setdefault("i", torch.zeros(I, 64))[oi[oi >= 0]] = m.iEmbd.weight.detach()[oi >= 0]
+            assert torch.equal(got["u"], ref["uEmbd.weight"]) and torch.equal(got["i"], ref["iEmbd.weight"]), (stages, world)
+
+
+def test_runner_parallel_flag_names_the_torchrun_command():
+    import run_Gowalla as RG
+    with pytest.raises(SystemExit) as e:
+        RG.parse(["--dataset", "ml100k", "--parallel", "True", "--epochs", "3"])
+    msg = str(e.value)
+    assert "torch.distributed.run" in msg and "--nproc-per-node" in msg and "run_Gowalla.py --dataset ml100k --epochs 3" in msg

@@ -220,3 +220,79 @@ def test_ranks_sharing_one_gpu_under_gloo_match_the_single_gpu_model(world, bf16
         assert err["score"] < tol_s and err["table"] < tol_s, (rank, err)
         assert max(err["gu"], err["gi"], err["gat"]) < tol_g and err["pad"] == 0.0, (rank, err)
     assert sum(err["edges"][0] for _, err in res) == res[0][1]["edges"][1]
+
+
+def _run_runner(tmp, flags, world):
+    """run_Gowalla.py as a user would start it: one process (world 1) or `world` processes with torchrun's environment, all on
+    cuda:0 with gloo collectives (RCCL refuses two ranks per GPU).  Returns rank 0's stdout."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base["PYTHONPATH"] = root + os.pathsep + base.get("PYTHONPATH", "")
+    cmd = [sys.executable, os.path.join(root, "run_Gowalla.py")] + flags
+    if world == 1:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp, env=base)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return r.stdout
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(world):
+        env = dict(base, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   NGACF_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, env=env))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    assert "train_loss" not in outs[1][0]                              # only rank 0 reports
+    return outs[0][0]
+
+
+def _parse_runner(out):
+    import ast
+    import re
+    losses = [float(x) for x in re.findall(r"train_loss:([0-9.eE+-]+)", out)]
+    metrics = [ast.literal_eval(m) for m in re.findall(r"metrics:(\{.*\})", out)]
+    return losses, metrics
+
+
+def test_run_gowalla_under_torchrun_environment_equals_the_single_process_run(tmp_path):
+    """`torchrun run_Gowalla.py` -- the reference's train / eval loop on the node partition.  Two ranks (both on
+    cuda:0, gloo) against the single-process runner, ml100k, README hyper-parameters without dropout (so that both are
+    deterministic): same epoch losses and the same Recall/NDCG/precision/hit ratio @1,5,10,20 (each rank ranks half of the users);
+    the checkpoint rank 0 wrote (reference layout) resumes in BOTH runners onto the same third epoch.  With dropout 0.2 the
+    two-rank run lands in the reference's own band (fixture g12)."""
+    flags = ["--dataset", "ml100k", "--model", "SPUIGACF", "--epochs", "2", "--eval_every", "1", "--save_every", "2", "--lr", "0.002",
+             "--weight_decay", "0.000001", "--droprate", "0.0", "--eager"]
+    d1, d2 = tmp_path / "one", tmp_path / "two"
+    d1.mkdir(); d2.mkdir()
+    l1, m1 = _parse_runner(_run_runner(str(d1), flags, 1))
+    out2 = _run_runner(str(d2), flags, 2)
+    l2, m2 = _parse_runner(out2)
+    assert "node partition over 2 ranks" in out2 and len(l1) == len(l2) == 2 and len(m1) == len(m2) == 2
+    assert np.allclose(l1, l2, rtol=2e-3), (l1, l2)
+    for a, b in zip(m1, m2):
+        for k in ("precision", "recall", "ndcg", "hit_ratio"):
+            assert np.allclose(a[k], b[k], atol=5e-3), (k, a[k], b[k])
+    # resume: the sharded run's checkpoint in the single-process runner and vice versa
+    import shutil
+    (d1 / "ckpts_own").mkdir()
+    shutil.copy(str(d2 / "ckpts" / "SPUIGACF_ml100k_002.pkl"), str(d1 / "ckpts" / "SPUIGACF_ml100k_002.pkl"))
+    res = flags[:4] + ["--epochs", "3", "--resume_from", "2"] + flags[6:]
+    l1r, _ = _parse_runner(_run_runner(str(d1), res, 1))
+    l2r, _ = _parse_runner(_run_runner(str(d2), res, 2))
+    assert len(l1r) == len(l2r) == 1 and np.allclose(l1r, l2r, rtol=2e-3) and l2r[0] < l2[1] * 1.05, (l1r, l2r, l2)
+    # with dropout: inside the reference's band (the distributional statement of test_ml100k_two_epochs_reach_reference_metrics)
+    from conftest import load_golden
+    ref = load_golden("g12_ref_ml100k_train")
+    d3 = tmp_path / "drop"
+    d3.mkdir()
+    flags_d = [f if f != "0.0" else "0.2" for f in flags]
+    _, m3 = _parse_runner(_run_runner(str(d3), flags_d, 2))
+    nref = len(ref["random_seeds"])
+    for key in ("recall", "ndcg"):
+        r = np.array([ref["%s.%d" % (key, j)][3] for j in range(nref)])
+        w = r.max() - r.min()
+        assert r.min() - 0.5 * w < m3[-1][key][3] < r.max() + 0.5 * w, (key, m3[-1][key][3], r)
