@@ -151,6 +151,31 @@ def copy_rate_GBps(torch, dev, gib=1, reps=10):
     return round(reps * 2 * (gib << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
+def usable_cpus():
+    """CPUs this process may really use: the smallest of os.cpu_count(), the scheduler affinity and the cgroup CPU quota (a GPU
+    box hands a one-GPU job a share of its host: 16 of 256 CPUs on the MI355X pool)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(math.ceil(int(txt[0]) / float(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(math.ceil(q / float(per)))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_model_name():
     try:
         for ln in open("/proc/cpuinfo"):

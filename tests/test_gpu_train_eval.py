@@ -417,7 +417,8 @@ def test_bench_prints_one_contract_line():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
-    assert d["cpu_baseline"]["cores"] <= 16 and ("all_cores" not in d["cpu_baseline"] or d["cpu_baseline"]["all_cores"]["cores"] == os.cpu_count())
+    ac = d["cpu_baseline"]["all_cores"]                                   # every usable core, or why that is the 16-thread figure already
+    assert d["cpu_baseline"]["cores"] <= 16 and (ac["value"] is not None or "skipped" in ac)
     assert "workload" in d["config"] and d["value"] > 1e9 and d["bpr_pairs_per_s"] > 1e5
     # the timed region: exactly `steps` steps of passes_per_step passes, sized to last about --target-seconds
     R = d["config"]["passes_per_step"]

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Regenerates the round's bench / profile files under gpurun_out/refresh/ on the GPU box (copy what is wanted into profiles/).
-#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh [tag]'
-tag=${1:-r02}
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh [tag] [part]'      part: all | bench | pmc | train
+tag=${1:-r03}
+part=${2:-all}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/refresh
@@ -13,20 +14,32 @@ prof() {   # prof <name> <bench args...>: rocprofv3 kernel stats of a bench run
   cp "$(find $out/prof_$name -name 'k_kernel_stats.csv' | head -1)" $out/${tag}_bench_${name}_kernel_stats.csv
   rm -rf $out/prof_$name $out/prof_$name.err
 }
-say "default bench (with probe)";        timeout -k 10 500 python bench.py > $out/${tag}_bench_gowalla_bf16.json 2> $out/err.log || exit 1
+if [ "$part" = all ] || [ "$part" = bench ]; then
+say "default bench (with the Yelp and 10^9-edge probes)"; timeout -k 10 600 python bench.py > $out/${tag}_bench_gowalla_bf16.json 2> $out/err.log || exit 1
 say "gowalla bf16 under rocprof";        prof gowalla_bf16 --steps 20 --warmup 5 --no-probe || exit 1
-for cfg in "yelp bf16" "yelp fp32" "gowalla fp32" "gowalla128 bf16"; do
+say "gowalla bf16, transforms as their own launches (A/B)"; NGACF_FUSE_NEXT=0 timeout -k 10 300 python bench.py --no-probe --no-cpu-baseline > $out/${tag}_bench_gowalla_bf16_unfused.json 2>> $out/err.log || exit 1
+for cfg in "yelp bf16" "yelp fp32" "gowalla fp32" "gowalla128 bf16" "gowalla128 fp32"; do
   set -- $cfg
   say "bench $1 $2";                     timeout -k 10 300 python bench.py --workload $1 --dtype $2 --no-probe --cpu-budget 4 > $out/${tag}_bench_$1_$2.json 2>> $out/err.log || exit 1
 done
 say "synthetic200m";                     timeout -k 10 500 python bench.py --workload synthetic200m --steps 10 --warmup 2 > $out/${tag}_bench_synthetic200m_bf16.json 2>> $out/err.log || exit 1
 say "synthetic200m under rocprof";       prof synthetic200m_bf16 --workload synthetic200m --steps 5 --warmup 1 --no-cpu-baseline || exit 1
 say "rehearsal (1 RCCL rank)";           NGACF_BENCH_FORCE_DIST=1 timeout -k 10 400 python bench.py --gpus 1 > $out/${tag}_bench_rehearsal_1rank_rccl.json 2>> $out/err.log || exit 1
+fi
+if [ "$part" = all ] || [ "$part" = pmc ]; then
+say "PMC traffic + L2 hit rate: gowalla"; timeout -k 10 600 python tools/traffic.py gowalla bf16,fp32 > $out/traffic_gowalla.log 2>&1 && cp gpurun_out/${tag}_traffic_gowalla.json $out/
+say "PMC traffic + L2 hit rate: yelp";    timeout -k 10 600 python tools/traffic.py yelp bf16,fp32 > $out/traffic_yelp.log 2>&1 && cp gpurun_out/${tag}_traffic_yelp.json $out/
+say "PMC traffic: synthetic1b";           timeout -k 10 900 python tools/traffic.py synthetic1b bf16 > $out/traffic_1b.log 2>&1 && cp gpurun_out/${tag}_traffic_synthetic1b.json $out/
+say "PMC traffic: synthetic200m";         timeout -k 10 600 python tools/traffic.py synthetic200m bf16 > $out/traffic_200m.log 2>&1 && cp gpurun_out/${tag}_traffic_synthetic200m.json $out/
+fi
+if [ "$part" = all ] || [ "$part" = train ]; then
 say "train step breakdown";              timeout -k 10 300 python tools/train_profile.py --profile > $out/tp_refsem.log 2>&1 && cp gpurun_out/trainprof_refsem.txt $out/${tag}_trainstep_kernels_refsem.txt
 timeout -k 10 300 python tools/train_profile.py --profile --shared > $out/tp_shared.log 2>&1 && cp gpurun_out/trainprof_shared.txt $out/${tag}_trainstep_kernels_shared.txt
 timeout -k 10 200 python tools/train_profile.py > $out/${tag}_trainstep.jsonl 2>/dev/null; timeout -k 10 200 python tools/train_profile.py --shared >> $out/${tag}_trainstep.jsonl 2>/dev/null
 NGACF_SPARSE_LAST=0 timeout -k 10 200 python tools/train_profile.py >> $out/${tag}_trainstep.jsonl 2>/dev/null
+NGACF_FUSE_NEXT=0 timeout -k 10 200 python tools/train_profile.py >> $out/${tag}_trainstep.jsonl 2>/dev/null
 timeout -k 10 200 python tools/train_profile.py --torch-adam >> $out/${tag}_trainstep.jsonl 2>/dev/null
-say "sparse stage probe";                timeout -k 10 300 python tools/sparse_probe.py > $out/${tag}_sparse_probe_gowalla.log 2>&1
+say "epoch + evaluation";                timeout -k 10 300 python tools/eval_bench.py --epochs 3 > $out/${tag}_epoch_eval_gowalla.log 2>&1
 rm -rf gpurun_out/trainprof
+fi
 say done
