@@ -236,6 +236,209 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// forward, exact fp32 matrix cores, second form (round 3): v_mfma_f32_16x16x4_f32 and K / V tiles staged through LDS.
+//   * workgroup = NW waves per (head, 32-query block); a STAGE = 32 * NW keys whose K and V rows every thread fetches once
+//     (16-byte pieces, coalesced per row) into registers while the previous stage is computed, then parks in LDS (K transposed:
+//     the score product's A operand becomes a conflict-free ds_read_b32) -- one barrier per stage, double buffered; the first
+//     form issued 16 dependent dword loads of V per wave and tile straight from global.
+//   * S^T block (16 keys x 16 queries) = K_blk . Q_blk^T, d_k / 4 MFMAs; lane (n = l & 15, g = l >> 4) then holds the scores of
+//     query n with keys 4g .. 4g+3 -- and register r of all lanes IS the B operand (keys {r, 4+r, 8+r, 12+r} x queries) of the
+//     next product O^T += V^T . P^T, as in the 32x32 form: no LDS round trip for P.  With 16-row output blocks a d_k = 8 head
+//     wastes half of the PV matrix-core rows instead of three quarters (768 instead of 1280 matrix-pipe cycles per 32 x 32 tile).
+//   * a lane owns TWO queries (n and 16 + n) and sees 8 of a tile's 32 keys for each: max / sum are 8 registers + two exchanges
+//     (lanes 16 and 32 apart); scale, mask and tail tests run only where they can matter.
+// Same semantics and outputs as mha_fwd_kernel (which stays for bf16 operands).
+// ---------------------------------------------------------------------------------------------------------
+typedef float mha_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lane_xor16(float v, int g) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((g & 1) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v, int g) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((g & 2) ? r[0] : r[1]);
+}
+
+template <int DK, int NW, bool DROP, bool MASK>
+__global__ __launch_bounds__(NW * 64) void mha_fwd16_kernel(const MhaArgs a) {
+    constexpr int SK = 32 * NW;                 // keys per stage
+    constexpr int NT = 64 * NW;
+    constexpr int FB = (DK + 15) / 16;          // 16-feature blocks of the output
+    constexpr int KQ = DK / 4;                  // k-steps of the score product
+    constexpr int PC = DK / 8;                  // 16-byte pieces per thread, stage and matrix  (SK * DK / 4 / NT)
+    extern __shared__ __attribute__((aligned(16))) float mha_lds[];
+    float* const Kt = mha_lds;                  // [2][DK][SK]   transposed key tile
+    float* const Vs = mha_lds + 2 * DK * SK;    // [2][SK][DK]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int qblocks = (a.Nq + 31) / 32;
+    const int h = blockIdx.x / qblocks, q0 = (blockIdx.x % qblocks) * 32;
+    const uint32_t salt_h = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + h) : 0u;
+    const int mwords = (a.Nk + 31) >> 5;
+    int qi[2];
+    float qreg[2][KQ];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qi[qb] = min(q0 + 16 * qb + n, a.Nq - 1);
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) qreg[qb][t] = a.Q[(size_t)qi[qb] * a.dim + h * DK + 4 * t + g];
+    }
+    mha_f32x4 o[FB][2];
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) o[fb][qb] = mha_f32x4{0.f, 0.f, 0.f, 0.f};
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+
+    float4 kst[PC], vst[PC];
+    auto fetch = [&](int s) {                   // stage s: this thread's pieces of K and V (rows beyond Nk: the last row, masked later)
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            const int p = tid + i * NT, key = p / (DK / 4), c = p % (DK / 4);
+            const size_t row = (size_t)min(s * SK + key, a.Nk - 1) * a.dim + h * DK + 4 * c;
+            kst[i] = *reinterpret_cast<const float4*>(a.K + row);
+            vst[i] = *reinterpret_cast<const float4*>(a.V + row);
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            const int p = tid + i * NT, key = p / (DK / 4), c = p % (DK / 4);
+            float* kt = Kt + buf * DK * SK + (4 * c) * SK + key;
+            kt[0] = kst[i].x; kt[SK] = kst[i].y; kt[2 * SK] = kst[i].z; kt[3 * SK] = kst[i].w;
+            *reinterpret_cast<float4*>(Vs + buf * SK * DK + key * DK + 4 * c) = vst[i];
+        }
+    };
+    const int nstage = (a.Nk + SK - 1) / SK;
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstage) fetch(s + 1);       // in flight under this stage's arithmetic
+        const int k0 = s * SK + 32 * wv;        // this wave's 32 keys
+        if (k0 < a.Nk) {
+            const float* kt = Kt + buf * DK * SK + 32 * wv;
+            const float* vs = Vs + buf * SK * DK + 32 * wv * DK;
+            mha_f32x4 sc[2][2];                 // [kb][qb]: keys 16 kb + 4 g + r, query 16 qb + n
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float ka[KQ];
+#pragma unroll
+                for (int t = 0; t < KQ; ++t) ka[t] = kt[(4 * t + g) * SK + 16 * kb + n];
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    mha_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < KQ; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[t], qreg[qb][t], acc, 0, 0, 0);
+                    sc[kb][qb] = acc;
+                }
+            }
+            const bool tail = k0 + 32 > a.Nk;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                uint32_t mw = 0xffffffffu;
+                if (MASK) mw = a.mask[(size_t)qi[qb] * mwords + (k0 >> 5)];
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kk = 16 * kb + 4 * g + r;
+                        float v = sc[kb][qb][r] * a.scale;
+                        if (MASK) v = ((mw >> kk) & 1u) ? v : MHA_MASKED;             // masked_fill(mask == 0, -1e9)
+                        if (tail) v = k0 + kk < a.Nk ? v : -INFINITY;
+                        sc[kb][qb][r] = v;
+                        tmax = fmaxf(tmax, v);
+                    }
+                tmax = fmaxf(tmax, lane_xor16(tmax, g));
+                tmax = fmaxf(tmax, lane_xor32(tmax, g));
+                const float mnew = fmaxf(m[qb], tmax);
+                const float corr = __expf(m[qb] - mnew);                              // exp(-inf) = 0 on the first tile
+                float psum = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p = __expf(sc[kb][qb][r] - mnew);
+                        psum += p;
+                        if (DROP) p *= drop_mul(a, salt_h, qi[qb], k0 + 16 * kb + 4 * g + r);
+                        sc[kb][qb][r] = p;
+                    }
+                psum += lane_xor16(psum, g);
+                psum += lane_xor32(psum, g);
+                l[qb] = l[qb] * corr + psum;
+                m[qb] = mnew;
+#pragma unroll
+                for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[fb][qb][r] *= corr;
+            }
+            // O^T += V^T . P^T: for register r of block kb the contraction runs over the keys 16 kb + 4 k + r, k = 0..3
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int fb = 0; fb < FB; ++fb) {
+                        const float va = (16 * fb + n < DK) ? vs[(16 * kb + 4 * g + r) * DK + 16 * fb + n] : 0.f;
+#pragma unroll
+                        for (int qb = 0; qb < 2; ++qb)
+                            o[fb][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(va, sc[kb][qb][r], o[fb][qb], 0, 0, 0);
+                    }
+        }
+        if (s + 1 < nstage) park(buf ^ 1);      // (every wave left that buffer at the previous barrier)
+        __syncthreads();
+    }
+    // merge the NW waves' (max, sum, O) of every query in wave order (deterministic); the stage buffers are free now
+    float* const mlb = mha_lds;                                   // [2][NW][2][16]
+    float* const ob = mha_lds + 2 * NW * 32;                      // [NW][FB * 2 * 4][64]
+    if (g == 0) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            mlb[(0 * NW + wv) * 32 + 16 * qb + n] = m[qb];
+            mlb[(1 * NW + wv) * 32 + 16 * qb + n] = l[qb];
+        }
+    }
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[(wv * FB * 8 + (fb * 2 + qb) * 4 + r) * 64 + lane] = o[fb][qb][r];
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float M = -INFINITY, L = 0.f, f[NW];
+#pragma unroll
+        for (int x = 0; x < NW; ++x) M = fmaxf(M, mlb[(0 * NW + x) * 32 + 16 * qb + n]);
+#pragma unroll
+        for (int x = 0; x < NW; ++x) {
+            f[x] = __expf(mlb[(0 * NW + x) * 32 + 16 * qb + n] - M);       // a wave without keys: m = -inf, factor 0
+            L = fmaf(mlb[(1 * NW + x) * 32 + 16 * qb + n], f[x], L);
+        }
+        const int q = q0 + 16 * qb + n;
+        const float inv = 1.f / L;
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int x = 0; x < NW; ++x) acc = fmaf(ob[(x * FB * 8 + (fb * 2 + qb) * 4 + r) * 64 + lane], f[x], acc);
+                v[r] = acc * inv;
+            }
+            if (q < a.Nq && 16 * fb + 4 * g < DK)
+                *reinterpret_cast<float4*>(a.O + (size_t)q * a.dim + h * DK + 16 * fb + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (q < a.Nq && g == 0) *reinterpret_cast<float2*>(a.LSE + 2 * ((size_t)q * a.heads + h)) = make_float2(M, inv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // backward 1: delta = dO . O per head, and dQ.  wave per (head, 32-query block); lane = query
 //   P = exp(s - LSE);  dPd = dO . V^T;  dS = P * (dPd * dropmul - delta) * scale on unmasked entries, 0 on masked ones
 //   (masked_fill cuts the gradient);  dQ = dS K
@@ -340,6 +543,17 @@ static int launch_mha(const MhaArgs& a, bool backward, bool drop, hipStream_t st
     const int qw = ((a.Nq + 31) / 32) * a.heads, kw = ((a.Nk + 31) / 32) * a.heads;
     const dim3 block(256), gq(qw), gk(kw);                           // one workgroup (4 waves) per 32-row block and head
     if (!backward) {
+        if constexpr (!BF) {                                         // exact fp32: the 16x16x4 form with LDS-staged K / V
+            constexpr int NW = DK == 32 ? 4 : 8;
+            constexpr size_t lds = (size_t)4 * DK * 32 * NW * sizeof(float);
+            const bool mk = a.mask != nullptr;
+#define NGACF_MHA16(DR, MK) hipLaunchKernelGGL((mha_fwd16_kernel<DK, NW, DR, MK>), gq, dim3(64 * NW), lds, st, a)
+            if (drop) { if (mk) NGACF_MHA16(true, true); else NGACF_MHA16(true, false); }
+            else      { if (mk) NGACF_MHA16(false, true); else NGACF_MHA16(false, false); }
+#undef NGACF_MHA16
+            NGACF_CHECK_LAUNCH();
+            return 0;
+        }
         if (drop) hipLaunchKernelGGL((mha_fwd_kernel<BF, DK, true>), gq, block, 0, st, a);
         else      hipLaunchKernelGGL((mha_fwd_kernel<BF, DK, false>), gq, block, 0, st, a);
         NGACF_CHECK_LAUNCH();
