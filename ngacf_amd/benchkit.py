@@ -21,6 +21,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md);
 ROOF_L2_GATHER_GBS = 17800.0     # ... an XCD's 4 MiB L2 (16.8-18.8 TB/s)
 ROOF_MALL_GATHER_GBS = 8600.0    # ... the 256 MiB Infinity Cache, random rows of a 38 MB table (151 MB: 7.4-7.9 TB/s)
 ROOF_HBM_GATHER_GBS = 5800.0     # ... HBM, random whole rows of a table far beyond the Infinity Cache, each fetched once
+L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md, "L2 (per XCD)": ~34.5 TB/s aggregate, the cache's own measured peak
 L2_BYTES_PER_XCD = 4 << 20
 MALL_BYTES = 256 << 20
 
