@@ -141,11 +141,13 @@ int ngacf_prop_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  * on the matrix cores (v_mfma_f32_16x16x32_bf16; operands = the bf16 values that `out` stores, fp32 accumulate, H' rounded
  * to bf16 and S' formed from the rounded values: what ngacf_transform_fwd computes from the stored table).  One dependent
  * launch and one write + read of the [N][d] table less per stage.
- *   next->panel   the next stage's W as bf16 matrix-core fragments, written by ngacf_transform_fwd_pack (2 * din * dout * 2 bytes)
- *   next->avec    float[2][dout']        next->H  [N][dout'] bf16        next->S  float[N][heads']
+ *   next->panel   bf16 storage: the next stage's W as bf16 matrix-core fragments, written by ngacf_transform_fwd_pack
+ *                 (2 * din * dout * 2 bytes); fp32 storage: the next stage's W itself, float[2][64][dout'] (exact fp32 matrix
+ *                 cores, v_mfma_f32_16x16x4_f32: the stand-alone fp32 transform's fmaf chains, the same bits)
+ *   next->avec    float[2][dout']        next->H  [N][dout'] in the stage's storage type        next->S  float[N][heads']
  *   next->dout in {64, 128}, next->heads in {1, dout' / 8}; next->feat_drop_p / next->seed: the next stage's feature dropout
  *   (mask keyed by (seed', n, c) exactly as in ngacf_transform_fwd; the device addend seed_dev is shared with this stage).
- * Restrictions: dtype NGACF_BF16, d == 64, heads == 8, NGACF_SCORE_ROW, no `needed`, no workgroup-per-row hubs (nhub == 0), and
+ * Restrictions: d == 64, heads == 8, NGACF_SCORE_ROW, no `needed`, no workgroup-per-row hubs (nhub == 0), and
  * hub rows finished in-kernel (part_split + tickets given) or absent.  `out` may be NULL (an evaluation forward needs only
  * H' and S'); agg / R as in ngacf_prop_fwd.  next == NULL: exactly ngacf_prop_fwd. */
 typedef struct ngacf_next_stage {

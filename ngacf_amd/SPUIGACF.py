@@ -325,13 +325,15 @@ class _GATBase(nn.Module):
         # weight panels are packed by the FIRST transform's launch (functional.StageLink).
         shapes = self.stage_shapes()
         fuse = [False] * L                                   # fuse[s]: stage s's transform is done by stage s-1's traversal
-        if NF.FUSE_NEXT and self.compute_dtype == torch.bfloat16 and features.is_cuda:
+        if NF.FUSE_NEXT and features.is_cuda:
             for s in range(1, L):
                 fuse[s] = (NF.ops.can_fuse_next(plan, self.compute_dtype, shapes[s - 1][1], shapes[s - 1][2])
                            and shapes[s][0] == 64 and shapes[s][1] in (64, 128))
         link = NF.StageLink() if any(fuse) else None
-        if link is not None:
-            link.pack = {s: ops_[s][0].detach() for s in range(1, L) if fuse[s]}
+        if link is not None and self.compute_dtype == torch.bfloat16:
+            link.pack = {s: ops_[s][0].detach() for s in range(1, L) if fuse[s]}       # bf16 fragments, packed by the first transform's launch
+        elif link is not None:
+            link.panels = {s: ops_[s][0].detach().contiguous().float() for s in range(1, L) if fuse[s]}   # fp32: the weights themselves
         for s, layers in enumerate(stages):
             W, avec = ops_[s]
             # feature dropout in front of every stage (:208,:213) and the ELU behind it (:397 inside

@@ -183,6 +183,94 @@ __device__ __forceinline__ void next_transform_tail(const PropArgs& a, uint4* xt
     mfma_fwd_epilogue<OT, NH, NEXT>(acc, ok ? nrow : 0, ok, h, av, a.next_H, a.next_S);
 }
 
+// The same for fp32 storage.  A lane group finishes a row of 64 fp32 columns with 16 lanes, so a wave finishes 4 rows and the
+// workgroup 16: exactly the 16 node columns of v_mfma_f32_16x16x4_f32, the exact-fp32 matrix-core instruction (its accumulation
+// is the fmaf chain of transform.hip's stand-alone kernel, k ascending: the same bits).
+//   tile   [16 rows][64 fp32], row stride 68 floats: the B-operand reads (node n, feature 4t + g) hit 64 distinct banks;
+//   panel  the next stage's W'[type] as it stands, [64][NEXT] fp32, brought in by LDS-DMA with the 16-float column blocks of
+//          row k XOR-ed by (k & 3) on the SOURCE side, so that the A-operand reads (four rows k = 4t + g of one column) spread
+//          over four bank groups instead of one;
+//   wave w owns the output columns 16 w .. +15 (and 64 + 16 w .. for NEXT = 128) of all 16 rows: 16 MFMAs per block, complete
+//   k chains; lane (n = l & 15, g = l >> 4) ends up with columns 16 cb + 4 g .. +3 of row n: one 16-byte store of H'.
+//   S' like transform.hip: 4-column partial dot products, then the same pairing tree (lane pairs, quads, and for a one-head stage
+//   the four column blocks, which meet through LDS).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int XROW_F32 = 68;
+
+template <int D, int NEXT, bool NONE>
+__device__ __forceinline__ void next_transform_tail_f32(const PropArgs& a, float* xtile, int* xmeta, const float* panel, const float* av,
+                                                        float* sx, bool valid, int row, int slot, int q, const float (&o)[4]) {
+    static_assert(D == 64, "fp32 fused transform: 64 input columns");
+    constexpr int CB = NEXT / 64;                        // column blocks of 16 per wave
+    constexpr int NH = NONE ? 1 : NEXT / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tr = 4 * wave + slot;
+    if (valid) {
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = o[j];
+        if (a.next_drop_thr) {
+            const uint32_t salt = salt_of(a.next_seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = feat_bits(salt, row, 4 * q + j) >= a.next_drop_thr ? x[j] * a.next_drop_scale : 0.f;
+        }
+        *reinterpret_cast<float4*>(xtile + tr * XROW_F32 + 4 * q) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+    if (q == 0) xmeta[tr] = valid ? row : -1;
+    __syncthreads();                                          // tile + panel (LDS-DMA drained in front of it) are in LDS
+    const int n = lane & 15, g = lane >> 4;
+    const int nrow = xmeta[n];
+    const bool ok = nrow >= 0;
+    f32x4_t acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int t = 0; t < D / 4; ++t) {
+        const int k = 4 * t + g;
+        const float xb = xtile[n * XROW_F32 + k];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int col = 64 * c + 16 * wave + n;
+            const float wa = panel[k * NEXT + (col ^ (16 * g))];            // (k & 3) == g: the panel's source-side swizzle
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xb, acc[c], 0, 0, 0);
+        }
+    }
+    float part[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int c0 = 64 * c + 16 * wave + 4 * g;
+        const float4 a4 = *reinterpret_cast<const float4*>(av + c0);
+        float p = 0.f;
+        p = fmaf(acc[c][0], a4.x, p); p = fmaf(acc[c][1], a4.y, p); p = fmaf(acc[c][2], a4.z, p); p = fmaf(acc[c][3], a4.w, p);
+        part[c] = p;
+        if (ok) *reinterpret_cast<float4*>(static_cast<float*>(a.next_H) + (size_t)nrow * NEXT + c0) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+    }
+    auto x16 = [&](float v) { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                              return __uint_as_float((g & 1) ? r[0] : r[1]); };
+    auto x32 = [&](float v) { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                              return __uint_as_float((g & 2) ? r[0] : r[1]); };
+    if constexpr (!NONE) {                                    // 8-wide heads: this lane's 4 columns + the 4 of the lane 16 away
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const float hsum = part[c] + x16(part[c]);
+            if (ok && (g & 1) == 0) a.next_S[(size_t)nrow * NH + 8 * c + 2 * wave + (g >> 1)] = hsum;
+        }
+    } else {
+        // one head: transform.hip adds a thread's 4-column partials of the 64-column groups first, then runs a tree over its 16
+        // threads (pairs, quads, eights, sixteen); the same order here -- pairs and quads across the lanes, the four column
+        // blocks of a group (= the four waves) through LDS
+        float p = part[0];
+#pragma unroll
+        for (int c = 1; c < CB; ++c) p += part[c];
+        p = p + x16(p);
+        p = p + x32(p);
+        if (g == 0) sx[wave * 16 + n] = p;
+        __syncthreads();
+        if (wave == 0 && g == 0 && ok) a.next_S[nrow] = (sx[n] + sx[16 + n]) + (sx[32 + n] + sx[48 + n]);
+    }
+}
+
 // one edge: score, exp(-leakyrelu), optional dropout, accumulate
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
 __device__ __forceinline__ void edge_step(const PropArgs& a, const float (&hv)[Slice<T>::VEC], float s_src, bool ok, int c,
@@ -461,13 +549,13 @@ template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, i
 __global__ __launch_bounds__(256, NEXT == 64 ? 5 : NEXT == 128 ? 4 : (sizeof(T) == 2 && D == 64 && !SPARSE ? 6 : 1)) void prop_fwd_kernel(const PropArgs a) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC, EPI = SH::EPI;
-    static_assert(NEXT == 0 || (sizeof(T) == 2 && D == 64 && !SPARSE), "fused next-stage transform: bf16 rows of 64 columns");
+    static_assert(NEXT == 0 || (D == 64 && !SPARSE), "fused next-stage transform: rows of 64 columns");
     int kind, widx, wend;
     locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, kind, widx, wend);
     bool rvalid = false;
     int rrow = 0;
     float ro[VEC];
-    if constexpr (NEXT > 0) {
+    if constexpr (NEXT > 0 && sizeof(T) == 2) {
         // the workgroup's weight panel (its rows are all users or all items) goes global -> LDS by LDS-DMA right here and lands
         // while the waves traverse; the barrier of the tail publishes it together with the finished rows
         constexpr int PANEL_U4 = (D / 16) * (NEXT / 32) * 64;
@@ -490,6 +578,32 @@ __global__ __launch_bounds__(256, NEXT == 64 ? 5 : NEXT == 128 ? 4 : (sizeof(T) 
         prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true>(a, kind, widx, wend, rvalid, rrow, ro);
         next_transform_tail<D, NEXT, NONE>(a, xtile_lds, xmeta_lds, panel_lds, reinterpret_cast<const float*>(avec_lds), rvalid, rrow,
                                            lane / SH::LPR, lane % SH::LPR, ro);
+    } else if constexpr (NEXT > 0) {
+        // fp32 storage: the panel is the next stage's fp32 W'[type] itself ([64][NEXT], no packing); a 1 KB LDS-DMA piece = 256
+        // consecutive floats of the LDS image; the lane's 16 bytes come from the column block the source-side swizzle names
+        __shared__ __attribute__((aligned(16))) float panel_f32[D * NEXT];
+        __shared__ __attribute__((aligned(16))) float xtile_f32[16 * XROW_F32];
+        __shared__ int xmeta_f32[16];
+        __shared__ __attribute__((aligned(16))) float avec_f32[NEXT];
+        __shared__ float sx_f32[(NEXT / 64) * 64];
+        const bool users = (int)blockIdx.x < a.order.b2;
+        const float* src = reinterpret_cast<const float*>(a.next_panel) + (users ? 0 : D * NEXT);
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int piece = threadIdx.x >> 6; piece < D * NEXT / 256; piece += 4) {
+            const int p = piece * 256 + lane * 4;                // float position in the LDS image: row k, columns cc .. cc+3
+            const int k = p / NEXT, cc = p % NEXT;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * NEXT + (cc ^ (16 * (k & 3)))),
+                                             (__attribute__((address_space(3))) void*)(panel_f32 + piece * 256), 16, 0, 0);
+        }
+        if (threadIdx.x < NEXT / 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.next_avec + (users ? 0 : NEXT) + 4 * lane),
+                                             (__attribute__((address_space(3))) void*)avec_f32, 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) ro[j] = 0.f;
+        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true>(a, kind, widx, wend, rvalid, rrow, ro);
+        next_transform_tail_f32<D, NEXT, NONE>(a, xtile_f32, xmeta_f32, panel_f32, avec_f32, sx_f32, rvalid, rrow, lane / SH::LPR,
+                                               lane % SH::LPR, ro);
     } else {
         prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, false>(a, kind, widx, wend, rvalid, rrow, ro);
     }
@@ -533,7 +647,7 @@ static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, b
     int nb = 0;
     a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, a.order.nhub, a.order.nhub_u, EPI, &nb);
     if (next_dout) {
-        if constexpr (sizeof(T) == 2 && D == 64 && HEADS == 8) {
+        if constexpr (D == 64 && HEADS == 8) {
             if (nb == 0) return 0;
             const dim3 grid(nb), block(256);
 #define NGACF_NEXT(ND, ONE)                                                                                              \
@@ -622,11 +736,11 @@ extern "C" int ngacf_prop_fwd_next(const int32_t* segs, int nseg, const int32_t*
     bool next_one = false;
     if (next) {
         if (!next->panel || !next->avec || !next->H || !next->S) return NGACF_E_ARG;
-        if (dtype != NGACF_BF16 || d != 64 || heads != 8 || !from_row || needed || nhub > 0) return NGACF_E_SHAPE;
+        if (d != 64 || heads != 8 || !from_row || needed || nhub > 0) return NGACF_E_SHAPE;
         if (nsplit > 0 && a.tickets == nullptr) return NGACF_E_ARG;             // hub rows must be finished inside the launch
         if ((next->dout != 64 && next->dout != 128) || (next->heads != 1 && next->heads != next->dout / 8)) return NGACF_E_SHAPE;
         if (!(next->feat_drop_p >= 0.f && next->feat_drop_p < 1.f)) return NGACF_E_ARG;
-        if ((uint64_t)N * (uint64_t)next->dout * 2 >= (1ull << 32)) return NGACF_E_SHAPE;
+        if ((uint64_t)N * (uint64_t)next->dout * elem >= (1ull << 32)) return NGACF_E_SHAPE;
         a.next_panel = static_cast<const uint4*>(next->panel); a.next_avec = next->avec; a.next_H = next->H; a.next_S = next->S;
         a.next_drop_thr = next->feat_drop_p > 0.f ? drop_threshold(next->feat_drop_p) : 0u;
         if (next->feat_drop_p > 0.f && a.next_drop_thr == 0) a.next_drop_thr = 1;     // (p below 2^-32: keep the branch, drop nothing measurable)

@@ -134,8 +134,9 @@ def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.
 
 
 class NextStage:
-    """The next stage's transform riding in this stage's traversal epilogue (ngacf_prop_fwd_next): its weight panel (from
-    transform_fwd(pack=...)), avec [2, dout], heads, feature dropout and seed.  prop_fwd(next=...) fills .H / .S."""
+    """The next stage's transform riding in this stage's traversal epilogue (ngacf_prop_fwd_next): its weight panel (bf16 storage:
+    from transform_fwd(pack=...); fp32 storage: the fp32 W [2, 64, dout] itself), avec [2, dout], heads, feature dropout and seed.
+    prop_fwd(next=...) fills .H / .S."""
     __slots__ = ("panel", "avec", "dout", "heads", "feat_drop_p", "seed", "H", "S")
 
     def __init__(self, panel, avec, heads, feat_drop_p=0.0, seed=0):
@@ -144,8 +145,8 @@ class NextStage:
 
 
 def can_fuse_next(plan, H_dtype, d, heads, needed=None):
-    """Can ngacf_prop_fwd_next serve this launch?  (bf16 rows of 64 columns in 8 heads, hub rows finished in-kernel or absent)"""
-    return (H_dtype == torch.bfloat16 and d == 64 and heads == 8 and needed is None and plan.nhub == 0
+    """Can ngacf_prop_fwd_next serve this launch?  (rows of 64 columns in 8 heads, hub rows finished in-kernel or absent)"""
+    return (H_dtype in _DT and d == 64 and heads == 8 and needed is None and plan.nhub == 0
             and (plan.nsplit == 0 or (INKERNEL_HUB_FINISH and plan.nparts <= INKERNEL_MAX_PARTS)))
 
 
@@ -295,10 +296,12 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     pa, pr = _scratch(scratch, plan, d, heads, dev)
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
     if next is not None:
-        next.H = torch.empty(N, next.dout, dtype=torch.bfloat16, device=dev)
+        next.H = torch.empty(N, next.dout, dtype=H.dtype, device=dev)
         next.S = torch.empty(N, next.heads, dtype=torch.float32, device=dev)
         panel = next.panel.get() if hasattr(next.panel, "get") else next.panel
-        ns = _lib.NextStage(_chk(panel, "next.panel", torch.uint8, 2 * 64 * next.dout * 2, dev), _chk(next.avec, "next.avec", torch.float32, 2 * next.dout, dev),
+        # bf16 storage: the packed fragments of transform_fwd(pack=...); fp32 storage: the next stage's fp32 W [2, 64, dout] itself
+        pdt, pn = (torch.uint8, 2 * 64 * next.dout * 2) if H.dtype == torch.bfloat16 else (torch.float32, 2 * 64 * next.dout)
+        ns = _lib.NextStage(_chk(panel, "next.panel", pdt, pn, dev), _chk(next.avec, "next.avec", torch.float32, 2 * next.dout, dev),
                             next.H.data_ptr(), next.S.data_ptr(), next.dout, next.heads, next.feat_drop_p, next.seed & 0xFFFFFFFFFFFFFFFF)
         _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd_next, *pp, hp,
                           _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,

@@ -815,14 +815,17 @@ def test_g15_spga_model_wrappers(dev):
         assert float(m.uEmbd.weight.grad.abs().sum()) > 0 and bool(torch.isfinite(m.uEmbd.weight.grad).all())
 
 
-def test_next_stage_transform_in_the_traversal_epilogue(dev):
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_next_stage_transform_in_the_traversal_epilogue(dev, dt):
     """ngacf_prop_fwd_next against the two-launch form it replaces (ngacf_prop_fwd, then ngacf_transform_fwd on the stored
     table): same `out` / agg / R AND the same H' / S', bit for bit -- the epilogue runs the stand-alone launch's tile step
-    (csrc/mfma_rows.hpp) on rows that are still on chip.
+    (bf16: csrc/mfma_rows.hpp, 32x32x16 bf16 matrix cores; fp32: the exact-fp32 16x16x4 matrix cores = transform.hip's fmaf
+    chains) on rows that are still on chip.
     Every row class (short rows, long rows, hub rows finished in-kernel, an isolated item), both next-stage widths, one head and
     8-wide heads, with and without the next stage's feature dropout, with and without writing `out`."""
     from ngacf_amd import ops
     from ngacf_amd.plan import build_plan
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
     rs = np.random.RandomState(5)
     U, I = 700, 500
     edge = _random_graph(U, I, 30000, 5, hub=450)
@@ -835,15 +838,20 @@ def test_next_stage_transform_in_the_traversal_epilogue(dev):
     for dout, heads2, p2 in ((64, 8, 0.0), (64, 1, 0.0), (128, 16, 0.0), (128, 1, 0.3), (64, 8, 0.25)):
         W2 = _t((rs.randn(2, 64, dout) * 0.2).astype(np.float32), dev)
         a2 = _t((rs.randn(2, dout) * 0.3).astype(np.float32), dev)
-        H, S, panels = ops.transform_fwd(X, W, avec, U, I, 8, torch.bfloat16, pack=[W2])
-        H0, S0 = ops.transform_fwd(X, W, avec, U, I, 8, torch.bfloat16)
-        assert torch.equal(H, H0) and torch.equal(S, S0)                       # the side jobs leave the transform alone
+        if dt == "bf16":
+            H, S, panels = ops.transform_fwd(X, W, avec, U, I, 8, tdt, pack=[W2])
+            H0, S0 = ops.transform_fwd(X, W, avec, U, I, 8, tdt)
+            assert torch.equal(H, H0) and torch.equal(S, S0)                   # the side jobs leave the transform alone
+            panel = panels[0]
+        else:
+            H, S = ops.transform_fwd(X, W, avec, U, I, 8, tdt)
+            panel = W2                                                         # fp32: the weights themselves
         for drop, save in ((0.0, False), (0.2, True)):
             ref = ops.prop_fwd(plan, H, S, S, avec, 8, drop_p=drop, seed=11, save=save)
             out_ref = ref[0] if save else ref
-            H2r, S2r = ops.transform_fwd(out_ref, W2, a2, U, I, heads2, torch.bfloat16, feat_drop_p=p2, seed=77)
+            H2r, S2r = ops.transform_fwd(out_ref, W2, a2, U, I, heads2, tdt, feat_drop_p=p2, seed=77)
             for want_out in (True, False):
-                nxt = ops.NextStage(panels[0], a2, heads2, p2, 77)
+                nxt = ops.NextStage(panel, a2, heads2, p2, 77)
                 got = ops.prop_fwd(plan, H, S, S, avec, 8, drop_p=drop, seed=11, save=save, next=nxt, want_out=want_out)
                 if want_out:
                     for a_, b_ in zip(got if save else (got,), ref if save else (ref,)):
@@ -852,13 +860,16 @@ def test_next_stage_transform_in_the_traversal_epilogue(dev):
                     assert got[0] is None and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
                 else:
                     assert got is None
-                assert torch.equal(nxt.H, H2r) and torch.equal(nxt.S, S2r), (dout, heads2, p2, drop, save, want_out)
+                assert nxt.H.dtype == tdt
+                assert torch.equal(nxt.H, H2r), (dt, dout, heads2, p2, drop, save, want_out, float((nxt.H.float() - H2r.float()).abs().max()))
+                assert torch.equal(nxt.S, S2r), (dt, dout, heads2, p2, drop, save, want_out, float((nxt.S - S2r).abs().max()))
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
 @pytest.mark.parametrize("kind", ["spuigacf", "multi", "d128L4"])
-def test_fused_stack_equals_unfused_stack(dev, kind):
+def test_fused_stack_equals_unfused_stack(dev, kind, dt):
     """The whole stack with NGACF_FUSE_NEXT on (default) and off: evaluation table, train-mode scores with dropout (same seeds =
-    same masks) and every gradient, bf16 storage.  (Both forms are checked against the reference's float64 numbers by the
+    same masks) and every gradient, bf16 and fp32 storage.  (Both forms are checked against the reference's float64 numbers by the
     golden tests; this is the A/B of the two launch plans.)"""
     import ngacf_amd
     from ngacf_amd import functional as NF
@@ -871,7 +882,8 @@ def test_fused_stack_equals_unfused_stack(dev, kind):
     m = mk().to(dev)
     with torch.no_grad():
         m.uEmbd.weight.mul_(30.0); m.iEmbd.weight.mul_(30.0)
-    ngacf_amd.set_compute_dtype(m, torch.bfloat16)
+    if dt == "bf16":
+        ngacf_amd.set_compute_dtype(m, torch.bfloat16)
     g = torch.Generator(device=dev); g.manual_seed(1)
     u, pi, ni = (torch.randint(0, k, (256,), device=dev, generator=g) for k in (U, I, I))
     res = {}
