@@ -81,7 +81,9 @@ int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, const float*
  * refreshes the fragments from the live fp32 weights, so a captured hipGraph never replays a stale copy after an optimizer
  * step).  Host arrays of n_pack entries: pack_W[k] float[2][din_k][dout_k] (device), pack_panel[k] device buffer of
  * 2 * din_k * dout_k * 2 bytes, din_k == 64, dout_k in {64, 128}.  Fragment layout (16 bytes = 8 bf16 each):
- *   index ((y * (din/32) + s) * (dout/16) + t) * 64 + l  holds  W[y][32 s + 8 (l >> 4) + j][16 t + (l & 15)], j = 0..7. */
+ *   index ((y * (din/16) + s) * (dout/32) + t) * 64 + l  holds  W[y][16 s + 8 (l >> 5) + j][32 t + (l & 31)], j = 0..7
+ *   (the A fragments of v_mfma_f32_32x32x16_bf16 with the output column on the A operand: csrc/mfma_rows.hpp).
+ * U == I == 0: only the panels are packed (X .. S are not read; the node-partitioned path, whose transforms run over row windows). */
 #define NGACF_MAX_PACK 4
 int ngacf_transform_fwd_pack(const void* X, int x_dtype, const float* W, const float* avec,
                              void* H, int h_dtype, float* S,

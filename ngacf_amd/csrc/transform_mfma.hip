@@ -262,7 +262,8 @@ extern "C" int ngacf_transform_fwd_pack(const void* X, int x_dtype, const float*
                                         int n_pack, const float* const* pack_W, void* const* pack_panel, const int* pack_din,
                                         const int* pack_dout, void* stream) {
     if (U < 0 || I < 0 || n_pack < 0 || n_pack > NGACF_MAX_PACK) return NGACF_E_ARG;
-    if (!X || !W || !avec || !H || !S) return NGACF_E_ARG;
+    if (U + I > 0 && (!X || !W || !avec || !H || !S)) return NGACF_E_ARG;     // (U = I = 0: the panels alone, nothing is transformed)
+    if (U + I == 0) { din = 64; dout = 64; heads = 8; }
     if (!(feat_drop_p >= 0.f && feat_drop_p < 1.f)) return NGACF_E_ARG;
     if (h_dtype != NGACF_BF16 || (x_dtype != NGACF_F32 && x_dtype != NGACF_BF16)) return NGACF_E_SHAPE;   // the matrix-core path only
     if (n_pack > 0 && (!pack_W || !pack_panel || !pack_din || !pack_dout)) return NGACF_E_ARG;

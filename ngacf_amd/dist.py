@@ -248,6 +248,22 @@ class _ShardedStack(torch.autograd.Function):
                                   cfg["feat_drop"], cfg["seeds"][s], **sd)
             pending[(s, t)] = comm.start_gather(t, Hs[s])
 
+        # Stage s+1's transform of a half rides in stage s's half-launch traversal where the library can do that
+        # (ngacf_prop_fwd_next: rows of 64 columns in 8 heads, hub rows finished in-kernel): V(s,A) and T(s+1,A) become ONE launch,
+        # four launches less per three-stage forward.  bf16 panels are packed by one small launch in front; fp32 takes the weights.
+        fuse = [False] * L
+        if cfg.get("fuse_next") and hasattr(be, "can_fuse_next"):
+            for s in range(1, L):
+                fuse[s] = (be.can_fuse_next(plan, cfg["h_dtype"], Ws[s - 1].shape[2], cfg["heads"][s - 1])
+                           and Ws[s].shape[1] == 64 and Ws[s].shape[2] in (64, 128))
+        panels = {}
+        if any(fuse):
+            idx = [s for s in range(1, L) if fuse[s]]
+            if cfg["h_dtype"] == torch.bfloat16:
+                panels = dict(zip(idx, be.pack_panels([Ws[s] for s in idx])))
+            else:
+                panels = {s: Ws[s] for s in idx}
+
         first = "user"
         T(0, OTHER[first])
         T(0, first)
@@ -256,17 +272,31 @@ class _ShardedStack(torch.autograd.Function):
             A, B = first, OTHER[first]
             H, S, heads = Hs[s], Ss[s], cfg["heads"][s]
             dout = H.shape[1]
-            out = torch.empty(N, dout, dtype=H.dtype, device=dev)
+            fused_next = s + 1 < L and fuse[s + 1]
+            keep_out = need or not fused_next                        # an evaluation forward never reads a fused stage's own table
+            out = torch.empty(N, dout, dtype=H.dtype, device=dev) if keep_out else None
             agg = torch.empty(N, dout, dtype=H.dtype, device=dev) if need else None
             R = torch.empty(N, heads, dtype=torch.float32, device=dev) if need else None
+            if fused_next and Hs[s + 1] is None:
+                Hs[s + 1] = torch.empty(N, Ws[s + 1].shape[2], dtype=cfg["h_dtype"], device=dev)
+                Ss[s + 1] = torch.empty(N, cfg["heads"][s + 1], dtype=torch.float32, device=dev)
             Xs = dict(X)
             for t in (A, B):
                 pending.pop((s, OTHER[t])).wait()                    # sources of the dst half t
-                be.prop_fwd(plan, H, S, S, As[s], heads, cfg["alpha"], True, True, True, cfg["drop"], cfg["seeds"][s],
-                            save=need, out=out, half=t, agg=agg, R=R, **sd)
-                if s + 1 < L:
-                    X[t] = part.block(out, t)
-                    T(s + 1, t)
+                if fused_next:
+                    nxt = be.NextStage(panels[s + 1], As[s + 1], cfg["heads"][s + 1], cfg["feat_drop"], cfg["seeds"][s + 1],
+                                       H=Hs[s + 1], S=Ss[s + 1])
+                    be.prop_fwd(plan, H, S, S, As[s], heads, cfg["alpha"], True, True, True, cfg["drop"], cfg["seeds"][s],
+                                save=need, out=out, half=t, agg=agg, R=R, next=nxt, want_out=keep_out, **sd)
+                    if keep_out:
+                        X[t] = part.block(out, t)
+                    pending[(s + 1, t)] = comm.start_gather(t, Hs[s + 1])
+                else:
+                    be.prop_fwd(plan, H, S, S, As[s], heads, cfg["alpha"], True, True, True, cfg["drop"], cfg["seeds"][s],
+                                save=need, out=out, half=t, agg=agg, R=R, **sd)
+                    if s + 1 < L:
+                        X[t] = part.block(out, t)
+                        T(s + 1, t)
             if need:
                 saved.append((Xs["user"], Xs["item"], Ws[s], As[s], H, S, out, agg, R))
             first = B                                                # the next stage starts with the other half
@@ -502,7 +532,7 @@ class ShardedSPUIGACF(nn.Module):
         cfg = {"part": self.part, "plan": plan, "comm": self.comm, "be": self.be, "heads": [len(l) for l in stages],
                "alpha": stages[0][0].alpha, "drop": drop, "feat_drop": drop,
                "seeds": [NF.stage_seed(base, s) for s in range(len(stages))], "h_dtype": self.compute_dtype,
-               "seed_dev": seed_dev, "grad_mode": torch.is_grad_enabled()}
+               "seed_dev": seed_dev, "grad_mode": torch.is_grad_enabled(), "fuse_next": NF.FUSE_NEXT}
         return _ShardedStack.apply(self.uEmbd.weight, self.iEmbd.weight, *params, cfg)
 
     def propagate(self, mask):

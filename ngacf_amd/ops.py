@@ -139,9 +139,9 @@ class NextStage:
     prop_fwd(next=...) fills .H / .S."""
     __slots__ = ("panel", "avec", "dout", "heads", "feat_drop_p", "seed", "H", "S")
 
-    def __init__(self, panel, avec, heads, feat_drop_p=0.0, seed=0):
+    def __init__(self, panel, avec, heads, feat_drop_p=0.0, seed=0, H=None, S=None):
         self.panel, self.avec, self.dout, self.heads = panel, avec, int(avec.shape[1]), int(heads)
-        self.feat_drop_p, self.seed, self.H, self.S = float(feat_drop_p), int(seed), None, None
+        self.feat_drop_p, self.seed, self.H, self.S = float(feat_drop_p), int(seed), H, S
 
 
 def can_fuse_next(plan, H_dtype, d, heads, needed=None):
@@ -278,7 +278,7 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
     hub = _hub(plan, dev, half)
     pp = _plan_ptrs(plan, dev, half, inkernel=hub[1] != 0)
-    if next is not None and (half is not None or not can_fuse_next(plan, H.dtype, d, heads, needed) or not score_from_row):
+    if next is not None and (not can_fuse_next(plan, H.dtype, d, heads, needed) or not score_from_row):
         raise ValueError("prop_fwd(next=...): not available for this launch (ops.can_fuse_next)")
     if next is None or want_out:
         if out is None:
@@ -296,8 +296,12 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     pa, pr = _scratch(scratch, plan, d, heads, dev)
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
     if next is not None:
-        next.H = torch.empty(N, next.dout, dtype=H.dtype, device=dev)
-        next.S = torch.empty(N, next.heads, dtype=torch.float32, device=dev)
+        # (a half launch of the node-partitioned path hands in the global-row tables of the next stage: both halves fill them)
+        if next.H is None:
+            next.H = torch.empty(N, next.dout, dtype=H.dtype, device=dev)
+            next.S = torch.empty(N, next.heads, dtype=torch.float32, device=dev)
+        _chk(next.H, "next.H", H.dtype, N * next.dout, dev)
+        _chk(next.S, "next.S", torch.float32, N * next.heads, dev)
         panel = next.panel.get() if hasattr(next.panel, "get") else next.panel
         # bf16 storage: the packed fragments of transform_fwd(pack=...); fp32 storage: the next stage's fp32 W [2, 64, dout] itself
         pdt, pn = (torch.uint8, 2 * 64 * next.dout * 2) if H.dtype == torch.bfloat16 else (torch.float32, 2 * 64 * next.dout)
@@ -576,6 +580,25 @@ def dropout_bits(kind, seed, a, b, c=None):
 # ---------------------------------------------------------------------------
 # row-window forms used by the node-partitioned (multi-GPU) path, ngacf_amd/dist.py
 # ---------------------------------------------------------------------------
+def pack_panels(Ws):
+    """bf16 matrix-core fragment panels of the stage weights Ws = [W [2, 64, dout], ...] for prop_fwd(next=...), by a launch of
+    their own (ngacf_transform_fwd_pack with no rows: the node-partitioned path, whose transforms run over row windows; the
+    single-GPU stack packs inside its first transform's launch instead)."""
+    dev, n = Ws[0].device, len(Ws)
+    if n > _lib.MAX_PACK:
+        raise ValueError("pack_panels: at most %d panels" % _lib.MAX_PACK)
+    for Wk in Ws:
+        if Wk.dim() != 3 or Wk.shape[0] != 2 or Wk.shape[1] != 64 or Wk.shape[2] not in (64, 128):
+            raise ValueError("pack: W [2, 64, 64 | 128], got %s" % (tuple(Wk.shape),))
+    panels = [torch.empty(2 * Wk.shape[1] * Wk.shape[2] * 2, dtype=torch.uint8, device=dev) for Wk in Ws]
+    P, Iarr = ctypes.c_void_p * n, ctypes.c_int * n
+    _lib.check(lib.ngacf_transform_fwd_pack(0, F32, 0, 0, 0, BF16, 0, 0, 0, 64, 64, 8, 0.0, 0, 0, n,
+                                            P(*[_chk(Wk, "pack W", torch.float32, Wk.numel(), dev) for Wk in Ws]), P(*[t.data_ptr() for t in panels]),
+                                            Iarr(*[int(Wk.shape[1]) for Wk in Ws]), Iarr(*[int(Wk.shape[2]) for Wk in Ws]), _stream()),
+               "ngacf_transform_fwd_pack")
+    return panels
+
+
 def transform_fwd_rows(X, W, avec, H, S, U, I, heads, win, x_local, feat_drop_p=0.0, seed=0, seed_dev=None):
     """Transform the rows of `win` = (u_lo, u_n, i_lo, i_n) into the global-row tables H [N,dout], S [N,heads].
     X is [u_n+i_n, din] when x_local else [N, din]."""

@@ -46,7 +46,7 @@ def main():
             row["L2_hit_rate"] = round(per["TCC_HIT_sum"] / max(per["TCC_HIT_sum"] + per["TCC_MISS_sum"], 1.0), 4)
         res["kernels"][name] = {"per_directed_edge": row, "launches": max(cnt[name].values())}
         print(name, json.dumps(res["kernels"][name]), flush=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r02_reqcount_%s_%s.json" % (wl, dt)), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r03_reqcount_%s_%s.json" % (wl, dt)), "w") as f:
         json.dump(res, f, indent=1)
 
 
