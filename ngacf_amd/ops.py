@@ -63,10 +63,6 @@ class KernelTimer:
         return out
 
 
-def _timed(name, fn, *args):
-    return fn(*args)
-
-
 def _chk(t, name, dtype, numel, dev, align=16):
     if t is None:
         raise ValueError("%s is required" % name)
@@ -307,12 +303,12 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
         pdt, pn = (torch.uint8, 2 * 64 * next.dout * 2) if H.dtype == torch.bfloat16 else (torch.float32, 2 * 64 * next.dout)
         ns = _lib.NextStage(_chk(panel, "next.panel", pdt, pn, dev), _chk(next.avec, "next.avec", torch.float32, 2 * next.dout, dev),
                             next.H.data_ptr(), next.S.data_ptr(), next.dout, next.heads, next.feat_drop_p, next.seed & 0xFFFFFFFFFFFFFFFF)
-        _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd_next, *pp, hp,
+        _lib.check(lib.ngacf_prop_fwd_next(*pp, hp,
                           _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
                           pa.data_ptr(), pr.data_ptr(), *hub, 0, 0, 0, 0, plan.U, N, d, heads, float(alpha),
                           float(drop_p), int(seed), _sd(seed_dev, dev), flags, ctypes.byref(ns), _stream()), "ngacf_prop_fwd_next")
         return (out, agg, R) if save else out
-    _lib.check(_timed("ngacf_prop_fwd", lib.ngacf_prop_fwd, *pp, hp,
+    _lib.check(lib.ngacf_prop_fwd(*pp, hp,
                       _DT[H.dtype], sd, ss, ap, op, agg.data_ptr() if save else 0, R.data_ptr() if save else 0,
                       pa.data_ptr(), pr.data_ptr(), *hub, *_needed_args(needed, plan, N, dev),
                       plan.U, N, d, heads, float(alpha),
@@ -544,7 +540,7 @@ def mha_fwd(Q, K, V, heads, mask=None, drop_p=0.0, seed=0, seed_dev=None, bf16_o
     O = torch.empty(Nq, dim, dtype=torch.float32, device=dev)
     LSE = torch.empty(Nq, heads, 2, dtype=torch.float32, device=dev)
     if Nq and Nk:
-        _lib.check(_timed("ngacf_mha_fwd", lib.ngacf_mha_fwd, qp, kp, vp, mp, O.data_ptr(), LSE.data_ptr(), Nq, Nk, dim, heads,
+        _lib.check(lib.ngacf_mha_fwd(qp, kp, vp, mp, O.data_ptr(), LSE.data_ptr(), Nq, Nk, dim, heads,
                           float(drop_p), int(seed), _sd(seed_dev, dev), int(bool(bf16_operands)), _stream()), "ngacf_mha_fwd")
     return O, LSE
 
