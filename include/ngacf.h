@@ -348,6 +348,35 @@ int ngacf_mha_bwd(const float* Q, const float* K, const float* V, const uint32_t
 int ngacf_timing_begin(void);
 int ngacf_timing_end(float* ms, int32_t* tags, int cap);
 
+/* Peer-store all-gather of the node-partitioned path (stands where the reference has nn.DataParallel's
+ * replicate / scatter / gather, parallel.py:94-196): a rank writes its block of a half-table straight into its peers' copies
+ * (device pointers mapped through hipIpc) and publishes a counter in each peer's flag word; a consumer waits on its own flag
+ * words in front of its traversal.  No collective launch; the epochs live in device memory, so captured graphs replay.
+ *   ngacf_peer_alloc / _free      zero-filled device memory owned by the library (hipMalloc): tables and flag words
+ *   ngacf_peer_export / _import   64-byte hipIpc handle of such an allocation / the peer's mapping of it (_close unmaps)
+ *   ngacf_peer_push   copy every region's src (this rank's block) to dst[0..npeers) (the same block inside each peer's table),
+ *                     then epoch = ++*sent and a system-scope release store of epoch to peer_flags[p] (the word of (slot, this
+ *                     rank) in peer p's flag array).  ticket: an int32 of scratch, zero between launches.  bytes % 4 == 0.
+ *   ngacf_peer_wait   one wave: until flags[r] has reached ++*expect for every r < n except self_rank, or timeout_ticks of the
+ *                     100 MHz clock have passed (*err = 1; the kernel leaves either way).  n <= 64. */
+#define NGACF_MAX_PEERS 15
+#define NGACF_PEER_MAX_REGIONS 2
+#define NGACF_PEER_HANDLE_BYTES 64
+typedef struct {
+    const void* src;
+    uint64_t bytes;
+    void* dst[NGACF_MAX_PEERS];
+} ngacf_peer_region;
+int ngacf_peer_alloc(uint64_t bytes, void** ptr);
+int ngacf_peer_free(void* ptr);
+int ngacf_peer_export(const void* ptr, void* handle);
+int ngacf_peer_import(const void* handle, void** ptr);
+int ngacf_peer_close(void* ptr);
+int ngacf_peer_push(const ngacf_peer_region* regions, int nregions, int npeers, int32_t* const* peer_flags,
+                    int32_t* sent, int32_t* ticket, void* stream);
+int ngacf_peer_wait(const int32_t* flags, int n, int self_rank, int32_t* expect, int32_t* err, uint64_t timeout_ticks,
+                    void* stream);
+
 /* Counter-hash dropout mask bits, exposed so tests can pin the device RNG against the
  * host restatement: bits[k] = the 32-bit hash the kernels compare against drop_p * 2^32.
  * kind 0: feature mask, a = node, b = column.  kind 1: edge mask, a = user, b = item (global id), c = head. */

@@ -55,6 +55,8 @@ SIGNATURES = {
     "ngacf_dropout_bits": [_i, _u64, _p, _p, _p, _p, _i, _p],
     "ngacf_timing_begin": [],
     "ngacf_timing_end": [_p, _p, _i],
+    "ngacf_peer_alloc": [_u64, _p], "ngacf_peer_free": [_p], "ngacf_peer_export": [_p, _p], "ngacf_peer_import": [_p, _p],
+    "ngacf_peer_close": [_p], "ngacf_peer_push": [_p, _i, _i, _p, _p, _p, _p], "ngacf_peer_wait": [_p, _i, _i, _p, _p, _u64, _p],
     "ngacf_mha_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _i, _p],
     "ngacf_mha_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _i, _p],
 }
@@ -64,6 +66,14 @@ class NextStage(ctypes.Structure):
     """ngacf_next_stage of include/ngacf.h"""
     _fields_ = [("panel", _p), ("avec", _p), ("H", _p), ("S", _p), ("dout", ctypes.c_int32), ("heads", ctypes.c_int32),
                 ("feat_drop_p", _f), ("seed", _u64)]
+
+
+MAX_PEERS, PEER_MAX_REGIONS, PEER_HANDLE_BYTES = 15, 2, 64       # NGACF_MAX_PEERS, NGACF_PEER_MAX_REGIONS, NGACF_PEER_HANDLE_BYTES
+
+
+class PeerRegion(ctypes.Structure):
+    """ngacf_peer_region of include/ngacf.h"""
+    _fields_ = [("src", _p), ("bytes", _u64), ("dst", _p * MAX_PEERS)]
 
 
 class NgacfError(RuntimeError):

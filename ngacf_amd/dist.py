@@ -33,6 +33,7 @@ torch stand-in to exercise partition + collectives + schedule under gloo; the pr
 """
 import contextlib
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -158,9 +159,25 @@ class Comm:
         self.timer = None                     # list -> (start event, end event, bytes received) per gather (bench, serial mode)
         self.dry_run = False                  # tools/shard_compute.py: one rank's kernels of a P-way partition, no collectives
 
+    peer_store = False                        # (ngacf_amd.peer.PeerComm: gathers by stores into the peers' tables)
+
     @property
     def active(self):
         return (self.world > 1 or self.force) and not self.dry_run
+
+    # Gathered tables are asked for here so that a transport that needs symmetric memory can hand out its own
+    # (PeerComm); this one has no such need: plain tensors, nothing to lease, nothing to join, nothing to check.
+    def new_lease(self):
+        return None
+
+    def table(self, key, shape, dtype, device, lease=None):
+        return torch.empty(*shape, dtype=dtype, device=device)
+
+    def join(self):
+        pass
+
+    def check(self):
+        pass
 
     def _region(self, full, t):
         p = self.part
@@ -238,12 +255,18 @@ class _ShardedStack(torch.autograd.Function):
         As = [params[2 * s + 1].contiguous().float() for s in range(L)]
         saved, pending = [], {}
         Hs, Ss = [None] * L, [None] * L
+        if comm.peer_store and comm.active and L < 2:
+            raise ValueError("peer-store all-gather needs a stack of at least two stages (ngacf_amd/peer.py)")
+        lease = comm.new_lease()
+
+        def new_H(s):
+            dout = Ws[s].shape[2]
+            Hs[s] = comm.table(("H", s), (N, dout), cfg["h_dtype"], dev, lease)
+            Ss[s] = torch.empty(N, cfg["heads"][s], dtype=torch.float32, device=dev)
 
         def T(s, t):
             if Hs[s] is None:
-                dout = Ws[s].shape[2]
-                Hs[s] = torch.empty(N, dout, dtype=cfg["h_dtype"], device=dev)
-                Ss[s] = torch.empty(N, cfg["heads"][s], dtype=torch.float32, device=dev)
+                new_H(s)
             be.transform_fwd_rows(X[t], Ws[s], As[s], Hs[s], Ss[s], part.Up, part.Ip, cfg["heads"][s], part.half_win(t), True,
                                   cfg["feat_drop"], cfg["seeds"][s], **sd)
             pending[(s, t)] = comm.start_gather(t, Hs[s])
@@ -278,8 +301,7 @@ class _ShardedStack(torch.autograd.Function):
             agg = torch.empty(N, dout, dtype=H.dtype, device=dev) if need else None
             R = torch.empty(N, heads, dtype=torch.float32, device=dev) if need else None
             if fused_next and Hs[s + 1] is None:
-                Hs[s + 1] = torch.empty(N, Ws[s + 1].shape[2], dtype=cfg["h_dtype"], device=dev)
-                Ss[s + 1] = torch.empty(N, cfg["heads"][s + 1], dtype=torch.float32, device=dev)
+                new_H(s + 1)
             Xs = dict(X)
             for t in (A, B):
                 pending.pop((s, OTHER[t])).wait()                    # sources of the dst half t
@@ -300,9 +322,13 @@ class _ShardedStack(torch.autograd.Function):
             if need:
                 saved.append((Xs["user"], Xs["item"], Ws[s], As[s], H, S, out, agg, R))
             first = B                                                # the next stage starts with the other half
+        comm.join()
         if need:
             ctx.cfg, ctx.L = cfg, L
             ctx.saved_stages = saved                                 # (held on ctx: views of the stage tables)
+            ctx.lease = lease                                        # (the H tables go back to the pool with the node)
+        elif lease is not None:
+            lease.release()
         return part.block(out, "user"), part.block(out, "item")
 
     @staticmethod
@@ -316,13 +342,14 @@ class _ShardedStack(torch.autograd.Function):
         g = {"user": gU.contiguous().to(h_dtype), "item": gI.contiguous().to(h_dtype)}
         dev = gU.device
         tabs, pending = [None] * L, {}
+        lease = comm.new_lease()
 
         def Nstep(s, t):
             _, _, _, _, H, S, out, agg, R = saved[s]
             if tabs[s] is None:
                 d, heads = H.shape[1], cfg["heads"][s]
-                tabs[s] = (torch.empty(N, d, dtype=torch.float32, device=dev), torch.empty(N, d, dtype=H.dtype, device=dev),
-                           torch.empty(N, heads, dtype=torch.float32, device=dev),
+                tabs[s] = (torch.empty(N, d, dtype=torch.float32, device=dev), comm.table(("Gn", s), (N, d), H.dtype, dev, lease),
+                           comm.table(("t", s), (N, heads), torch.float32, dev, lease),
                            torch.zeros(N, d, dtype=H.dtype, device=dev), torch.zeros(N, heads, dtype=torch.float32, device=dev))
             G, Gn, ST, _, _ = tabs[s]
             be.prop_bwd_node(out, agg, R, g[t], S, G, Gn, ST, part.Up, cfg["heads"][s], part.half_win(t), True, True)
@@ -354,7 +381,12 @@ class _ShardedStack(torch.autograd.Function):
                 comm.all_reduce_sum(dW, da)
             grads[2 * s], grads[2 * s + 1] = dW, da
             first = OTHER[first]
+        comm.join()
         ctx.saved_stages = None
+        for ls in (lease, getattr(ctx, "lease", None)):
+            if ls is not None:
+                ls.release()
+        ctx.lease = None
         return (g["user"], g["item"]) + tuple(grads) + (None,)
 
 
@@ -394,7 +426,7 @@ class ShardedSPUIGACF(nn.Module):
     selects the degree-balanced partition; without either the blocks are runs of consecutive ids."""
 
     def __init__(self, userNum, itemNum, embedSize, layers, droprate, world=None, rank=None, stages=2,
-                 group=None, backend=None, device=None, adj=None, degrees=None, partition=None):
+                 group=None, backend=None, device=None, adj=None, degrees=None, partition=None, peer_store=None):
         super().__init__()
         world = dist.get_world_size(group) if world is None else world
         rank = dist.get_rank(group) if rank is None else rank
@@ -404,7 +436,15 @@ class ShardedSPUIGACF(nn.Module):
             degrees = (torch.bincount(a[0], minlength=userNum), torch.bincount(a[1], minlength=itemNum))
         self.part = partition if partition is not None else \
             Partition(userNum, itemNum, world, rank, *(degrees if degrees is not None else (None, None)))
-        self.comm = Comm(self.part, group)
+        # peer_store (or NGACF_PEER_GATHER=1): the half-table gathers of the propagation go by stores into the peers' tables
+        # (ngacf_amd/peer.py) instead of one RCCL all-gather launch each; everything else stays on the process group
+        if peer_store is None:
+            peer_store = os.environ.get("NGACF_PEER_GATHER", "0") == "1"
+        if peer_store:
+            from .peer import PeerComm
+            self.comm = PeerComm(self.part, group, device=device)
+        else:
+            self.comm = Comm(self.part, group)
         self.be = backend if backend is not None else _hip_ops
         p = self.part
         # Same values on every rank -- and at every world size -- as the unsharded model under the same torch seed: the random

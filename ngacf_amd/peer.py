@@ -1,0 +1,197 @@
+"""Peer-store all-gather for the node-partitioned path (ngacf_amd/dist.py): `PeerComm` stands where `Comm` issues an RCCL
+all-gather per half-table and stage.  A stage at Gowalla scale moves ~1 MB per rank, and a collective LAUNCH costs more than the
+traversal it should hide behind; here a rank's block goes into its peers' tables by a 64-workgroup copy kernel
+through hipIpc-mapped pointers, followed by one flag word per peer, and a consumer's traversal is preceded by a one-wave kernel
+that waits on its own flag words (csrc/peer.hip: ngacf_peer_push / ngacf_peer_wait).  No host, no collective on the path; the
+epochs live in device memory, so the captured hipGraph of a pass replays unchanged.
+
+What has to hold for that, and how it is kept:
+  symmetric tables   every gathered table (H of a stage; Gn and t of a backward stage) comes from a POOL of library-owned
+                     allocations (ngacf_peer_alloc) whose hipIpc handles were exchanged once (all_gather_object on the process
+                     group: host work, done on first use = the eager warm-up pass, never inside a capture).  All ranks run the
+                     same program, so the k-th acquisition of a key picks the k-th buffer everywhere; a buffer goes back to the
+                     pool when the autograd node that leased it is done (`_Lease`).
+  no early overwrite a peer writes stage s of pass k+1 into my table only after it has consumed my stage s-1 of pass k+1 (s > 0)
+                     or, for s = 0, after it has finished pass k, whose last stage needed a block that I sent AFTER my own
+                     stage-0 traversals of pass k: with at least two stages a table is never written while its previous
+                     content is still being read.  One-stage stacks are refused.
+  visibility         push: stores -> system-scope release fence -> last-workgroup ticket -> release store of the epoch per peer;
+                     wait: system-scope acquire loads of the flag words; the traversal is a NEW kernel (its start drops what its
+                     caches held of the table).  A peer that never arrives costs `timeout_s`, sets an error word (check()) and the
+                     kernel leaves: wrong numbers reported by the host, never a hung GPU.
+The push runs on a side stream (under the other half's traversal, like the asynchronous all-gather it replaces); join() brings
+it back before a pass ends.  Everything that is not a pool table (state-dict / evaluation gathers) takes the base class's path.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .dist import Comm, _Handle
+
+SLOTS = 1024                      # flag slots: two per pool buffer (user half, item half)
+
+
+class _Raw:
+    """library-owned device memory as a __cuda_array_interface__ object (torch.as_tensor makes a non-owning view of it)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class _Buf:
+    def __init__(self, ptr, nbytes, peers, index, device):
+        self.ptr, self.nbytes, self.peers, self.index = ptr, nbytes, peers, index     # peers: rank -> this process's mapping
+        self.bytes_view = torch.as_tensor(_Raw(ptr, nbytes), device=device)
+        self.busy = False
+
+
+class _Lease:
+    """The pool buffers one autograd node holds; release() (idempotent; also on garbage collection) returns them."""
+
+    def __init__(self):
+        self.bufs = []
+
+    def release(self):
+        for b in self.bufs:
+            b.busy = False
+        self.bufs = []
+
+    def __del__(self):
+        self.release()
+
+
+class PeerComm(Comm):
+    peer_store = True
+
+    def __init__(self, part, group=None, device=None, timeout_s=5.0):
+        super().__init__(part, group)
+        if part.P - 1 > _lib.MAX_PEERS:
+            raise ValueError("peer-store all-gather: at most %d ranks" % (_lib.MAX_PEERS + 1))
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.rank, self.W = part.rank, part.P
+        self.others = [r for r in range(self.W) if r != self.rank]
+        self.side = torch.cuda.Stream(self.device)
+        self.timeout_ticks = int(timeout_s * 100e6)           # s_memrealtime: 100 MHz
+        self._bufs, self._pool, self._by_ptr = [], {}, {}
+        # control block: flags[SLOTS][W] (written by the peers) | sent[SLOTS] | expect[SLOTS] | ticket[SLOTS] | err
+        self._ctrl = self._symmetric(4 * (SLOTS * self.W + 3 * SLOTS + 1))
+        self.pushes = 0
+
+    # ---- symmetric memory -------------------------------------------------------------------------------------------------
+    def _symmetric(self, nbytes):
+        """nbytes of zeroed device memory on every rank, each rank holding a mapping of every peer's (collective, host side)."""
+        ptr = ctypes.c_void_p()
+        _lib.check(_lib.lib.ngacf_peer_alloc(nbytes, ctypes.byref(ptr)), "ngacf_peer_alloc")
+        peers = {}
+        if self.W > 1:
+            h = ctypes.create_string_buffer(_lib.PEER_HANDLE_BYTES)
+            _lib.check(_lib.lib.ngacf_peer_export(ptr, h), "ngacf_peer_export")
+            handles = [None] * self.W
+            dist.all_gather_object(handles, bytes(h.raw), group=self.group)
+            for r in self.others:
+                q = ctypes.c_void_p()
+                _lib.check(_lib.lib.ngacf_peer_import(ctypes.create_string_buffer(handles[r], _lib.PEER_HANDLE_BYTES), ctypes.byref(q)),
+                           "ngacf_peer_import (rank %d's memory)" % r)
+                peers[r] = q.value
+        b = _Buf(ptr.value, nbytes, peers, len(self._bufs), self.device)
+        self._bufs.append(b)
+        return b
+
+    def _ctrl_addr(self, base, what, slot):
+        off = {"flags": slot * self.W, "sent": SLOTS * self.W + slot, "expect": SLOTS * self.W + SLOTS + slot,
+               "ticket": SLOTS * self.W + 2 * SLOTS + slot, "err": SLOTS * self.W + 3 * SLOTS}[what]
+        return base + 4 * off
+
+    # ---- the pool ---------------------------------------------------------------------------------------------------------
+    def new_lease(self):
+        return _Lease()
+
+    def table(self, key, shape, dtype, device, lease=None):
+        """A gathered table: the first free pool buffer of `key` (a new symmetric allocation when there is none)."""
+        if lease is None:
+            raise ValueError("peer-store tables are leased")
+        key = (key, tuple(shape), dtype)
+        nbytes = int(torch.empty(0, dtype=dtype).element_size())
+        for n in shape:
+            nbytes *= int(n)
+        free = [b for b in self._pool.setdefault(key, []) if not b.busy]
+        if free:
+            b = free[0]
+        else:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("peer-store table %r first needed inside a stream capture: run one eager pass first" % (key,))
+            if 2 * len(self._bufs) + 1 >= SLOTS:
+                raise RuntimeError("peer-store pool: out of flag slots")
+            b = self._symmetric(max(nbytes, 16))
+            self._pool[key].append(b)
+            self._by_ptr[b.ptr] = b
+        b.busy = True
+        lease.bufs.append(b)
+        return b.bytes_view[:nbytes].view(dtype).view(*shape)
+
+    # ---- the exchange -----------------------------------------------------------------------------------------------------
+    def start_gather(self, t, *fulls):
+        if not self.active:
+            return _Handle()
+        bufs = [self._by_ptr.get(f.data_ptr()) for f in fulls]
+        if any(b is None for b in bufs) or len(fulls) > _lib.PEER_MAX_REGIONS:
+            return super().start_gather(t, *fulls)            # not a pool table: the collective path
+        p = self.part
+        lo, n = (p.rank * p.cu, p.cu) if t == "user" else (p.Up + p.rank * p.ci, p.ci)
+        regs = (_lib.PeerRegion * len(fulls))()
+        for k, (f, b) in enumerate(zip(fulls, bufs)):
+            rowb = f.stride(0) * f.element_size()
+            regs[k].src = b.ptr + lo * rowb
+            regs[k].bytes = n * rowb
+            for j, r in enumerate(self.others):
+                regs[k].dst[j] = b.peers[r] + lo * rowb
+        slot = 2 * bufs[0].index + (0 if t == "user" else 1)
+        flags = (ctypes.c_void_p * max(len(self.others), 1))()
+        for j, r in enumerate(self.others):                   # my word in peer r's flag array
+            flags[j] = self._ctrl_addr(self._ctrl.peers[r], "flags", slot) + 4 * self.rank
+        cur = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.side.wait_event(ev)
+        _lib.check(_lib.lib.ngacf_peer_push(regs, len(fulls), len(self.others), flags, self._ctrl_addr(self._ctrl.ptr, "sent", slot),
+                                            self._ctrl_addr(self._ctrl.ptr, "ticket", slot), ctypes.c_void_p(self.side.cuda_stream)),
+                   "ngacf_peer_push")
+        self.launches += 1
+        self.pushes += 1
+
+        def wait(slot=slot):
+            _lib.check(_lib.lib.ngacf_peer_wait(self._ctrl_addr(self._ctrl.ptr, "flags", slot), self.W, self.rank,
+                                                self._ctrl_addr(self._ctrl.ptr, "expect", slot), self._ctrl_addr(self._ctrl.ptr, "err", 0),
+                                                self.timeout_ticks, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                       "ngacf_peer_wait")
+        h = _Handle(done=wait)
+        if not self.overlap:
+            h.wait()
+        return h
+
+    def join(self):
+        """The side stream's pushes rejoin the current stream (end of a pass; before a capture ends)."""
+        torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+    def check(self):
+        """Synchronises; raises if a wait ever timed out (a peer never published its block)."""
+        torch.cuda.synchronize(self.device)
+        n = SLOTS * self.W + 3 * SLOTS
+        err = int(self._ctrl.bytes_view[4 * n:4 * n + 4].view(torch.int32).item())
+        if err:
+            raise RuntimeError("peer-store all-gather: a wait timed out (a peer did not publish its block)")
+
+    def close(self):
+        torch.cuda.synchronize(self.device)
+        if self.W > 1 and dist.is_initialized():
+            dist.barrier(group=self.group)
+        for b in self._bufs:
+            for q in b.peers.values():
+                _lib.lib.ngacf_peer_close(ctypes.c_void_p(q))
+        if self.W > 1 and dist.is_initialized():
+            dist.barrier(group=self.group)
+        for b in self._bufs:
+            _lib.lib.ngacf_peer_free(ctypes.c_void_p(b.ptr))
+        self._bufs, self._pool, self._by_ptr = [], {}, {}

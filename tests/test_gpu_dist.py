@@ -296,3 +296,107 @@ def test_run_gowalla_under_torchrun_environment_equals_the_single_process_run(tm
         r = np.array([ref["%s.%d" % (key, j)][3] for j in range(nref)])
         w = r.max() - r.min()
         assert r.min() - 0.5 * w < m3[-1][key][3] < r.max() + 0.5 * w, (key, m3[-1][key][3], r)
+
+
+def _peer_worker(rank, world, port, q, bf16, graph):
+    """One rank of a world-`world` run on cuda:0 whose half-table gathers go by PEER STORES (ngacf_amd/peer.py: hipIpc-mapped
+    tables, push + flag, wait kernel) -- next to the same model on the process group's all-gather (gloo here)."""
+    try:
+        import os
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import ngacf_amd
+        from ngacf_amd.dist import ShardedSPUIGACF
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        U, I = 333, 251
+        edge = _graph(U, I, 7000, 3).to(dev)
+        torch.manual_seed(1)
+        ref = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev).train()
+        with torch.no_grad():
+            ref.uEmbd.weight.mul_(30); ref.iEmbd.weight.mul_(30)
+        models = []
+        for peer in (False, True):
+            m = ShardedSPUIGACF(U, I, 64, [64, 64], 0.0, world, rank, stages=3, adj=edge, peer_store=peer).to(dev).train()
+            m.load_full_state_dict(ref.state_dict())
+            if bf16:
+                m.compute_dtype = torch.bfloat16
+            models.append(m)
+        a, b = models
+        assert b.comm.peer_store and not a.comm.peer_store
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        u = torch.randint(0, U, (128,), device=dev, generator=g); it = torch.randint(0, I, (128,), device=dev, generator=g)
+        err = {}
+        for step in range(3):                                  # (tables are reused from the second step on)
+            for m in models:
+                m.zero_grad(set_to_none=True)
+            sa, sb = a(u, it, edge), b(u, it, edge)
+            sa.sum().backward(); sb.sum().backward()
+            b.comm.check()
+            same = torch.equal(sa, sb)                         # the forward: bit for bit
+            diffs = {"score": float((sa - sb).abs().max())}
+            for (k, p), (_, qq) in zip(a.named_parameters(), b.named_parameters()):
+                # (the score backward adds with float atomics: two runs of ONE model differ in the last bits too)
+                diffs[k] = float((p.grad - qq.grad).abs().max() / p.grad.abs().max().clamp_min(1e-20))
+                same = same and diffs[k] < (2e-2 if bf16 else 1e-5)
+            err["step%d" % step] = bool(same)
+            if not same:
+                err["diffs%d" % step] = diffs
+        with torch.no_grad():
+            ta, tb = a.propagate(edge), b.propagate(edge)
+            b.comm.check()
+            err["table"] = bool(torch.equal(ta, tb))
+            if graph:                                          # the evaluation forward as ONE replayed hipGraph on every rank
+                b.eval()
+                want = b.propagate_local(edge)
+                torch.cuda.synchronize()
+                dist.barrier()
+                gr = torch.cuda.CUDAGraph()
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    with torch.cuda.graph(gr, stream=s):
+                        got = b.propagate_local(edge)
+                ok = True
+                for _ in range(5):
+                    got[0].zero_(); got[1].zero_()
+                    gr.replay()
+                    torch.cuda.synchronize()
+                    ok = ok and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+                b.comm.check()
+                err["graph"] = bool(ok)
+        err["pushes"] = b.comm.pushes
+        dist.barrier()
+        q.put((rank, err))
+        b.comm.close()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, {"exception": "%s\n%s" % (e, traceback.format_exc())}))
+
+
+@pytest.mark.parametrize("world,bf16,graph", [(2, False, True), (3, True, False)])
+def test_peer_store_gather_equals_the_collective_path_bitwise(world, bf16, graph):
+    """the half-table all-gathers of forward and backward by stores into the peers' tables through hipIpc-mapped
+    pointers + flag words (no collective launch), `world` processes on the ONE GPU: scores and the propagated table BITWISE
+    equal to the same model on the process group's all-gather (gradients to 1e-5: the score backward's float atomics), over three steps (pool tables are reused from the
+    second on), no wait ever timed out; and the evaluation forward replayed as one hipGraph per rank."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, q, bf16, graph)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err in res:
+        assert "exception" not in err, err.get("exception")
+        assert all(err["step%d" % k] for k in range(3)) and err["table"], (rank, err)
+        assert err.get("graph", True), (rank, err)
+        assert err["pushes"] > 0
