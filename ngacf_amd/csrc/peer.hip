@@ -3,9 +3,10 @@
 // a consumer spins on its own flag words in front of its traversal.  No collective launch, no host on the path; both kernels
 // take their epoch from device memory, so a captured hipGraph replays them unchanged.
 //
-//   push   grid-stride 16-byte copies of (peer, region, chunk); every workgroup: system-scope release fence, then a ticket;
-//          the LAST workgroup (ticket == grid - 1): acquire fence, epoch = ++*sent, one system-scope release store of the epoch
-//          per peer.  A flag can therefore only be seen after every byte of every region has left this GPU.
+//   push   grid-stride 16-byte copies of (peer, region, chunk) as system-scope write-through stores; every workgroup: vmcnt(0)
+//          (its stores are acknowledged), barrier, then a ticket; the LAST workgroup (ticket == grid - 1): epoch = ++*sent, one
+//          system-scope store of the epoch per peer.  A flag can therefore only be seen after every byte of every region has
+//          been written.  (The counter form of the guide's fence-free hand-off, at system scope: no cache-wide write-back.)
 //   wait   one wave: lane r polls flag word r (system-scope loads: served at the coherent level, never by a cache) until it
 //          has reached ++*expect, or `timeout_ticks` of the 100 MHz clock have gone by (then *err = 1 and the wave LEAVES: a
 //          stalled peer costs a wrong answer that the host reports, not a hung GPU).  The traversal that follows is a new
@@ -27,6 +28,19 @@ struct PushArgs {
     int32_t* ticket;
 };
 
+// System-scope write-through stores (sc0 sc1): the bytes leave this GPU's caches with the store itself (to a peer's memory they
+// are uncached anyway), so publishing needs no cache-wide write-back -- a `buffer_wbl2` here would also flush what the traversal
+// running beside the push keeps in L2.  Inline asm: hipcc does not count these in its own vmcnt bookkeeping; the explicit
+// s_waitcnt vmcnt(0) below is the only consumer of their completion.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sys(uint4* p, const uint4 v) {
+    const u32x4 w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void store_sys(uint32_t* p, const uint32_t v) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 __global__ __launch_bounds__(256) void peer_push_kernel(const PushArgs a) {
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
     for (int r = 0; r < a.nreg; ++r) {
@@ -37,26 +51,28 @@ __global__ __launch_bounds__(256) void peer_push_kernel(const PushArgs a) {
             if (wide && (reinterpret_cast<uintptr_t>(g.dst[p]) & 15) == 0) {
                 const uint4* s = static_cast<const uint4*>(g.src);
                 uint4* d = static_cast<uint4*>(g.dst[p]);
-                for (size_t i = tid; i < g.bytes / 16; i += nth) d[i] = s[i];
+                for (size_t i = tid; i < g.bytes / 16; i += nth) store_sys(d + i, s[i]);
             } else {
                 const uint32_t* s = static_cast<const uint32_t*>(g.src);
                 uint32_t* d = static_cast<uint32_t*>(g.dst[p]);
-                for (size_t i = tid; i < g.bytes / 4; i += nth) d[i] = s[i];
+                for (size_t i = tid; i < g.bytes / 4; i += nth) store_sys(d + i, s[i]);
             }
         }
     }
-    __threadfence_system();                                   // this thread's stores are out before its workgroup's ticket
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's stores have been acknowledged ...
+    __syncthreads();                                          // ... and so have the workgroup's, before its ticket
     if (threadIdx.x != 0) return;
-    const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t != (int)gridDim.x - 1) return;
     __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // clean for the next launch
-    __threadfence_system();
     const int32_t e = *a.sent + 1;
     *a.sent = e;
-    for (int p = 0; p < a.npeers; ++p) __hip_atomic_store(a.flag[p], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int p = 0; p < a.npeers; ++p) __hip_atomic_store(a.flag[p], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// No acquire in here: the kernel only has to END after the flags are up -- the traversal behind it is a new dispatch, and its
+// start-of-kernel acquire is what drops stale lines of the table (an acquire fence in this wave would invalidate one XCD's L2
+// under the kernels running beside it and help nobody).
 __global__ __launch_bounds__(64) void peer_wait_kernel(const int32_t* flags, int n, int self, int32_t* expect, int32_t* err,
                                                        unsigned long long timeout_ticks) {
     const int lane = threadIdx.x;
@@ -65,14 +81,13 @@ __global__ __launch_bounds__(64) void peer_wait_kernel(const int32_t* flags, int
     bool late = false;
     if (lane < n && lane != self) {
         for (;;) {
-            const int32_t v = __hip_atomic_load(flags + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const int32_t v = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((int32_t)((uint32_t)v - (uint32_t)e) >= 0) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) { late = true; break; }
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(4);
         }
     }
     if (late) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
     __syncthreads();                                          // (one wave: every lane has read *expect before lane 0 moves it on)
     if (lane == 0) *expect = e;
 }

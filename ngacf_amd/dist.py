@@ -827,9 +827,12 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
                 "allgather": {"per_forward": launches_fwd, "avg_us_serial": round(ag_ms * 1e3, 2),
                               "avg_bytes_received_per_rank": int(ag_bytes),
                               "GBps_received_per_rank": round(ag_bytes / max(ag_ms * 1e-3, 1e-12) / 1e9, 1) if ag else None,
-                              "note": "one async all-gather per half-table per stage (in place, RCCL); serial-pass "
-                                      "duration start -> wait, rank 0"}}
+                              "transport": "peer stores through hipIpc-mapped tables + flag words (NGACF_PEER_GATHER=1)"
+                                           if model.comm.peer_store else "RCCL all-gather (in place)",
+                              "note": "one async all-gather per half-table per stage; serial-pass duration start -> wait, "
+                                      "rank 0 (collective transport only)"}}
     extra = {"ms_per_pass_eager": round(1e3 * t_eager / args.steps / R, 5), "roofline": roofline}
+    model.comm.check()                            # (peer stores: no wait has timed out so far)
 
     def line(t_fwd, windows, launch, extra, R=None):
         R = R_eager if R is None else R
@@ -960,11 +963,12 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
             R_graph = args.passes_per_step or BK.passes_per_step(allmax(BK.pass_time(graph.replay, sync)), args.steps, args.target_seconds)
             t_graph, win_graph = BK.timed_steps(graph.replay, args.steps, R_graph, sync, torch)
             t_graph = allmax(t_graph)
+            model.comm.check()
     except Exception as e:                         # capture refused here (maybe not on the peers): the eager numbers stand
         print("[bench] sharded hipGraph capture not used: %r" % (e,), file=sys.stderr, flush=True)
         finish(eager_line, True, "capture failed: %r" % (e,))
     better = t_graph / R_graph < t_eager / R_eager    # t_* are already max-over-ranks: every rank decides alike
-    glaunch = "hipGraph replay (kernels + RCCL launches)"
+    glaunch = "hipGraph replay (kernels + %s)" % ("peer-store push / wait kernels" if model.comm.peer_store else "RCCL launches")
     best = line(t_graph, win_graph, glaunch, extra, R_graph) if better else eager_line
     # ---- (4) the train step as one hipGraph (sampler-free: fixed batch, as in (2)), same watchdog ------------------
     if not args.no_train:

@@ -15,12 +15,17 @@ What has to hold for that, and how it is kept:
                      or, for s = 0, after it has finished pass k, whose last stage needed a block that I sent AFTER my own
                      stage-0 traversals of pass k: with at least two stages a table is never written while its previous
                      content is still being read.  One-stage stacks are refused.
-  visibility         push: stores -> system-scope release fence -> last-workgroup ticket -> release store of the epoch per peer;
-                     wait: system-scope acquire loads of the flag words; the traversal is a NEW kernel (its start drops what its
-                     caches held of the table).  A peer that never arrives costs `timeout_s`, sets an error word (check()) and the
+  visibility         push: system-scope write-through stores -> vmcnt(0) -> last-workgroup ticket -> system-scope store of the
+                     epoch per peer (no cache-wide write-back: it would flush the L2 under the traversal running beside it);
+                     wait: system-scope loads of the flag words; the traversal is a NEW kernel (its start drops what its caches
+                     held of the table).  A peer that never arrives costs `timeout_s`, sets an error word (check()) and the
                      kernel leaves: wrong numbers reported by the host, never a hung GPU.
-The push runs on a side stream (under the other half's traversal, like the asynchronous all-gather it replaces); join() brings
-it back before a pass ends.  Everything that is not a pool table (state-dict / evaluation gathers) takes the base class's path.
+  a step boundary    in training, a peer's next forward may only start after my backward has finished reading the tables it
+                     will overwrite: the per-step all-reduce of the weight gradients (reduce_grads) is that barrier.
+The push runs on a side stream (under the other half's traversal, like the asynchronous all-gather it replaces; overlap=False:
+in line on the current stream, no fork); join() brings it back before a pass ends.  Everything that is not a pool table
+(state-dict / evaluation gathers) takes the base class's path.  Validated as 2-4 processes on ONE GPU (tests/test_gpu_dist.py,
+tools/peer_probe.py); between GPUs it has never run: opt-in (NGACF_PEER_GATHER=1 / peer_store=True).
 """
 import ctypes
 
@@ -152,11 +157,15 @@ class PeerComm(Comm):
         for j, r in enumerate(self.others):                   # my word in peer r's flag array
             flags[j] = self._ctrl_addr(self._ctrl.peers[r], "flags", slot) + 4 * self.rank
         cur = torch.cuda.current_stream(self.device)
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        self.side.wait_event(ev)
+        if self.overlap:                                      # under the other half's traversal: a fork to the side stream
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.side.wait_event(ev)
+            st = self.side
+        else:                                                 # serial schedule: push and wait in line (no fork, no join: the
+            st = cur                                          # cheapest per exchange when the blocks are small)
         _lib.check(_lib.lib.ngacf_peer_push(regs, len(fulls), len(self.others), flags, self._ctrl_addr(self._ctrl.ptr, "sent", slot),
-                                            self._ctrl_addr(self._ctrl.ptr, "ticket", slot), ctypes.c_void_p(self.side.cuda_stream)),
+                                            self._ctrl_addr(self._ctrl.ptr, "ticket", slot), ctypes.c_void_p(st.cuda_stream)),
                    "ngacf_peer_push")
         self.launches += 1
         self.pushes += 1
