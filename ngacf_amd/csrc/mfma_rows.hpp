@@ -8,6 +8,8 @@
 //   Weight panel = A fragments: index ((y * KS + s) * OT + t) * 64 + l, KS = din / 16, OT = dout / 32, 8 bf16 each:
 //   lane l holds W[y][16 s + 8 (l >> 5) + j][32 t + (l & 31)], j = 0..7.
 #pragma once
+#include <stdlib.h>
+
 #include "ngacf_common.hpp"
 
 namespace ngacf {
@@ -33,9 +35,22 @@ __device__ __forceinline__ void pack_panel_job(const float* __restrict__ W, void
 
 // Epilogue of one 32-node tile: H rows (bf16, 16-byte stores) and the per-node scores S = H . a, formed from the ROUNDED H.
 //   nd: the lane's node (row of H / S), ok: the node exists; h = lane >> 5; av = avec of the tile's node type [DOUT].
-template <int OT, int HEADS, int DOUT>
+//   staged: the rounded H' goes through otile -- 32 x (DOUT / 8 + 1) uint4 of LDS private to this wave, tr: the
+//   lane's row in it, row_of(tile row) -> row of H or -1 -- so that the tile leaves as whole 128-byte lines (a wave instruction
+//   = 8 full rows) instead of 32 x 32-byte pieces per instruction.  Same values.  It pays where H streams to HBM (15 M rows:
+//   the launch goes from 4.3-4.8 to 5.4-5.6 TB/s) and costs a little where the table is cache-resident and the launch is
+//   latency-bound (Gowalla: +0.7 us per launch; as a run-time branch +1.7 us even when not taken), so the host picks the
+//   instantiation by table size (stage_out_pays).
+inline bool stage_out_pays(uint64_t n_rows, int dout) {
+    static const char* force = getenv("NGACF_STAGE_OUT");           // "0" / "1": one form everywhere (tests compare the two)
+    if (force && (force[0] == '0' || force[0] == '1')) return force[0] == '1';
+    return n_rows * (uint64_t)dout * 2 >= (64ull << 20);
+}
+
+template <int OT, int HEADS, int DOUT, bool staged, typename RowOf>
 __device__ __forceinline__ void mfma_fwd_epilogue(const f32x16 (&acc)[OT], int nd, bool ok, int h, const float* __restrict__ av,
-                                                  void* Hout, float* __restrict__ S) {
+                                                  void* Hout, float* __restrict__ S, uint4* otile, int tr, RowOf row_of) {
+    constexpr int OROW = DOUT / 8 + 1;
     float head_part[OT * 4];
     float total = 0.f;
     char* Hrow = reinterpret_cast<char*>(Hout) + (size_t)nd * DOUT * 2;
@@ -66,9 +81,21 @@ __device__ __forceinline__ void mfma_fwd_epilogue(const f32x16 (&acc)[OT], int n
             // turns two 8-byte stores per lane into one 16-byte store (lower half: group gp, upper half: group gp+1)
             const auto rx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
             const auto ry = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-            if (ok)
-                *reinterpret_cast<uint4*>(Hrow + 64 * t + 16 * gp + 16 * h) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            const uint4 piece = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            if (staged) otile[tr * OROW + 4 * t + gp + h] = piece;
+            else if (ok) *reinterpret_cast<uint4*>(Hrow + 64 * t + 16 * gp + 16 * h) = piece;
         }
+    if (staged) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < DOUT / 16; ++j) {                  // 32 rows x DOUT bf16 = DOUT / 16 wave stores of 1 KB
+            const int o = j * 1024 + lane * 16;
+            const int orow = o / (DOUT * 2), cb = o % (DOUT * 2);
+            const uint4 v = otile[orow * OROW + cb / 16];
+            const int g = row_of(orow);
+            if (g >= 0) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Hout) + (size_t)g * DOUT * 2 + cb) = v;
+        }
+    }
     if (HEADS == 1) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(total), __float_as_uint(total), false, false);
         total += __uint_as_float(h ? r[0] : r[1]);

@@ -137,7 +137,7 @@ __device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, in
 //      v_mfma_f32_32x32x16_bf16, mfma_fwd_epilogue (H' rows as 16-byte stores, S' from the rounded H').  Same arithmetic, same
 //      order, same bits as the stand-alone launch on the stored table.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int D, int NEXT, bool NONE>
+template <int D, int NEXT, bool NONE, bool STAGE_OUT>
 __device__ __forceinline__ void next_transform_tail(const PropArgs& a, uint4* xtile, int* xmeta, const uint4* panel, const float* av,
                                                     bool valid, int row, int slot, int q, const float (&o)[8]) {
     constexpr int KS = D / 16, OT = NEXT / 32, NH = NONE ? 1 : NEXT / 8;
@@ -180,7 +180,9 @@ __device__ __forceinline__ void next_transform_tail(const PropArgs& a, uint4* xt
 #pragma unroll
         for (int t = 0; t < OT; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, panel[(sk * OT + t) * 64 + lane]), bf[sk], acc[t], 0, 0, 0);
-    mfma_fwd_epilogue<OT, NH, NEXT>(acc, ok ? nrow : 0, ok, h, av, a.next_H, a.next_S);
+    // (H' leaves through the tile too -- every lane of this wave has its fragments, nobody else reads the tile any more)
+    mfma_fwd_epilogue<OT, NH, NEXT, STAGE_OUT>(acc, ok ? nrow : 0, ok, h, av, a.next_H, a.next_S, xtile, r,
+                                    [&](int tr) { return xmeta[tr]; });
 }
 
 // The same for fp32 storage.  A lane group finishes a row of 64 fp32 columns with 16 lanes, so a wave finishes 4 rows and the
@@ -545,7 +547,7 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
 }
 
 // NEXT > 0 (= the next stage's output width; NONE: that stage has ONE head): the fused form of ngacf_prop_fwd_next.
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int NEXT = 0, bool NONE = false>
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int NEXT = 0, bool NONE = false, bool STAGE_OUT = false>
 __global__ __launch_bounds__(256, NEXT == 64 ? 5 : NEXT == 128 ? 4 : (sizeof(T) == 2 && D == 64 && !SPARSE ? 6 : 1)) void prop_fwd_kernel(const PropArgs a) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC, EPI = SH::EPI;
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256, NEXT == 64 ? 5 : NEXT == 128 ? 4 : (sizeof(T) 
         // while the waves traverse; the barrier of the tail publishes it together with the finished rows
         constexpr int PANEL_U4 = (D / 16) * (NEXT / 32) * 64;
         __shared__ __attribute__((aligned(16))) uint4 panel_lds[PANEL_U4];
-        __shared__ __attribute__((aligned(16))) uint4 xtile_lds[32 * XROW_U4];
+        __shared__ __attribute__((aligned(16))) uint4 xtile_lds[32 * (NEXT / 8 + 1)];      // (rows of 9 going in, of NEXT / 8 + 1 going out)
         __shared__ int xmeta_lds[32];
         __shared__ __attribute__((aligned(16))) float4 avec_lds[NEXT / 4];
         const bool users = (int)blockIdx.x < a.order.b2;
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256, NEXT == 64 ? 5 : NEXT == 128 ? 4 : (sizeof(T) 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) ro[j] = 0.f;
         prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true>(a, kind, widx, wend, rvalid, rrow, ro);
-        next_transform_tail<D, NEXT, NONE>(a, xtile_lds, xmeta_lds, panel_lds, reinterpret_cast<const float*>(avec_lds), rvalid, rrow,
+        next_transform_tail<D, NEXT, NONE, STAGE_OUT>(a, xtile_lds, xmeta_lds, panel_lds, reinterpret_cast<const float*>(avec_lds), rvalid, rrow,
                                            lane / SH::LPR, lane % SH::LPR, ro);
     } else if constexpr (NEXT > 0) {
         // fp32 storage: the panel is the next stage's fp32 W'[type] itself ([64][NEXT], no packing); a 1 KB LDS-DMA piece = 256
@@ -642,7 +644,8 @@ __global__ __launch_bounds__(256) void prop_fwd_split_kernel(const PropArgs a, c
 }
 
 template <typename T, int D, int HEADS>
-static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st, int next_dout = 0, bool next_one = false) {
+static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st, int next_dout = 0, bool next_one = false,
+                      bool next_staged = false) {
     constexpr int EPI = Shape<T, D, HEADS>::EPI;
     int nb = 0;
     a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, a.order.nhub, a.order.nhub_u, EPI, &nb);
@@ -650,15 +653,22 @@ static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, b
         if constexpr (D == 64 && HEADS == 8) {
             if (nb == 0) return 0;
             const dim3 grid(nb), block(256);
-#define NGACF_NEXT(ND, ONE)                                                                                              \
+#define NGACF_NEXT(ND, ONE, STG)                                                                                         \
             do {                                                                                                         \
-                if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, true, false, ND, ONE>, grid, block, 0, st, a);   \
-                else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, false, ND, ONE>, grid, block, 0, st, a);  \
+                if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, true, false, ND, ONE, STG>, grid, block, 0, st, a);   \
+                else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, false, ND, ONE, STG>, grid, block, 0, st, a);  \
             } while (0)
-            if (next_dout == 64 && !next_one) NGACF_NEXT(64, false);
-            else if (next_dout == 64) NGACF_NEXT(64, true);
-            else if (next_dout == 128 && !next_one) NGACF_NEXT(128, false);
-            else if (next_dout == 128) NGACF_NEXT(128, true);
+            constexpr bool B16 = sizeof(T) == 2;             // (the staged form exists for bf16 storage only)
+            if (B16 && next_staged) {
+                if (next_dout == 64 && !next_one) NGACF_NEXT(64, false, B16);
+                else if (next_dout == 64) NGACF_NEXT(64, true, B16);
+                else if (next_dout == 128 && !next_one) NGACF_NEXT(128, false, B16);
+                else if (next_dout == 128) NGACF_NEXT(128, true, B16);
+                else return NGACF_E_SHAPE;
+            } else if (next_dout == 64 && !next_one) NGACF_NEXT(64, false, false);
+            else if (next_dout == 64) NGACF_NEXT(64, true, false);
+            else if (next_dout == 128 && !next_one) NGACF_NEXT(128, false, false);
+            else if (next_dout == 128) NGACF_NEXT(128, true, false);
             else return NGACF_E_SHAPE;
 #undef NGACF_NEXT
             NGACF_CHECK_LAUNCH();
@@ -733,7 +743,7 @@ extern "C" int ngacf_prop_fwd_next(const int32_t* segs, int nseg, const int32_t*
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int next_dout = 0;
-    bool next_one = false;
+    bool next_one = false, next_staged = false;
     if (next) {
         if (!next->panel || !next->avec || !next->H || !next->S) return NGACF_E_ARG;
         if (d != 64 || heads != 8 || !from_row || needed || nhub > 0) return NGACF_E_SHAPE;
@@ -746,8 +756,9 @@ extern "C" int ngacf_prop_fwd_next(const int32_t* segs, int nseg, const int32_t*
         if (next->feat_drop_p > 0.f && a.next_drop_thr == 0) a.next_drop_thr = 1;     // (p below 2^-32: keep the branch, drop nothing measurable)
         a.next_drop_scale = 1.f / (1.f - next->feat_drop_p); a.next_seed = next->seed;
         next_dout = next->dout; next_one = next->heads == 1;
+        next_staged = dtype == NGACF_BF16 && stage_out_pays((uint64_t)N, next->dout);
     }
-#define NGACF_CASE(T, D, HD) return launch_fwd<T, D, HD>(a, split, nsplit, from_row, drop, st, next_dout, next_one)
+#define NGACF_CASE(T, D, HD) return launch_fwd<T, D, HD>(a, split, nsplit, from_row, drop, st, next_dout, next_one, next_staged)
     if (dtype == NGACF_F32) {
         if (d == 64 && heads == 8) NGACF_CASE(float, 64, 8);
         if (d == 64 && heads == 1) NGACF_CASE(float, 64, 1);

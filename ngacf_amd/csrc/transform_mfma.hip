@@ -49,7 +49,7 @@ __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
 }
 
 // TB: type of the node-row operand (bf16_t or float); TO: output element type; FWD: forward (else dX)
-template <typename TB, typename TO, int DIN, int DOUT, bool FWD, int HEADS, bool DROP>
+template <typename TB, typename TO, int DIN, int DOUT, bool FWD, int HEADS, bool DROP, bool STAGE_OUT = false>
 __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
     constexpr int KD = FWD ? DIN : DOUT;           // contraction width
     constexpr int OD = FWD ? DOUT : DIN;           // output width
@@ -77,41 +77,63 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
     const uint32_t salt = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
 
     const int r = lane & 31, h = lane >> 5;
-    const TB* Bg = static_cast<const TB*>(a.B);
-    // node-row operand of one 32-row tile -> bf16 B fragments (16 contiguous bytes of the node's row per k-step)
-    auto load_tile = [&](int it, bf16x8 (&bf)[KS], int& nd_out, bool& ok_out) {
-        const int tile = (bl * 4 + wave) * a.tpw + it;
-        const int node = win_lo + tile * 32 + r;
-        const bool ok = tile < ntiles && node < win_end;
-        const int nd = ok ? node : win_end - 1;
-        nd_out = nd; ok_out = ok;
-        const size_t brow = (size_t)(a.b_local ? nd - loc_off : nd);
+    // Node rows of one 32-row tile -> bf16 B fragments (16 contiguous bytes of the node's row per k-step), THROUGH LDS: the tile
+    // is 32 consecutive rows = one contiguous span of 32 * RB bytes, fetched as RB / 32 fully coalesced 1 KB wave loads (every
+    // cache line requested once), converted (+ feature dropout) and laid down as bf16 rows in the wave's own LDS tile; the
+    // fragment of lane (r, h) for k-step s is then one 16-byte LDS read.  (Fetching the fragments straight from global memory
+    // made every wave instruction touch 32 lines for 1 KB -- each line requested 4-8 times: the launch ran at a third of the
+    // copy rate.)  The tile is wave-private: LDS executes a wave's instructions in order, no barrier.
+    constexpr int RB = KD * (int)sizeof(TB);                 // bytes of a node row: 128, 256 or 512
+    constexpr int NLD = RB / 32;                             // 16-byte loads per lane and tile
+    constexpr int TROW = KD / 8 + 1;                         // LDS tile row in uint4: the bf16 row + 16 B (fragment reads: no bank conflict)
+    constexpr int TSZ = 32 * ((KD > OD ? KD : OD) / 8 + 1);  // (the forward's epilogue sends H' through the same tile)
+    uint4* tile = reinterpret_cast<uint4*>(lds_raw + (size_t)KS * OT * 64 * 16) + wave * TSZ;
+    const char* Bg = static_cast<const char*>(a.B);
+    uint4 raw[NLD];
+    int base = 0, rows = 0;                                  // the tile in `raw`: first node, number of valid rows
+    auto issue = [&](int it) {
+        const int ti = (bl * 4 + wave) * a.tpw + it;
+        base = win_lo + ti * 32;
+        rows = ti < ntiles ? min(32, win_end - base) : 0;
+        const char* src = Bg + (size_t)(a.b_local ? base - loc_off : base) * RB;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int c0 = 16 * s + 8 * h;
-            if constexpr (sizeof(TB) == 2 && !(FWD && DROP)) {
-                bf[s] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const uint16_t*>(Bg) + brow * KD + c0);
+        for (int j = 0; j < NLD; ++j) {
+            const int o = j * 1024 + lane * 16;
+            raw[j] = o < rows * RB ? *reinterpret_cast<const uint4*>(src + o) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stage = [&]() {                                     // raw -> the LDS tile
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int o = j * 1024 + lane * 16;
+            const int tr = o / RB, cb = o % RB;              // tile row, byte offset inside the node's row
+            if constexpr (sizeof(TB) == 2) {
+                uint4 v = raw[j];
+                if constexpr (FWD && DROP) {
+                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
+                        const int c = cb / 2 + 2 * k;
+                        const float l2 = feat_bits(salt, base + tr, c) >= a.drop_thr ? lo * a.drop_scale : 0.f;
+                        const float h2 = feat_bits(salt, base + tr, c + 1) >= a.drop_thr ? hi * a.drop_scale : 0.f;
+                        w[k] = f32_to_bf16(l2) | (f32_to_bf16(h2) << 16);
+                    }
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                tile[tr * TROW + cb / 16] = v;
             } else {
-                float f[8];
-                if constexpr (sizeof(TB) == 2) {
-                    Slice<bf16_t>::load(reinterpret_cast<const bf16_t*>(Bg) + brow * KD + c0, f);
-                } else {
-                    const float4 v0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Bg) + brow * KD + c0);
-                    const float4 v1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Bg) + brow * KD + c0 + 4);
-                    f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
-                }
-                if (FWD && DROP) {
+                float f[4] = {__uint_as_float(raw[j].x), __uint_as_float(raw[j].y), __uint_as_float(raw[j].z), __uint_as_float(raw[j].w)};
+                if constexpr (FWD && DROP) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = feat_bits(salt, nd, c0 + j) >= a.drop_thr ? f[j] * a.drop_scale : 0.f;
+                    for (int k = 0; k < 4; ++k) f[k] = feat_bits(salt, base + tr, cb / 4 + k) >= a.drop_thr ? f[k] * a.drop_scale : 0.f;
                 }
-                bf[s] = pack8(f);
+                reinterpret_cast<uint2*>(tile)[(tr * TROW * 16 + cb / 2) / 8] =
+                    make_uint2(f32_to_bf16(f[0]) | (f32_to_bf16(f[1]) << 16), f32_to_bf16(f[2]) | (f32_to_bf16(f[3]) << 16));
             }
         }
     };
-    bf16x8 bf[KS];
-    int nd;
-    bool ok;
-    load_tile(0, bf, nd, ok);            // in flight while the workgroup builds the weight panel
+    issue(0);                            // in flight while the workgroup builds the weight panel
 
     {   // weight panel -> bf16 A fragments: A[i][k] = W[k][i] (forward) or W[i][k] (dX)
         const float* M = a.M + (size_t)type * DIN * DOUT;
@@ -129,6 +151,14 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
 #pragma unroll 1
     for (int it = 0; it < a.tpw; ++it) {
         if ((bl * 4 + wave) * a.tpw + it >= ntiles) break;
+        stage();
+        const bool ok_cur = r < rows;
+        const int nd_cur = ok_cur ? base + r : win_end - 1;
+        bf16x8 bf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bf[s] = __builtin_bit_cast(bf16x8, tile[r * TROW + 2 * s + h]);
+        const int base_done = base, rows_done = rows;
+        if (it + 1 < a.tpw) issue(it + 1);                   // next tile's rows fly under this tile's MFMAs and epilogue
         f32x16 acc[OT];
 #pragma unroll
         for (int t = 0; t < OT; ++t)
@@ -140,12 +170,11 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
             for (int t = 0; t < OT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[(s * OT + t) * 64 + lane], bf[s], acc[t], 0, 0, 0);
 
-        const int nd_cur = nd;
-        const bool ok_cur = ok;
-        if (it + 1 < a.tpw) load_tile(it + 1, bf, nd, ok);     // next tile's rows fly under this tile's epilogue
         // lane: node r (+ half h); acc[t][4g + j] = output column 32t + 8g + 4h + j
         if constexpr (FWD) {
-            mfma_fwd_epilogue<OT, HEADS, DOUT>(acc, nd_cur, ok_cur, h, a.avec + type * DOUT, a.out, a.S);
+            const int base_cur = base_done, rows_cur = rows_done;
+            mfma_fwd_epilogue<OT, HEADS, DOUT, STAGE_OUT>(acc, nd_cur, ok_cur, h, a.avec + type * DOUT, a.out, a.S, tile, r,
+                                               [&](int tr) { return tr < rows_cur ? base_cur + tr : -1; });
         } else {
             const size_t orow = (size_t)(a.out_local ? nd_cur - loc_off : nd_cur);
 #pragma unroll
@@ -192,12 +221,16 @@ static int launch_mfma(MfmaArgs a, bool drop, hipStream_t st) {
     if (a.tpw < 1) a.tpw = 1;
     a.nb_main = (tiles_u + 4 * a.tpw - 1) / (4 * a.tpw) + (tiles_i + 4 * a.tpw - 1) / (4 * a.tpw);
     if (!FWD) a.npack = 0;
+    const bool stage_out = FWD && stage_out_pays((uint64_t)a.U + a.I, DOUT);    // H' through the LDS tile as whole lines
     const int nb = a.nb_main + 2 * a.npack;
     if (nb == 0) return 0;
-    constexpr size_t lds = (size_t)(KD / 16) * (OD / 32) * 64 * 16;
+    constexpr size_t lds = (size_t)(KD / 16) * (OD / 32) * 64 * 16 + (size_t)4 * 32 * ((KD > OD ? KD : OD) / 8 + 1) * 16;   // panel + the four waves' row tiles
     if (!FWD) {
         if (drop) hipLaunchKernelGGL((transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, true>), dim3(nb), dim3(256), lds, st, a);
         else      hipLaunchKernelGGL((transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, false>), dim3(nb), dim3(256), lds, st, a);
+    } else if (stage_out) {
+        if (drop) launch_k(NGACF_TAG_TRANSFORM_FWD, transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, true, FWD>, dim3(nb), dim3(256), lds, st, a);
+        else      launch_k(NGACF_TAG_TRANSFORM_FWD, transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, false, FWD>, dim3(nb), dim3(256), lds, st, a);
     } else {
         if (drop) launch_k(NGACF_TAG_TRANSFORM_FWD, transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, true>, dim3(nb), dim3(256), lds, st, a);
         else      launch_k(NGACF_TAG_TRANSFORM_FWD, transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, false>, dim3(nb), dim3(256), lds, st, a);

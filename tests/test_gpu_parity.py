@@ -907,3 +907,59 @@ def test_fused_stack_equals_unfused_stack(dev, kind, dt):
         a_, b_ = res[True][2][n].double(), res[False][2][n].double()
         # (the backward is the same code on the same saved tensors; float atomics in the score gradient reorder a few sums)
         assert float((a_ - b_).norm() / b_.norm().clamp_min(1e-30)) < 1e-5, n
+
+
+_STAGE_OUT_SCRIPT = r'''
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from ngacf_amd import ops
+from ngacf_amd.plan import build_plan
+dev = torch.device("cuda:0")
+rs = np.random.RandomState(9)
+U, I = 700, 501                                   # (a last tile that is not full)
+N = U + I
+src = rs.randint(0, U, 30000); dst = rs.randint(0, I, 30000)
+edge = torch.from_numpy(np.unique(np.stack([src, dst]), axis=1)).to(dev)
+plan = build_plan(edge, U, I, seg_len=128)
+h = hashlib.sha1()
+def eat(*ts):
+    for t in ts:
+        h.update(t.detach().contiguous().view(torch.uint8).cpu().numpy().tobytes())
+X = torch.from_numpy(rs.randn(N, 64).astype(np.float32)).to(dev)
+for xdt in (torch.float32, torch.bfloat16):
+    for dout, heads in ((64, 8), (64, 1), (128, 16), (128, 1)):
+        W = torch.from_numpy((rs.randn(2, 64, dout) * 0.2).astype(np.float32)).to(dev)
+        a = torch.from_numpy((rs.randn(2, dout) * 0.3).astype(np.float32)).to(dev)
+        H, S = ops.transform_fwd(X.to(xdt), W, a, U, I, heads, torch.bfloat16, feat_drop_p=0.2, seed=5)
+        eat(H, S)
+W = torch.from_numpy((rs.randn(2, 64, 64) * 0.2).astype(np.float32)).to(dev)
+a = torch.from_numpy((rs.randn(2, 64) * 0.3).astype(np.float32)).to(dev)
+for dout, heads in ((64, 8), (64, 1), (128, 16), (128, 1)):
+    W2 = torch.from_numpy((rs.randn(2, 64, dout) * 0.2).astype(np.float32)).to(dev)
+    a2 = torch.from_numpy((rs.randn(2, dout) * 0.3).astype(np.float32)).to(dev)
+    H, S, panels = ops.transform_fwd(X, W, a, U, I, 8, torch.bfloat16, pack=[W2])
+    nxt = ops.NextStage(panels[0], a2, heads, 0.1, 77)
+    out = ops.prop_fwd(plan, H, S, S, a, 8, drop_p=0.1, seed=11, next=nxt)
+    eat(out, nxt.H, nxt.S)
+torch.cuda.synchronize()
+print("DIGEST", h.hexdigest())
+'''
+
+
+def test_h_rows_leave_the_same_through_the_lds_tile_as_directly(dev):
+    """The bf16 transform's H' rows are written either piece by piece from the accumulator layout or -- for tables that stream to
+    HBM (mfma_rows.hpp: stage_out_pays, >= 64 MB) -- through the wave's LDS tile as whole 128-byte lines; NGACF_STAGE_OUT=0 / 1
+    forces one form everywhere.  Same bits from the stand-alone launch (fp32 and bf16 input rows, 64 / 128 wide, 8-wide heads and
+    one head, feature dropout, a ragged last tile) and from the traversal epilogue (ngacf_prop_fwd_next)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for force in ("0", "1"):
+        env = dict(os.environ, NGACF_STAGE_OUT=force)
+        r = subprocess.run([sys.executable, "-c", _STAGE_OUT_SCRIPT % root], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
