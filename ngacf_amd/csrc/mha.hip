@@ -538,6 +538,350 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const MhaArgs a) {
     store_accT<DK>(a.dV + (size_t)key * a.dim + h * DK, dv, kh, 1.f);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// backward, exact fp32 matrix cores, second form (round 3): the two passes above on v_mfma_f32_16x16x4_f32 with the streamed
+// side staged through LDS, as in mha_fwd16_kernel.
+//   pass Q   workgroup = NW waves per (head, 32-query block); a stage = 32 * NW keys: K and V transposed (A operands of the
+//            S^T = K Q^T and dP^T = V dO^T blocks, conflict-free ds_read_b32) and K row-major (A operand of dQ^T += K^T dS^T, whose
+//            B operand IS register r of the dS^T block: no LDS round trip).  A lane owns two queries (n, 16 + n): max, 1 / sum
+//            and delta are lane scalars.  No running maximum in a backward pass: nothing is rescaled.
+//   pass KV  workgroup per (head, 32-key block); a stage = 32 * NW queries: Q and dO transposed (A operands of S = Q K^T and
+//            dP = dO V^T) and row-major (A operands of dV^T += dO^T Pd, dK^T += Q^T dS), plus the queries' (max, 1 / sum, delta,
+//            mask word of this key block).  A lane owns two keys; the rows of a block are queries 4 g + r.
+// Waves add their partial sums through LDS in wave order (deterministic); no atomics.  Same semantics as the 32x32 form.
+// ---------------------------------------------------------------------------------------------------------
+template <int DK, int NW, bool DROP, bool MASK>
+__global__ __launch_bounds__(NW * 64) void mha_bwd16_q_kernel(const MhaArgs a) {
+    constexpr int SK = 32 * NW, NT = 64 * NW, FB = (DK + 15) / 16, KQ = DK / 4, PC = DK / 8;
+    constexpr int BUF = 3 * DK * SK;            // floats per stage buffer: Kt [DK][SK] | Vt [DK][SK] | Ks [SK][DK]
+    extern __shared__ __attribute__((aligned(16))) float mha_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int qblocks = (a.Nq + 31) / 32;
+    const int h = blockIdx.x / qblocks, q0 = (blockIdx.x % qblocks) * 32;
+    const uint32_t salt_h = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + h) : 0u;
+    const int mwords = (a.Nk + 31) >> 5;
+    int qi[2];
+    float qreg[2][KQ], doreg[2][KQ], mx[2], il[2], dl[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qi[qb] = min(q0 + 16 * qb + n, a.Nq - 1);
+        const size_t row = (size_t)qi[qb] * a.dim + h * DK;
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) {
+            qreg[qb][t] = a.Q[row + 4 * t + g];
+            doreg[qb][t] = a.dO[row + 4 * t + g];
+            part = fmaf(doreg[qb][t], a.O[row + 4 * t + g], part);
+        }
+        part += lane_xor16(part, g);
+        part += lane_xor32(part, g);
+        dl[qb] = part;                                                            // delta = dO . O over the head's features
+        const float2 ml = *reinterpret_cast<const float2*>(a.LSE + 2 * ((size_t)qi[qb] * a.heads + h));   // (max, 1 / sum)
+        mx[qb] = ml.x; il[qb] = ml.y;
+    }
+    mha_f32x4 dq[FB][2];
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) dq[fb][qb] = mha_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 kst[PC], vst[PC];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            const int p = tid + i * NT, key = p / (DK / 4), c = p % (DK / 4);
+            const size_t row = (size_t)min(s * SK + key, a.Nk - 1) * a.dim + h * DK + 4 * c;
+            kst[i] = *reinterpret_cast<const float4*>(a.K + row);
+            vst[i] = *reinterpret_cast<const float4*>(a.V + row);
+        }
+    };
+    auto park = [&](int buf) {
+        float* const B = mha_lds + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            const int p = tid + i * NT, key = p / (DK / 4), c = p % (DK / 4);
+            float* kt = B + (4 * c) * SK + key;
+            kt[0] = kst[i].x; kt[SK] = kst[i].y; kt[2 * SK] = kst[i].z; kt[3 * SK] = kst[i].w;
+            float* vt = B + DK * SK + (4 * c) * SK + key;
+            vt[0] = vst[i].x; vt[SK] = vst[i].y; vt[2 * SK] = vst[i].z; vt[3 * SK] = vst[i].w;
+            *reinterpret_cast<float4*>(B + 2 * DK * SK + key * DK + 4 * c) = kst[i];
+        }
+    };
+    const int nstage = (a.Nk + SK - 1) / SK;
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstage) fetch(s + 1);
+        const int k0 = s * SK + 32 * wv;
+        if (k0 < a.Nk) {
+            const float* kt = mha_lds + buf * BUF + 32 * wv;
+            const float* vt = kt + DK * SK;
+            const float* ks = mha_lds + buf * BUF + 2 * DK * SK + 32 * wv * DK;
+            mha_f32x4 sc[2][2], dp[2][2];       // [kb][qb]: keys 16 kb + 4 g + r, query 16 qb + n
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float ka[KQ], va[KQ];
+#pragma unroll
+                for (int t = 0; t < KQ; ++t) {
+                    ka[t] = kt[(4 * t + g) * SK + 16 * kb + n];
+                    va[t] = vt[(4 * t + g) * SK + 16 * kb + n];
+                }
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    mha_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < KQ; ++t) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[t], qreg[qb][t], acc, 0, 0, 0);
+                        acd = __builtin_amdgcn_mfma_f32_16x16x4f32(va[t], doreg[qb][t], acd, 0, 0, 0);
+                    }
+                    sc[kb][qb] = acc;
+                    dp[kb][qb] = acd;
+                }
+            }
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                uint32_t mw = 0xffffffffu;
+                if (MASK) mw = a.mask[(size_t)qi[qb] * mwords + (k0 >> 5)];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kk = 16 * kb + 4 * g + r, key = k0 + kk;
+                        const bool inr = key < a.Nk;
+                        const bool open = (mw >> kk) & 1u;
+                        const float sv = open ? sc[kb][qb][r] * a.scale : MHA_MASKED;
+                        const float p = inr ? __expf(sv - mx[qb]) * il[qb] : 0.f;
+                        float dpe = dp[kb][qb][r];
+                        if (DROP) dpe *= drop_mul(a, salt_h, qi[qb], min(key, a.Nk - 1));
+                        sc[kb][qb][r] = (open && inr) ? p * (dpe - dl[qb]) * a.scale : 0.f;
+                    }
+            }
+            // dQ^T += K^T . dS^T: register r of block kb contracts over the keys 16 kb + 4 k + r, k = 0..3
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int fb = 0; fb < FB; ++fb) {
+                        const float kav = (16 * fb + n < DK) ? ks[(16 * kb + 4 * g + r) * DK + 16 * fb + n] : 0.f;
+#pragma unroll
+                        for (int qb = 0; qb < 2; ++qb)
+                            dq[fb][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kav, sc[kb][qb][r], dq[fb][qb], 0, 0, 0);
+                    }
+        }
+        if (s + 1 < nstage) park(buf ^ 1);
+        __syncthreads();
+    }
+    float* const ob = mha_lds;                                    // [NW][FB * 2 * 4][64]
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[(wv * FB * 8 + (fb * 2 + qb) * 4 + r) * 64 + lane] = dq[fb][qb][r];
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = q0 + 16 * qb + n;
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int x = 0; x < NW; ++x) acc += ob[(x * FB * 8 + (fb * 2 + qb) * 4 + r) * 64 + lane];
+                v[r] = acc;
+            }
+            if (q < a.Nq && 16 * fb + 4 * g < DK)
+                *reinterpret_cast<float4*>(a.dQ + (size_t)q * a.dim + h * DK + 16 * fb + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (q < a.Nq && g == 0) a.delta[(size_t)q * a.heads + h] = dl[qb];
+    }
+}
+
+template <int DK, int NW, bool DROP, bool MASK>
+__global__ __launch_bounds__(NW * 64) void mha_bwd16_kv_kernel(const MhaArgs a) {
+    constexpr int SQ = 32 * NW, NT = 64 * NW, FB = (DK + 15) / 16, KQ = DK / 4, PC = DK / 8;
+    constexpr int BUF = 4 * DK * SQ + 4 * SQ;   // floats per stage buffer: Qt | dOt [DK][SQ] | Qs | dOs [SQ][DK] | max | 1/sum | delta | mask word
+    extern __shared__ __attribute__((aligned(16))) float mha_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int kblocks = (a.Nk + 31) / 32;
+    const int h = blockIdx.x / kblocks, k0 = (blockIdx.x % kblocks) * 32;
+    const uint32_t salt_h = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + h) : 0u;
+    const int mwords = (a.Nk + 31) >> 5;
+    int ki[2];
+    float kreg[2][KQ], vreg[2][KQ];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        ki[kb] = min(k0 + 16 * kb + n, a.Nk - 1);
+        const size_t row = (size_t)ki[kb] * a.dim + h * DK;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) {
+            kreg[kb][t] = a.K[row + 4 * t + g];
+            vreg[kb][t] = a.V[row + 4 * t + g];
+        }
+    }
+    mha_f32x4 dk[FB][2], dv[FB][2];
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { dk[fb][kb] = mha_f32x4{0.f, 0.f, 0.f, 0.f}; dv[fb][kb] = mha_f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    float4 qst[PC], dst[PC];
+    float s_m = 0.f, s_i = 0.f, s_d = 0.f;
+    uint32_t s_w = 0xffffffffu;
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            const int p = tid + i * NT, qq = p / (DK / 4), c = p % (DK / 4);
+            const size_t row = (size_t)min(s * SQ + qq, a.Nq - 1) * a.dim + h * DK + 4 * c;
+            qst[i] = *reinterpret_cast<const float4*>(a.Q + row);
+            dst[i] = *reinterpret_cast<const float4*>(a.dO + row);
+        }
+        if (tid < SQ) {
+            const int q = min(s * SQ + tid, a.Nq - 1);
+            const float2 ml = *reinterpret_cast<const float2*>(a.LSE + 2 * ((size_t)q * a.heads + h));
+            s_m = ml.x; s_i = ml.y;
+            s_d = a.delta[(size_t)q * a.heads + h];
+            if (MASK) s_w = a.mask[(size_t)q * mwords + (k0 >> 5)];
+        }
+    };
+    auto park = [&](int buf) {
+        float* const B = mha_lds + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+            const int p = tid + i * NT, qq = p / (DK / 4), c = p % (DK / 4);
+            float* qt = B + (4 * c) * SQ + qq;
+            qt[0] = qst[i].x; qt[SQ] = qst[i].y; qt[2 * SQ] = qst[i].z; qt[3 * SQ] = qst[i].w;
+            float* dt = B + DK * SQ + (4 * c) * SQ + qq;
+            dt[0] = dst[i].x; dt[SQ] = dst[i].y; dt[2 * SQ] = dst[i].z; dt[3 * SQ] = dst[i].w;
+            *reinterpret_cast<float4*>(B + 2 * DK * SQ + qq * DK + 4 * c) = qst[i];
+            *reinterpret_cast<float4*>(B + 3 * DK * SQ + qq * DK + 4 * c) = dst[i];
+        }
+        if (tid < SQ) {
+            float* sc4 = B + 4 * DK * SQ;
+            sc4[tid] = s_m; sc4[SQ + tid] = s_i; sc4[2 * SQ + tid] = s_d; sc4[3 * SQ + tid] = __uint_as_float(s_w);
+        }
+    };
+    const int nstage = (a.Nq + SQ - 1) / SQ;
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstage) fetch(s + 1);
+        const int qw = 32 * wv, q0 = s * SQ + qw;                  // this wave's 32 queries (index in the stage, global)
+        if (q0 < a.Nq) {
+            const float* B = mha_lds + buf * BUF;
+            const float* qt = B + qw;
+            const float* dt = B + DK * SQ + qw;
+            const float* qs = B + 2 * DK * SQ + qw * DK;
+            const float* ds_ = B + 3 * DK * SQ + qw * DK;
+            const float* sc4 = B + 4 * DK * SQ + qw;
+            mha_f32x4 sc[2][2], dp[2][2];       // [qb][kb]: queries 16 qb + 4 g + r, key 16 kb + n
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float qa[KQ], da[KQ];
+#pragma unroll
+                for (int t = 0; t < KQ; ++t) {
+                    qa[t] = qt[(4 * t + g) * SQ + 16 * qb + n];
+                    da[t] = dt[(4 * t + g) * SQ + 16 * qb + n];
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    mha_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < KQ; ++t) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[t], kreg[kb][t], acc, 0, 0, 0);
+                        acd = __builtin_amdgcn_mfma_f32_16x16x4f32(da[t], vreg[kb][t], acd, 0, 0, 0);
+                    }
+                    sc[qb][kb] = acc;
+                    dp[qb][kb] = acd;
+                }
+            }
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = 16 * qb + 4 * g + r, q = q0 + qq;
+                    const bool inq = q < a.Nq;
+                    const int qc = inq ? q : a.Nq - 1;
+                    const float M = sc4[qq], inv = sc4[SQ + qq], dlt = sc4[2 * SQ + qq];
+                    const uint32_t mw = __float_as_uint(sc4[3 * SQ + qq]);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const int kk = 16 * kb + n;
+                        const bool inr = inq && k0 + kk < a.Nk;
+                        const bool open = !MASK || ((mw >> kk) & 1u);
+                        const float sv = open ? sc[qb][kb][r] * a.scale : MHA_MASKED;
+                        const float p = inr ? __expf(sv - M) * inv : 0.f;
+                        const float mul = DROP ? drop_mul(a, salt_h, qc, ki[kb]) : 1.f;
+                        sc[qb][kb][r] = (open && inr) ? p * (dp[qb][kb][r] * mul - dlt) * a.scale : 0.f;
+                        dp[qb][kb][r] = p * mul;
+                    }
+                }
+            // dV^T += dO^T . Pd, dK^T += Q^T . dS: register r of block qb contracts over the queries 16 qb + 4 k + r, k = 0..3
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int fb = 0; fb < FB; ++fb) {
+                        const bool live = 16 * fb + n < DK;
+                        const float dov = live ? ds_[(16 * qb + 4 * g + r) * DK + 16 * fb + n] : 0.f;
+                        const float qv = live ? qs[(16 * qb + 4 * g + r) * DK + 16 * fb + n] : 0.f;
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb) {
+                            dv[fb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dov, dp[qb][kb][r], dv[fb][kb], 0, 0, 0);
+                            dk[fb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, sc[qb][kb][r], dk[fb][kb], 0, 0, 0);
+                        }
+                    }
+        }
+        if (s + 1 < nstage) park(buf ^ 1);
+        __syncthreads();
+    }
+    float* const ob = mha_lds;                                    // [2][NW][FB * 2 * 4][64]
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ob[(wv * FB * 8 + (fb * 2 + kb) * 4 + r) * 64 + lane] = dk[fb][kb][r];
+                ob[((NW + wv) * FB * 8 + (fb * 2 + kb) * 4 + r) * 64 + lane] = dv[fb][kb][r];
+            }
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = k0 + 16 * kb + n;
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) {
+            float vk[4], vv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float ak = 0.f, av = 0.f;
+#pragma unroll
+                for (int x = 0; x < NW; ++x) {
+                    ak += ob[(x * FB * 8 + (fb * 2 + kb) * 4 + r) * 64 + lane];
+                    av += ob[((NW + x) * FB * 8 + (fb * 2 + kb) * 4 + r) * 64 + lane];
+                }
+                vk[r] = ak; vv[r] = av;
+            }
+            if (key < a.Nk && 16 * fb + 4 * g < DK) {
+                *reinterpret_cast<float4*>(a.dK + (size_t)key * a.dim + h * DK + 16 * fb + 4 * g) = make_float4(vk[0], vk[1], vk[2], vk[3]);
+                *reinterpret_cast<float4*>(a.dV + (size_t)key * a.dim + h * DK + 16 * fb + 4 * g) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            }
+        }
+    }
+}
+
 template <bool BF, int DK>
 static int launch_mha(const MhaArgs& a, bool backward, bool drop, hipStream_t st) {
     const int qw = ((a.Nq + 31) / 32) * a.heads, kw = ((a.Nk + 31) / 32) * a.heads;
@@ -556,6 +900,31 @@ static int launch_mha(const MhaArgs& a, bool backward, bool drop, hipStream_t st
         }
         if (drop) hipLaunchKernelGGL((mha_fwd_kernel<BF, DK, true>), gq, block, 0, st, a);
         else      hipLaunchKernelGGL((mha_fwd_kernel<BF, DK, false>), gq, block, 0, st, a);
+        NGACF_CHECK_LAUNCH();
+        return 0;
+    }
+    if constexpr (!BF) {                                             // exact fp32: the 16x16x4 form, both passes
+        constexpr int NW = DK == 32 ? 4 : 8;
+        constexpr size_t lq = (size_t)2 * 3 * DK * 32 * NW * sizeof(float);
+        constexpr size_t lkv = (size_t)2 * (4 * DK * 32 * NW + 4 * 32 * NW) * sizeof(float);
+        const bool mk = a.mask != nullptr;
+#define NGACF_MHAB(KERNEL, GRID, LDS, DR, MK)                                                                             \
+        do {                                                                                                              \
+            static bool big_lds_ok = false;   /* > 64 KB of dynamic LDS must be asked for once per kernel */              \
+            if ((LDS) > 65536 && !big_lds_ok) {                                                                           \
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<DK, NW, DR, MK>),          \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));         \
+                if (e != hipSuccess) return static_cast<int>(e);                                                          \
+                big_lds_ok = true;                                                                                        \
+            }                                                                                                             \
+            hipLaunchKernelGGL((KERNEL<DK, NW, DR, MK>), GRID, dim3(64 * NW), LDS, st, a);                                \
+        } while (0)
+        if (drop) { if (mk) NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, true, true); else NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, true, false); }
+        else      { if (mk) NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, false, true); else NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, false, false); }
+        NGACF_CHECK_LAUNCH();
+        if (drop) { if (mk) NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, true, true); else NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, true, false); }
+        else      { if (mk) NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, false, true); else NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, false, false); }
+#undef NGACF_MHAB
         NGACF_CHECK_LAUNCH();
         return 0;
     }
