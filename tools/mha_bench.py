@@ -63,7 +63,7 @@ def main():
                     "fwd_us": round(tf * 1e6, 1), "bwd_us": round(tb * 1e6, 1),
                     "fwd_TFLOPs": round(fl / tf / 1e12, 2), "fwd_frac_of_mfma_peak": round(fl / tf / peak, 5),
                     "fwd_Gexp_per_s": round(ex / tf / 1e9, 1), "fwd_frac_of_exp_issue_peak": round(ex / tf / EXP_PEAK, 4),
-                    "bwd_TFLOPs": round(2.5 * fl / tb / 1e12, 2),
+                    "bwd_TFLOPs": round(2.5 * fl / tb / 1e12, 2), "bwd_frac_of_mfma_peak": round(2.5 * fl / tb / peak, 5),
                     "reference_score_tensor_MB": round(2 * a.heads * Nq * Nk * 4 / 1e6, 1)})
         print(json.dumps(out[-1]), flush=True)
 

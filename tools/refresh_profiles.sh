@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the round's bench / profile files under gpurun_out/refresh/ on the GPU box (copy what is wanted into profiles/).
-#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh [tag] [part]'      part: all | bench | pmc | train
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh [tag] [part]'      part: all | bench | pmc | train | aux
 tag=${1:-r03}
 part=${2:-all}
 cd /tmp && export TMPDIR=/tmp
@@ -41,5 +41,15 @@ NGACF_FUSE_NEXT=0 timeout -k 10 200 python tools/train_profile.py >> $out/${tag}
 timeout -k 10 200 python tools/train_profile.py --torch-adam >> $out/${tag}_trainstep.jsonl 2>/dev/null
 say "epoch + evaluation";                timeout -k 10 300 python tools/eval_bench.py --epochs 3 > $out/${tag}_epoch_eval_gowalla.log 2>&1
 rm -rf gpurun_out/trainprof
+fi
+if [ "$part" = all ] || [ "$part" = aux ]; then
+say "dense attention (N4)"; : > $out/${tag}_mha_bench_ml100k.jsonl
+for fl in "" "--dim 128" "--dim 256" "--bf16"; do timeout -k 10 200 python tools/mha_bench.py $fl >> $out/${tag}_mha_bench_ml100k.jsonl 2>> $out/err.log || exit 1; done
+say "stand-alone transform at 70 k and 15 M rows"; timeout -k 10 200 python tools/transform_probe.py > $out/${tag}_transform_probe.jsonl 2>> $out/err.log || exit 1
+say "peer-store exchange, 2 and 4 ranks sharing the GPU"; timeout -k 10 300 python tools/peer_probe.py --world 2 > $out/${tag}_peer_probe.jsonl 2>> $out/err.log || exit 1
+timeout -k 10 300 python tools/peer_probe.py --world 4 >> $out/${tag}_peer_probe.jsonl 2>> $out/err.log || exit 1
+say "one-rank rehearsal with peer stores (overlapped, then in line)"
+NGACF_BENCH_FORCE_DIST=1 NGACF_PEER_GATHER=1 timeout -k 10 400 python bench.py --gpus 1 --no-probe --no-cpu-baseline --no-train > $out/${tag}_bench_rehearsal_1rank_peer.json 2>> $out/err.log || exit 1
+NGACF_BENCH_FORCE_DIST=1 NGACF_PEER_GATHER=1 timeout -k 10 400 python bench.py --gpus 1 --no-probe --no-cpu-baseline --no-train --no-overlap > $out/${tag}_bench_rehearsal_1rank_peer_inline.json 2>> $out/err.log || exit 1
 fi
 say done
