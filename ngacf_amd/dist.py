@@ -692,8 +692,10 @@ def scaling_probe(args, world, rank, dev, d=64):
         t_eager = allmax(t_eager)
         best, launch = t_eager, "eager"
         try:
+            from .graphs import quiesce_collectives
             graph = torch.cuda.CUDAGraph()
             mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+            quiesce_collectives()                      # (the watchdog must have retired every eager collective: graphs.py)
             with torch.cuda.graph(graph, capture_error_mode=mode):
                 fwd()
             graph.replay()
@@ -953,8 +955,11 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
                 fwd()
             torch.cuda.current_stream().wait_stream(side)
             sync()
+            from .graphs import quiesce_collectives
             graph = torch.cuda.CUDAGraph()
-            # thread-local capture mode: the c10d watchdog thread may query events while this thread captures
+            # thread-local capture mode: the c10d watchdog thread may query events while this thread captures -- and it must have
+            # retired every eager collective before c10d's stream joins the capture (graphs.quiesce_collectives)
+            quiesce_collectives()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 fwd()
             for _ in range(args.warmup):

@@ -6,6 +6,8 @@ host's launch rate, not by the GPU.  `GraphedBPRStep` captures one whole step --
 optimizer -- into one graph and replays it; dropout seeds come from a device-side counter that a captured add
 advances, so every replay draws fresh masks.  `GraphedPropagate` does the same for the eval-mode propagation.
 """
+import os
+
 import torch
 
 
@@ -22,6 +24,20 @@ def _capture_mode():
     (seen as an intermittent SIGABRT in ProcessGroupNCCL::Watchdog::run).  Thread-local mode restricts only this thread."""
     import torch.distributed as dist
     return "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+
+
+def quiesce_collectives():
+    """Call right before a capture when a process group is alive.  c10d's watchdog keeps every EAGER collective in a list until
+    one of its 100 ms polls sees the work's end event complete; if such a poll comes while c10d's own stream has joined a capture
+    (it does as soon as the captured region issues a collective), HIP answers the event query with hipErrorCapturedEvent -- the
+    event's STREAM is capturing, although this event was recorded long before -- and the watchdog aborts the process
+    (tools/capture_race.py: async all-gathers in front of a capture die within two iterations; with this pause 60 of 60 pass).
+    So: finish the eager work, then give the watchdog time to retire it, and issue no collective in between."""
+    import time
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        torch.cuda.synchronize()
+        time.sleep(float(os.environ.get("NGACF_CAPTURE_QUIESCE_S", "0.5")))
 
 
 def _gats(model):
@@ -161,6 +177,7 @@ class GraphedBPRStep:
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         optim.zero_grad(set_to_none=True)
+        quiesce_collectives()
         with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.loss = step()
         if data is not None:                                # (the capture itself does not execute; begin_epoch() resets anyway)
@@ -211,6 +228,7 @@ class GraphedPropagate:
                 model.propagate(adj)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
+        quiesce_collectives()
         with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.out = model.propagate(adj)
 

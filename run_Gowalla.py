@@ -91,8 +91,9 @@ def main(args):
     if sharded:
         model = SL.create_model(args.model, args.stages, data.U, data.I, args.embedSize, args.layers, args.droprate, adj, dev,
                                 torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-        say("node partition over %d ranks: %d user rows + %d item rows per rank, %d of %d directed edges on rank 0"
-            % (world, model.part.cu, model.part.ci, model._plan(adj).n_edges_directed, 2 * adj.shape[1]))
+        say("node partition over %d ranks: %d user rows + %d item rows per rank, %d of %d directed edges on rank 0; half-table gathers: %s"
+            % (world, model.part.cu, model.part.ci, model._plan(adj).n_edges_directed, 2 * adj.shape[1],
+               "peer stores (NGACF_PEER_GATHER=1)" if model.comm.peer_store else "all-gather"))
         train_fn, eval_fn, save_fn, load_fn = SL.train_bpr, SL.eval_neg_all, SL.save_checkpoint, SL.load_checkpoint
     else:
         model = create_model(args, data.U, data.I, dev)
@@ -129,6 +130,7 @@ def main(args):
             history.append((epoch, loss, m))
     if sharded:
         import torch.distributed as dist
+        model.comm.check()                            # (peer-store transport: no wait ever timed out)
         dist.barrier()
     return history
 

@@ -222,7 +222,7 @@ def test_ranks_sharing_one_gpu_under_gloo_match_the_single_gpu_model(world, bf16
     assert sum(err["edges"][0] for _, err in res) == res[0][1]["edges"][1]
 
 
-def _run_runner(tmp, flags, world):
+def _run_runner(tmp, flags, world, extra_env=None):
     """run_Gowalla.py as a user would start it: one process (world 1) or `world` processes with torchrun's environment, all on
     cuda:0 with gloo collectives (RCCL refuses two ranks per GPU).  Returns rank 0's stdout."""
     import os
@@ -232,6 +232,7 @@ def _run_runner(tmp, flags, world):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     base["PYTHONPATH"] = root + os.pathsep + base.get("PYTHONPATH", "")
+    base.update(extra_env or {})
     cmd = [sys.executable, os.path.join(root, "run_Gowalla.py")] + flags
     if world == 1:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp, env=base)
@@ -400,3 +401,22 @@ def test_peer_store_gather_equals_the_collective_path_bitwise(world, bf16, graph
         assert all(err["step%d" % k] for k in range(3)) and err["table"], (rank, err)
         assert err.get("graph", True), (rank, err)
         assert err["pushes"] > 0
+
+
+def test_run_gowalla_on_peer_stores_equals_the_collective_run(tmp_path):
+    """The whole train / eval loop of `torchrun run_Gowalla.py` with the peer-store transport (NGACF_PEER_GATHER=1, two ranks on
+    cuda:0): Adam moves the tables every step, the pool's tables are rewritten by the peer every step -- same epoch losses and
+    metrics as the two-rank run on the process group's all-gather, with and without dropout (same seeds = same masks)."""
+    for drop in ("0.0", "0.2"):
+        flags = ["--dataset", "ml100k", "--model", "SPUIGACF", "--epochs", "2", "--eval_every", "1", "--lr", "0.002",
+                 "--weight_decay", "0.000001", "--droprate", drop, "--eager"]
+        da, db = tmp_path / ("gather" + drop), tmp_path / ("peer" + drop)
+        da.mkdir(); db.mkdir()
+        la, ma = _parse_runner(_run_runner(str(da), flags, 2))
+        outb = _run_runner(str(db), flags, 2, {"NGACF_PEER_GATHER": "1"})
+        lb, mb = _parse_runner(outb)
+        assert "peer stores" in outb and len(la) == len(lb) == 2
+        assert np.allclose(la, lb, rtol=1e-4), (drop, la, lb)
+        for a, b in zip(ma, mb):
+            for k in ("precision", "recall", "ndcg", "hit_ratio"):
+                assert np.allclose(a[k], b[k], atol=2e-3), (drop, k, a[k], b[k])
