@@ -26,8 +26,7 @@ def worker(rank, world, port, q, a):
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        import ctypes
-        from ngacf_amd import _lib, data as D
+        from ngacf_amd import data as D
         from ngacf_amd.dist import Partition, ShardedSPUIGACF
         from ngacf_amd.peer import PeerComm
         dev = torch.device("cuda:0")
