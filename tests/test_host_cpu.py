@@ -427,8 +427,38 @@ def test_header_constants_match_the_python_side():
     defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+NGACF_(\w+)\s+(-?\d+|\(-\d+\))", h.replace("(-", "-").replace(")", ""))}
     want = {"ELU": _lib.FLAG_ELU, "RESIDUAL": _lib.FLAG_RESIDUAL, "SCORE_ROW": _lib.FLAG_SCORE_ROW, "SKIP_NODE": _lib.FLAG_SKIP_NODE,
             "GOUT_F32": _lib.FLAG_GOUT_F32, "TBWD_BLOCKS": _lib.TBWD_BLOCKS, "ADAM_MAX_TENSORS": _lib.ADAM_MAX_TENSORS,
-            "TICK_MAX": _lib.TICK_MAX, "F32": _lib.F32, "BF16": _lib.BF16}
+            "TICK_MAX": _lib.TICK_MAX, "F32": _lib.F32, "BF16": _lib.BF16, "MAX_PACK": _lib.MAX_PACK, "MAX_PEERS": _lib.MAX_PEERS,
+            "PEER_MAX_REGIONS": _lib.PEER_MAX_REGIONS, "PEER_HANDLE_BYTES": _lib.PEER_HANDLE_BYTES}
     for k, v in want.items():
         assert defs.get(k) == v, (k, defs.get(k), v)
     flags = [defs[k] for k in ("ELU", "RESIDUAL", "SCORE_ROW", "SKIP_NODE", "GOUT_F32")]
     assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)          # distinct single bits
+
+
+def test_peer_store_entries_reject_bad_arguments_before_touching_a_device():
+    """include/ngacf.h, peer-store all-gather: every argument error is caught on the host (NGACF_E_ARG = -1), before any HIP call --
+    too many peers or regions, null tables, byte counts that are not whole words, misaligned blocks, a wait over more than one
+    wave of flag words."""
+    import ctypes
+    from ngacf_amd import _lib
+    L = _lib.lib
+    assert ctypes.sizeof(_lib.PeerRegion) == 8 + 8 + 8 * _lib.MAX_PEERS
+    word = ctypes.c_int32(0)
+    wp = ctypes.cast(ctypes.pointer(word), ctypes.c_void_p)
+    regs = (_lib.PeerRegion * 1)()
+    flags = (ctypes.c_void_p * 1)(wp.value)
+    assert L.ngacf_peer_alloc(0, ctypes.byref(ctypes.c_void_p())) == -1 and L.ngacf_peer_alloc(16, None) == -1
+    assert L.ngacf_peer_free(None) == -1 and L.ngacf_peer_close(None) == -1
+    assert L.ngacf_peer_export(None, wp) == -1 and L.ngacf_peer_import(wp, None) == -1
+    assert L.ngacf_peer_push(regs, _lib.PEER_MAX_REGIONS + 1, 1, flags, wp, wp, None) == -1        # too many regions
+    assert L.ngacf_peer_push(regs, 1, _lib.MAX_PEERS + 1, flags, wp, wp, None) == -1               # too many peers
+    assert L.ngacf_peer_push(regs, 1, 1, flags, None, wp, None) == -1                               # no epoch counter
+    assert L.ngacf_peer_push(regs, 1, 1, flags, wp, wp, None) == -1                                 # region without a source
+    regs[0].src, regs[0].bytes, regs[0].dst[0] = wp.value, 6, wp.value
+    assert L.ngacf_peer_push(regs, 1, 1, flags, wp, wp, None) == -1                                 # 6 bytes: not whole words
+    regs[0].bytes, regs[0].dst[0] = 4, wp.value + 2
+    assert L.ngacf_peer_push(regs, 1, 1, flags, wp, wp, None) == -1                                 # misaligned destination
+    regs[0].dst[0] = 0
+    assert L.ngacf_peer_push(regs, 1, 1, flags, wp, wp, None) == -1                                 # a peer without a table
+    assert L.ngacf_peer_wait(wp, 65, 0, wp, wp, 1, None) == -1 and L.ngacf_peer_wait(None, 2, 0, wp, wp, 1, None) == -1
+    assert L.ngacf_peer_wait(wp, 2, 0, None, wp, 1, None) == -1
