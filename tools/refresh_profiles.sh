@@ -48,6 +48,10 @@ for fl in "" "--dim 128" "--dim 256" "--bf16"; do timeout -k 10 200 python tools
 say "stand-alone transform at 70 k and 15 M rows"; timeout -k 10 200 python tools/transform_probe.py > $out/${tag}_transform_probe.jsonl 2>> $out/err.log || exit 1
 say "peer-store exchange, 2 and 4 ranks sharing the GPU"; timeout -k 10 300 python tools/peer_probe.py --world 2 > $out/${tag}_peer_probe.jsonl 2>> $out/err.log || exit 1
 timeout -k 10 300 python tools/peer_probe.py --world 4 >> $out/${tag}_peer_probe.jsonl 2>> $out/err.log || exit 1
+say "peer-store protocol soak (+ negative control)"
+timeout -k 10 400 python tools/peer_soak.py --world 2 --rounds 20000 2>> $out/err.log | grep "^{" > $out/${tag}_peer_soak.jsonl || exit 1
+timeout -k 10 400 python tools/peer_soak.py --world 3 --rounds 10000 2>> $out/err.log | grep "^{" >> $out/${tag}_peer_soak.jsonl || exit 1
+timeout -k 10 200 python tools/peer_soak.py --world 2 --rounds 2000 --no-wait 2>> $out/err.log | grep "^{" >> $out/${tag}_peer_soak.jsonl
 say "one-rank rehearsal with peer stores (overlapped, then in line)"
 NGACF_BENCH_FORCE_DIST=1 NGACF_PEER_GATHER=1 timeout -k 10 400 python bench.py --gpus 1 --no-probe --no-cpu-baseline --no-train > $out/${tag}_bench_rehearsal_1rank_peer.json 2>> $out/err.log || exit 1
 NGACF_BENCH_FORCE_DIST=1 NGACF_PEER_GATHER=1 timeout -k 10 400 python bench.py --gpus 1 --no-probe --no-cpu-baseline --no-train --no-overlap > $out/${tag}_bench_rehearsal_1rank_peer_inline.json 2>> $out/err.log || exit 1
