@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
     constexpr int TROW = KD / 8 + 1;                         // LDS tile row in uint4: the bf16 row + 16 B (fragment reads: no bank conflict)
     constexpr int TSZ = 32 * ((KD > OD ? KD : OD) / 8 + 1);  // (the forward's epilogue sends H' through the same tile)
     uint4* tile = reinterpret_cast<uint4*>(lds_raw + (size_t)KS * OT * 64 * 16) + wave * TSZ;
+    float* const avs = reinterpret_cast<float*>(reinterpret_cast<uint4*>(lds_raw + (size_t)KS * OT * 64 * 16) + 4 * TSZ);   // the type's attention vector (forward)
     const char* Bg = static_cast<const char*>(a.B);
     uint4 raw[NLD];
     int base = 0, rows = 0;                                  // the tile in `raw`: first node, number of valid rows
@@ -145,6 +146,9 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
             for (int j = 0; j < 8; ++j) f[j] = FWD ? M[(size_t)(k0 + j) * DOUT + i] : M[(size_t)i * DOUT + k0 + j];
             Af[slot] = pack8(f);
         }
+        if constexpr (FWD) {
+            if (tid < DOUT / 4) reinterpret_cast<float4*>(avs)[tid] = reinterpret_cast<const float4*>(a.avec + type * DOUT)[tid];
+        }
     }
     __syncthreads();
 
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
         // lane: node r (+ half h); acc[t][4g + j] = output column 32t + 8g + 4h + j
         if constexpr (FWD) {
             const int base_cur = base_done, rows_cur = rows_done;
-            mfma_fwd_epilogue<OT, HEADS, DOUT, STAGE_OUT>(acc, nd_cur, ok_cur, h, a.avec + type * DOUT, a.out, a.S, tile, r,
+            mfma_fwd_epilogue<OT, HEADS, DOUT, STAGE_OUT>(acc, nd_cur, ok_cur, h, avs, a.out, a.S, tile, r,
                                                [&](int tr) { return tr < rows_cur ? base_cur + tr : -1; });
         } else {
             const size_t orow = (size_t)(a.out_local ? nd_cur - loc_off : nd_cur);
@@ -224,7 +228,7 @@ static int launch_mfma(MfmaArgs a, bool drop, hipStream_t st) {
     const bool stage_out = FWD && stage_out_pays((uint64_t)a.U + a.I, DOUT);    // H' through the LDS tile as whole lines
     const int nb = a.nb_main + 2 * a.npack;
     if (nb == 0) return 0;
-    constexpr size_t lds = (size_t)(KD / 16) * (OD / 32) * 64 * 16 + (size_t)4 * 32 * ((KD > OD ? KD : OD) / 8 + 1) * 16;   // panel + the four waves' row tiles
+    constexpr size_t lds = (size_t)(KD / 16) * (OD / 32) * 64 * 16 + (size_t)4 * 32 * ((KD > OD ? KD : OD) / 8 + 1) * 16 + (size_t)OD * 4;   // panel + the four waves' row tiles + the attention vector
     if (!FWD) {
         if (drop) hipLaunchKernelGGL((transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, true>), dim3(nb), dim3(256), lds, st, a);
         else      hipLaunchKernelGGL((transform_mfma_kernel<TB, TO, DIN, DOUT, FWD, HEADS, false>), dim3(nb), dim3(256), lds, st, a);
