@@ -22,6 +22,13 @@ What has to hold for that, and how it is kept:
                      kernel leaves: wrong numbers reported by the host, never a hung GPU.
   a step boundary    in training, a peer's next forward may only start after my backward has finished reading the tables it
                      will overwrite: the per-step all-reduce of the weight gradients (reduce_grads) is that barrier.
+  hardware queues    a wait kernel SPINS: everything behind it in the same hardware queue waits with it.  HIP maps a process's
+                     streams onto a few hardware queues (4 by default); as long as a rank's streams fit (compute, this side
+                     stream, a warm-up stream) a push never lands behind a wait that needs a peer's LATER push.  The step's two
+                     forwards as parallel branches break that: two branch streams + the side stream + the warm-up streams
+                     alias, a push sits behind the other branch's spinning wait on BOTH ranks, and the exchange only moves
+                     when waits time out (seen as a 300 s stall of a two-rank test).  The sharded step therefore keeps its
+                     forwards one after the other with this transport too.
 The push runs on a side stream (under the other half's traversal, like the asynchronous all-gather it replaces; overlap=False:
 in line on the current stream, no fork); join() brings it back before a pass ends.  Everything that is not a pool table
 (state-dict / evaluation gathers) takes the base class's path.  Validated as 2-4 processes on ONE GPU (tests/test_gpu_dist.py,
@@ -79,7 +86,7 @@ class PeerComm(Comm):
         self.others = [r for r in range(self.W) if r != self.rank]
         self.side = torch.cuda.Stream(self.device)
         self.timeout_ticks = int(timeout_s * 100e6)           # s_memrealtime: 100 MHz
-        self._bufs, self._pool, self._by_ptr = [], {}, {}
+        self._bufs, self._pool, self._by_ptr, self._ar = [], {}, {}, {}
         # control block: flags[SLOTS][W] (written by the peers) | sent[SLOTS] | expect[SLOTS] | ticket[SLOTS] | err
         self._ctrl = self._symmetric(4 * (SLOTS * self.W + 3 * SLOTS + 1))
         self.pushes = 0
@@ -145,40 +152,80 @@ class PeerComm(Comm):
             return super().start_gather(t, *fulls)            # not a pool table: the collective path
         p = self.part
         lo, n = (p.rank * p.cu, p.cu) if t == "user" else (p.Up + p.rank * p.ci, p.ci)
-        regs = (_lib.PeerRegion * len(fulls))()
-        for k, (f, b) in enumerate(zip(fulls, bufs)):
+        regions = []
+        for f, b in zip(fulls, bufs):
             rowb = f.stride(0) * f.element_size()
-            regs[k].src = b.ptr + lo * rowb
-            regs[k].bytes = n * rowb
-            for j, r in enumerate(self.others):
-                regs[k].dst[j] = b.peers[r] + lo * rowb
+            regions.append((b, lo * rowb, n * rowb))
         slot = 2 * bufs[0].index + (0 if t == "user" else 1)
+        self._push(regions, slot, side=self.overlap)
+        h = _Handle(done=lambda slot=slot: self._wait(slot))
+        if not self.overlap:
+            h.wait()
+        return h
+
+    def _push(self, regions, slot, side):
+        """regions: [(pool buffer, byte offset, bytes)]: the same span of every peer's copy of the buffer receives mine; then the
+        flag word of (slot, this rank) goes up on every peer.  side: on the side stream, behind everything the current stream
+        holds so far (under the other half's traversal); else in line."""
+        regs = (_lib.PeerRegion * len(regions))()
+        for k, (b, off, nbytes) in enumerate(regions):
+            regs[k].src = b.ptr + off
+            regs[k].bytes = nbytes
+            for j, r in enumerate(self.others):
+                regs[k].dst[j] = b.peers[r] + off
         flags = (ctypes.c_void_p * max(len(self.others), 1))()
         for j, r in enumerate(self.others):                   # my word in peer r's flag array
             flags[j] = self._ctrl_addr(self._ctrl.peers[r], "flags", slot) + 4 * self.rank
         cur = torch.cuda.current_stream(self.device)
-        if self.overlap:                                      # under the other half's traversal: a fork to the side stream
+        st = cur
+        if side:
             ev = torch.cuda.Event()
             ev.record(cur)
             self.side.wait_event(ev)
             st = self.side
-        else:                                                 # serial schedule: push and wait in line (no fork, no join: the
-            st = cur                                          # cheapest per exchange when the blocks are small)
-        _lib.check(_lib.lib.ngacf_peer_push(regs, len(fulls), len(self.others), flags, self._ctrl_addr(self._ctrl.ptr, "sent", slot),
+        _lib.check(_lib.lib.ngacf_peer_push(regs, len(regions), len(self.others), flags, self._ctrl_addr(self._ctrl.ptr, "sent", slot),
                                             self._ctrl_addr(self._ctrl.ptr, "ticket", slot), ctypes.c_void_p(st.cuda_stream)),
                    "ngacf_peer_push")
         self.launches += 1
         self.pushes += 1
 
-        def wait(slot=slot):
-            _lib.check(_lib.lib.ngacf_peer_wait(self._ctrl_addr(self._ctrl.ptr, "flags", slot), self.W, self.rank,
-                                                self._ctrl_addr(self._ctrl.ptr, "expect", slot), self._ctrl_addr(self._ctrl.ptr, "err", 0),
-                                                self.timeout_ticks, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
-                       "ngacf_peer_wait")
-        h = _Handle(done=wait)
-        if not self.overlap:
-            h.wait()
-        return h
+    def _wait(self, slot):
+        _lib.check(_lib.lib.ngacf_peer_wait(self._ctrl_addr(self._ctrl.ptr, "flags", slot), self.W, self.rank,
+                                            self._ctrl_addr(self._ctrl.ptr, "expect", slot), self._ctrl_addr(self._ctrl.ptr, "err", 0),
+                                            self.timeout_ticks, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                   "ngacf_peer_wait")
+
+    def all_reduce_sum(self, *ts):
+        """Sum over the ranks without a collective: every rank stores its tensor into row `rank` of a [W, n] buffer on every
+        peer, waits for the others' rows and adds the W rows in rank order -- the same order on every rank, so the results are
+        bit-identical everywhere (the row exchange of the scores and the stage weights' gradient sum: with them the whole step
+        of the node-partitioned loop is free of RCCL).  Push and wait go IN LINE on the caller's stream: a rank's push always
+        precedes its own wait in one hardware queue, so the peer's wait is always served.
+        Two buffers per (size, dtype) taken in turn: a rank may start the next sum while a slow peer still adds the rows of
+        this one -- it cannot start the one after before that peer has sent its share of the next."""
+        if not self.active or any((not t.is_cuda) or (t.numel() * t.element_size()) % 4 or not t.is_contiguous() for t in ts):
+            return super().all_reduce_sum(*ts)
+        for t in ts:
+            n = t.numel()
+            key = ("all_reduce", n, t.dtype)
+            st = self._ar.get(key)
+            if st is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("peer-store all-reduce of %d x %s first needed inside a stream capture: run one eager "
+                                       "step first" % (n, t.dtype))
+                st = self._ar[key] = {"bufs": [self._symmetric(max(self.W * n * t.element_size(), 16)) for _ in range(2)], "turn": 0}
+            b = st["bufs"][st["turn"]]
+            st["turn"] ^= 1
+            rows = b.bytes_view[:self.W * n * t.element_size()].view(t.dtype).view(self.W, n)
+            rows[self.rank].copy_(t.reshape(-1))
+            slot = 2 * b.index
+            self._push([(b, self.rank * n * t.element_size(), n * t.element_size())], slot, side=False)
+            self._wait(slot)
+            acc = rows[0].clone() if self.W == 1 else rows[0] + rows[1]
+            for r in range(2, self.W):
+                acc += rows[r]
+            t.copy_(acc.view_as(t))
+        return ts[0] if len(ts) == 1 else ts
 
     def join(self):
         """The side stream's pushes rejoin the current stream (end of a pass; before a capture ends)."""
@@ -203,4 +250,4 @@ class PeerComm(Comm):
             dist.barrier(group=self.group)
         for b in self._bufs:
             _lib.lib.ngacf_peer_free(ctypes.c_void_p(b.ptr))
-        self._bufs, self._pool, self._by_ptr = [], {}, {}
+        self._bufs, self._pool, self._by_ptr, self._ar = [], {}, {}, {}

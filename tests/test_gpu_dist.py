@@ -420,3 +420,88 @@ def test_run_gowalla_on_peer_stores_equals_the_collective_run(tmp_path):
         for a, b in zip(ma, mb):
             for k in ("precision", "recall", "ndcg", "hit_ratio"):
                 assert np.allclose(a[k], b[k], atol=2e-3), (drop, k, a[k], b[k])
+
+
+def _peer_step_worker(rank, world, port, q):
+    """The whole BPR train step of the node-partitioned model on peer stores -- half-table gathers, the scores' row exchange and
+    the weight-gradient sum, no collective inside -- captured as ONE hipGraph, against eager steps of the same model on the
+    process group (gloo)."""
+    try:
+        import os
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import ngacf_amd
+        from ngacf_amd.dist import ShardedSPUIGACF
+        from ngacf_amd.graphs import GraphedBPRStep
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        U, I, B = 333, 251, 256
+        edge = _graph(U, I, 7000, 3).to(dev)
+        torch.manual_seed(1)
+        ref = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev)
+        with torch.no_grad():
+            ref.uEmbd.weight.mul_(30); ref.iEmbd.weight.mul_(30)
+        ms = []
+        for peer in (False, True):
+            m = ShardedSPUIGACF(U, I, 64, [64, 64], 0.0, world, rank, stages=3, adj=edge, peer_store=peer).to(dev).train()
+            m.load_full_state_dict(ref.state_dict())
+            m.comm.defer_weight_reduce = True
+            ms.append(m)
+        a, b = ms
+        lossfn = ngacf_amd.BPRLoss()
+        oa = ngacf_amd.optim.Adam(a.parameters(), lr=1e-2)
+        ob = ngacf_amd.optim.Adam(b.parameters(), lr=1e-2)
+        gs = GraphedBPRStep(b, lossfn, ob, edge, B, preserve_state=True, concurrent_forwards=False, after_backward=b.reduce_grads)
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        worst, losses = 0.0, []
+        for step in range(4):
+            u = torch.randint(0, U, (B,), device=dev, generator=g)
+            p = torch.randint(0, I, (B,), device=dev, generator=g)
+            n = torch.randint(0, I, (B,), device=dev, generator=g)
+            oa.zero_grad(set_to_none=True)
+            la = lossfn(a(u, p, edge), a(u, n, edge))
+            la.backward()
+            a.reduce_grads()
+            oa.step()
+            lb = gs(torch.stack([u, p, n]))
+            torch.cuda.synchronize()
+            losses.append((float(la), float(lb)))
+            for pa, pb in zip(a.parameters(), b.parameters()):
+                worst = max(worst, float((pa - pb).abs().max() / pa.abs().max().clamp_min(1e-12)))
+        b.comm.check()
+        dist.barrier()
+        q.put((rank, {"worst": worst, "losses": losses, "pushes": b.comm.pushes}))
+        b.comm.close()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, {"exception": "%s\n%s" % (e, traceback.format_exc())}))
+
+
+def test_peer_store_train_step_without_a_collective_as_one_graph():
+    """With every exchange of the step on peer stores (PeerComm.all_reduce_sum for the scores' row exchange and the weight-gradient
+    sum) the captured step holds no collective at all.  Two ranks on cuda:0, four Adam steps replayed from ONE hipGraph per rank:
+    losses and every parameter against eager steps on the process group's collectives (1e-4: float atomics in the score
+    backward).  (The two forwards stay one after the other: parallel branches put pushes behind spinning waits in shared
+    hardware queues, ngacf_amd/peer.py.)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_peer_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, out in res:
+        assert "exception" not in out, out.get("exception")
+        assert out["worst"] < 1e-4, (rank, out)
+        for la, lb in out["losses"]:
+            assert abs(la - lb) <= 1e-5 * max(1.0, abs(la)), (rank, out["losses"])
+        assert out["pushes"] > 0
