@@ -38,7 +38,7 @@ __device__ __forceinline__ void pack_panel_job(const float* __restrict__ W, void
 //   staged: the rounded H' goes through otile -- 32 x (DOUT / 8 + 1) uint4 of LDS private to this wave, tr: the
 //   lane's row in it, row_of(tile row) -> row of H or -1 -- so that the tile leaves as whole 128-byte lines (a wave instruction
 //   = 8 full rows) instead of 32 x 32-byte pieces per instruction.  Same values.  It pays where H streams to HBM (15 M rows:
-//   the launch goes from 4.3-4.8 to 5.4-5.6 TB/s) and costs a little where the table is cache-resident and the launch is
+//   the launch goes from 4.3-4.8 to 5.0-5.6 TB/s) and costs a little where the table is cache-resident and the launch is
 //   latency-bound (Gowalla: +0.7 us per launch; as a run-time branch +1.7 us even when not taken), so the host picks the
 //   instantiation by table size (stage_out_pays).
 inline bool stage_out_pays(uint64_t n_rows, int dout) {
