@@ -56,6 +56,8 @@ def parse(argv=None):
     ap.add_argument("--target-seconds", type=float, default=0.6, help="length of the timed region the pass count R is sized for")
     ap.add_argument("--passes-per-step", type=int, default=0, help="R (0 = sized from --target-seconds)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: serial all-gather -> traversal schedule")
+    ap.add_argument("--renumber", default="degree", choices=["degree", "none"],
+                    help="node numbering at ingest (run_Gowalla.py --renumber): by degree, descending, or the generator's ids")
     ap.add_argument("--no-probe", action="store_true", help="skip the 10^9-edge scaling probe of the default (gowalla) line")
     a = ap.parse_args(argv)
     if not a.stages:
@@ -282,7 +284,7 @@ def worker(args):
         return ND.bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg)
 
     torch.manual_seed(2019)
-    edge = D.workload_graph(wl, dev)
+    edge = ingest_graph(D, wl, dev, args)
     E = int(edge.shape[1])
     N = U + I
     model = make_model(ng, torch, U, I, d, args.stages, args.droprate, args.dtype, dev)
@@ -387,7 +389,9 @@ def worker(args):
                       "seg_len": args.seg_len, "parallelism": "1 GPU",
                       "launch": "eager" if args.eager else "hipGraph replay",
                       "launches_per_pass": (L + 1 if fused else 2 * L),
-                      "fused_next_stage_transform": bool(fused)},
+                      "fused_next_stage_transform": bool(fused),
+                      "node_numbering": "by degree, descending, at ingest (ngacf_amd.data.degree_order: run_Gowalla.py's default)"
+                                        if args.renumber == "degree" else "the generator's ids"},
            "ms_per_pass": round(ms_per_step / R, 5), "timed_region_s": round(t_fwd, 4),
            "value_median_window": round(trav_per_step / (med_ms * 1e-3), 1) if med_ms > 0 else None,
            "window_ms": {"median": round(med_ms, 4), "min": round(min(windows), 4), "max": round(max(windows), 4)},
@@ -415,13 +419,23 @@ def worker(args):
     emit(json.dumps(out))
 
 
+def ingest_graph(D, wl, dev, args):
+    """The workload's graph as the product's ingest hands it to the model: the generator's [2,E] indices, node ids renumbered by
+    degree (ngacf_amd.data.degree_order -- run_Gowalla.py's default, --renumber degree; a relabelling of the same graph)."""
+    U, I, _ = D.SHAPES[wl]
+    edge = D.workload_graph(wl, dev)
+    if args.renumber == "degree":
+        edge = D.renumber(edge, *D.degree_order(edge, U, I))
+    return edge
+
+
 def yelp_probe(args, torch, ng, BK, D, NF, ops, dev):
     """The headline measurement repeated at Yelp scale (BASELINE config 2's graph; north_star: ">= 50 % of the HBM roofline on
     the attention-propagation kernel at Yelp scale on 1 GPU"): forward only, ~0.3 s timed region, its own roofline."""
     wl = "yelp"
     U, I, _ = D.SHAPES[wl]
     torch.manual_seed(2019)
-    edge = D.workload_graph(wl, dev)
+    edge = ingest_graph(D, wl, dev, args)
     E = int(edge.shape[1])
     elem = 2 if args.dtype == "bf16" else 4
     model = make_model(ng, torch, U, I, 64, 3, args.droprate, args.dtype, dev)

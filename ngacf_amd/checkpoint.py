@@ -103,18 +103,50 @@ def n_reference_params(model):
     return len(_layout(model)[0])
 
 
-def save_checkpoint(path, model, optim):
-    """run_Gowalla.py:142-143 -- both halves in the reference's layout."""
-    torch.save({"model": model.state_dict(), "optim": optim_state_to_reference(model, optim.state_dict())}, path)
+def renumber_reference_checkpoint(model_sd, optim_ref_sd, idx_u, idx_i):
+    """A checkpoint in the reference's layout with its embedding rows (and their Adam moments: optimizer entries 0 / 1) taken
+    in another order: out_row[j] = row[idx[j]].  Saving a run that renumbered its nodes at ingest: idx = perm (data set id ->
+    internal id) puts the rows back in the data set's order; loading: idx = the inverse."""
+    msd = dict(model_sd)
+    for k, idx in (("uEmbd.weight", idx_u), ("iEmbd.weight", idx_i)):
+        msd[k] = msd[k][idx.to(msd[k].device)]
+    osd = {"state": dict(optim_ref_sd["state"]), "param_groups": optim_ref_sd["param_groups"]}
+    ids = optim_ref_sd["param_groups"][0]["params"]
+    for j, idx in ((0, idx_u), (1, idx_i)):
+        st = osd["state"].get(ids[j])
+        if st is not None:
+            osd["state"][ids[j]] = {k: (v[idx.to(v.device)] if torch.is_tensor(v) and v.dim() == 2 and v.shape[0] == idx.numel() else v)
+                                    for k, v in st.items()}
+    return msd, osd
 
 
-def load_checkpoint(path, model, optim, map_location=None):
+def _inverse(perm):
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel(), device=perm.device)
+    return inv
+
+
+def save_checkpoint(path, model, optim, perm=None):
+    """run_Gowalla.py:142-143 -- both halves in the reference's layout.  perm = (perm_u, perm_i) of a run that renumbered its
+    nodes at ingest (Interactions(renumber="degree")): the file is written in the DATA SET's numbering all the same."""
+    msd, osd = model.state_dict(), optim_state_to_reference(model, optim.state_dict())
+    if perm is not None:
+        msd, osd = renumber_reference_checkpoint(msd, osd, perm[0], perm[1])
+    torch.save({"model": msd, "optim": osd}, path)
+
+
+def load_checkpoint(path, model, optim, map_location=None, perm=None):
     """run_Gowalla.py:127-130: a checkpoint written by the reference or by save_checkpoint (or, for completeness, one in
-    this package's own optimizer layout)."""
+    this package's own optimizer layout).  perm: as in save_checkpoint (the file speaks the data set's numbering)."""
     ck = torch.load(path, map_location=map_location)
-    model.load_state_dict(ck["model"])
     osd = ck["optim"]
     n = len(osd["param_groups"][0]["params"]) if len(osd["param_groups"]) == 1 else -1
+    if perm is not None:
+        if n != n_reference_params(model):
+            raise ValueError("a run with renumbered nodes resumes from checkpoints in the reference's optimizer layout")
+        ck = dict(ck)
+        ck["model"], osd = renumber_reference_checkpoint(ck["model"], osd, _inverse(perm[0]), _inverse(perm[1]))
+    model.load_state_dict(ck["model"])
     if n == n_reference_params(model) and n != len(list(model.parameters())):
         osd = optim_state_from_reference(model, osd)
     # the hyper-parameters of the running optimizer win where the implementations differ (fused / capturable flags)

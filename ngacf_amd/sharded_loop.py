@@ -102,26 +102,33 @@ def full_optim_state(model, optim):
     return ref
 
 
-def save_checkpoint(path, model, optim):
-    """run_Gowalla.py:142-143: {'model': ..., 'optim': ...} in the reference's layout, written by rank 0 (collective call)."""
+def save_checkpoint(path, model, optim, perm=None):
+    """run_Gowalla.py:142-143: {'model': ..., 'optim': ...} in the reference's layout, written by rank 0 (collective call).
+    perm: (perm_u, perm_i) of a run that renumbered its nodes at ingest -- the file speaks the data set's numbering."""
     msd = model.full_state_dict()
     osd = full_optim_state(model, optim)
     if model.part.rank == 0:
-        torch.save({"model": {k: v.cpu() for k, v in msd.items()}, "optim": osd}, path)
+        msd = {k: v.cpu() for k, v in msd.items()}
+        if perm is not None:
+            msd, osd = CK.renumber_reference_checkpoint(msd, osd, perm[0].cpu(), perm[1].cpu())
+        torch.save({"model": msd, "optim": osd}, path)
     if model.comm.active:
         dist.barrier(group=model.comm.group)
 
 
-def load_checkpoint(path, model, optim, map_location=None):
+def load_checkpoint(path, model, optim, map_location=None, perm=None):
     """run_Gowalla.py:127-130 for the sharded model: a checkpoint written by the reference, by the single-GPU runner or by
-    save_checkpoint above at ANY world size.  Every rank reads the file and keeps its rows."""
+    save_checkpoint above at ANY world size.  Every rank reads the file and keeps its rows.  perm: as in save_checkpoint."""
     ck = torch.load(path, map_location="cpu")
-    model.load_full_state_dict(ck["model"])
     osd = ck["optim"]
     n = len(osd["param_groups"][0]["params"]) if len(osd["param_groups"]) == 1 else -1
     if n != CK.n_reference_params(model):
         raise ValueError("the sharded runner resumes from checkpoints in the reference's optimizer layout (%d parameters), got %d"
                          % (CK.n_reference_params(model), n))
+    if perm is not None:
+        ck = dict(ck)
+        ck["model"], osd = CK.renumber_reference_checkpoint(ck["model"], osd, CK._inverse(perm[0].cpu()), CK._inverse(perm[1].cpu()))
+    model.load_full_state_dict(ck["model"])
     ou, oi = model.part.local_original_ids("cpu")
     ids = osd["param_groups"][0]["params"]
     state = dict(osd["state"])

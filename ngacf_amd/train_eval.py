@@ -28,12 +28,25 @@ class Interactions:
     train_u/train_i: rows of train_df in file order (the batch order of train_bpr);
     item pool: the distinct items of train ∪ test (`rt`, run_Gowalla.py:46,85)."""
 
-    def __init__(self, train_u, train_i, test_u, test_i, U, I, device):
+    def __init__(self, train_u, train_i, test_u, test_i, U, I, device, renumber=None):
+        """renumber="degree": users and items get internal ids by degree over train + test (ngacf_amd.data.degree_order) -- every
+        tensor of this object, the adjacency it hands out and hence the model speak the internal numbering; perm_u / perm_i
+        (data set id -> internal id) are kept for whoever has to speak the data set's (checkpoints)."""
         dev = torch.device(device)
         t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.long, device=dev)
         self.U, self.I, self.device = U, I, dev
         self.train_u, self.train_i = t(train_u), t(train_i)
         self.test_u, self.test_i = t(test_u), t(test_i)
+        self.perm_u = self.perm_i = None
+        if renumber == "degree":
+            from .data import degree_order
+            allp = torch.stack([torch.cat([self.train_u, self.test_u]), torch.cat([self.train_i, self.test_i])])
+            key = torch.unique(allp[0] * I + allp[1])
+            self.perm_u, self.perm_i = degree_order(torch.stack([key // I, key % I]), U, I)
+            self.train_u, self.train_i = self.perm_u[self.train_u], self.perm_i[self.train_i]
+            self.test_u, self.test_i = self.perm_u[self.test_u], self.perm_i[self.test_i]
+        elif renumber not in (None, "none"):
+            raise ValueError("renumber: 'degree' or None")
         self.train_keys = torch.unique(self.train_u * I + self.train_i)            # sorted (user, item) keys
         self.test_keys = torch.unique(self.test_u * I + self.test_i)
         ku = self.train_keys // I

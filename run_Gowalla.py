@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Counterpart of the reference's run_Gowalla.py (:41-194) on the HIP path: same flags, same epoch /
-eval / checkpoint cadence, same scalar names.  Additions: --dtype, --stages, --data_root, --synthetic.
+eval / checkpoint cadence, same scalar names.  Additions: --dtype, --stages, --data_root, --synthetic, --renumber.
 
   python run_Gowalla.py --dataset ml100k --model SPUIGACF --adj_type ui_mat --train_mode PairSampling \
       --eval_mode AllNeg --epochs 2 --eval_every 1 --lr 0.002 --weight_decay 0.000001 --droprate 0.2
@@ -45,7 +45,7 @@ def prepare_data(args, dev):
         te = np.loadtxt(os.path.join(root, pre + "_test.csv"), delimiter=",", dtype=np.int64, usecols=(0, 1))
         U = int(max(tr[:, 0].max(), te[:, 0].max())) + 1
         I = int(max(tr[:, 1].max(), te[:, 1].max())) + 1
-        return Interactions(tr[:, 0], tr[:, 1], te[:, 0], te[:, 1], U, I, dev)
+        return Interactions(tr[:, 0], tr[:, 1], te[:, 0], te[:, 1], U, I, dev, renumber=args.renumber)
     else:
         raise SystemExit("dataset %s: provide --data_root or --synthetic" % args.dataset)
     if split:
@@ -56,7 +56,7 @@ def prepare_data(args, dev):
             perm = np.random.permutation(len(u))
             te, tr = perm[:len(u) // 5], perm[len(u) // 5:]
         # keep users with at least one train interaction evaluable: test rows of train-less users are dropped
-        return Interactions(u[tr], i[tr], u[te], i[te], U, I, dev)
+        return Interactions(u[tr], i[tr], u[te], i[te], U, I, dev, renumber=args.renumber)
 
 
 def create_model(args, U, I, dev):
@@ -88,6 +88,9 @@ def main(args):
     say("userNum:{}, itemNum:{}".format(data.U, data.I))
     say("lenth of traindf", data.train_u.numel(), "lenth of test_df", data.test_u.numel())
     say("adj.shape", tuple(adj.shape))
+    # nodes renumbered by degree at ingest (ngacf_amd.data.degree_order): the model, the sampler and the evaluation speak the
+    # internal numbering; checkpoints are written and read in the data set's (the reference's) numbering
+    perm = (data.perm_u, data.perm_i) if data.perm_u is not None else None
     if sharded:
         model = SL.create_model(args.model, args.stages, data.U, data.I, args.embedSize, args.layers, args.droprate, adj, dev,
                                 torch.bfloat16 if args.dtype == "bf16" else torch.float32)
@@ -107,7 +110,7 @@ def main(args):
     if args.resume_from:
         # a checkpoint of the reference (run_Gowalla.py:143) or of this runner (any world size): both halves in the reference's
         # layout; the optimizer state is converted to the fused stage parameters (ngacf_amd/checkpoint.py)
-        load_fn("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, args.resume_from), model, optim, map_location=dev)
+        load_fn("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, args.resume_from), model, optim, map_location=dev, perm=perm)
         say("=> loaded checkpoint 'ckpts/{}_{:03d}.pkl'".format(args.model, args.resume_from))
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed)                        # (the same on every rank: every rank draws the same batches)
@@ -121,7 +124,7 @@ def main(args):
         torch.cuda.synchronize()
         say("------epoch:{}, train_loss:{:5f}, time consuming:{:.2f}s".format(epoch, loss, time.time() - t0), flush=True)
         if (epoch + 1) % args.save_every == 0:
-            save_fn("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, epoch + 1), model, optim)
+            save_fn("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, epoch + 1), model, optim, perm=perm)
         if (epoch + 1) % args.eval_every == 0:
             t0 = time.time()
             m = eval_fn(model, args.batch_size, data, adj)
@@ -160,6 +163,9 @@ def parse(argv=None):
     p.add_argument("--stages", type=int, default=0, help="0 = the model's own depth; L>0 = SPUIStackedGACF with L stages")
     p.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of one hipGraph replay per batch")
     p.add_argument("--sharded_graph", action="store_true", help="under torchrun: replay each batch as one hipGraph (kernels + RCCL launches)")
+    p.add_argument("--renumber", type=str, default="degree", choices=["degree", "none"],
+                   help="internal node numbering: by degree, descending (hot rows contiguous: faster gathers) or the data set's; "
+                        "checkpoints are in the data set's numbering either way")
     p.add_argument("--data_root", type=str, default="")
     p.add_argument("--synthetic", type=str, default="", choices=["", "ml100k", "gowalla", "yelp"])
     a = p.parse_args(argv)

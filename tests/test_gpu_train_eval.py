@@ -649,3 +649,40 @@ def test_checkpoint_written_from_the_library_adam_is_the_references_layout(tmp_p
         assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
         assert sb["step"].is_cuda and float(sb["step"]) == 2.0
     assert opt2.param_groups[0]["capturable"] is True
+
+
+def test_a_renumbered_run_evaluates_the_same_model_to_the_same_metrics(tmp_path):
+    """Interactions(renumber="degree") end to end on the device path: a model in the data set's numbering, saved as a
+    reference-layout checkpoint and loaded into a run that renumbered its nodes by degree at ingest (checkpoint perm mapping,
+    the relabelled adjacency, train / test sets and item pool in internal ids), ranks every user's items the same way --
+    eval_neg_all gives the same Recall / NDCG / precision / hit ratio @1,5,10,20 (ml100k, the reference's split)."""
+    import ngacf_amd
+    from ngacf_amd import checkpoint as CK
+    from test_oracle_golden import g11_split
+    from ngacf_amd.train_eval import Interactions, eval_neg_all
+    dev = torch.device("cuda:0")
+    u, i, tr, te, g = g11_split()
+    U, I = int(g["U"]), int(g["I"])
+    plain = Interactions(u[tr], i[tr], u[te], i[te], U, I, dev)
+    ren = Interactions(u[tr], i[tr], u[te], i[te], U, I, dev, renumber="degree")
+    assert ren.perm_u is not None and not torch.equal(ren.perm_u, torch.arange(U, device=dev))
+    torch.manual_seed(4)
+    a = ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.0).to(dev)
+    with torch.no_grad():
+        a.uEmbd.weight.mul_(40); a.iEmbd.weight.mul_(40)          # (scores far apart: the ranking must not hang on rounding)
+    oa = ngacf_amd.optim.Adam(a.parameters(), lr=1e-3)
+    path = str(tmp_path / "m.pkl")
+    CK.save_checkpoint(path, a, oa)                                # the data set's numbering (the reference's layout)
+    b = ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.0).to(dev)
+    ob = ngacf_amd.optim.Adam(b.parameters(), lr=1e-3)
+    CK.load_checkpoint(path, b, ob, map_location=dev, perm=(ren.perm_u, ren.perm_i))
+    assert torch.equal(b.uEmbd.weight[ren.perm_u], a.uEmbd.weight)
+    ma = eval_neg_all(a, 2048, plain, plain.adjacency())
+    mb = eval_neg_all(b, 2048, ren, ren.adjacency())
+    for k in ("precision", "recall", "ndcg", "hit_ratio"):
+        assert np.allclose(ma[k], mb[k], rtol=0, atol=2e-4), (k, ma[k], mb[k])
+    # and the propagated tables are the same rows under the two numberings
+    with torch.no_grad():
+        ta, tb = a.eval().propagate(plain.adjacency()), b.eval().propagate(ren.adjacency())
+    assert float((tb[:U][ren.perm_u] - ta[:U]).abs().max()) < 2e-5 * float(ta.abs().max())
+    assert float((tb[U:][ren.perm_i] - ta[U:]).abs().max()) < 2e-5 * float(ta.abs().max())

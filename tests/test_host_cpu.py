@@ -370,14 +370,21 @@ def test_runner_makes_the_references_seeded_split():
     import run_Gowalla as RG
     from ngacf_amd import data as D
     g = load_golden("g11_eval_neg_all")
-    args = RG.parse(["--dataset", "ml100k"])
-    torch.manual_seed(args.seed)
-    np.random.seed(args.seed)
-    data = RG.prepare_data(args, "cpu")
     u, i, _ = D.load_ml100k()
-    assert np.array_equal(data.train_u.numpy(), u[g["train_rows"]]) and np.array_equal(data.train_i.numpy(), i[g["train_rows"]])
-    assert np.array_equal(data.test_u.numpy(), u[g["test_rows"]]) and np.array_equal(data.test_i.numpy(), i[g["test_rows"]])
-    assert int(data.train_users.numel()) == int(g["n_train_users"])
+    for flags in (["--renumber", "none"], []):                 # the data set's ids; the default: internal ids by degree
+        args = RG.parse(["--dataset", "ml100k"] + flags)
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed)
+        data = RG.prepare_data(args, "cpu")
+        if flags:
+            assert data.perm_u is None
+            mu, mi = (lambda x: x), (lambda x: x)
+        else:                                                  # the same rows, relabelled
+            pu, pi = data.perm_u.numpy(), data.perm_i.numpy()
+            mu, mi = (lambda x: pu[x]), (lambda x: pi[x])
+        assert np.array_equal(data.train_u.numpy(), mu(u[g["train_rows"]])) and np.array_equal(data.train_i.numpy(), mi(i[g["train_rows"]]))
+        assert np.array_equal(data.test_u.numpy(), mu(u[g["test_rows"]])) and np.array_equal(data.test_i.numpy(), mi(i[g["test_rows"]]))
+        assert int(data.train_users.numel()) == int(g["n_train_users"])
 
 
 def test_grad_sink_parks_parameter_gradients_and_adam_refuses_what_it_cannot_step():
@@ -462,3 +469,58 @@ def test_peer_store_entries_reject_bad_arguments_before_touching_a_device():
     assert L.ngacf_peer_push(regs, 1, 1, flags, wp, wp, None) == -1                                 # a peer without a table
     assert L.ngacf_peer_wait(wp, 65, 0, wp, wp, 1, None) == -1 and L.ngacf_peer_wait(None, 2, 0, wp, wp, 1, None) == -1
     assert L.ngacf_peer_wait(wp, 2, 0, None, wp, 1, None) == -1
+
+
+def test_degree_renumbering_is_a_relabelling_and_checkpoints_keep_the_data_sets_numbering(tmp_path):
+    """ngacf_amd.data.degree_order / renumber and Interactions(renumber="degree"): a bijection per node type, degrees descending
+    in the internal numbering (ties in the data set's order), the same graph under other labels -- and a checkpoint of a
+    renumbered run is written in the DATA SET's numbering (row j of the file = the embedding of data-set user j, Adam moments
+    alike) and read back into the internal one."""
+    import ngacf_amd
+    from ngacf_amd import checkpoint as CK, data as D
+    from ngacf_amd.train_eval import Interactions
+    rs = np.random.RandomState(3)
+    U, I, n = 37, 23, 400
+    tu, ti = rs.randint(0, U, n), (rs.zipf(1.6, n) - 1) % I
+    tu = np.concatenate([tu, np.arange(U)]); ti = np.concatenate([ti, rs.randint(0, I, U)])     # every user has an edge
+    te_u, te_i = rs.randint(0, U, 50), rs.randint(0, I, 50)
+    plain = Interactions(tu, ti, te_u, te_i, U, I, "cpu")
+    ren = Interactions(tu, ti, te_u, te_i, U, I, "cpu", renumber="degree")
+    pu, pi = ren.perm_u, ren.perm_i
+    assert sorted(pu.tolist()) == list(range(U)) and sorted(pi.tolist()) == list(range(I))
+    adj, adj_r = plain.adjacency(), ren.adjacency()
+    assert torch.equal(adj_r, D.renumber(adj, pu, pi))                                   # the same graph, relabelled, sorted
+    for ids, m in ((adj_r[0], U), (adj_r[1], I)):
+        deg = torch.bincount(ids, minlength=m)
+        assert bool((deg[:-1] >= deg[1:]).all())                                         # hot rows first
+    du = torch.bincount(adj[0], minlength=U)
+    inv_u = CK._inverse(pu)
+    same = du[inv_u][:-1] == du[inv_u][1:]
+    assert bool((inv_u[:-1][same] < inv_u[1:][same]).all())                              # ties keep the data set's order
+    assert torch.equal(ren.train_u, pu[plain.train_u]) and torch.equal(ren.test_i, pi[plain.test_i])
+    # checkpoint: internal rows carry the data-set id they belong to; the file must read 0, 1, 2, ... per table
+    torch.manual_seed(0)
+    m = ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.0)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    with torch.no_grad():
+        m.uEmbd.weight.copy_(CK._inverse(pu).float()[:, None].expand(U, 64))
+        m.iEmbd.weight.copy_(CK._inverse(pi).float()[:, None].expand(I, 64))
+    sum(p.sum() for p in m.parameters()).backward()
+    opt.step()
+    with torch.no_grad():                                                                # moments that name their row, too
+        opt.state[m.uEmbd.weight]["exp_avg"].copy_(CK._inverse(pu).float()[:, None].expand(U, 64))
+        m.uEmbd.weight.copy_(CK._inverse(pu).float()[:, None].expand(U, 64))
+        m.iEmbd.weight.copy_(CK._inverse(pi).float()[:, None].expand(I, 64))
+    path = str(tmp_path / "ck.pkl")
+    CK.save_checkpoint(path, m, opt, perm=(pu, pi))
+    ck = torch.load(path)
+    assert torch.equal(ck["model"]["uEmbd.weight"][:, 0], torch.arange(U).float())
+    assert torch.equal(ck["model"]["iEmbd.weight"][:, 5], torch.arange(I).float())
+    assert torch.equal(ck["optim"]["state"][ck["optim"]["param_groups"][0]["params"][0]]["exp_avg"][:, 0], torch.arange(U).float())
+    m2 = ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.0)
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    CK.load_checkpoint(path, m2, opt2, perm=(pu, pi))
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert torch.equal(opt2.state[m2.uEmbd.weight]["exp_avg"], opt.state[m.uEmbd.weight]["exp_avg"])
+    assert torch.equal(opt2.state[m2.iEmbd.weight]["exp_avg_sq"], opt.state[m.iEmbd.weight]["exp_avg_sq"])
