@@ -31,7 +31,8 @@ def main():
     first[1:] = edge[0, 1:] != edge[0, :-1]
     te &= ~first                                                   # every user keeps a train interaction
     tr = ~te
-    data = Interactions(edge[0, tr].cpu().numpy(), edge[1, tr].cpu().numpy(), edge[0, te].cpu().numpy(), edge[1, te].cpu().numpy(), U, I, dev)
+    data = Interactions(edge[0, tr].cpu().numpy(), edge[1, tr].cpu().numpy(), edge[0, te].cpu().numpy(), edge[1, te].cpu().numpy(), U, I, dev,
+                        renumber="degree")                      # the product's ingest (run_Gowalla.py --renumber degree)
     adj = data.adjacency()
     torch.manual_seed(0)
     m = ng.SPUIMultiGACF(U, I, 64, [64, 64], 0.1).to(dev)

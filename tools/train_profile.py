@@ -26,6 +26,8 @@ def run(args):
     wl = args.workload
     U, I, _ = D.SHAPES[wl]
     edge = D.workload_graph(wl, dev)
+    if os.environ.get("NGACF_RENUMBER", "degree") == "degree":       # the product's ingest (run_Gowalla.py --renumber degree)
+        edge = D.renumber(edge, *D.degree_order(edge, U, I))
     model = bench.make_model(ng, torch, U, I, 64, args.stages, 0.1, args.dtype, dev)
     model.train()
     from ngacf_amd.optim import Adam
