@@ -117,4 +117,93 @@ __device__ __forceinline__ void mfma_fwd_epilogue(const f32x16 (&acc)[OT], int n
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same row transform in EXACT fp32 on v_mfma_f32_16x16x4_f32 (its accumulation is an fmaf chain, k ascending), for rows of 64
+// fp32 columns: one workgroup (4 waves) and a tile of 16 rows.  Shared by the traversal epilogue (propagate.hip) and the
+// stand-alone launch (transform.hip).
+//   tile   [16 rows][64 fp32], row stride 68 floats: the B-operand reads (node n, feature 4t + g) hit 64 distinct banks;
+//   panel  W'[type] as it stands, [64][NEXT] fp32, brought in by LDS-DMA with the 16-float column blocks of row k XOR-ed by
+//          (k & 3) on the SOURCE side, so that the A-operand reads (four rows k = 4t + g of one column) spread over four bank
+//          groups instead of one;
+//   wave w owns the output columns 16 w .. +15 (and 64 + 16 w .. for NEXT = 128) of all 16 rows: 16 MFMAs per block, complete
+//   k chains; lane (n = l & 15, g = l >> 4) ends up with columns 16 cb + 4 g .. +3 of row n: one 16-byte store of H'.
+//   S': 4-column partial dot products, then a pairing tree (lane pairs, quads, and for a one-head stage the four column blocks,
+//   which meet through LDS).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int XROW_F32 = 68;
+
+// W [64][NEXT] fp32 (global) -> the swizzled LDS image; a 1 KB LDS-DMA piece = 256 consecutive floats of the image, the lane's 16
+// bytes come from the column block the swizzle names.  256 threads; complete at the next barrier.
+template <int NEXT>
+__device__ __forceinline__ void load_panel_f32(float* panel_lds, const float* __restrict__ src) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int piece = threadIdx.x >> 6; piece < 64 * NEXT / 256; piece += 4) {
+        const int p = piece * 256 + lane * 4;                // float position in the LDS image: row k, columns cc .. cc+3
+        const int k = p / NEXT, cc = p % NEXT;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * NEXT + (cc ^ (16 * (k & 3)))),
+                                         (__attribute__((address_space(3))) void*)(panel_lds + piece * 256), 16, 0, 0);
+    }
+}
+
+// The tile step: tile, row numbers (xmeta[n] = row of H or -1) and panel are in LDS (a barrier lies behind them).  NONE: the stage
+// has ONE head (sx: 64 floats of LDS; one more barrier inside).
+template <int NEXT, bool NONE>
+__device__ __forceinline__ void f32_tile_step(const float* xtile, const int* xmeta, const float* panel, const float* av, float* sx,
+                                              void* Hout, float* __restrict__ S) {
+    constexpr int CB = NEXT / 64;                        // column blocks of 16 per wave
+    constexpr int NH = NONE ? 1 : NEXT / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int nrow = xmeta[n];
+    const bool ok = nrow >= 0;
+    f32x4_t acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int t = 0; t < 64 / 4; ++t) {
+        const int k = 4 * t + g;
+        const float xb = xtile[n * XROW_F32 + k];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int col = 64 * c + 16 * wave + n;
+            const float wa = panel[k * NEXT + (col ^ (16 * g))];            // (k & 3) == g: the panel's source-side swizzle
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xb, acc[c], 0, 0, 0);
+        }
+    }
+    float part[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int c0 = 64 * c + 16 * wave + 4 * g;
+        const float4 a4 = *reinterpret_cast<const float4*>(av + c0);
+        float p = 0.f;
+        p = fmaf(acc[c][0], a4.x, p); p = fmaf(acc[c][1], a4.y, p); p = fmaf(acc[c][2], a4.z, p); p = fmaf(acc[c][3], a4.w, p);
+        part[c] = p;
+        if (ok) *reinterpret_cast<float4*>(static_cast<float*>(Hout) + (size_t)nrow * NEXT + c0) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+    }
+    auto x16 = [&](float v) { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                              return __uint_as_float((g & 1) ? r[0] : r[1]); };
+    auto x32 = [&](float v) { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                              return __uint_as_float((g & 2) ? r[0] : r[1]); };
+    if constexpr (!NONE) {                                    // 8-wide heads: this lane's 4 columns + the 4 of the lane 16 away
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const float hsum = part[c] + x16(part[c]);
+            if (ok && (g & 1) == 0) S[(size_t)nrow * NH + 8 * c + 2 * wave + (g >> 1)] = hsum;
+        }
+    } else {
+        // one head: a thread's 4-column partials of the 64-column groups first, then a tree over 16 lanes' worth (pairs, quads,
+        // eights, sixteen) -- pairs and quads across the lanes, the four column blocks of a group (= the four waves) through LDS
+        float p = part[0];
+#pragma unroll
+        for (int c = 1; c < CB; ++c) p += part[c];
+        p = p + x16(p);
+        p = p + x32(p);
+        if (g == 0) sx[wave * 16 + n] = p;
+        __syncthreads();
+        if (wave == 0 && g == 0 && ok) S[nrow] = (sx[n] + sx[16 + n]) + (sx[32 + n] + sx[48 + n]);
+    }
+}
+
 }  // namespace ngacf

@@ -9,6 +9,7 @@
 // round (4 workgroups per CU) whenever the graph allows: a persistent 2-per-CU variant measured
 // slower (too few loads in flight per CU), see DESIGN.md.
 #include "ngacf_common.hpp"
+#include "mfma_rows.hpp"
 
 namespace ngacf {
 
@@ -188,8 +189,79 @@ static int launch_transform(const TransArgs& a, bool drop, hipStream_t st) {
     return launch_transform_rpt<TX, TH, DIN, DOUT, HEADS, 6>(a, drop, st);
 }
 
+// fp32 rows of 64 columns: the exact-fp32 matrix-core form (mfma_rows.hpp: f32_tile_step, the step the traversal epilogue runs:
+// same fmaf chains, same bits as transform_fwd_kernel above).  A workgroup keeps W'[type] in LDS (LDS-DMA, 16 / 32 KB) and walks
+// `tpb` consecutive 16-row tiles: 256 threads fetch a tile as ONE coalesced 4 KB read (thread = 16 bytes), the next tile's read is
+// in flight while this one's 16 MFMAs per wave run.  15.2 -> 10-11 us at Gowalla size (transform_fwd_kernel stays for the other
+// shapes: 128 input columns, bf16 input rows).
+template <int NEXT, bool NONE, bool DROP>
+__global__ __launch_bounds__(256) void transform_f32_tiles_kernel(const TransArgs a, int tpb) {
+    __shared__ __attribute__((aligned(16))) float panel[64 * NEXT];
+    __shared__ __attribute__((aligned(16))) float xtile[16 * XROW_F32];
+    __shared__ int xmeta[16];
+    __shared__ __attribute__((aligned(16))) float avs[NEXT];
+    __shared__ float sx[64];
+    const int tid = threadIdx.x, row = tid >> 4, q = tid & 15;
+    const int tiles_u = (a.u_n + 15) / 16, tiles_i = (a.i_n + 15) / 16;
+    const int nbu = (tiles_u + tpb - 1) / tpb;
+    const bool users = (int)blockIdx.x < nbu;
+    const int type = users ? 0 : 1;
+    const int bl = users ? blockIdx.x : blockIdx.x - nbu;
+    const int win_lo = users ? a.u_lo : a.U + a.i_lo;
+    const int win_end = win_lo + (users ? a.u_n : a.i_n);
+    const int ntiles = users ? tiles_u : tiles_i;
+    const int loc_off = users ? a.u_lo : a.U + a.i_lo - a.u_n;  // global row - loc_off = local row
+    const uint32_t salt = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
+    load_panel_f32<NEXT>(panel, a.W + (size_t)type * 64 * NEXT);
+    if (tid < NEXT / 4) reinterpret_cast<float4*>(avs)[tid] = reinterpret_cast<const float4*>(a.avec + type * NEXT)[tid];
+    const float* X = static_cast<const float*>(a.X);
+    auto fetch = [&](int it, float4& v, int& node) {
+        const int tile = bl * tpb + it;
+        const int nd = win_lo + tile * 16 + row;
+        const bool ok = tile < ntiles && nd < win_end;
+        node = ok ? nd : -1;
+        v = ok ? *reinterpret_cast<const float4*>(X + (size_t)(a.x_local ? nd - loc_off : nd) * 64 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 v;
+    int node;
+    fetch(0, v, node);
+    for (int it = 0; it < tpb; ++it) {
+        if (bl * tpb + it >= ntiles) break;                  // (uniform)
+        float x[4] = {v.x, v.y, v.z, v.w};
+        if (DROP && node >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = feat_bits(salt, node, 4 * q + j) >= a.drop_thr ? x[j] * a.drop_scale : 0.f;
+        }
+        *reinterpret_cast<float4*>(xtile + row * XROW_F32 + 4 * q) = make_float4(x[0], x[1], x[2], x[3]);
+        if (q == 0) xmeta[row] = node;
+        if (it + 1 < tpb) fetch(it + 1, v, node);            // the next tile's rows fly under this tile's step
+        __syncthreads();                                     // tile (and, the first time, panel + avec) in LDS
+        f32_tile_step<NEXT, NONE>(xtile, xmeta, panel, avs, sx, a.H, a.S);
+        __syncthreads();                                     // the tile may be overwritten
+    }
+}
+
+template <int NEXT, bool NONE>
+static int launch_transform_f32_tiles(const TransArgs& a, bool drop, hipStream_t st) {
+    const int tiles = (a.u_n + 15) / 16 + (a.i_n + 15) / 16;
+    int tpb = (tiles + 2047) / 2048;                         // ~2 k workgroups: the 16-32 KB panel is read once per 16 * tpb rows
+    if (tpb < 3) tpb = 3;
+    const int nb = ((a.u_n + 15) / 16 + tpb - 1) / tpb + ((a.i_n + 15) / 16 + tpb - 1) / tpb;
+    if (nb == 0) return 0;
+    if (drop) launch_k(NGACF_TAG_TRANSFORM_FWD, transform_f32_tiles_kernel<NEXT, NONE, true>, dim3(nb), dim3(256), 0, st, a, tpb);
+    else      launch_k(NGACF_TAG_TRANSFORM_FWD, transform_f32_tiles_kernel<NEXT, NONE, false>, dim3(nb), dim3(256), 0, st, a, tpb);
+    NGACF_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename TX, typename TH>
 static int dispatch_transform(const TransArgs& a, int din, int dout, int heads, bool drop, hipStream_t st) {
+    if constexpr (sizeof(TX) == 4 && sizeof(TH) == 4) {       // fp32 rows in, fp32 rows out, 64 columns in: the matrix-core form
+        if (din == 64 && dout == 64 && heads == 8) return launch_transform_f32_tiles<64, false>(a, drop, st);
+        if (din == 64 && dout == 64 && heads == 1) return launch_transform_f32_tiles<64, true>(a, drop, st);
+        if (din == 64 && dout == 128 && heads == 16) return launch_transform_f32_tiles<128, false>(a, drop, st);
+        if (din == 64 && dout == 128 && heads == 1) return launch_transform_f32_tiles<128, true>(a, drop, st);
+    }
     if (din == 64 && dout == 64 && heads == 8) return launch_transform<TX, TH, 64, 64, 8>(a, drop, st);
     if (din == 64 && dout == 64 && heads == 1) return launch_transform<TX, TH, 64, 64, 1>(a, drop, st);
     if (din == 128 && dout == 64 && heads == 8) return launch_transform<TX, TH, 128, 64, 8>(a, drop, st);
