@@ -22,13 +22,13 @@ What has to hold for that, and how it is kept:
                      kernel leaves: wrong numbers reported by the host, never a hung GPU.
   a step boundary    in training, a peer's next forward may only start after my backward has finished reading the tables it
                      will overwrite: the per-step all-reduce of the weight gradients (reduce_grads) is that barrier.
-  hardware queues    a wait kernel SPINS: everything behind it in the same hardware queue waits with it.  HIP maps a process's
-                     streams onto a few hardware queues (4 by default); as long as a rank's streams fit (compute, this side
-                     stream, a warm-up stream) a push never lands behind a wait that needs a peer's LATER push.  The step's two
-                     forwards as parallel branches break that: two branch streams + the side stream + the warm-up streams
-                     alias, a push sits behind the other branch's spinning wait on BOTH ranks, and the exchange only moves
-                     when waits time out (seen as a 300 s stall of a two-rank test).  The sharded step therefore keeps its
-                     forwards one after the other with this transport too.
+  sequential forwards a wait kernel SPINS: everything behind it in the same hardware queue waits with it.  As long as a rank has
+                     its compute stream, this push stream and a warm-up stream, a push never lands behind a wait that needs a
+                     peer's LATER push.  The step's two forwards as parallel branches (tools/peer_branches_probe.py) do not
+                     finish: the working explanation is that branch, push and warm-up streams alias onto HIP's few hardware
+                     queues and pushes sit behind the other branch's spinning wait on both ranks, so only time-outs move the
+                     exchange (unproven: GPU_MAX_HW_QUEUES=8 changes nothing).  The sharded step keeps its forwards one after
+                     the other with this transport too.
 The push runs on a side stream (under the other half's traversal, like the asynchronous all-gather it replaces; overlap=False:
 in line on the current stream, no fork); join() brings it back before a pass ends.  Everything that is not a pool table
 (state-dict / evaluation gathers) takes the base class's path.  Validated as 2-4 processes on ONE GPU (tests/test_gpu_dist.py,

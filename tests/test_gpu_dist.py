@@ -486,8 +486,7 @@ def test_peer_store_train_step_without_a_collective_as_one_graph():
     """With every exchange of the step on peer stores (PeerComm.all_reduce_sum for the scores' row exchange and the weight-gradient
     sum) the captured step holds no collective at all.  Two ranks on cuda:0, four Adam steps replayed from ONE hipGraph per rank:
     losses and every parameter against eager steps on the process group's collectives (1e-4: float atomics in the score
-    backward).  (The two forwards stay one after the other: parallel branches put pushes behind spinning waits in shared
-    hardware queues, ngacf_amd/peer.py.)"""
+    backward).  (The two forwards stay one after the other: as parallel branches the step stalls, ngacf_amd/peer.py.)"""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
