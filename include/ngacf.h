@@ -354,8 +354,9 @@ int ngacf_timing_end(float* ms, int32_t* tags, int cap);
  * words in front of its traversal.  No collective launch; the epochs live in device memory, so captured graphs replay.
  *   ngacf_peer_alloc / _free      zero-filled device memory owned by the library (hipMalloc): tables and flag words
  *   ngacf_peer_export / _import   64-byte hipIpc handle of such an allocation / the peer's mapping of it (_close unmaps)
- *   ngacf_peer_push   copy every region's src (this rank's block) to dst[0..npeers) (the same block inside each peer's table),
- *                     then epoch = ++*sent and a system-scope release store of epoch to peer_flags[p] (the word of (slot, this
+ *   ngacf_peer_push   copy every region's src (this rank's block) to dst[0..npeers) (the same block inside each peer's table)
+ *                     with system-scope write-through stores; when every workgroup has seen its stores acknowledged, the last
+ *                     one (ticket) sets epoch = ++*sent and stores it, system scope, to peer_flags[p] (the word of (slot, this
  *                     rank) in peer p's flag array).  ticket: an int32 of scratch, zero between launches.  bytes % 4 == 0.
  *   ngacf_peer_wait   one wave: until flags[r] has reached ++*expect for every r < n except self_rank, or timeout_ticks of the
  *                     100 MHz clock have passed (*err = 1; the kernel leaves either way).  n <= 64. */
