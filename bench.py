@@ -432,8 +432,11 @@ def two_in_flight(torch, model, edge, E, L, seconds=0.3):
     import time
     from ngacf_amd.graphs import GraphedPropagate
     with torch.no_grad():
-        runs = [GraphedPropagate(model, edge), GraphedPropagate(model, edge)]
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        runs = []
+        for st in streams:                                   # captured on its OWN stream: the hub rows' arrival counters are
+            runs.append(GraphedPropagate(model, edge, stream=st))   # per stream (plan.tickets_for); two passes in flight must not share them
+        want = model.propagate(edge).clone()
 
         def burst(n):
             cur = torch.cuda.current_stream()
@@ -455,7 +458,11 @@ def two_in_flight(torch, model, edge, E, L, seconds=0.3):
         burst(n)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        same = bool(torch.equal(runs[0].out, want)) and bool(torch.equal(runs[1].out, want))
+    if not same:
+        raise RuntimeError("two passes in flight: a pass differs from the sequential forward")
     return {"value": round(L * 2 * E * n / dt, 1), "unit": "edges/s", "passes": n, "ms_per_pass_throughput": round(1e3 * dt / n, 5),
+            "outputs_equal_the_sequential_forward": same,
             "note": "two complete, independent passes in flight on two streams (two captured graphs with their own tables); "
                     "NOT the headline: `value` above times passes one after the other"}
 

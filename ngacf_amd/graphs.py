@@ -218,7 +218,9 @@ class GraphedBPRStep:
 class GraphedPropagate:
     """propagate() -> the [N, d] propagated embeddings of the model in eval mode (static output buffer)."""
 
-    def __init__(self, model, adj, warmup=2):
+    def __init__(self, model, adj, warmup=2, stream=None):
+        """stream: the capture stream (default: torch's shared one).  Per-stream state of the launches -- the hub rows' arrival
+        counters, plan.tickets_for -- is keyed by it: graphs that are to run CONCURRENTLY must be captured on different streams."""
         self.model = model
         model.eval()
         side = torch.cuda.Stream()
@@ -229,7 +231,7 @@ class GraphedPropagate:
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         quiesce_collectives()
-        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=_capture_mode()):
             self.out = model.propagate(adj)
 
     def __call__(self):
