@@ -16,7 +16,8 @@ invariants the kernels rely on, because a bad index is a GPU fault, not an excep
 import torch
 
 
-_TICKET_SETS = 16        # arrival-counter sets per plan: one per stream that launches it
+_TICKET_SETS = 80        # arrival-counter sets per plan: one per stream that launches it (torch hands out streams from pools of
+                         # 32 per priority: every handle a process can meet gets a row of the pool, none is ever allocated later)
 
 
 class GraphPlan:
