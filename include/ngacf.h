@@ -83,14 +83,17 @@ int ngacf_transform_fwd(const void* X, int x_dtype, const float* W, const float*
  * 2 * din_k * dout_k * 2 bytes, din_k == 64, dout_k in {64, 128}.  Fragment layout (16 bytes = 8 bf16 each):
  *   index ((y * (din/16) + s) * (dout/32) + t) * 64 + l  holds  W[y][16 s + 8 (l >> 5) + j][32 t + (l & 31)], j = 0..7
  *   (the A fragments of v_mfma_f32_32x32x16_bf16 with the output column on the A operand: csrc/mfma_rows.hpp).
+ * pack_kind (host array, or NULL = all 0): 0 = the forward fragments above; 1 = the fragments of the TRANSPOSED product
+ * dX = dH @ W^T for ngacf_prop_bwd_dx (din_k == dout_k == 64):
+ *   index ((y * (dout/16) + s) * (din/32) + t) * 64 + l  holds  W[y][32 t + (l & 31)][16 s + 8 (l >> 5) + j], j = 0..7.
  * U == I == 0: only the panels are packed (X .. S are not read; the node-partitioned path, whose transforms run over row windows). */
-#define NGACF_MAX_PACK 4
+#define NGACF_MAX_PACK 8
 int ngacf_transform_fwd_pack(const void* X, int x_dtype, const float* W, const float* avec,
                              void* H, int h_dtype, float* S,
                              int U, int I, int din, int dout, int heads,
                              float feat_drop_p, uint64_t seed, const uint64_t* seed_dev,
                              int n_pack, const float* const* pack_W, void* const* pack_panel,
-                             const int* pack_din, const int* pack_dout, void* stream);
+                             const int* pack_din, const int* pack_dout, const int* pack_kind, void* stream);
 
 /* The same over row windows (node-partitioned runs, ngacf_amd/dist.py): users [u_lo, u_lo+u_n) and items
  * [i_lo, i_lo+i_n) (global row = U + i).  H and S are indexed by global row; with x_local != 0, X holds only
@@ -180,8 +183,8 @@ int ngacf_prop_fwd_next(const int32_t* segs, int nseg, const int32_t* split, int
  *   gout [N,d] dtype (the gradient arrives in the storage type of `out`)   out [N,d] dtype (forward output)
  *   agg, R: as saved by the forward
  *   G float[N][d], Gn [N][d] dtype, ST float[N][heads] (the t table): workspace    dH [N][d] dtype (H's storage type), dS float[N][heads]: results
- *   G may be NULL when this call runs both steps (no NGACF_SKIP_NODE): step 2 then recomputes g from gout and out, bit for bit,
- *   and the 4-byte-per-element table is neither written nor read back
+ *   G may be NULL when gout and out are given as global-row tables: step 2 then recomputes g from gout and out, bit for bit,
+ *   and the 4-byte-per-element table is neither written nor read back (also with NGACF_SKIP_NODE, when Gn / ST come from elsewhere)
  *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows; part_split / tickets: as in ngacf_prop_fwd
  *   (both given: the last-arriving slice of a hub row finishes it inside the launch; NULL: a second kernel does)
  *   needed / rows / nrows / short_max (NULL / NULL / 0 / 0, or the forward's): the forward ran with these flags, i.e. gout is
@@ -202,6 +205,48 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
+
+/* ngacf_prop_bwd whose launch ALSO runs the stage's transform backward for the rows it finishes, and step 1 of the PREVIOUS
+ * stage's backward on the result -- the mirror image of ngacf_prop_fwd_next (autograd of SPUIGACF.py:356-357 chained through
+ * :207-215; the reference's autograd runs these as separate ATen kernels):
+ *   dX[n, :] = mask * (dH[n, :] @ W[type(n)]^T)      what ngacf_transform_bwd's dX half computes from the stored dH, bit for bit
+ *   and with prev_*: g = dX * ELU'(prev_out);  prev_Gn = g / prev_R;  prev_T[n, h] = (prev_Gn . prev_agg)_h
+ *                                                    what ngacf_prop_bwd_node computes from the stored dX, bit for bit
+ * so the previous stage's backward is then called with NGACF_SKIP_NODE, gout = dX, Gn = prev_Gn, ST = prev_T.
+ *   panel   bf16 A fragments of W[type]^T: ngacf_transform_fwd_pack with pack_kind 1 (2 * din * d * 2 bytes)
+ *   dX      [N][din]: NGACF_BF16 when prev_* are given (dX is the gradient of the previous stage's bf16 output),
+ *           NGACF_F32 without them (the first stage: the gradient of the fp32 embedding table)
+ *   feat_drop_p, seed: the stage's feature dropout (the mask of ngacf_transform_fwd)
+ *   prev_out, prev_agg [N][din] bf16, prev_R float[N][din/8]: as the previous stage's forward saved them (8-column heads);
+ *   prev_Gn [N][din] bf16, prev_T float[N][din/8]: results;   prev_flags: NGACF_ELU of the previous stage
+ * dH and dS are written as by ngacf_prop_bwd (the weights' gradient still needs them: ngacf_transform_bwd with dX == NULL).
+ * Restrictions: dtype == NGACF_BF16, d == 64, din == 64, NGACF_SCORE_ROW, G == NULL, nhub == 0, hub rows finished in-kernel
+ * (part_split + tickets) or absent.  dx == NULL: exactly ngacf_prop_bwd. */
+typedef struct ngacf_bwd_dx {
+    const void* panel;
+    void* dX;
+    int32_t din, dx_dtype;
+    float feat_drop_p;
+    uint64_t seed;
+    const void* prev_out;
+    const void* prev_agg;
+    const float* prev_R;
+    void* prev_Gn;
+    float* prev_T;
+    int32_t prev_flags;
+} ngacf_bwd_dx;
+int ngacf_prop_bwd_dx(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                      const int32_t* srow, int nshort, int nseg_user, int nshort_user,
+                      const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
+                      const int32_t* col, const void* H, int dtype,
+                      const float* S_dst, const float* S_src, const float* avec,
+                      const void* out, const void* agg, const float* R, const void* gout,
+                      float* G, void* Gn, float* ST, void* dH, float* dS,
+                      float* part_acc, float* part_r, const int32_t* part_split, int32_t* tickets,
+                      const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
+                      int U, int N, int d, int heads, float alpha,
+                      float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
+                      const ngacf_bwd_dx* dx, void* stream);
 
 /* Sets bit u[b] and bit U + i[b] of needed (uint32[ceil((U+I)/32)], ALLOCATED up to the next multiple of 16 words: the clear
  * writes whole 64-byte units) for b < B (after zeroing the table when clear != 0): the rows a scored batch reads

@@ -329,9 +329,18 @@ class _GATBase(nn.Module):
             for s in range(1, L):
                 fuse[s] = (NF.ops.can_fuse_next(plan, self.compute_dtype, shapes[s - 1][1], shapes[s - 1][2])
                            and shapes[s][0] == 64 and shapes[s][1] in (64, 128))
-        link = NF.StageLink() if any(fuse) else None
+        # The backward's mirror image (ngacf_prop_bwd_dx): stage s's edge backward also produces dX of its transform and runs stage
+        # s-1's step 1 on it -- bf16 64 -> 64 stages whose input is the fp32 table (s = 0) or an 8-head stage's bf16 output.
+        fuse_b = [False] * L
+        if NF.ops.FUSE_BWD and features.is_cuda and torch.is_grad_enabled() and self.compute_dtype == torch.bfloat16:
+            for s in range(L):
+                x_dtype = features.dtype if s == 0 else self.compute_dtype
+                has_prev = s > 0 and shapes[s - 1][1] == 64 and shapes[s - 1][2] == 8
+                fuse_b[s] = NF.ops.can_fuse_bwd(plan, self.compute_dtype, shapes[s][1], shapes[s][0], x_dtype, has_prev)
+        link = NF.StageLink() if any(fuse) or any(fuse_b) else None
         if link is not None and self.compute_dtype == torch.bfloat16:
             link.pack = {s: ops_[s][0].detach() for s in range(1, L) if fuse[s]}       # bf16 fragments, packed by the first transform's launch
+            link.pack_t = {s: ops_[s][0].detach() for s in range(L) if fuse_b[s]}
         elif link is not None:
             link.panels = {s: ops_[s][0].detach().contiguous().float() for s in range(1, L) if fuse[s]}   # fp32: the weights themselves
         for s, layers in enumerate(stages):
@@ -342,14 +351,14 @@ class _GATBase(nn.Module):
                 needed = needed()                           # the batch's rows are marked HERE, in front of the stage that wants them
             if score is not None and needed is not None and s == L - 1:
                 return NF.stage_score(x, W, avec, plan, len(layers), needed, score[0], score[1], layers[0].alpha, True, p, p,
-                                      NF.stage_seed(base, s), self.compute_dtype, seed_dev, link=link)
+                                      NF.stage_seed(base, s), self.compute_dtype, seed_dev, link=link, sidx=s)
             nxt = None
             if s + 1 < L and fuse[s + 1]:
                 nxt = NF.ops.NextStage(None, ops_[s + 1][1].detach().contiguous().float(), len(stages[s + 1]), p, NF.stage_seed(base, s + 1))
                 nxt.panel = _PanelRef(link, s + 1)           # resolved at launch: the stack's first transform packs the panels
             x = NF.stage(x, W, avec, plan, len(layers), layers[0].alpha, True, p, p,
                          NF.stage_seed(base, s), self.compute_dtype, seed_dev,
-                         needed=needed if s == L - 1 else None, link=link, nxt=nxt)
+                         needed=needed if s == L - 1 else None, link=link, nxt=nxt, sidx=s)
             if getattr(self, "debug_asserts", False) and needed is not None and s == L - 1:
                 assert not bool(torch.isnan(x[needed.mask()]).any()), "NaN after propagation stage %d" % s
             elif getattr(self, "debug_asserts", False) and x is not None:

@@ -19,7 +19,7 @@ FLAG_ELU, FLAG_RESIDUAL, FLAG_SCORE_ROW, FLAG_SKIP_NODE, FLAG_GOUT_F32 = 1, 2, 4
 ADAM_MAX_TENSORS = 24            # NGACF_ADAM_MAX_TENSORS
 TICK_MAX = 48                      # NGACF_TICK_MAX
 TBWD_BLOCKS = 1024
-MAX_PACK = 4                       # NGACF_MAX_PACK
+MAX_PACK = 8                       # NGACF_MAX_PACK
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -33,9 +33,11 @@ SIGNATURES = {
                        _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p],
     "ngacf_prop_fwd_next": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                             _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p, _p],
-    "ngacf_transform_fwd_pack": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _i, _p, _p, _p, _p, _p],
+    "ngacf_transform_fwd_pack": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _i, _p, _p, _p, _p, _p, _p],
     "ngacf_prop_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
                        _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p],
+    "ngacf_prop_bwd_dx": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
+                          _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p, _p],
     "ngacf_adam_step": [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p],
     "ngacf_bpr_fwd_bwd": [_p, _p, _p, _p, _p, _i, _p],
     "ngacf_tick": [_p, _p, _i, _p, _i, _p],
@@ -66,6 +68,12 @@ class NextStage(ctypes.Structure):
     """ngacf_next_stage of include/ngacf.h"""
     _fields_ = [("panel", _p), ("avec", _p), ("H", _p), ("S", _p), ("dout", ctypes.c_int32), ("heads", ctypes.c_int32),
                 ("feat_drop_p", _f), ("seed", _u64)]
+
+
+class BwdDx(ctypes.Structure):
+    """ngacf_bwd_dx of include/ngacf.h"""
+    _fields_ = [("panel", _p), ("dX", _p), ("din", ctypes.c_int32), ("dx_dtype", ctypes.c_int32), ("feat_drop_p", _f), ("seed", _u64),
+                ("prev_out", _p), ("prev_agg", _p), ("prev_R", _p), ("prev_Gn", _p), ("prev_T", _p), ("prev_flags", ctypes.c_int32)]
 
 
 MAX_PEERS, PEER_MAX_REGIONS, PEER_HANDLE_BYTES = 15, 2, 64       # NGACF_MAX_PEERS, NGACF_PEER_MAX_REGIONS, NGACF_PEER_HANDLE_BYTES

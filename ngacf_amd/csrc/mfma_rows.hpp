@@ -33,6 +33,23 @@ __device__ __forceinline__ void pack_panel_job(const float* __restrict__ W, void
     }
 }
 
+// The same for the transposed product dX = dH @ W^T (ngacf_prop_bwd_dx, transform_dw_mfma_kernel<WITH_DX>): the contraction
+// runs over dout, the output column over din:  slot ((y * DKS + s) * DOT + t) * 64 + l = W[y][32 t + (l & 31)][16 s + 8 (l >> 5) + j].
+__device__ __forceinline__ void pack_panel_job_t(const float* __restrict__ W, void* F, int din, int dout, int y, int tid) {
+    const int DKS = dout / 16, DOT = din / 32;
+    const float* M = W + (size_t)y * din * dout;
+    uint4* out = reinterpret_cast<uint4*>(F) + (size_t)y * DKS * DOT * 64;
+    for (int slot = tid; slot < DKS * DOT * 64; slot += 256) {
+        const int l = slot & 63, t = (slot >> 6) % DOT, sk = (slot >> 6) / DOT;
+        const int i = 32 * t + (l & 31), k0 = 16 * sk + 8 * (l >> 5);
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w[j] = f32_to_bf16(M[(size_t)i * dout + k0 + 2 * j]) | (f32_to_bf16(M[(size_t)i * dout + k0 + 2 * j + 1]) << 16);
+        out[slot] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // Epilogue of one 32-node tile: H rows (bf16, 16-byte stores) and the per-node scores S = H . a, formed from the ROUNDED H.
 //   nd: the lane's node (row of H / S), ok: the node exists; h = lane >> 5; av = avec of the tile's node type [DOUT].
 //   staged: the rounded H' goes through otile -- 32 x (DOUT / 8 + 1) uint4 of LDS private to this wave, tr: the

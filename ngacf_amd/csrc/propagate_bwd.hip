@@ -60,6 +60,20 @@ struct PropBwdArgs {
     const int* rows;               // with needed: the same rows as a list (duplicates allowed, -1 = skip)
     int nrows;
     int short_max;                 // with needed: degree bound of the plan's short rows
+    // The fused tail (ngacf_prop_bwd_dx; fx_dX == nullptr: none): the stage's transform backward dX = mask * (dH @ W[type]^T) of the
+    // rows a workgroup has just finished, and on that dX row step 1 of the PREVIOUS stage's backward (pv_*: that stage's saved
+    // out / agg / R; its Gn and t tables are the results).
+    const void* fx_panel;          // [2][d/16][din/32][64] x 16 B: bf16 A fragments of W[type]^T (ngacf_transform_fwd_pack, kind 1)
+    void* fx_dX;                   // [N][din]: bf16 (with pv_*), or fp32 (the first stage: the embedding table's gradient)
+    uint32_t fx_drop_thr;          // the stage's feature dropout (0 = none)
+    float fx_drop_scale;
+    uint64_t fx_seed;
+    const void* pv_out;
+    const void* pv_agg;
+    const float* pv_R;
+    void* pv_Gn;
+    float* pv_T;
+    int pv_flags;                  // NGACF_ELU of the previous stage
 };
 
 template <typename T, int D, int HEADS>
@@ -307,9 +321,9 @@ __device__ __forceinline__ void sparse_edges_b(const PropBwdArgs& a, const RowCt
 }
 
 template <typename T, int D, int HEADS, int VEC>
-__device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum) {
+__device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum, float (&o)[VEC]) {
     constexpr int HW = D / HEADS;
-    float g[VEC], o[VEC];
+    float g[VEC];
     if ((a.flags & NGACF_RESIDUAL) && a.G) load_f32<VEC>(a.G + (size_t)row * D + q * VEC, g);
     else if ((a.flags & NGACF_RESIDUAL) && a.needed && !flagged(a.needed, row)) {          // outside the batch: g = 0, out is not valid
 #pragma unroll
@@ -333,8 +347,44 @@ __device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int 
     if ((q * VEC) % HW == 0) a.dS[(size_t)row * HEADS + head] = dsum;
 }
 
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE>
-__global__ __launch_bounds__(256, SPARSE ? (DROP ? 5 : 4) : 1) void prop_bwd_kernel(const PropBwdArgs a) {
+template <typename T, int D, int HEADS, int VEC>
+__device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum) {
+    float o[VEC];
+    finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum, o);
+}
+
+// What a lane group hands to the fused tail: the dH row it has finished (this lane's 16-byte slice, fp32 before the store's
+// rounding) and, for the previous stage's step 1, the same slice of that stage's out / agg rows and its R entry.
+template <int VEC>
+struct RowDone {
+    float o[VEC];
+    uint4 pvo, pva;
+    float pvr;
+    int row;
+    bool valid;
+};
+
+template <typename T, int D, int HEADS, int FUSE, int VEC>
+__device__ __forceinline__ void finish_row_t(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum, RowDone<VEC>& rd) {
+    if constexpr (FUSE == 0) {
+        finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
+    } else {
+        if constexpr (FUSE == 2) {       // issued in front of finish_row_b's own loads: one round trip for all of them
+            const size_t off = (size_t)row * D * sizeof(T) + (size_t)q * 16;
+            rd.pvo = *reinterpret_cast<const uint4*>(static_cast<const char*>(a.pv_out) + off);
+            rd.pva = *reinterpret_cast<const uint4*>(static_cast<const char*>(a.pv_agg) + off);
+            rd.pvr = a.pv_R[(size_t)row * (D / 8) + (q * VEC) / 8];             // (the previous stage: heads of 8 columns)
+        }
+        finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum, rd.o);
+        rd.row = row;
+        rd.valid = true;
+    }
+}
+
+// The traversal of one wave's work item(s).  FUSE != 0 (ngacf_prop_bwd_dx): the row this lane's group finished is also handed
+// back in `rd` for the workgroup's tail, and no path leaves the KERNEL before that tail (the returns below leave this function).
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int FUSE>
+__device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, int widx, int wend, int* qmem, RowDone<Slice<T>::VEC>& rd) {
     using SH = BShape<T, D, HEADS>;
     constexpr int UNR = UNROLL;
     constexpr int LPR = SH::LPR, EPI = SH::EPI, HW = SH::HW, VEC = SH::VEC;
@@ -347,9 +397,6 @@ __global__ __launch_bounds__(256, SPARSE ? (DROP ? 5 : 4) : 1) void prop_bwd_ker
     float dsum = 0.f;
     RowCtx<VEC> x;
 
-    int kind, widx, wend;
-    locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, kind, widx, wend);
-    __shared__ int qmem[SPARSE ? 4 * EPI * (QCAP + 1) : 1];                // SPARSE: a column queue per lane group (odd stride: no bank clash)
     int* qbuf = qmem + (SPARSE ? ((threadIdx.x >> 6) * EPI + slot) * (QCAP + 1) : 0);
     if (kind == WORK_HUB) {
         // ------------------------------------------------------------------ hub rows: workgroup per row (as in the forward)
@@ -412,7 +459,7 @@ __global__ __launch_bounds__(256, SPARSE ? (DROP ? 5 : 4) : 1) void prop_bwd_ker
         load_ctx<T, D, HEADS, FROM_ROW, DROP, SPARSE>(a, row, q, head, x);
         if (SPARSE) {                                        // outside the batch: only the edges into the batch take part (the queue)
             sparse_edges_b<T, D, HEADS, FROM_ROW, DROP>(a, x, qbuf, row, beg, 1, deg, slot, q, head, acc, dsum);
-            if (live) finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
+            if (live) finish_row_t<T, D, HEADS, FUSE, VEC>(a, row, q, head, acc, dsum, rd);
             return;
         }
         const int last = deg > 0 ? beg + deg - 1 : 0;
@@ -439,7 +486,7 @@ __global__ __launch_bounds__(256, SPARSE ? (DROP ? 5 : 4) : 1) void prop_bwd_ker
             }
             colv = coln;
         }
-        if (live) finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
+        if (live) finish_row_t<T, D, HEADS, FUSE, VEC>(a, row, q, head, acc, dsum, rd);
         return;
     }
 
@@ -485,7 +532,7 @@ __global__ __launch_bounds__(256, SPARSE ? (DROP ? 5 : 4) : 1) void prop_bwd_ker
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     dsum = group_sum<LPR, WAVE>(dsum);
     if (part < 0) {
-        if (slot == 0) finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
+        if (slot == 0) finish_row_t<T, D, HEADS, FUSE, VEC>(a, row, q, head, acc, dsum, rd);
         return;
     }
     // slice of a hub row: leave the partial sums in slot `part`
@@ -534,8 +581,185 @@ __global__ __launch_bounds__(256, SPARSE ? (DROP ? 5 : 4) : 1) void prop_bwd_ker
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     dsum = group_sum<LPR, WAVE>(dsum);
-    if (slot == 0) finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
+    if (slot == 0) finish_row_t<T, D, HEADS, FUSE, VEC>(a, row, q, head, acc, dsum, rd);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The fused tail (ngacf_prop_bwd_dx), the mirror image of the forward's next-stage transform (propagate.hip): the rows THIS
+// WORKGROUP has just finished go through the stage's transform backward while they are on chip,
+//     dX[n, :] = mask * (dH[n, :] @ W[type(n)]^T)                    (transform_bwd.hip: the dX half of transform_dw_mfma_kernel)
+// and, when dX is the gradient of the previous stage's output (FUSE == 2), that stage's step 1 runs on the finished dX row:
+//     g = dX * ELU'(out_prev);  Gn_prev = g / R_prev;  t_prev = (Gn_prev . agg_prev)_h          (prop_bwd_node_kernel)
+//   1. every wave writes its finished dH rows -- the bf16 values the dH table stores -- into the workgroup's 32-row LDS tile
+//      (and the same rows of out_prev / agg_prev / R_prev, fetched together with the row's own gout / out); the weight panel
+//      (bf16 A fragments of W[type]^T, packed once per step: ngacf_transform_fwd_pack kind 1) has arrived by LDS-DMA meanwhile;
+//   2. ONE barrier; waves 1..3 leave;
+//   3. wave 0: DKS x DOT v_mfma_f32_32x32x16_bf16 with the node on the lane, k ascending -- the arithmetic, order and bits of
+//      transform_dw_mfma_kernel<WITH_DX> -- then mask, rounding, the half-waves' exchange (a lane then holds 8 consecutive
+//      columns = one head of the previous stage) and the node step in prop_bwd_node_kernel's own operation order.
+// A dense launch's workgroups hold rows of one node type (work order); a launch with row flags (SPARSE) can mix them at the
+// seams of its groups: wave 0 then makes a second pass with the other type's panel (fetched by itself: rare).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bw_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float bw_f32x16;
+constexpr int GROW_U4 = 9;           // a staged row: 128 B of bf16 + 16 B pad (36-dword stride: 16 rows hit 64 distinct banks)
+
+template <int D, int DIN, int FUSE, bool SPARSE>
+__device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, uint4* otile, uint4* atile, float* rtile, int* xmeta,
+                                            uint4* panel, int primary, const RowDone<8>& rd, int slot, int q) {
+    static_assert(D == 64 && DIN == 64, "fused dX: 64 -> 64 stages");
+    constexpr int DKS = D / 16, DOT = DIN / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tr = 8 * wave + slot;
+    if (rd.valid) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = f32_to_bf16(rd.o[2 * j]) | (f32_to_bf16(rd.o[2 * j + 1]) << 16);
+        gtile[tr * GROW_U4 + q] = make_uint4(w[0], w[1], w[2], w[3]);
+        if constexpr (FUSE == 2) {
+            otile[tr * GROW_U4 + q] = rd.pvo;
+            atile[tr * GROW_U4 + q] = rd.pva;
+            rtile[tr * GROW_U4 + q] = rd.pvr;
+        }
+    }
+    if (q == 0) xmeta[tr] = rd.valid ? rd.row : -1;
+    __syncthreads();                                          // (the compiler drains the LDS-DMA of the panel in front of it)
+    if (wave != 0) return;
+    const int r = lane & 31, hh = lane >> 5;
+    const int nrow = xmeta[r];
+    const bool ok = nrow >= 0;
+    const int node = ok ? nrow : 0;
+    bw_bf16x8 bf[DKS];
+#pragma unroll
+    for (int sk = 0; sk < DKS; ++sk) bf[sk] = __builtin_bit_cast(bw_bf16x8, gtile[r * GROW_U4 + 2 * sk + hh]);
+    const uint32_t salt = a.fx_drop_thr ? salt_of(a.fx_seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
+#pragma unroll 1
+    for (int pass = 0; pass < (SPARSE ? 2 : 1); ++pass) {
+        bool mine = ok;
+        if constexpr (SPARSE) {
+            const int ty = pass == 0 ? primary : 1 - primary;
+            mine = ok && (node >= a.U ? 1 : 0) == ty;
+            if (pass == 1) {
+                if (__ballot(mine) == 0ull) break;
+                const uint4* src = reinterpret_cast<const uint4*>(a.fx_panel) + (size_t)ty * DKS * DOT * 64;
+#pragma unroll
+                for (int piece = 0; piece < DKS * DOT; ++piece) panel[piece * 64 + lane] = src[piece * 64 + lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < DOT; ++t) {
+            bw_f32x16 dacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dacc[e] = 0.f;
+#pragma unroll
+            for (int sk = 0; sk < DKS; ++sk)
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bw_bf16x8, panel[(sk * DOT + t) * 64 + lane]), bf[sk], dacc, 0, 0, 0);
+            // lane: node r (+ half hh); dacc[4g + j] = dX column 32t + 8g + 4hh + j
+#pragma unroll
+            for (int gp = 0; gp < 4; gp += 2) {
+                float v[2][4];
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[gg][j] = dacc[4 * (gp + gg) + j];
+                        if (a.fx_drop_thr)
+                            v[gg][j] = feat_bits(salt, node, 32 * t + 8 * (gp + gg) + 4 * hh + j) >= a.fx_drop_thr ? v[gg][j] * a.fx_drop_scale : 0.f;
+                    }
+                if constexpr (FUSE == 1) {                    // fp32 rows (the embedding table's gradient): no previous stage
+                    if (mine) {
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg)
+                            *reinterpret_cast<float4*>(static_cast<float*>(a.fx_dX) + (size_t)node * DIN + 32 * t + 8 * (gp + gg) + 4 * hh) =
+                                make_float4(v[gg][0], v[gg][1], v[gg][2], v[gg][3]);
+                    }
+                } else {
+                    uint2 pk[2];
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg)
+                        pk[gg] = make_uint2(f32_to_bf16(v[gg][0]) | (f32_to_bf16(v[gg][1]) << 16), f32_to_bf16(v[gg][2]) | (f32_to_bf16(v[gg][3]) << 16));
+                    const auto rx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                    const auto ry = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                    // this lane now holds piece pc = 4t + gp + hh of its node's dX row: columns 8 pc .. 8 pc + 7
+                    const uint32_t w[4] = {rx[0], ry[0], rx[1], ry[1]};
+                    const int pc = 4 * t + gp + hh;
+                    if (mine) *reinterpret_cast<uint4*>(static_cast<char*>(a.fx_dX) + (size_t)node * DIN * 2 + 16 * pc) = make_uint4(w[0], w[1], w[2], w[3]);
+                    // step 1 of the previous stage's backward on this piece = head pc of that stage (prop_bwd_node_kernel, bf16, 8 heads)
+                    const uint4 ov = otile[r * GROW_U4 + pc], gv = atile[r * GROW_U4 + pc];
+                    const float rr = rtile[r * GROW_U4 + pc];
+                    const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w}, aw[4] = {gv.x, gv.y, gv.z, gv.w};
+                    float g[8], o[8], ag[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        g[2 * j] = __uint_as_float(w[j] << 16);   g[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+                        o[2 * j] = __uint_as_float(ow[j] << 16);  o[2 * j + 1] = __uint_as_float(ow[j] & 0xffff0000u);
+                        ag[2 * j] = __uint_as_float(aw[j] << 16); ag[2 * j + 1] = __uint_as_float(aw[j] & 0xffff0000u);
+                    }
+                    if (a.pv_flags & NGACF_ELU) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) g[j] *= o[j] > 0.f ? 1.f : o[j] + 1.f;
+                    }
+                    const float inv = rr > 0.f ? 1.f / rr : 0.f;
+                    float gn[8], p = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        gn[j] = Slice<bf16_t>::round(g[j] * inv);
+                        p = fmaf(gn[j], ag[j], p);
+                    }
+                    if (mine) {
+                        Slice<bf16_t>::store(static_cast<bf16_t*>(a.pv_Gn) + (size_t)node * DIN + 8 * pc, gn);
+                        a.pv_T[(size_t)node * (DIN / 8) + pc] = p;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int FUSE = 0>
+__global__ __launch_bounds__(256, FUSE != 0 ? (DROP ? 5 : (SPARSE ? 4 : 1)) : (SPARSE ? (DROP ? 5 : 4) : 1)) void prop_bwd_kernel(const PropBwdArgs a) {
+    using SH = BShape<T, D, HEADS>;
+    constexpr int EPI = SH::EPI, VEC = SH::VEC;
+    int kind, widx, wend;
+    locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, kind, widx, wend);
+    __shared__ int qmem[SPARSE ? 4 * EPI * (QCAP + 1) : 1];                // SPARSE: a column queue per lane group (odd stride: no bank clash)
+    RowDone<VEC> rd;
+    rd.valid = false;
+    rd.row = 0;
+    if constexpr (FUSE != 0) {
+        static_assert(sizeof(T) == 2 && D == 64 && FROM_ROW, "fused dX: bf16 rows of 64 columns");
+        constexpr int DIN = 64, PANEL_U4 = (D / 16) * (DIN / 32) * 64;
+        __shared__ __attribute__((aligned(16))) uint4 panel_lds[PANEL_U4];
+        __shared__ __attribute__((aligned(16))) uint4 gtile_lds[32 * GROW_U4];
+        __shared__ __attribute__((aligned(16))) uint4 otile_lds[FUSE == 2 ? 32 * GROW_U4 : 1];
+        __shared__ __attribute__((aligned(16))) uint4 atile_lds[FUSE == 2 ? 32 * GROW_U4 : 1];
+        __shared__ float rtile_lds[FUSE == 2 ? 32 * GROW_U4 : 1];
+        __shared__ int xmeta_lds[32];
+        const int lane = threadIdx.x & 63;
+        int primary;
+        if constexpr (!SPARSE) {
+            primary = (int)blockIdx.x < a.order.b2 ? 0 : 1;
+        } else {                                              // the node type of the first row of wave 0's work
+            int k0, w0, e0;
+            locate(a.order, blockIdx.x, 0, EPI, k0, w0, e0);
+            int row0 = 0;
+            if (w0 < e0) row0 = k0 == WORK_SHORT ? a.srow[w0] : w0 < a.order.nseg_u ? a.rows[w0] : a.segs[w0 - a.order.nseg_u].x;
+            primary = uniform(row0) >= a.U ? 1 : 0;
+        }
+        const uint4* src = reinterpret_cast<const uint4*>(a.fx_panel) + (size_t)primary * PANEL_U4;
+#pragma unroll
+        for (int piece = threadIdx.x >> 6; piece < PANEL_U4 / 64; piece += 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(panel_lds + piece * 64), 16, 0, 0);
+        prop_bwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, FUSE>(a, kind, widx, wend, qmem, rd);
+        bwd_dx_tail<D, DIN, FUSE, SPARSE>(a, gtile_lds, otile_lds, atile_lds, rtile_lds, xmeta_lds, panel_lds, primary, rd, lane / SH::LPR, lane % SH::LPR);
+    } else {
+        prop_bwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, 0>(a, kind, widx, wend, qmem, rd);
+    }
+}
+
 
 template <typename T, int D, int HEADS>
 __global__ __launch_bounds__(256) void prop_bwd_split_kernel(const PropBwdArgs a, const int* __restrict__ split, int nsplit) {
@@ -566,7 +790,7 @@ __global__ __launch_bounds__(256) void prop_bwd_split_kernel(const PropBwdArgs a
 
 template <typename T, int D, int HEADS>
 static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st,
-                      bool do_node, bool do_edges) {
+                      bool do_node, bool do_edges, int fuse = 0) {
     constexpr int EPI = BShape<T, D, HEADS>::EPI;
     if (do_node && (a.needed ? a.nrows : a.nu_n + a.ni_n) > 0) {
         const size_t threads = (size_t)(a.needed ? a.nrows : a.nu_n + a.ni_n) * BShape<T, D, HEADS>::LPR;
@@ -576,6 +800,26 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
     if (!do_edges) return 0;
     int nb = 0;
     a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, a.order.nhub, a.order.nhub_u, EPI, &nb);
+    if (fuse != 0) {                    // ngacf_prop_bwd_dx: the transform's dX (and the previous stage's step 1) in the tail
+        if constexpr (sizeof(T) == 2 && D == 64) {
+            if (nb == 0) return 0;
+            const dim3 grid(nb), block(256);
+#define NGACF_FX(F)                                                                                                          \
+            do {                                                                                                             \
+                if (a.needed && drop) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, true, true, F>, grid, block, 0, st, a);    \
+                else if (a.needed)    launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, false, true, F>, grid, block, 0, st, a);   \
+                else if (drop)        launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, true, false, F>, grid, block, 0, st, a);   \
+                else                  launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, false, false, F>, grid, block, 0, st, a);  \
+            } while (0)
+            if (fuse == 1) NGACF_FX(1);
+            else NGACF_FX(2);
+#undef NGACF_FX
+            NGACF_CHECK_LAUNCH();
+            return 0;
+        } else {
+            return NGACF_E_SHAPE;
+        }
+    }
     if (nb > 0) {
         const dim3 grid(nb), block(256);
         if (a.needed) {                 // (only with NGACF_SCORE_ROW: checked by the caller)
@@ -612,7 +856,8 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
                          int U, int N, int d, int heads, float alpha,
                          float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
                          int nu_lo, int nu_n, int ni_lo, int ni_n, int gout_local, bool do_node, bool do_edges,
-                         const uint32_t* needed, const int32_t* rows, int nrows, int short_max, void* stream) {
+                         const uint32_t* needed, const int32_t* rows, int nrows, int short_max, void* stream,
+                         const ngacf_bwd_dx* dx = nullptr) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
     if (nseg_user < 0 || nseg_user > nseg || nshort_user < 0 || nshort_user > nshort || (nshort_user % 16 != 0 && nshort_user != nshort))
         return NGACF_E_ARG;
@@ -620,7 +865,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     if (nu_lo < 0 || nu_n < 0 || ni_lo < 0 || ni_n < 0 || nu_lo + nu_n > U || ni_lo + ni_n > N - U) return NGACF_E_ARG;
     if (N == 0) return 0;
     if (!S_src || !Gn || !ST) return NGACF_E_ARG;
-    if (!G && !(do_node && do_edges && !gout_local)) return NGACF_E_ARG;   // G may be left out only when one call runs both steps on global-row gout
+    if (!G && !(do_edges && !gout_local && out && gout)) return NGACF_E_ARG;   // without G the edge step recomputes g from global-row gout and out
     if (do_node && (!out || !agg || !R || !gout)) return NGACF_E_ARG;
     if (do_edges) {
         if (!col || !rowptr || !H || !S_dst || !avec || !dH || !dS) return NGACF_E_ARG;
@@ -647,7 +892,27 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     }
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define NGACF_CASE(T, D, HD) return launch_bwd<T, D, HD>(a, split, nsplit, from_row, drop, st, do_node, do_edges)
+    a.fx_panel = nullptr; a.fx_dX = nullptr; a.fx_drop_thr = 0; a.fx_drop_scale = 1.f; a.fx_seed = 0;
+    a.pv_out = a.pv_agg = nullptr; a.pv_R = nullptr; a.pv_Gn = nullptr; a.pv_T = nullptr; a.pv_flags = 0;
+    int fuse = 0;
+    if (dx) {
+        if (!dx->panel || !dx->dX) return NGACF_E_ARG;
+        if (!do_edges || G || gout_local || nhub > 0 || !from_row) return NGACF_E_ARG;
+        if (nsplit > 0 && a.tickets == nullptr) return NGACF_E_ARG;             // hub rows must be finished inside the launch
+        if (dtype != NGACF_BF16 || d != 64 || dx->din != 64) return NGACF_E_SHAPE;
+        if (nu_lo != 0 || nu_n != U || ni_lo != 0 || ni_n != N - U) return NGACF_E_ARG;
+        if (!(dx->feat_drop_p >= 0.f && dx->feat_drop_p < 1.f)) return NGACF_E_ARG;
+        const bool prev = dx->prev_out || dx->prev_agg || dx->prev_R || dx->prev_Gn || dx->prev_T;
+        if (prev && !(dx->prev_out && dx->prev_agg && dx->prev_R && dx->prev_Gn && dx->prev_T)) return NGACF_E_ARG;
+        if (prev ? dx->dx_dtype != NGACF_BF16 : dx->dx_dtype != NGACF_F32) return NGACF_E_SHAPE;   // bf16 rows <=> a previous stage
+        a.fx_panel = dx->panel; a.fx_dX = dx->dX;
+        a.fx_drop_thr = dx->feat_drop_p > 0.f ? drop_threshold(dx->feat_drop_p) : 0u;
+        a.fx_drop_scale = 1.f / (1.f - dx->feat_drop_p); a.fx_seed = dx->seed;
+        a.pv_out = dx->prev_out; a.pv_agg = dx->prev_agg; a.pv_R = dx->prev_R; a.pv_Gn = dx->prev_Gn; a.pv_T = dx->prev_T;
+        a.pv_flags = dx->prev_flags;
+        fuse = prev ? 2 : 1;
+    }
+#define NGACF_CASE(T, D, HD) return launch_bwd<T, D, HD>(a, split, nsplit, from_row, drop, st, do_node, do_edges, fuse)
     if (dtype == NGACF_F32) {
         if (d == 64 && heads == 8) NGACF_CASE(float, 64, 8);
         if (d == 64 && heads == 1) NGACF_CASE(float, 64, 1);
@@ -678,6 +943,24 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
     return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, nseg_user, nshort_user, hrow, nhub, nhub_user, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
                          G, Gn, ST, dH, dS, part_acc, part_r, part_split, tickets, U, N, d, heads, alpha, drop_p, seed, seed_dev, flags,
                          0, U, 0, N - U, 0, !skip_node, true, needed, rows, nrows, short_max, stream);
+}
+
+extern "C" int ngacf_prop_bwd_dx(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
+                                 const int32_t* srow, int nshort, int nseg_user, int nshort_user,
+                                 const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
+                                 const int32_t* col, const void* H, int dtype,
+                                 const float* S_dst, const float* S_src, const float* avec,
+                                 const void* out, const void* agg, const float* R, const void* gout,
+                                 float* G, void* Gn, float* ST, void* dH, float* dS,
+                                 float* part_acc, float* part_r, const int32_t* part_split, int32_t* tickets,
+                                 const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
+                                 int U, int N, int d, int heads, float alpha,
+                                 float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
+                                 const ngacf_bwd_dx* dx, void* stream) {
+    const bool skip_node = (flags & NGACF_SKIP_NODE) != 0;
+    return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, nseg_user, nshort_user, hrow, nhub, nhub_user, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
+                         G, Gn, ST, dH, dS, part_acc, part_r, part_split, tickets, U, N, d, heads, alpha, drop_p, seed, seed_dev, flags,
+                         0, U, 0, N - U, 0, !skip_node, true, needed, rows, nrows, short_max, stream, dx);
 }
 
 extern "C" int ngacf_prop_bwd_node(const void* out, int dtype, const void* agg, const float* R, const void* gout,

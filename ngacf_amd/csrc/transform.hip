@@ -279,7 +279,8 @@ static int dispatch_transform(const TransArgs& a, int din, int dout, int heads, 
 int transform_fwd_mfma(const void* X, int x_dtype, const float* W, const float* avec, void* H, float* S,
                        int U, int I, int din, int dout, int heads, int u_lo, int u_n, int i_lo, int i_n, int x_local,
                        float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st,
-                       int n_pack, const float* const* pack_W, void* const* pack_panel, const int* pack_din, const int* pack_dout);
+                       int n_pack, const float* const* pack_W, void* const* pack_panel, const int* pack_din, const int* pack_dout,
+                       const int* pack_kind);
 
 }  // namespace ngacf
 
@@ -304,7 +305,7 @@ extern "C" int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float*
     if ((x_dtype != NGACF_F32 && x_dtype != NGACF_BF16) || (h_dtype != NGACF_F32 && h_dtype != NGACF_BF16)) return NGACF_E_SHAPE;
     if (h_dtype == NGACF_BF16)                     // bf16 storage: bf16 MFMA, fp32 accumulate
         return transform_fwd_mfma(X, x_dtype, W, avec, H, S, U, I, din, dout, heads, u_lo, u_n, i_lo, i_n, x_local,
-                                  feat_drop_p, seed, seed_dev, st, 0, nullptr, nullptr, nullptr, nullptr);
+                                  feat_drop_p, seed, seed_dev, st, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (x_dtype == NGACF_F32) return dispatch_transform<float, float>(a, din, dout, heads, drop, st);
     return dispatch_transform<bf16_t, float>(a, din, dout, heads, drop, st);
 }

@@ -38,7 +38,7 @@ struct MfmaArgs {
     int nb_main, npack;
     const float* pack_W[NGACF_MAX_PACK];
     void* pack_F[NGACF_MAX_PACK];
-    int pack_din[NGACF_MAX_PACK], pack_dout[NGACF_MAX_PACK];
+    int pack_din[NGACF_MAX_PACK], pack_dout[NGACF_MAX_PACK], pack_kind[NGACF_MAX_PACK];   // kind 1: the transposed (dX) fragments
 };
 
 __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void transform_mfma_kernel(const MfmaArgs a) {
     if constexpr (FWD) {
         if ((int)blockIdx.x >= a.nb_main) {                  // a side job: one (stage, node type) weight panel
             const int job = blockIdx.x - a.nb_main;
-            pack_panel_job(a.pack_W[job >> 1], a.pack_F[job >> 1], a.pack_din[job >> 1], a.pack_dout[job >> 1], job & 1, tid);
+            if (a.pack_kind[job >> 1]) pack_panel_job_t(a.pack_W[job >> 1], a.pack_F[job >> 1], a.pack_din[job >> 1], a.pack_dout[job >> 1], job & 1, tid);
+            else pack_panel_job(a.pack_W[job >> 1], a.pack_F[job >> 1], a.pack_din[job >> 1], a.pack_dout[job >> 1], job & 1, tid);
             return;
         }
     }
@@ -260,10 +261,14 @@ static int dispatch_mfma(const MfmaArgs& a, int din, int dout, int heads, bool d
 int transform_fwd_mfma(const void* X, int x_dtype, const float* W, const float* avec, void* H, float* S,
                        int U, int I, int din, int dout, int heads, int u_lo, int u_n, int i_lo, int i_n, int x_local,
                        float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st,
-                       int n_pack, const float* const* pack_W, void* const* pack_panel, const int* pack_din, const int* pack_dout) {
+                       int n_pack, const float* const* pack_W, void* const* pack_panel, const int* pack_din, const int* pack_dout,
+                       const int* pack_kind) {
     MfmaArgs a;
     a.npack = n_pack;
-    for (int k = 0; k < n_pack; ++k) { a.pack_W[k] = pack_W[k]; a.pack_F[k] = pack_panel[k]; a.pack_din[k] = pack_din[k]; a.pack_dout[k] = pack_dout[k]; }
+    for (int k = 0; k < n_pack; ++k) {
+        a.pack_W[k] = pack_W[k]; a.pack_F[k] = pack_panel[k]; a.pack_din[k] = pack_din[k]; a.pack_dout[k] = pack_dout[k];
+        a.pack_kind[k] = pack_kind ? pack_kind[k] : 0;
+    }
     a.B = X; a.M = W; a.avec = avec; a.out = H; a.S = S; a.U = U; a.I = I;
     a.u_lo = u_lo; a.u_n = u_n; a.i_lo = i_lo; a.i_n = i_n; a.b_local = x_local; a.out_local = 0;
     a.drop_thr = drop_threshold(feat_drop_p); a.drop_scale = 1.f / (1.f - feat_drop_p); a.seed = seed; a.seed_dev = seed_dev; a.tpw = 1;
@@ -297,7 +302,7 @@ extern "C" int ngacf_transform_fwd_pack(const void* X, int x_dtype, const float*
                                         int U, int I, int din, int dout, int heads,
                                         float feat_drop_p, uint64_t seed, const uint64_t* seed_dev,
                                         int n_pack, const float* const* pack_W, void* const* pack_panel, const int* pack_din,
-                                        const int* pack_dout, void* stream) {
+                                        const int* pack_dout, const int* pack_kind, void* stream) {
     if (U < 0 || I < 0 || n_pack < 0 || n_pack > NGACF_MAX_PACK) return NGACF_E_ARG;
     if (U + I > 0 && (!X || !W || !avec || !H || !S)) return NGACF_E_ARG;     // (U = I = 0: the panels alone, nothing is transformed)
     if (U + I == 0) { din = 64; dout = 64; heads = 8; }
@@ -307,7 +312,8 @@ extern "C" int ngacf_transform_fwd_pack(const void* X, int x_dtype, const float*
     for (int k = 0; k < n_pack; ++k) {
         if (!pack_W[k] || !pack_panel[k]) return NGACF_E_ARG;
         if (pack_din[k] != 64 || (pack_dout[k] != 64 && pack_dout[k] != 128)) return NGACF_E_SHAPE;      // what ngacf_prop_fwd_next takes
+        if (pack_kind && pack_kind[k] != 0 && (pack_kind[k] != 1 || pack_dout[k] != 64)) return NGACF_E_SHAPE;   // what ngacf_prop_bwd_dx takes
     }
     return transform_fwd_mfma(X, x_dtype, W, avec, H, S, U, I, din, dout, heads, 0, U, 0, I, 0, feat_drop_p, seed, seed_dev,
-                              static_cast<hipStream_t>(stream), n_pack, pack_W, pack_panel, pack_din, pack_dout);
+                              static_cast<hipStream_t>(stream), n_pack, pack_W, pack_panel, pack_din, pack_dout, pack_kind);
 }

@@ -16,10 +16,14 @@ class StageLink:
     """What travels from one stage of a stack to the next when the next stage's transform rides in this stage's traversal
     (ngacf_prop_fwd_next): `pack` (stage 0 only) = the later stages' weights to pack in the first transform's launch, `panels` =
     the packed panels by stage index, `pre` = (H, S) of the coming stage, produced by the previous traversal."""
-    __slots__ = ("pack", "panels", "pre")
+    __slots__ = ("pack", "panels", "pre", "pack_t", "panels_t", "saved", "node_pre")
 
     def __init__(self):
         self.pack, self.panels, self.pre = None, {}, None
+        # the backward's mirror image (ngacf_prop_bwd_dx): pack_t = {stage: W} whose dX fragments the first transform's launch
+        # packs too, panels_t = those panels; saved[s] = (out, agg, R, elu) of stage s's forward, read by stage s+1's backward,
+        # which runs stage s's step 1 on the dX it produces and parks (dX, Gn, t) in node_pre[s]
+        self.pack_t, self.panels_t, self.saved, self.node_pre = None, {}, {}, {}
 
 
 def _transform_or_pre(X, W, avec, plan, heads, h_dtype, feat_drop_p, seed, seed_dev, link):
@@ -28,14 +32,53 @@ def _transform_or_pre(X, W, avec, plan, heads, h_dtype, feat_drop_p, seed, seed_
     if link is not None and link.pre is not None:
         pre, link.pre = link.pre, None
         return pre
-    if link is not None and link.pack:
-        idx = sorted(link.pack)
+    if link is not None and (link.pack or link.pack_t):
+        idx, idx_t = sorted(link.pack or {}), sorted(link.pack_t or {})
         H, S, panels = ops.transform_fwd(X, W, avec, plan.U, plan.I, heads, h_dtype, feat_drop_p, seed, seed_dev,
-                                         pack=[link.pack[k].contiguous().float() for k in idx])
-        link.panels.update(zip(idx, panels))
-        link.pack = None
+                                         pack=[link.pack[k].contiguous().float() for k in idx] + [link.pack_t[k].contiguous().float() for k in idx_t],
+                                         pack_kind=[0] * len(idx) + [1] * len(idx_t))
+        link.panels.update(zip(idx, panels[:len(idx)]))
+        link.panels_t.update(zip(idx_t, panels[len(idx):]))
+        link.pack = link.pack_t = None
         return H, S
     return ops.transform_fwd(X, W, avec, plan.U, plan.I, heads, h_dtype, feat_drop_p, seed, seed_dev)
+
+
+def _remember(link, sidx, out, agg, R, elu, needed):
+    """forward: leave this stage's saved tables where the NEXT stage's backward finds them (StageLink.saved)"""
+    if link is None or sidx is None:
+        return None
+    if needed is None:                                   # (a stage computed for a batch's rows only is nobody's previous stage)
+        link.saved[sidx] = (out, agg, R, elu)
+    return (link, sidx)
+
+
+def _bwd_links(bw, gout, X, H, plan, feat_drop_p, seed, want_dx):
+    """backward of stage s: node = (Gn, t) when the next stage's backward already ran this stage's step 1 on exactly this gout;
+    dx = ops.BwdDx when this stage's launch can produce dX (and the previous stage's step 1) itself."""
+    if bw is None or X is None:
+        return None, None
+    link, s = bw
+    node = dx = None
+    pre = link.node_pre.pop(s, None)
+    if pre is not None and pre[0] is not None and pre[0].data_ptr() == gout.data_ptr() and pre[0].dtype == gout.dtype and gout.is_contiguous():
+        node = (pre[1], pre[2])
+    if want_dx and s in link.panels_t:
+        prev = link.saved.get(s - 1) if X.dtype == torch.bfloat16 else None
+        if prev is not None and prev[0].data_ptr() != X.data_ptr():
+            prev = None                                  # X is not the previous stage's output table
+        if ops.can_fuse_bwd(plan, H.dtype, H.shape[1], X.shape[1], X.dtype, prev is not None):
+            dx = ops.BwdDx(link.panels_t[s], X.dtype, feat_drop_p, seed, prev)
+    return node, dx
+
+
+def _transform_bwd_after(bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed, seed_dev):
+    if dx is None:
+        return ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
+    if dx.prev is not None:
+        bw[0].node_pre[bw[1] - 1] = (dx.dX, dx.Gn, dx.T)
+    _, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev, part="dw")
+    return dx.dX, dW, da
 
 
 class _Stage(torch.autograd.Function):
@@ -47,7 +90,7 @@ class _Stage(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev=None, residual=True, grad_mode=True,
-                needed=None, link=None, nxt=None):
+                needed=None, link=None, nxt=None, sidx=None):
         X = X.contiguous()
         W = W.contiguous().float()
         avec = avec.contiguous().float()
@@ -60,6 +103,7 @@ class _Stage(torch.autograd.Function):
                                        seed_dev=seed_dev, needed=needed, next=nxt)
             ctx.save_for_backward(X, W, avec, H, S, out, agg, R)
             ctx.cfg = (plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual, needed)
+            ctx.bw = _remember(link, sidx, out, agg, R, elu, needed)
         else:
             out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, seed_dev=seed_dev, needed=needed, next=nxt)
         if nxt is not None:
@@ -70,11 +114,13 @@ class _Stage(torch.autograd.Function):
     def backward(ctx, gout):
         X, W, avec, H, S, out, agg, R = ctx.saved_tensors
         plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual, needed = ctx.cfg
+        node, dx = _bwd_links(ctx.bw, gout, X, H, plan, feat_drop_p, seed, ctx.needs_input_grad[0])
         gout = gout.contiguous().to(H.dtype)              # already H's type under autograd: no cast kernel
         # (needed: the rows of this stage's output the caller read -- gout is zero elsewhere and `out` is not valid there)
-        dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, alpha, elu, residual, None, drop_p, seed, seed_dev, needed)
-        dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
-        return (dX, dW, da) + (None,) * 14
+        dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, alpha, elu, residual, None, drop_p, seed, seed_dev, needed,
+                              dx=dx, node=node)
+        dX, dW, da = _transform_bwd_after(ctx.bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed, seed_dev)
+        return (dX, dW, da) + (None,) * 15
 
 
 class _StageScore(torch.autograd.Function):
@@ -83,7 +129,7 @@ class _StageScore(torch.autograd.Function):
     (zeroed when the batch was marked) and the traversal's backward reads it there in fp32 -- no [N, d] zero fill, no cast."""
 
     @staticmethod
-    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev, residual, grad_mode, rows, link, u, *items):
+    def forward(ctx, X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev, residual, grad_mode, rows, link, sidx, u, *items):
         U, I = plan.U, plan.I
         X, W, avec = (X.contiguous() if X is not None else None), W.contiguous().float(), avec.contiguous().float()
         H, S = _transform_or_pre(X, W, avec, plan, heads, h_dtype, feat_drop_p, seed, seed_dev, link)
@@ -96,6 +142,7 @@ class _StageScore(torch.autograd.Function):
                                        seed_dev=seed_dev, needed=rows)
             ctx.save_for_backward(X, W, avec, H, S, out, agg, R, u, *items)
             ctx.cfg = (plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual, rows)
+            ctx.bw = _remember(link, sidx, out, agg, R, elu, rows)
         else:
             out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, seed_dev=seed_dev, needed=rows)
         return tuple(ops.score_fwd(out, u, it, U) for it in items)
@@ -111,21 +158,22 @@ class _StageScore(torch.autograd.Function):
         for it, g in zip(items, gs):
             if g is not None:
                 ops.score_bwd(out, u, it, g.contiguous().float(), plan.U, into=rows.g32)
+        _, dx = _bwd_links(ctx.bw, rows.g32, X, H, plan, feat_drop_p, seed, ctx.needs_input_grad[0])
         dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, rows.g32, heads, alpha, elu, residual, None, drop_p, seed, seed_dev,
-                              rows, gout_f32=True)
-        dX, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
-        return (dX, dW, da) + (None,) * (14 + len(items))
+                              rows, gout_f32=True, dx=dx)
+        dX, dW, da = _transform_bwd_after(ctx.bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed, seed_dev)
+        return (dX, dW, da) + (None,) * (15 + len(items))
 
 
 def stage_score(X, W, avec, plan, heads, rows, u, items, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=0.0, seed=0, h_dtype=None,
-                seed_dev=None, residual=True, link=None):
+                seed_dev=None, residual=True, link=None, sidx=None):
     """scores[k][b] = out[u[b]] . out[U + items[k][b]] of the stage's output, computed for the rows of `rows` only."""
     return _StageScore.apply(X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, X.dtype if h_dtype is None else h_dtype,
-                             seed_dev, residual, torch.is_grad_enabled(), rows, link, u, *items)
+                             seed_dev, residual, torch.is_grad_enabled(), rows, link, sidx, u, *items)
 
 
 def stage(X, W, avec, plan, heads, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=0.0, seed=0, h_dtype=None, seed_dev=None,
-          residual=True, needed=None, link=None, nxt=None):
+          residual=True, needed=None, link=None, nxt=None, sidx=None):
     """needed: ops.BatchRows (ops.mark_rows) -- ONLY those rows of the result are computed and may be read; the
     gradient flowing back must be zero elsewhere (true for a result that is only read through those rows).
     link / nxt: see _Stage.  Without autograd (evaluation) and with nxt, the stage's own output table is never written: the
@@ -142,7 +190,7 @@ def stage(X, W, avec, plan, heads, alpha=0.2, elu=True, drop_p=0.0, feat_drop_p=
             link.pre = (nxt.H, nxt.S)
         return out
     return _Stage.apply(X, W, avec, plan, heads, alpha, elu, drop_p, feat_drop_p, seed, h_dtype, seed_dev, residual, torch.is_grad_enabled(),
-                        needed, link, nxt)
+                        needed, link, nxt, sidx)
 
 
 def stage_seed(base, s):

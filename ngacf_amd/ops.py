@@ -91,10 +91,11 @@ def _sd(seed_dev, dev):
     return _chk(seed_dev, "seed_dev", torch.int64, 1, dev)
 
 
-def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.0, seed=0, seed_dev=None, pack=None):
+def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.0, seed=0, seed_dev=None, pack=None, pack_kind=None):
     """H[N,dout], S[N,heads] = ngacf_transform_fwd(X[N,din], W[2,din,dout], avec[2,dout]).
-    pack = [W_k float[2,64,dout_k], ...] (bf16 storage only): the same launch also writes those LATER stages' weight panels as
-    matrix-core fragments (ngacf_transform_fwd_pack); returns (H, S, [panel_k uint8 tensors]) then."""
+    pack = [W_k float[2,64,dout_k], ...] (bf16 storage only): the same launch also writes those stages' weight panels as
+    matrix-core fragments (ngacf_transform_fwd_pack); returns (H, S, [panel_k uint8 tensors]) then.  pack_kind[k] = 0: the
+    forward fragments (prop_fwd(next=...)); 1: the fragments of dX = dH @ W^T (prop_bwd(dx=...))."""
     dev, N = X.device, U + I
     din, dout = W.shape[1], W.shape[2]
     _heads_ok(dout, heads)
@@ -118,9 +119,13 @@ def transform_fwd(X, W, avec, U, I, heads, h_dtype=torch.float32, feat_drop_p=0.
         P, Iarr = ctypes.c_void_p * n, ctypes.c_int * n
         pw = P(*[_chk(Wk, "pack W", torch.float32, Wk.numel(), dev) for Wk in pack])
         pf = P(*[t.data_ptr() for t in panels])
+        kinds = [0] * n if pack_kind is None else [int(k) for k in pack_kind]
+        if len(kinds) != n or any(k not in (0, 1) for k in kinds) or any(k == 1 and Wk.shape[2] != 64 for k, Wk in zip(kinds, pack)):
+            raise ValueError("pack_kind: one of 0 / 1 per panel; kind 1 for [2, 64, 64] weights")
         _lib.check(lib.ngacf_transform_fwd_pack(xp, _DT[X.dtype], wp, ap, H.data_ptr(), _DT[h_dtype], S.data_ptr(), U, I, din, dout, heads,
                                                 float(feat_drop_p), int(seed), _sd(seed_dev, dev), n, pw, pf,
-                                                Iarr(*[int(Wk.shape[1]) for Wk in pack]), Iarr(*[int(Wk.shape[2]) for Wk in pack]), _stream()),
+                                                Iarr(*[int(Wk.shape[1]) for Wk in pack]), Iarr(*[int(Wk.shape[2]) for Wk in pack]),
+                                                Iarr(*kinds), _stream()),
                    "ngacf_transform_fwd_pack")
         return H, S, panels
     _lib.check(lib.ngacf_transform_fwd(xp, _DT[X.dtype], wp, ap, H.data_ptr(), _DT[h_dtype], S.data_ptr(),
@@ -316,9 +321,34 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     return (out, agg, R) if save else out
 
 
+class BwdDx:
+    """The stage's transform backward riding in its edge backward (ngacf_prop_bwd_dx): `panel` = the kind-1 fragments of the
+    stage's W [2, 64, 64] (transform_fwd(pack=..., pack_kind=1) / pack_panels), x_dtype = the type of the stage's input X (dX's),
+    the stage's feature dropout and seed; prev = (out, agg, R, elu) of the PREVIOUS stage's forward when X is that stage's
+    output -- the launch then also runs that stage's step 1 on dX.  prop_bwd(dx=...) fills .dX (and .Gn / .T with prev)."""
+    __slots__ = ("panel", "x_dtype", "feat_drop_p", "seed", "prev", "dX", "Gn", "T")
+
+    def __init__(self, panel, x_dtype, feat_drop_p=0.0, seed=0, prev=None):
+        self.panel, self.x_dtype, self.feat_drop_p, self.seed, self.prev = panel, x_dtype, float(feat_drop_p), int(seed), prev
+        self.dX = self.Gn = self.T = None
+
+
+FUSE_BWD = __import__("os").environ.get("NGACF_FUSE_BWD", "1") != "0"       # A/B switch: "0" = dX and the node steps as their own launches
+
+
+def can_fuse_bwd(plan, H_dtype, d, din, x_dtype, has_prev):
+    """Can ngacf_prop_bwd_dx serve this stage's backward?  (bf16 rows, a 64 -> 64 stage, the whole graph in the plan, hub rows
+    finished in-kernel or absent; its dX is bf16 with a previous stage behind it, fp32 without)"""
+    return (FUSE_BWD and H_dtype == torch.bfloat16 and d == 64 and din == 64 and plan.nhub == 0 and plan.n_rows == plan.N
+            and (plan.nsplit == 0 or (INKERNEL_HUB_FINISH and plan.nparts <= INKERNEL_MAX_PARTS))
+            and x_dtype == (torch.bfloat16 if has_prev else torch.float32))
+
+
 def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, elu=True, residual=True,
-             score_from_row=None, drop_p=0.0, seed=0, seed_dev=None, needed=None, gout_f32=False, scratch=None):
-    """Returns dH [N,d] in H's dtype (with the dS*avec term) and dS [N,heads] fp32.  scratch: as in prop_fwd."""
+             score_from_row=None, drop_p=0.0, seed=0, seed_dev=None, needed=None, gout_f32=False, scratch=None, dx=None, node=None):
+    """Returns dH [N,d] in H's dtype (with the dS*avec term) and dS [N,heads] fp32.  scratch: as in prop_fwd.
+    node = (Gn [N,d] in H's dtype, t float [N,heads]): step 1 has been run elsewhere (a later stage's prop_bwd(dx=...)) on this gout.
+    dx = BwdDx: the launch also writes the gradient of the stage's input (dx.dX) and, with dx.prev, the previous stage's step 1."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
     if score_from_row is None:
@@ -333,15 +363,39 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     go = _chk(gout, "gout", torch.float32 if gout_f32 else H.dtype, N * d, dev)
     pp = _plan_ptrs(plan, dev)
     f32 = dict(dtype=torch.float32, device=dev)
-    dH = torch.empty(N, d, dtype=H.dtype, device=dev)      # (no G table: one call runs both steps, step 2 recomputes g = gout * ELU'(out))
-    Gn = torch.empty(N, d, dtype=H.dtype, device=dev)
-    t, dS = torch.empty(N, heads, **f32), torch.empty(N, heads, **f32)
+    dH = torch.empty(N, d, dtype=H.dtype, device=dev)      # (no G table: step 2 recomputes g = gout * ELU'(out))
+    if node is None:
+        Gn, t = torch.empty(N, d, dtype=H.dtype, device=dev), torch.empty(N, heads, **f32)
+    else:
+        Gn, t = node
+        _chk(Gn, "node Gn", H.dtype, N * d, dev)
+        _chk(t, "node t", torch.float32, N * heads, dev)
+    dS = torch.empty(N, heads, **f32)
     pa, pr = _scratch(scratch, plan, d, heads, dev)
     if plan.n_rows != N:
         dH.zero_()
         dS.zero_()
     flags = ((FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) |
-             (_lib.FLAG_GOUT_F32 if gout_f32 else 0))
+             (_lib.FLAG_GOUT_F32 if gout_f32 else 0) | (_lib.FLAG_SKIP_NODE if node is not None else 0))
+    if dx is not None:
+        din = 64
+        if not can_fuse_bwd(plan, H.dtype, d, din, dx.x_dtype, dx.prev is not None) or not score_from_row:
+            raise ValueError("prop_bwd(dx=...): not available for this launch (ops.can_fuse_bwd)")
+        dx.dX = torch.empty(N, din, dtype=dx.x_dtype, device=dev)
+        panel = dx.panel.get() if hasattr(dx.panel, "get") else dx.panel
+        pv = [0, 0, 0, 0, 0, 0]
+        if dx.prev is not None:
+            p_out, p_agg, p_R, p_elu = dx.prev
+            dx.Gn, dx.T = torch.empty(N, din, dtype=H.dtype, device=dev), torch.empty(N, din // 8, **f32)
+            pv = [_chk(p_out, "prev out", H.dtype, N * din, dev), _chk(p_agg, "prev agg", H.dtype, N * din, dev),
+                  _chk(p_R, "prev R", torch.float32, N * (din // 8), dev), dx.Gn.data_ptr(), dx.T.data_ptr(), FLAG_ELU if p_elu else 0]
+        st = _lib.BwdDx(_chk(panel, "dx.panel", torch.uint8, 2 * din * d * 2, dev), dx.dX.data_ptr(), din, _DT[dx.x_dtype],
+                        dx.feat_drop_p, dx.seed & 0xFFFFFFFFFFFFFFFF, *pv)
+        _lib.check(lib.ngacf_prop_bwd_dx(*pp, hp, _DT[H.dtype], sd, ss, ap,
+                                         op, gp, rp, go, 0, Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
+                                         dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev), *_needed_args(needed, plan, N, dev), plan.U, N, d, heads, float(alpha),
+                                         float(drop_p), int(seed), _sd(seed_dev, dev), flags, ctypes.byref(st), _stream()), "ngacf_prop_bwd_dx")
+        return dH, dS
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, ss, ap,
                                   op, gp, rp, go, 0, Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
                                   dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev), *_needed_args(needed, plan, N, dev), plan.U, N, d, heads, float(alpha),
@@ -576,11 +630,12 @@ def dropout_bits(kind, seed, a, b, c=None):
 # ---------------------------------------------------------------------------
 # row-window forms used by the node-partitioned (multi-GPU) path, ngacf_amd/dist.py
 # ---------------------------------------------------------------------------
-def pack_panels(Ws):
-    """bf16 matrix-core fragment panels of the stage weights Ws = [W [2, 64, dout], ...] for prop_fwd(next=...), by a launch of
-    their own (ngacf_transform_fwd_pack with no rows: the node-partitioned path, whose transforms run over row windows; the
-    single-GPU stack packs inside its first transform's launch instead)."""
+def pack_panels(Ws, kinds=None):
+    """bf16 matrix-core fragment panels of the stage weights Ws = [W [2, 64, dout], ...] for prop_fwd(next=...) (kind 0) or
+    prop_bwd(dx=...) (kind 1), by a launch of their own (ngacf_transform_fwd_pack with no rows: the node-partitioned path, whose
+    transforms run over row windows; the single-GPU stack packs inside its first transform's launch instead)."""
     dev, n = Ws[0].device, len(Ws)
+    kinds = [0] * n if kinds is None else [int(k) for k in kinds]
     if n > _lib.MAX_PACK:
         raise ValueError("pack_panels: at most %d panels" % _lib.MAX_PACK)
     for Wk in Ws:
@@ -590,7 +645,7 @@ def pack_panels(Ws):
     P, Iarr = ctypes.c_void_p * n, ctypes.c_int * n
     _lib.check(lib.ngacf_transform_fwd_pack(0, F32, 0, 0, 0, BF16, 0, 0, 0, 64, 64, 8, 0.0, 0, 0, n,
                                             P(*[_chk(Wk, "pack W", torch.float32, Wk.numel(), dev) for Wk in Ws]), P(*[t.data_ptr() for t in panels]),
-                                            Iarr(*[int(Wk.shape[1]) for Wk in Ws]), Iarr(*[int(Wk.shape[2]) for Wk in Ws]), _stream()),
+                                            Iarr(*[int(Wk.shape[1]) for Wk in Ws]), Iarr(*[int(Wk.shape[2]) for Wk in Ws]), Iarr(*kinds), _stream()),
                "ngacf_transform_fwd_pack")
     return panels
 

@@ -1,0 +1,166 @@
+"""The backward's fused launch plan (ngacf_prop_bwd_dx: the stage's dX and the previous stage's step 1 in the edge backward's
+tail) against the separate launches it replaces -- bit for bit at the level of one stage, and through the whole stack.
+Both plans are checked against the reference's float64 gradients by the golden tests; this is their A/B.
+Reference: autograd of graphattention/SPUIGACF.py:356-397 chained through :207-215."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _graph(U, I, E, seed, hub=0):
+    rs = np.random.RandomState(seed)
+    u = np.concatenate([np.arange(U), rs.randint(0, U, E - U)])
+    i = np.concatenate([rs.randint(0, I - 3, U), rs.randint(0, I - 3, E - U)])     # last 3 items isolated
+    if hub:
+        u = np.concatenate([u, rs.permutation(U)[:hub]])
+        i = np.concatenate([i, np.zeros(hub, dtype=np.int64)])
+    key = np.unique(u.astype(np.int64) * I + i)
+    return np.stack([key // I, key % I])
+
+
+def _bits(t):
+    return t.detach().contiguous().view(torch.uint8)
+
+
+@pytest.mark.parametrize("heads", [8, 1])
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+@pytest.mark.parametrize("sparse", [False, True])
+def test_edge_backward_with_dx_and_previous_node_step_bitwise(dev, heads, drop, sparse):
+    """One stage: prop_bwd(dx=...) against prop_bwd + transform_bwd + prop_bwd_node on the same inputs: dH, dS, dX, and the
+    previous stage's Gn / t, every row class (short rows, long rows, hub rows finished in-kernel, isolated items), with and
+    without dropout, over all rows and over a scored batch's rows (the batch lists duplicates and an odd number of rows, so
+    workgroups mix users and items)."""
+    from ngacf_amd import ops
+    from ngacf_amd.plan import build_plan
+    U, I = 1100, 901
+    N = U + I
+    edge = torch.from_numpy(_graph(U, I, 45000, 5, hub=700)).to(dev)
+    plan = build_plan(edge, U, I, seg_len=128)
+    assert plan.nsplit > 0 and plan.nseg > 0 and plan.nshort > 0
+    rs = np.random.RandomState(11 + heads)
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    bf = torch.bfloat16
+    X = t(rs.randn(N, 64).astype(np.float32) * 0.5, bf)                 # the stage's input = the previous stage's output
+    W = t((rs.randn(2, 64, 64) * 0.2).astype(np.float32))
+    a = t((rs.randn(2, 64) * 0.3).astype(np.float32))
+    H, S = ops.transform_fwd(X, W, a, U, I, heads, bf, feat_drop_p=drop, seed=5)
+    rows = None
+    if sparse:
+        g = torch.Generator(device=dev); g.manual_seed(3)
+        B = 203                                                          # odd: the row list's user / item seam falls inside a workgroup
+        bu, bi = torch.randint(0, U, (B,), device=dev, generator=g), torch.randint(0, I, (B,), device=dev, generator=g)
+        bu[:7] = bu[7:14]                                                # duplicates
+        rows = ops.mark_rows(bu, bi, U, I, grad_d=64)
+        rows.g32.zero_()
+        gsel = torch.cat([bu, U + bi])
+        rows.g32[gsel] = t(rs.randn(2 * B, 64).astype(np.float32) * 0.1)
+        gout = rows.g32
+    else:
+        gout = t(rs.randn(N, 64).astype(np.float32) * 0.1, bf)
+    out, agg, R = ops.prop_fwd(plan, H, S, S, a, heads, drop_p=drop, seed=9, save=True, needed=rows)
+    p_out = t(rs.randn(N, 64).astype(np.float32) * 0.5, bf)
+    p_agg = t(rs.randn(N, 64).astype(np.float32) * 0.5, bf)
+    p_R = t(np.abs(rs.randn(N, 8)).astype(np.float32) + 0.1)
+    p_R[5, 3] = 0.0
+    p_R[U + 2] = 0.0                                                     # an isolated row of the previous stage: its Gn and t are 0
+    kw = dict(drop_p=drop, seed=9, needed=rows, gout_f32=sparse)
+    for x_dtype in (bf, torch.float32):
+        Xs = X if x_dtype == bf else X.float()
+        # the separate launches
+        dH, dS = ops.prop_bwd(plan, H, S, S, a, out, agg, R, gout, heads, **kw)
+        dX, dW, da = ops.transform_bwd(Xs, W, H, dH, dS, U, I, heads, drop, 5)
+        if x_dtype == bf:
+            G = torch.empty(N, 64, dtype=torch.float32, device=dev)
+            Gn = torch.empty(N, 64, dtype=bf, device=dev)
+            T = torch.empty(N, 8, dtype=torch.float32, device=dev)
+            ops.prop_bwd_node(p_out, p_agg, p_R, dX, torch.zeros(N, 8, device=dev), G, Gn, T, U, 8, (0, U, 0, I), False, elu=True)
+        # the fused launch
+        panel = ops.pack_panels([W], kinds=[1])[0]
+        dx = ops.BwdDx(panel, x_dtype, drop, 5, prev=(p_out, p_agg, p_R, True) if x_dtype == bf else None)
+        dH2, dS2 = ops.prop_bwd(plan, H, S, S, a, out, agg, R, gout, heads, dx=dx, **kw)
+        _, dW2, da2 = ops.transform_bwd(Xs, W, H, dH2, dS2, U, I, heads, drop, 5, part="dw")
+        torch.cuda.synchronize()
+        assert torch.equal(_bits(dH), _bits(dH2)) and torch.equal(_bits(dS), _bits(dS2))
+        assert torch.equal(_bits(dX), _bits(dx.dX)), (x_dtype, float((dX.float() - dx.dX.float()).abs().max()))
+        assert torch.equal(_bits(dW), _bits(dW2)) and torch.equal(_bits(da), _bits(da2))
+        if x_dtype == bf:
+            assert torch.equal(_bits(Gn), _bits(dx.Gn)) and torch.equal(_bits(T), _bits(dx.T))
+            assert float(dx.Gn[U + 2].float().abs().max()) == 0.0 and float(dx.T[5, 3]) == 0.0
+            # ... and an 8-head stage's edge backward fed with them (node=) equals the call that runs its own step 1 on that dX
+            if not sparse and heads == 8:
+                dHa, dSa = ops.prop_bwd(plan, H, S, S, a, p_out, p_agg, p_R, dx.dX, 8, drop_p=drop, seed=9)
+                dHb, dSb = ops.prop_bwd(plan, H, S, S, a, p_out, p_agg, p_R, dx.dX, 8, drop_p=drop, seed=9, node=(dx.Gn, dx.T))
+                torch.cuda.synchronize()
+                assert torch.equal(_bits(dHa), _bits(dHb)) and torch.equal(_bits(dSa), _bits(dSb))
+
+
+@pytest.mark.parametrize("kind", ["spuigacf", "multi"])
+@pytest.mark.parametrize("sparse_last", [True, False])
+def test_fused_backward_stack_equals_unfused_backward_stack(dev, kind, sparse_last):
+    """The whole train step's gradients with NGACF_FUSE_BWD on (default) and off, bf16 storage, dropout on (same seeds = same
+    masks): the loss is bitwise the same; gradients to 1e-5 (the score gradient's float atomics reorder a few sums in front of
+    both plans alike)."""
+    import ngacf_amd
+    from ngacf_amd import ops
+    U, I = 900, 700
+    edge = torch.from_numpy(_graph(U, I, 40000, 3, hub=500)).to(dev)
+    mk = {"spuigacf": lambda: ngacf_amd.SPUIGACF(U, I, 64, [64, 64], 0.1),
+          "multi": lambda: ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.1)}[kind]
+    torch.manual_seed(4)
+    m = mk().to(dev)
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30.0); m.iEmbd.weight.mul_(30.0)
+    ngacf_amd.set_compute_dtype(m, torch.bfloat16)
+    m.sparse_last_stage = sparse_last
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    u, pi, ni = (torch.randint(0, k, (255,), device=dev, generator=g) for k in (U, I, I))
+    res = {}
+    was = ops.FUSE_BWD
+    try:
+        for fuse in (True, False):
+            ops.FUSE_BWD = fuse
+            m.train()
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(9)
+            n0 = _count_dx_calls()
+            loss = ngacf_amd.BPRLoss()(m(u, pi, edge), m(u, ni, edge))
+            loss.backward()
+            torch.cuda.synchronize()
+            res[fuse] = (float(loss.detach()), {n: p.grad.clone() for n, p in m.named_parameters()}, _count_dx_calls() - n0)
+    finally:
+        ops.FUSE_BWD = was
+    L = 2 if kind == "spuigacf" else 3
+    assert res[True][2] == 2 * L and res[False][2] == 0, (res[True][2], res[False][2])     # every stage of both chains took the fused launch
+    assert res[True][0] == res[False][0]
+    for n in res[True][1]:
+        a_, b_ = res[True][1][n].double(), res[False][1][n].double()
+        assert float((a_ - b_).norm() / b_.norm().clamp_min(1e-30)) < 1e-5, n
+
+
+_DX_CALLS = [0]
+
+
+def _count_dx_calls():
+    return _DX_CALLS[0]
+
+
+@pytest.fixture(autouse=True)
+def _spy_on_dx(monkeypatch):
+    """count the fused launches (so the A/B test knows the fused plan really ran)"""
+    from ngacf_amd import ops
+    real = ops.prop_bwd
+
+    def spy(*a, **k):
+        if k.get("dx") is not None:
+            _DX_CALLS[0] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(ops, "prop_bwd", spy)
+    yield
