@@ -214,8 +214,8 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  *                                                    what ngacf_prop_bwd_node computes from the stored dX, bit for bit
  * so the previous stage's backward is then called with NGACF_SKIP_NODE, gout = dX, Gn = prev_Gn, ST = prev_T.
  *   panel   bf16 A fragments of W[type]^T: ngacf_transform_fwd_pack with pack_kind 1 (2 * din * d * 2 bytes)
- *   dX      [N][din]: NGACF_BF16 when prev_* are given (dX is the gradient of the previous stage's bf16 output),
- *           NGACF_F32 without them (the first stage: the gradient of the fp32 embedding table)
+ *   dX      [N][din], NGACF_BF16 or NGACF_F32 (X's type); with prev_* NGACF_BF16 (dX is the gradient of the previous stage's bf16
+ *           output); NGACF_F32 e.g. for the first stage (the gradient of the fp32 embedding table)
  *   feat_drop_p, seed: the stage's feature dropout (the mask of ngacf_transform_fwd)
  *   prev_out, prev_agg [N][din] bf16, prev_R float[N][din/8]: as the previous stage's forward saved them (8-column heads);
  *   prev_Gn [N][din] bf16, prev_T float[N][din/8]: results;   prev_flags: NGACF_ELU of the previous stage
@@ -234,6 +234,8 @@ typedef struct ngacf_bwd_dx {
     void* prev_Gn;
     float* prev_T;
     int32_t prev_flags;
+    int32_t rows_user;    /* with `needed`: how many leading entries of `rows` are user rows (ngacf_mark_rows lists the users first); a
+                             hint for which node type's panel a workgroup fetches first -- results do not depend on it */
 } ngacf_bwd_dx;
 int ngacf_prop_bwd_dx(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                       const int32_t* srow, int nshort, int nseg_user, int nshort_user,

@@ -74,6 +74,7 @@ struct PropBwdArgs {
     void* pv_Gn;
     float* pv_T;
     int pv_flags;                  // NGACF_ELU of the previous stage
+    int sp_rows_u, sp_nseg_u, sp_nshort_u;   // with needed: leading user entries of rows / segs / srow (which panel a workgroup fetches first)
 };
 
 template <typename T, int D, int HEADS>
@@ -320,9 +321,18 @@ __device__ __forceinline__ void sparse_edges_b(const PropBwdArgs& a, const RowCt
     }
 }
 
+// dH[n] = g[n] + acc[n] + dS[n, h] * avec[type(n)]: the row's value (calc) and the two stores (store).  The fused launch puts the
+// workgroup's barrier BETWEEN them: a wave that has stores in flight waits for their acknowledgement at the barrier (vmcnt counts
+// stores too), which held every wave for a write round trip -- 114 against 81 us per launch inside the train step.
 template <typename T, int D, int HEADS, int VEC>
-__device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum, float (&o)[VEC]) {
+__device__ __forceinline__ void finish_row_store(const PropBwdArgs& a, int row, int q, int head, const float (&o)[VEC], float dsum) {
     constexpr int HW = D / HEADS;
+    Slice<T>::store(static_cast<T*>(a.dH) + (size_t)row * D + q * VEC, o);
+    if ((q * VEC) % HW == 0) a.dS[(size_t)row * HEADS + head] = dsum;
+}
+
+template <typename T, int D, int HEADS, int VEC>
+__device__ __forceinline__ void finish_row_calc(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum, float (&o)[VEC]) {
     float g[VEC];
     if ((a.flags & NGACF_RESIDUAL) && a.G) load_f32<VEC>(a.G + (size_t)row * D + q * VEC, g);
     else if ((a.flags & NGACF_RESIDUAL) && a.needed && !flagged(a.needed, row)) {          // outside the batch: g = 0, out is not valid
@@ -343,39 +353,58 @@ __device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int 
     const float* ao = a.avec + (row < a.U ? 0 : D) + q * VEC;      // the node's own type
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o[j] = g[j] + acc[j] + dsum * ao[j];
-    Slice<T>::store(static_cast<T*>(a.dH) + (size_t)row * D + q * VEC, o);
-    if ((q * VEC) % HW == 0) a.dS[(size_t)row * HEADS + head] = dsum;
 }
 
 template <typename T, int D, int HEADS, int VEC>
 __device__ __forceinline__ void finish_row_b(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum) {
     float o[VEC];
-    finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum, o);
+    finish_row_calc<T, D, HEADS, VEC>(a, row, q, head, acc, dsum, o);
+    finish_row_store<T, D, HEADS, VEC>(a, row, q, head, o, dsum);
 }
 
-// What a lane group hands to the fused tail: the dH row it has finished (this lane's 16-byte slice, fp32 before the store's
-// rounding) and, for the previous stage's step 1, the same slice of that stage's out / agg rows and its R entry.
+// What a lane group hands to the fused tail: the dH row it has finished (this lane's 16-byte slice, fp32 before the store's rounding;
+// the tail stores it, behind its barrier) and the row's dS entry.
 template <int VEC>
 struct RowDone {
     float o[VEC];
-    uint4 pvo, pva;
-    float pvr;
+    float dsum;
     int row;
     bool valid;
 };
+
+// The previous stage's rows of the fused tail (FUSE == 2) go global -> LDS by LDS-DMA when the wave learns its row(s): no VGPRs,
+// nobody waits, and the traversal hides the round trip.  (A finish that starts these loads itself adds a dependent trip to memory
+// to every wave's life -- with row flags most rows' finish has no load at all, and that launch went from 38 to 64 us.)
+// Tile layout: [32 rows][8 pieces of 16 B], no padding (a wave instruction writes 1 KB = the 8 rows of a wave, contiguous);
+// lane (slot, q) fetches piece q ^ slot, so position (row r, p) holds piece p ^ (r & 7) and the tail's reads of ONE piece over
+// 16 rows spread over all banks.  R: [32 rows][8 heads] floats.
+template <typename T, int D, int VEC>
+struct PrevTiles {
+    uint4* otile;
+    uint4* atile;
+    float* rtile;
+};
+
+template <typename T, int D, int VEC>
+__device__ __forceinline__ void dma_prev(const PropBwdArgs& a, const PrevTiles<T, D, VEC>& pt, int row, int slot, int q) {
+    static_assert(sizeof(T) == 2 && D == 64, "bf16 rows of 64 columns");
+    const int wave = threadIdx.x >> 6;
+    const size_t off = (size_t)row * D * sizeof(T) + (size_t)((q ^ slot) * 16);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.pv_out) + off),
+                                     (__attribute__((address_space(3))) void*)(pt.otile + wave * 64), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.pv_agg) + off),
+                                     (__attribute__((address_space(3))) void*)(pt.atile + wave * 64), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.pv_R + (size_t)row * 8 + q),
+                                     (__attribute__((address_space(3))) void*)(pt.rtile + wave * 64), 4, 0, 0);
+}
 
 template <typename T, int D, int HEADS, int FUSE, int VEC>
 __device__ __forceinline__ void finish_row_t(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum, RowDone<VEC>& rd) {
     if constexpr (FUSE == 0) {
         finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum);
     } else {
-        if constexpr (FUSE == 2) {       // issued in front of finish_row_b's own loads: one round trip for all of them
-            const size_t off = (size_t)row * D * sizeof(T) + (size_t)q * 16;
-            rd.pvo = *reinterpret_cast<const uint4*>(static_cast<const char*>(a.pv_out) + off);
-            rd.pva = *reinterpret_cast<const uint4*>(static_cast<const char*>(a.pv_agg) + off);
-            rd.pvr = a.pv_R[(size_t)row * (D / 8) + (q * VEC) / 8];             // (the previous stage: heads of 8 columns)
-        }
-        finish_row_b<T, D, HEADS, VEC>(a, row, q, head, acc, dsum, rd.o);
+        finish_row_calc<T, D, HEADS, VEC>(a, row, q, head, acc, dsum, rd.o);
+        rd.dsum = dsum;
         rd.row = row;
         rd.valid = true;
     }
@@ -384,7 +413,8 @@ __device__ __forceinline__ void finish_row_t(const PropBwdArgs& a, int row, int 
 // The traversal of one wave's work item(s).  FUSE != 0 (ngacf_prop_bwd_dx): the row this lane's group finished is also handed
 // back in `rd` for the workgroup's tail, and no path leaves the KERNEL before that tail (the returns below leave this function).
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int FUSE>
-__device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, int widx, int wend, int* qmem, RowDone<Slice<T>::VEC>& rd) {
+__device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, int widx, int wend, int* qmem, RowDone<Slice<T>::VEC>& rd,
+                                              const PrevTiles<T, D, Slice<T>::VEC>& pt) {
     using SH = BShape<T, D, HEADS>;
     constexpr int UNR = UNROLL;
     constexpr int LPR = SH::LPR, EPI = SH::EPI, HW = SH::HW, VEC = SH::VEC;
@@ -457,6 +487,7 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
         if (SPARSE && flagged(a.needed, row)) { live = false; deg = 0; }      // a row of the batch: the row list carries it (long path)
         const int maxdeg = uniform(deg);                     // rows are sorted: slot 0 holds the longest
         load_ctx<T, D, HEADS, FROM_ROW, DROP, SPARSE>(a, row, q, head, x);
+        if constexpr (FUSE == 2) dma_prev<T, D, VEC>(a, pt, row, slot, q);
         if (SPARSE) {                                        // outside the batch: only the edges into the batch take part (the queue)
             sparse_edges_b<T, D, HEADS, FROM_ROW, DROP>(a, x, qbuf, row, beg, 1, deg, slot, q, head, acc, dsum);
             if (live) finish_row_t<T, D, HEADS, FUSE, VEC>(a, row, q, head, acc, dsum, rd);
@@ -504,6 +535,7 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
         row = uniform(sg.x); beg = uniform(sg.y); end = uniform(sg.z); part = uniform(sg.w);
     }
     load_ctx<T, D, HEADS, FROM_ROW, DROP, SPARSE>(a, row, q, head, x);
+    if constexpr (FUSE == 2) dma_prev<T, D, VEC>(a, pt, row, slot, q);     // (a hub row's slices fetch it too: any of them may finish the row)
     if (SPARSE && !x.in_batch) {                    // the lane group's edges: beg + slot, + EPI, ... (the dense loop's assignment)
         const int mine = end - beg - slot;
         sparse_edges_b<T, D, HEADS, FROM_ROW, DROP>(a, x, qbuf, row, beg + slot, EPI, mine > 0 ? (mine + EPI - 1) / EPI : 0, slot, q, head, acc, dsum);
@@ -590,9 +622,9 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
 //     dX[n, :] = mask * (dH[n, :] @ W[type(n)]^T)                    (transform_bwd.hip: the dX half of transform_dw_mfma_kernel)
 // and, when dX is the gradient of the previous stage's output (FUSE == 2), that stage's step 1 runs on the finished dX row:
 //     g = dX * ELU'(out_prev);  Gn_prev = g / R_prev;  t_prev = (Gn_prev . agg_prev)_h          (prop_bwd_node_kernel)
-//   1. every wave writes its finished dH rows -- the bf16 values the dH table stores -- into the workgroup's 32-row LDS tile
-//      (and the same rows of out_prev / agg_prev / R_prev, fetched together with the row's own gout / out); the weight panel
-//      (bf16 A fragments of W[type]^T, packed once per step: ngacf_transform_fwd_pack kind 1) has arrived by LDS-DMA meanwhile;
+//   1. every wave writes its finished dH rows -- the bf16 values the dH table stores -- into the workgroup's 32-row LDS tile;
+//      the same rows of out_prev / agg_prev / R_prev (dma_prev, issued when the wave learnt its rows) and the weight panel
+//      (bf16 A fragments of W[type]^T, packed once per step: ngacf_transform_fwd_pack kind 1) have arrived by LDS-DMA meanwhile;
 //   2. ONE barrier; waves 1..3 leave;
 //   3. wave 0: DKS x DOT v_mfma_f32_32x32x16_bf16 with the node on the lane, k ascending -- the arithmetic, order and bits of
 //      transform_dw_mfma_kernel<WITH_DX> -- then mask, rounding, the half-waves' exchange (a lane then holds 8 consecutive
@@ -604,9 +636,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bw_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float bw_f32x16;
 constexpr int GROW_U4 = 9;           // a staged row: 128 B of bf16 + 16 B pad (36-dword stride: 16 rows hit 64 distinct banks)
 
-template <int D, int DIN, int FUSE, bool SPARSE>
-__device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, uint4* otile, uint4* atile, float* rtile, int* xmeta,
-                                            uint4* panel, int primary, const RowDone<8>& rd, int slot, int q) {
+template <typename T, int HEADS, int D, int DIN, int FUSE, bool SPARSE>
+__device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, int gwave, uint4* otile, uint4* atile, float* rtile, int* xmeta,
+                                            int primary, const RowDone<8>& rd, int slot, int q) {
     static_assert(D == 64 && DIN == 64, "fused dX: 64 -> 64 stages");
     constexpr int DKS = D / 16, DOT = DIN / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -615,15 +647,23 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
         uint32_t w[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] = f32_to_bf16(rd.o[2 * j]) | (f32_to_bf16(rd.o[2 * j + 1]) << 16);
-        gtile[tr * GROW_U4 + q] = make_uint4(w[0], w[1], w[2], w[3]);
-        if constexpr (FUSE == 2) {
-            otile[tr * GROW_U4 + q] = rd.pvo;
-            atile[tr * GROW_U4 + q] = rd.pva;
-            rtile[tr * GROW_U4 + q] = rd.pvr;
-        }
+        gtile[wave * gwave + slot * GROW_U4 + q] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     if (q == 0) xmeta[tr] = rd.valid ? rd.row : -1;
-    __syncthreads();                                          // (the compiler drains the LDS-DMA of the panel in front of it)
+    __syncthreads();        // (all this wave's loads, the LDS-DMA of the previous stage's rows included, were consumed before `rd` existed)
+    // The weight panel (8 KB of bf16 A fragments, L2-resident) goes straight into wave 0's registers, requested in front of the
+    // wave's own stores: the MFMAs then wait for these loads only.  (As an LDS-DMA image it cost every workgroup 8 KB of LDS for
+    // its whole life: two of these launches share the CUs in a train step, and with row flags that halved the workgroups in flight.)
+    bw_bf16x8 af[DKS * DOT];
+    if (wave == 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.fx_panel) + (size_t)primary * DKS * DOT * 64;
+#pragma unroll
+        for (int i = 0; i < DKS * DOT; ++i) af[i] = __builtin_bit_cast(bw_bf16x8, src[i * 64 + lane]);
+    }
+    if (rd.valid) finish_row_store<T, D, HEADS, 8>(a, rd.row, q, (q * 8) / (D / HEADS), rd.o, rd.dsum);
+    // Wave 0 alone runs the tile step.  (Sharing it among the four waves by output columns -- each its own 4-MFMA chain and two of
+    // the eight pieces -- was measured and lost: 74-76 against 69-73 us per dense launch, 53 against 52 with row flags: four times
+    // the fragment reads and twice the MFMAs for a tail that is not what the launch waits for.)
     if (wave != 0) return;
     const int r = lane & 31, hh = lane >> 5;
     const int nrow = xmeta[r];
@@ -631,7 +671,7 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
     const int node = ok ? nrow : 0;
     bw_bf16x8 bf[DKS];
 #pragma unroll
-    for (int sk = 0; sk < DKS; ++sk) bf[sk] = __builtin_bit_cast(bw_bf16x8, gtile[r * GROW_U4 + 2 * sk + hh]);
+    for (int sk = 0; sk < DKS; ++sk) bf[sk] = __builtin_bit_cast(bw_bf16x8, gtile[(r >> 3) * gwave + (r & 7) * GROW_U4 + 2 * sk + hh]);
     const uint32_t salt = a.fx_drop_thr ? salt_of(a.fx_seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
 #pragma unroll 1
     for (int pass = 0; pass < (SPARSE ? 2 : 1); ++pass) {
@@ -643,9 +683,7 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
                 if (__ballot(mine) == 0ull) break;
                 const uint4* src = reinterpret_cast<const uint4*>(a.fx_panel) + (size_t)ty * DKS * DOT * 64;
 #pragma unroll
-                for (int piece = 0; piece < DKS * DOT; ++piece) panel[piece * 64 + lane] = src[piece * 64 + lane];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                for (int i = 0; i < DKS * DOT; ++i) af[i] = __builtin_bit_cast(bw_bf16x8, src[i * 64 + lane]);
             }
         }
 #pragma unroll
@@ -655,7 +693,7 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
             for (int e = 0; e < 16; ++e) dacc[e] = 0.f;
 #pragma unroll
             for (int sk = 0; sk < DKS; ++sk)
-                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bw_bf16x8, panel[(sk * DOT + t) * 64 + lane]), bf[sk], dacc, 0, 0, 0);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sk * DOT + t], bf[sk], dacc, 0, 0, 0);
             // lane: node r (+ half hh); dacc[4g + j] = dX column 32t + 8g + 4hh + j
 #pragma unroll
             for (int gp = 0; gp < 4; gp += 2) {
@@ -686,9 +724,10 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
                     const uint32_t w[4] = {rx[0], ry[0], rx[1], ry[1]};
                     const int pc = 4 * t + gp + hh;
                     if (mine) *reinterpret_cast<uint4*>(static_cast<char*>(a.fx_dX) + (size_t)node * DIN * 2 + 16 * pc) = make_uint4(w[0], w[1], w[2], w[3]);
+                    if constexpr (FUSE == 3) continue;        // (bf16 dX only: the previous stage runs its own step 1)
                     // step 1 of the previous stage's backward on this piece = head pc of that stage (prop_bwd_node_kernel, bf16, 8 heads)
-                    const uint4 ov = otile[r * GROW_U4 + pc], gv = atile[r * GROW_U4 + pc];
-                    const float rr = rtile[r * GROW_U4 + pc];
+                    const uint4 ov = otile[r * 8 + (pc ^ (r & 7))], gv = atile[r * 8 + (pc ^ (r & 7))];   // (dma_prev's layout)
+                    const float rr = rtile[r * 8 + pc];
                     const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w}, aw[4] = {gv.x, gv.y, gv.z, gv.w};
                     float g[8], o[8], ag[8];
 #pragma unroll
@@ -719,44 +758,46 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
 }
 
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int FUSE = 0>
-__global__ __launch_bounds__(256, FUSE != 0 ? (DROP ? 5 : (SPARSE ? 4 : 1)) : (SPARSE ? (DROP ? 5 : 4) : 1)) void prop_bwd_kernel(const PropBwdArgs a) {
+__global__ __launch_bounds__(256, FUSE != 0 ? (DROP || SPARSE ? 4 : 1) : (SPARSE ? (DROP ? 5 : 4) : 1)) void prop_bwd_kernel(const PropBwdArgs a) {
+    // (FUSE: 4 waves per SIMD = 128 VGPRs.  Bounded to 5 = 96 VGPRs the 8-head dropout instantiations spill one or two registers to
+    //  scratch, and the one with row flags then faulted on the GPU; 5 against 4 waves per SIMD is worth ~1 % in this kernel.)
     using SH = BShape<T, D, HEADS>;
     constexpr int EPI = SH::EPI, VEC = SH::VEC;
     int kind, widx, wend;
     locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, kind, widx, wend);
-    __shared__ int qmem[SPARSE ? 4 * EPI * (QCAP + 1) : 1];                // SPARSE: a column queue per lane group (odd stride: no bank clash)
+    __shared__ __attribute__((aligned(16))) int qmem[SPARSE ? 4 * EPI * (QCAP + 1) : 4];   // SPARSE: a column queue per lane group (odd stride: no bank clash)
     RowDone<VEC> rd;
     rd.valid = false;
     rd.row = 0;
     if constexpr (FUSE != 0) {
         static_assert(sizeof(T) == 2 && D == 64 && FROM_ROW, "fused dX: bf16 rows of 64 columns");
-        constexpr int DIN = 64, PANEL_U4 = (D / 16) * (DIN / 32) * 64;
-        __shared__ __attribute__((aligned(16))) uint4 panel_lds[PANEL_U4];
-        __shared__ __attribute__((aligned(16))) uint4 gtile_lds[32 * GROW_U4];
-        __shared__ __attribute__((aligned(16))) uint4 otile_lds[FUSE == 2 ? 32 * GROW_U4 : 1];
-        __shared__ __attribute__((aligned(16))) uint4 atile_lds[FUSE == 2 ? 32 * GROW_U4 : 1];
-        __shared__ float rtile_lds[FUSE == 2 ? 32 * GROW_U4 : 1];
+        constexpr int DIN = 64;
+        // the finished dH rows: 8 rows of 144 B per wave.  With row flags they take over the wave's OWN column queues (2 080 B per
+        // wave, dead once the wave has finished its rows -- and only the wave itself ever touched them)
+        constexpr int QWAVE_U4 = EPI * (QCAP + 1) * 4 / 16;                 // a wave's queues in uint4 units (130)
+        static_assert(!SPARSE || (EPI * (QCAP + 1) * 4) % 16 == 0, "queue region of a wave: whole uint4s");
+        static_assert(!SPARSE || QWAVE_U4 >= 8 * GROW_U4, "a wave's rows fit its queues");
+        __shared__ __attribute__((aligned(16))) uint4 gtile_own[SPARSE ? 1 : 32 * GROW_U4];
+        uint4* gtile_lds = SPARSE ? reinterpret_cast<uint4*>(qmem) : gtile_own;
+        constexpr int gwave = SPARSE ? QWAVE_U4 : 8 * GROW_U4;
+        __shared__ __attribute__((aligned(16))) uint4 otile_lds[FUSE == 2 ? 32 * 8 : 1];
+        __shared__ __attribute__((aligned(16))) uint4 atile_lds[FUSE == 2 ? 32 * 8 : 1];
+        __shared__ __attribute__((aligned(16))) float rtile_lds[FUSE == 2 ? 32 * 8 : 4];
+        const PrevTiles<T, D, VEC> pt{otile_lds, atile_lds, rtile_lds};
         __shared__ int xmeta_lds[32];
         const int lane = threadIdx.x & 63;
         int primary;
         if constexpr (!SPARSE) {
             primary = (int)blockIdx.x < a.order.b2 ? 0 : 1;
-        } else {                                              // the node type of the first row of wave 0's work
+        } else {                                              // the node type of wave 0's first work item, from the lists' user counts
             int k0, w0, e0;
             locate(a.order, blockIdx.x, 0, EPI, k0, w0, e0);
-            int row0 = 0;
-            if (w0 < e0) row0 = k0 == WORK_SHORT ? a.srow[w0] : w0 < a.order.nseg_u ? a.rows[w0] : a.segs[w0 - a.order.nseg_u].x;
-            primary = uniform(row0) >= a.U ? 1 : 0;
+            primary = k0 == WORK_SHORT ? w0 >= a.sp_nshort_u : w0 < a.order.nseg_u ? w0 >= a.sp_rows_u : w0 - a.order.nseg_u >= a.sp_nseg_u;
         }
-        const uint4* src = reinterpret_cast<const uint4*>(a.fx_panel) + (size_t)primary * PANEL_U4;
-#pragma unroll
-        for (int piece = threadIdx.x >> 6; piece < PANEL_U4 / 64; piece += 4)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64 + lane),
-                                             (__attribute__((address_space(3))) void*)(panel_lds + piece * 64), 16, 0, 0);
-        prop_bwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, FUSE>(a, kind, widx, wend, qmem, rd);
-        bwd_dx_tail<D, DIN, FUSE, SPARSE>(a, gtile_lds, otile_lds, atile_lds, rtile_lds, xmeta_lds, panel_lds, primary, rd, lane / SH::LPR, lane % SH::LPR);
+        prop_bwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, FUSE>(a, kind, widx, wend, qmem, rd, pt);
+        bwd_dx_tail<T, HEADS, D, DIN, FUSE, SPARSE>(a, gtile_lds, gwave, otile_lds, atile_lds, rtile_lds, xmeta_lds, primary, rd, lane / SH::LPR, lane % SH::LPR);
     } else {
-        prop_bwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, 0>(a, kind, widx, wend, qmem, rd);
+        prop_bwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, 0>(a, kind, widx, wend, qmem, rd, PrevTiles<T, D, VEC>{nullptr, nullptr, nullptr});
     }
 }
 
@@ -812,7 +853,8 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
                 else                  launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, false, false, F>, grid, block, 0, st, a);  \
             } while (0)
             if (fuse == 1) NGACF_FX(1);
-            else NGACF_FX(2);
+            else if (fuse == 2) NGACF_FX(2);
+            else NGACF_FX(3);
 #undef NGACF_FX
             NGACF_CHECK_LAUNCH();
             return 0;
@@ -887,7 +929,9 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     if (needed && (!from_row || nrows < 0 || (nrows > 0 && !rows))) return NGACF_E_ARG;          // row flags: the SPUIGACF stages only
     a.needed = needed; a.rows = rows; a.nrows = nrows; a.short_max = short_max;
     if (needed && G) return NGACF_E_ARG;                       // (the G table is a node-partitioned run's; not with row flags)
+    a.sp_rows_u = a.sp_nseg_u = a.sp_nshort_u = 0;
     if (needed) {              // groups: [the batch's row list, a wave per short row][-][all segments][all short rows minus the batch's]
+        a.sp_nseg_u = nseg_user; a.sp_nshort_u = nshort_user; a.sp_rows_u = dx ? dx->rows_user : 0;
         a.order.nshort_u = 0; a.nseg = nrows + nseg; a.order.nseg_u = nrows;
     }
     const bool drop = drop_p > 0.f;
@@ -904,13 +948,13 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
         if (!(dx->feat_drop_p >= 0.f && dx->feat_drop_p < 1.f)) return NGACF_E_ARG;
         const bool prev = dx->prev_out || dx->prev_agg || dx->prev_R || dx->prev_Gn || dx->prev_T;
         if (prev && !(dx->prev_out && dx->prev_agg && dx->prev_R && dx->prev_Gn && dx->prev_T)) return NGACF_E_ARG;
-        if (prev ? dx->dx_dtype != NGACF_BF16 : dx->dx_dtype != NGACF_F32) return NGACF_E_SHAPE;   // bf16 rows <=> a previous stage
+        if (dx->dx_dtype != NGACF_BF16 && (prev || dx->dx_dtype != NGACF_F32)) return NGACF_E_SHAPE;   // a previous stage's output is bf16
         a.fx_panel = dx->panel; a.fx_dX = dx->dX;
         a.fx_drop_thr = dx->feat_drop_p > 0.f ? drop_threshold(dx->feat_drop_p) : 0u;
         a.fx_drop_scale = 1.f / (1.f - dx->feat_drop_p); a.fx_seed = dx->seed;
         a.pv_out = dx->prev_out; a.pv_agg = dx->prev_agg; a.pv_R = dx->prev_R; a.pv_Gn = dx->prev_Gn; a.pv_T = dx->prev_T;
         a.pv_flags = dx->prev_flags;
-        fuse = prev ? 2 : 1;
+        fuse = prev ? 2 : dx->dx_dtype == NGACF_F32 ? 1 : 3;
     }
 #define NGACF_CASE(T, D, HD) return launch_bwd<T, D, HD>(a, split, nsplit, from_row, drop, st, do_node, do_edges, fuse)
     if (dtype == NGACF_F32) {

@@ -53,7 +53,10 @@ def _remember(link, sidx, out, agg, R, elu, needed):
     return (link, sidx)
 
 
-def _bwd_links(bw, gout, X, H, plan, feat_drop_p, seed, want_dx):
+FUSE_SPARSE = __import__("os").environ.get("NGACF_FUSE_SPARSE", "1") != "0"
+
+
+def _bwd_links(bw, gout, X, H, plan, feat_drop_p, seed, want_dx, sparse=False):
     """backward of stage s: node = (Gn, t) when the next stage's backward already ran this stage's step 1 on exactly this gout;
     dx = ops.BwdDx when this stage's launch can produce dX (and the previous stage's step 1) itself."""
     if bw is None or X is None:
@@ -63,8 +66,8 @@ def _bwd_links(bw, gout, X, H, plan, feat_drop_p, seed, want_dx):
     pre = link.node_pre.pop(s, None)
     if pre is not None and pre[0] is not None and pre[0].data_ptr() == gout.data_ptr() and pre[0].dtype == gout.dtype and gout.is_contiguous():
         node = (pre[1], pre[2])
-    if want_dx and s in link.panels_t:
-        prev = link.saved.get(s - 1) if X.dtype == torch.bfloat16 else None
+    if want_dx and s in link.panels_t and (FUSE_SPARSE or not sparse):
+        prev = link.saved.get(s - 1) if X.dtype == torch.bfloat16 and ops.FUSE_BWD >= 2 else None
         if prev is not None and prev[0].data_ptr() != X.data_ptr():
             prev = None                                  # X is not the previous stage's output table
         if ops.can_fuse_bwd(plan, H.dtype, H.shape[1], X.shape[1], X.dtype, prev is not None):
@@ -158,7 +161,7 @@ class _StageScore(torch.autograd.Function):
         for it, g in zip(items, gs):
             if g is not None:
                 ops.score_bwd(out, u, it, g.contiguous().float(), plan.U, into=rows.g32)
-        _, dx = _bwd_links(ctx.bw, rows.g32, X, H, plan, feat_drop_p, seed, ctx.needs_input_grad[0])
+        _, dx = _bwd_links(ctx.bw, rows.g32, X, H, plan, feat_drop_p, seed, ctx.needs_input_grad[0], sparse=True)
         dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, rows.g32, heads, alpha, elu, residual, None, drop_p, seed, seed_dev,
                               rows, gout_f32=True, dx=dx)
         dX, dW, da = _transform_bwd_after(ctx.bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed, seed_dev)

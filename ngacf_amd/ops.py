@@ -207,10 +207,11 @@ def _hub(plan, dev, half=None):
 class BatchRows:
     """The rows of the propagated table a scored batch reads (SPUIGACF.py:49-52): one flag bit per row (int32 words) and the
     same rows as an int32 list (first `n` entries; duplicates allowed), both written by ngacf_mark_rows."""
-    __slots__ = ("needed", "rows", "n", "U", "I", "g32", "consumed")
+    __slots__ = ("needed", "rows", "n", "U", "I", "g32", "consumed", "n_user")
 
     def __init__(self, needed, rows, n, U, I, g32=None):
         self.needed, self.rows, self.n, self.U, self.I = needed, rows, n, U, I
+        self.n_user = 0         # leading user entries of the list (the first marking's B)
         self.g32 = g32          # float [U+I, d], ZERO at the batch's rows (the rest is never read): where the scores' gradient lands
         self.consumed = False   # one backward per marking: a second one would add to the first one's gradient rows
 
@@ -229,6 +230,7 @@ def mark_rows(u, i, U, I, into=None, grad_d=0):
         into = BatchRows(torch.empty(((U + I + 31) // 32 + 15) // 16 * 16, dtype=torch.int32, device=dev)[:(U + I + 31) // 32], torch.empty(max(3 * B, 1), dtype=torch.int32, device=dev), 0, U, I,
                          torch.empty(U + I, grad_d, dtype=torch.float32, device=dev) if grad_d else None)
         up, clear, add = (_idx(u, "userIdx", B, dev) if B else 0), 1, 2 * B
+        into.n_user = B
     else:
         if into.n + B > into.rows.numel() or (into.U, into.I) != (U, I):
             raise ValueError("mark_rows: the row list has no room for %d more rows" % B)
@@ -333,15 +335,17 @@ class BwdDx:
         self.dX = self.Gn = self.T = None
 
 
-FUSE_BWD = __import__("os").environ.get("NGACF_FUSE_BWD", "1") != "0"       # A/B switch: "0" = dX and the node steps as their own launches
+# A/B switch of the backward's launch plan: 0 = dX and the node steps as their own launches; 1 = dX in the edge backward's tail;
+# 2 = dX and the previous stage's step 1 in the tail
+FUSE_BWD = int(__import__("os").environ.get("NGACF_FUSE_BWD", "1"))
 
 
 def can_fuse_bwd(plan, H_dtype, d, din, x_dtype, has_prev):
     """Can ngacf_prop_bwd_dx serve this stage's backward?  (bf16 rows, a 64 -> 64 stage, the whole graph in the plan, hub rows
-    finished in-kernel or absent; its dX is bf16 with a previous stage behind it, fp32 without)"""
-    return (FUSE_BWD and H_dtype == torch.bfloat16 and d == 64 and din == 64 and plan.nhub == 0 and plan.n_rows == plan.N
+    finished in-kernel or absent; with a previous stage behind it its dX is bf16)"""
+    return (bool(FUSE_BWD) and H_dtype == torch.bfloat16 and d == 64 and din == 64 and plan.nhub == 0 and plan.n_rows == plan.N
             and (plan.nsplit == 0 or (INKERNEL_HUB_FINISH and plan.nparts <= INKERNEL_MAX_PARTS))
-            and x_dtype == (torch.bfloat16 if has_prev else torch.float32))
+            and x_dtype in (torch.bfloat16, torch.float32) and not (has_prev and x_dtype != torch.bfloat16))
 
 
 def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, elu=True, residual=True,
@@ -390,7 +394,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
             pv = [_chk(p_out, "prev out", H.dtype, N * din, dev), _chk(p_agg, "prev agg", H.dtype, N * din, dev),
                   _chk(p_R, "prev R", torch.float32, N * (din // 8), dev), dx.Gn.data_ptr(), dx.T.data_ptr(), FLAG_ELU if p_elu else 0]
         st = _lib.BwdDx(_chk(panel, "dx.panel", torch.uint8, 2 * din * d * 2, dev), dx.dX.data_ptr(), din, _DT[dx.x_dtype],
-                        dx.feat_drop_p, dx.seed & 0xFFFFFFFFFFFFFFFF, *pv)
+                        dx.feat_drop_p, dx.seed & 0xFFFFFFFFFFFFFFFF, *pv, needed.n_user if needed is not None else 0)
         _lib.check(lib.ngacf_prop_bwd_dx(*pp, hp, _DT[H.dtype], sd, ss, ap,
                                          op, gp, rp, go, 0, Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
                                          dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev), *_needed_args(needed, plan, N, dev), plan.U, N, d, heads, float(alpha),

@@ -94,6 +94,10 @@ def test_edge_backward_with_dx_and_previous_node_step_bitwise(dev, heads, drop, 
         if x_dtype == bf:
             assert torch.equal(_bits(Gn), _bits(dx.Gn)) and torch.equal(_bits(T), _bits(dx.T))
             assert float(dx.Gn[U + 2].float().abs().max()) == 0.0 and float(dx.T[5, 3]) == 0.0
+            dx3 = ops.BwdDx(panel, bf, drop, 5)                          # bf16 dX alone (the previous stage runs its own step 1)
+            dH3, dS3 = ops.prop_bwd(plan, H, S, S, a, out, agg, R, gout, heads, dx=dx3, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(_bits(dH), _bits(dH3)) and torch.equal(_bits(dS), _bits(dS3)) and torch.equal(_bits(dX), _bits(dx3.dX))
             # ... and an 8-head stage's edge backward fed with them (node=) equals the call that runs its own step 1 on that dX
             if not sparse and heads == 8:
                 dHa, dSa = ops.prop_bwd(plan, H, S, S, a, p_out, p_agg, p_R, dx.dX, 8, drop_p=drop, seed=9)
@@ -104,10 +108,11 @@ def test_edge_backward_with_dx_and_previous_node_step_bitwise(dev, heads, drop, 
 
 @pytest.mark.parametrize("kind", ["spuigacf", "multi"])
 @pytest.mark.parametrize("sparse_last", [True, False])
-def test_fused_backward_stack_equals_unfused_backward_stack(dev, kind, sparse_last):
-    """The whole train step's gradients with NGACF_FUSE_BWD on (default) and off, bf16 storage, dropout on (same seeds = same
-    masks): the loss is bitwise the same; gradients to 1e-5 (the score gradient's float atomics reorder a few sums in front of
-    both plans alike)."""
+@pytest.mark.parametrize("level", [1, 2])
+def test_fused_backward_stack_equals_unfused_backward_stack(dev, kind, sparse_last, level):
+    """The whole train step's gradients with NGACF_FUSE_BWD = 1 (dX in the edge backward's tail) / 2 (and the previous stage's
+    step 1) against 0 (separate launches), bf16 storage, dropout on (same seeds = same masks): the loss is bitwise the same;
+    gradients to 1e-5 (the score gradient's float atomics reorder a few sums in front of both plans alike)."""
     import ngacf_amd
     from ngacf_amd import ops
     U, I = 900, 700
@@ -126,7 +131,7 @@ def test_fused_backward_stack_equals_unfused_backward_stack(dev, kind, sparse_la
     was = ops.FUSE_BWD
     try:
         for fuse in (True, False):
-            ops.FUSE_BWD = fuse
+            ops.FUSE_BWD = level if fuse else 0
             m.train()
             m.zero_grad(set_to_none=True)
             torch.manual_seed(9)
