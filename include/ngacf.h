@@ -276,6 +276,27 @@ int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* 
                         int U, int I, int din, int dout, int heads,
                         float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
+/* The weight halves (dW, davec) of ngacf_transform_bwd for up to NGACF_DW_BATCH_MAX stages in ONE launch plus one reduction --
+ * 64 -> 64 stages with bf16 H / dH (the stages whose dX came out of ngacf_prop_bwd_dx).  A train step needs these sums only
+ * at the optimizer, so the per-stage launches between the edge backwards (each latency-bound at 18 MB) collapse into one behind
+ * the chain's last edge backward.  jobs: HOST array (copied into the kernel's arguments).
+ *   work float[njobs][work_blocks][64*64 + 64]: per-workgroup partial sums, reduced in workgroup order (bitwise reproducible;
+ *   the sums' order differs from ngacf_transform_bwd's when work_blocks differs from its 384 workgroups). */
+#define NGACF_DW_BATCH_MAX 6
+typedef struct ngacf_dw_job {
+    const void* X;        /* [N][64] x_dtype: the stage's input */
+    const void* H;        /* [N][64] bf16 */
+    const void* dH;       /* [N][64] bf16 */
+    const float* dS;      /* [N][heads] */
+    float* dW;            /* [2][64][64] */
+    float* davec;         /* [2][64] */
+    int32_t x_dtype, din, dout, heads;
+    float feat_drop_p;
+    uint64_t seed;
+} ngacf_dw_job;
+int ngacf_transform_dw_batch(const ngacf_dw_job* jobs, int njobs, float* work, int work_blocks,
+                             int U, int I, const uint64_t* seed_dev, void* stream);
+
 /* Row-window form (see ngacf_transform_fwd_rows): X and dX local when x_local != 0; dW and davec are the
  * sums over the window rows only (all-reduce them across ranks). */
 int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,

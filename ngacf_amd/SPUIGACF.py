@@ -338,6 +338,8 @@ class _GATBase(nn.Module):
                 has_prev = NF.ops.FUSE_BWD >= 2 and s > 0 and shapes[s - 1][1] == 64 and shapes[s - 1][2] == 8
                 fuse_b[s] = NF.ops.can_fuse_bwd(plan, self.compute_dtype, shapes[s][1], shapes[s][0], x_dtype, has_prev)
         link = NF.StageLink() if any(fuse) or any(fuse_b) else None
+        if link is not None:
+            link.defer_dw = NF.sink_active()
         if link is not None and self.compute_dtype == torch.bfloat16:
             link.pack = {s: ops_[s][0].detach() for s in range(1, L) if fuse[s]}       # bf16 fragments, packed by the first transform's launch
             link.pack_t = {s: ops_[s][0].detach() for s in range(L) if fuse_b[s]}

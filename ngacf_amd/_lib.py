@@ -38,6 +38,7 @@ SIGNATURES = {
                        _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p],
     "ngacf_prop_bwd_dx": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
                           _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p, _p],
+    "ngacf_transform_dw_batch": [_p, _i, _p, _i, _i, _i, _p, _p],
     "ngacf_adam_step": [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p],
     "ngacf_bpr_fwd_bwd": [_p, _p, _p, _p, _p, _i, _p],
     "ngacf_tick": [_p, _p, _i, _p, _i, _p],
@@ -68,6 +69,15 @@ class NextStage(ctypes.Structure):
     """ngacf_next_stage of include/ngacf.h"""
     _fields_ = [("panel", _p), ("avec", _p), ("H", _p), ("S", _p), ("dout", ctypes.c_int32), ("heads", ctypes.c_int32),
                 ("feat_drop_p", _f), ("seed", _u64)]
+
+
+DW_BATCH_MAX = 6                   # NGACF_DW_BATCH_MAX
+
+
+class DwJob(ctypes.Structure):
+    """ngacf_dw_job of include/ngacf.h"""
+    _fields_ = [("X", _p), ("H", _p), ("dH", _p), ("dS", _p), ("dW", _p), ("davec", _p), ("x_dtype", ctypes.c_int32),
+                ("din", ctypes.c_int32), ("dout", ctypes.c_int32), ("heads", ctypes.c_int32), ("feat_drop_p", _f), ("seed", _u64)]
 
 
 class BwdDx(ctypes.Structure):

@@ -501,6 +501,173 @@ __global__ __launch_bounds__(256) void transform_bwd_reduce_kernel(const float* 
     else davec[(size_t)type * (wsz - dwsz) + (k - dwsz)] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// ngacf_transform_dw_batch: the dW / davec partials of SEVERAL stages' row transforms in ONE launch (64 -> 64 stages, bf16 dH
+// and H), and one launch that reduces them.  A train step whose edge backward also produces dX (ngacf_prop_bwd_dx) needs the
+// weights' gradients only at the optimizer: its three per-stage dW launches -- each latency-bound at 18 MB, each in front of the
+// next stage's edge backward -- become one launch behind the chain's last edge backward.  Per job the arithmetic is
+// transform_dw_mfma_kernel<WITH_DX = false>'s (same tiles, same fragments, same order within a workgroup); X's type, the head
+// count and the dropout threshold are run-time values of the job.
+// ---------------------------------------------------------------------------------------------------------
+struct DwBatchArgs {
+    ngacf_dw_job job[NGACF_DW_BATCH_MAX];
+    int njobs, nb;                 // workgroups per job
+    int nbu, nbi;                  // ... of which user rows / item rows
+    float* work;                   // [njobs][nb][64 * 64 + 64]
+    int U, I;
+    const uint64_t* seed_dev;
+};
+
+__global__ __launch_bounds__(256) void transform_dw_batch_kernel(const DwBatchArgs a) {
+    constexpr int DIN = 64, DOUT = 64, TN = 64;
+    constexpr int SX = DIN * 2 + 64, SG = DOUT * 2 + 64;
+    constexpr int XI = TN * (DIN / 8) / 256, GI = TN * (DOUT / 8) / 256;
+    __shared__ __attribute__((aligned(16))) char lds_raw[TN * SX + TN * SG];
+    char* Xs = lds_raw;
+    char* Gs = lds_raw + TN * SX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wc = wave & 1;
+    const int jb = blockIdx.x / a.nb, bj = blockIdx.x % a.nb;
+    const ngacf_dw_job& J = a.job[jb];
+    const bool xf32 = J.x_dtype == NGACF_F32;
+    const int HW = DOUT / J.heads;
+    const uint32_t drop_thr = J.feat_drop_p > 0.f ? drop_threshold(J.feat_drop_p) : 0u;
+    const float drop_scale = 1.f / (1.f - J.feat_drop_p);
+    const bool drop = J.feat_drop_p > 0.f;
+    const uint32_t salt = drop ? salt_of(J.seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
+    const bool users = bj < a.nbu;
+    const int nb = users ? a.nbu : a.nbi;
+    const int bl = users ? bj : bj - a.nbu;
+    const int rbeg = users ? 0 : a.U, rend = users ? a.U : a.U + a.I;
+    const int ntiles = (rend - rbeg + TN - 1) / TN;
+    const uint16_t* Hg = static_cast<const uint16_t*>(J.H);
+
+    dw_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float da[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) da[e] = 0.f;
+    uint4 xr[XI], gr[GI];
+    auto fetch = [&](int tile) {
+        const int row0 = rbeg + tile * TN;
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int i = tid + 256 * j, r = i / (DIN / 8), q = i % (DIN / 8);
+            const int row = row0 + r;
+            float f[8];
+            if (row < rend) {
+                if (!xf32) {
+                    if (!drop) {
+                        xr[j] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(J.X) + (size_t)row * DIN + 8 * q);
+                        continue;
+                    }
+                    Slice<bf16_t>::load(static_cast<const bf16_t*>(J.X) + (size_t)row * DIN + 8 * q, f);
+                } else {
+                    const float4 v0 = *reinterpret_cast<const float4*>(static_cast<const float*>(J.X) + (size_t)row * DIN + 8 * q);
+                    const float4 v1 = *reinterpret_cast<const float4*>(static_cast<const float*>(J.X) + (size_t)row * DIN + 8 * q + 4);
+                    f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+                }
+                if (drop) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = feat_bits(salt, row, 8 * q + e) >= drop_thr ? f[e] * drop_scale : 0.f;
+                }
+                xr[j] = pack_bf16x8(f);
+            } else {
+                xr[j] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GI; ++j) {
+            const int i = tid + 256 * j, r = i / (DOUT / 8), q = i % (DOUT / 8);
+            const int row = row0 + r;
+            if (row < rend) {
+                gr[j] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(J.dH) + (size_t)row * DOUT + 8 * q);
+                const uint4 hv = *reinterpret_cast<const uint4*>(Hg + (size_t)row * DOUT + 8 * q);
+                const float sc = J.dS[(size_t)row * J.heads + (8 * q) / HW];
+                const uint32_t w[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    da[2 * e] = fmaf(sc, bf16_to_f32(w[e] & 0xffffu), da[2 * e]);
+                    da[2 * e + 1] = fmaf(sc, bf16_to_f32(w[e] >> 16), da[2 * e + 1]);
+                }
+            } else {
+                gr[j] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    const int g4 = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int node_in_step = 8 * (g4 >> 1) + qq;
+    const int col_in_blk = 16 * (g4 & 1) + 4 * pp;
+    int tile = bl;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += nb) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int i = tid + 256 * j, r = i / (DIN / 8), q = i % (DIN / 8);
+            *reinterpret_cast<uint4*>(Xs + r * SX + 16 * q) = xr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < GI; ++j) {
+            const int i = tid + 256 * j, r = i / (DOUT / 8), q = i % (DOUT / 8);
+            *reinterpret_cast<uint4*>(Gs + r * SG + 16 * q) = gr[j];
+        }
+        __syncthreads();
+        if (tile + nb < ntiles) fetch(tile + nb);
+#pragma unroll
+        for (int st = 0; st < TN / 16; ++st) {
+            const int offa = (16 * st + node_in_step) * SX + (32 * wk + col_in_blk) * 2;
+            const int offb = (16 * st + node_in_step) * SG + (32 * wc + col_in_blk) * 2;
+            const dw_bf16x8 af = tr_frag(Xs, offa, offa + 4 * SX), bf = tr_frag(Gs, offb, offb + 4 * SG);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+        }
+    }
+    float* wkp = a.work + ((size_t)jb * a.nb + bj) * (DIN * DOUT + DOUT);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int k = 32 * wk + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        wkp[(size_t)k * DOUT + 32 * wc + (lane & 31)] = acc[e];
+    }
+    {
+        constexpr int QN = DOUT / 8, TG = 256 / QN;
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds_raw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = da[e];
+        __syncthreads();
+        if (tid < DOUT) {
+            const int q = tid >> 3, e = tid & 7;
+            float sm = 0.f;
+#pragma unroll 8
+            for (int m = 0; m < TG; ++m) sm += red[(q + QN * m) * 8 + e];
+            wkp[DIN * DOUT + tid] = sm;
+        }
+    }
+}
+
+// dW[type], davec[type] of every job = the sums of that job's and type's workgroup partials, in workgroup order
+__global__ __launch_bounds__(256) void transform_dw_batch_reduce_kernel(const DwBatchArgs a) {
+    constexpr int wsz = 64 * 64 + 64, dwsz = 64 * 64, PER_JOB = (2 * wsz + 63) / 64;
+    __shared__ float red[256];
+    const int jb = blockIdx.x / PER_JOB, blk = blockIdx.x % PER_JOB;
+    const int o = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int idx = blk * 64 + o;
+    const bool ok = idx < 2 * wsz;
+    const int type = ok ? idx / wsz : 0, k = ok ? idx % wsz : 0;
+    const int b0 = type == 0 ? 0 : a.nbu, b1 = type == 0 ? a.nbu : a.nbu + a.nbi;
+    const float* work = a.work + (size_t)jb * a.nb * wsz;
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = b0 + pg; b < b1; b += 4) s += work[(size_t)b * wsz + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pg != 0 || !ok) return;
+    s = (red[o] + red[64 + o]) + (red[128 + o] + red[192 + o]);
+    if (k < dwsz) a.job[jb].dW[(size_t)type * dwsz + k] = s;
+    else a.job[jb].davec[(size_t)type * 64 + (k - dwsz)] = s;
+}
+
 int transform_dx_mfma(const void* dH, int dh_dtype, const float* W, void* dX, int dx_dtype, int U, int I, int din, int dout, int heads,
                       int u_lo, int u_n, int i_lo, int i_n, int x_local,
                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t st);   // transform_mfma.hip
@@ -630,4 +797,46 @@ extern "C" int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, c
                                    float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     return ngacf_transform_bwd_rows(X, x_dtype, W, H, h_dtype, dH, dS, dX, dW, davec, work, U, I, din, dout, heads,
                                     0, U, 0, I, 0, feat_drop_p, seed, seed_dev, stream);
+}
+
+extern "C" int ngacf_transform_dw_batch(const ngacf_dw_job* jobs, int njobs, float* work, int work_blocks,
+                                        int U, int I, const uint64_t* seed_dev, void* stream) {
+    if (njobs < 0 || njobs > NGACF_DW_BATCH_MAX || U < 0 || I < 0) return NGACF_E_ARG;
+    if (njobs == 0) return 0;
+    if (!jobs || !work || work_blocks < 2) return NGACF_E_ARG;
+    DwBatchArgs a;
+    for (int k = 0; k < njobs; ++k) {
+        const ngacf_dw_job& j = jobs[k];
+        if (!j.X || !j.H || !j.dH || !j.dS || !j.dW || !j.davec) return NGACF_E_ARG;
+        if (j.din != 64 || j.dout != 64 || (j.heads != 8 && j.heads != 1)) return NGACF_E_SHAPE;
+        if (j.x_dtype != NGACF_F32 && j.x_dtype != NGACF_BF16) return NGACF_E_SHAPE;
+        if (!(j.feat_drop_p >= 0.f && j.feat_drop_p < 1.f)) return NGACF_E_ARG;
+        a.job[k] = j;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (U + I == 0) {
+        for (int k = 0; k < njobs; ++k) {
+            hipError_t e = hipMemsetAsync(jobs[k].dW, 0, sizeof(float) * 2 * 64 * 64, st);
+            if (e == hipSuccess) e = hipMemsetAsync(jobs[k].davec, 0, sizeof(float) * 2 * 64, st);
+            if (e != hipSuccess) return static_cast<int>(e);
+        }
+        return 0;
+    }
+    const int tu = (U + 63) / 64, ti = (I + 63) / 64;
+    int nb = work_blocks;
+    if (tu + ti < nb) { a.nbu = tu; a.nbi = ti; }
+    else {
+        a.nbu = (int)((long long)nb * tu / (tu + ti));
+        if (tu > 0 && a.nbu == 0) a.nbu = 1;
+        if (ti > 0 && a.nbu == nb) a.nbu = nb - 1;
+        a.nbi = ti > 0 ? nb - a.nbu : 0;
+        if (tu == 0) a.nbu = 0;
+    }
+    a.nb = a.nbu + a.nbi; a.njobs = njobs; a.work = work; a.U = U; a.I = I; a.seed_dev = seed_dev;
+    hipLaunchKernelGGL(transform_dw_batch_kernel, dim3(njobs * a.nb), dim3(256), 0, st, a);
+    NGACF_CHECK_LAUNCH();
+    constexpr int wsz = 64 * 64 + 64;
+    hipLaunchKernelGGL(transform_dw_batch_reduce_kernel, dim3(njobs * ((2 * wsz + 63) / 64)), dim3(256), 0, st, a);
+    NGACF_CHECK_LAUNCH();
+    return 0;
 }

@@ -16,7 +16,7 @@ class StageLink:
     """What travels from one stage of a stack to the next when the next stage's transform rides in this stage's traversal
     (ngacf_prop_fwd_next): `pack` (stage 0 only) = the later stages' weights to pack in the first transform's launch, `panels` =
     the packed panels by stage index, `pre` = (H, S) of the coming stage, produced by the previous traversal."""
-    __slots__ = ("pack", "panels", "pre", "pack_t", "panels_t", "saved", "node_pre")
+    __slots__ = ("pack", "panels", "pre", "pack_t", "panels_t", "saved", "node_pre", "defer_dw", "dw_jobs", "bwd_stages")
 
     def __init__(self):
         self.pack, self.panels, self.pre = None, {}, None
@@ -24,6 +24,10 @@ class StageLink:
         # packs too, panels_t = those panels; saved[s] = (out, agg, R, elu) of stage s's forward, read by stage s+1's backward,
         # which runs stage s's step 1 on the dX it produces and parks (dX, Gn, t) in node_pre[s]
         self.pack_t, self.panels_t, self.saved, self.node_pre = None, {}, {}, {}
+        # defer_dw (a gradient sink is active: nobody reads a weight gradient before the stack's backward has finished): the stages
+        # whose dX came out of the edge backward leave their dW / davec to ONE batched launch behind the stack's last backward
+        # (ngacf_transform_dw_batch); dw_jobs = the pending jobs, bwd_stages = the stages that have a backward
+        self.defer_dw, self.dw_jobs, self.bwd_stages = False, [], set()
 
 
 def _transform_or_pre(X, W, avec, plan, heads, h_dtype, feat_drop_p, seed, seed_dev, link):
@@ -48,12 +52,16 @@ def _remember(link, sidx, out, agg, R, elu, needed):
     """forward: leave this stage's saved tables where the NEXT stage's backward finds them (StageLink.saved)"""
     if link is None or sidx is None:
         return None
+    link.bwd_stages.add(sidx)
     if needed is None:                                   # (a stage computed for a batch's rows only is nobody's previous stage)
         link.saved[sidx] = (out, agg, R, elu)
     return (link, sidx)
 
 
-FUSE_SPARSE = __import__("os").environ.get("NGACF_FUSE_SPARSE", "1") != "0"
+# The stage of a scored batch (row flags) keeps its separate launches by default: most of its rows finish without a single load,
+# and a tail with a barrier, a tile step and the previous stage's rows costs it more (38 -> 55 us stand-alone) than the launches
+# it replaces (dX 4 us, the previous stage's step 1 10 us); "1" fuses it too (tested, bitwise the same numbers).
+FUSE_SPARSE = __import__("os").environ.get("NGACF_FUSE_SPARSE", "0") != "0"
 
 
 def _bwd_links(bw, gout, X, H, plan, feat_drop_p, seed, want_dx, sparse=False):
@@ -75,12 +83,34 @@ def _bwd_links(bw, gout, X, H, plan, feat_drop_p, seed, want_dx, sparse=False):
     return node, dx
 
 
+DEFER_DW = __import__("os").environ.get("NGACF_DEFER_DW", "1") != "0"      # A/B switch of the batched, deferred weight gradients
+
+
+def _flush_dw(bw, plan, seed_dev):
+    """the stack's last backward stage: every deferred weight gradient in one launch"""
+    if bw is None:
+        return
+    link, s = bw
+    if link.dw_jobs and s == min(link.bwd_stages):
+        jobs, link.dw_jobs = link.dw_jobs, []
+        for k in range(0, len(jobs), ops._lib.DW_BATCH_MAX):
+            ops.transform_dw_batch(jobs[k:k + ops._lib.DW_BATCH_MAX], plan.U, plan.I, seed_dev)
+
+
 def _transform_bwd_after(bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed, seed_dev):
     if dx is None:
-        return ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
+        r = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
+        _flush_dw(bw, plan, seed_dev)
+        return r
+    link, s = bw
     if dx.prev is not None:
-        bw[0].node_pre[bw[1] - 1] = (dx.dX, dx.Gn, dx.T)
-    _, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev, part="dw")
+        link.node_pre[s - 1] = (dx.dX, dx.Gn, dx.T)
+    if link.defer_dw and DEFER_DW and tuple(W.shape) == (2, 64, 64) and H.dtype == torch.bfloat16:
+        dW, da = torch.empty(2, 64, 64, dtype=torch.float32, device=H.device), torch.empty(2, 64, dtype=torch.float32, device=H.device)
+        link.dw_jobs.append((X, H, dH, dS, heads, feat_drop_p, seed, dW, da))
+    else:
+        _, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev, part="dw")
+    _flush_dw(bw, plan, seed_dev)
     return dx.dX, dW, da
 
 
@@ -233,6 +263,11 @@ class grad_sink:
 
     def __exit__(self, *exc):
         _SINKS.stack.pop()
+
+
+def sink_active():
+    stack = _SINKS.__dict__.get("stack")
+    return bool(stack) and stack[-1] is not None
 
 
 def through_sink(p):

@@ -336,8 +336,11 @@ class BwdDx:
 
 
 # A/B switch of the backward's launch plan: 0 = dX and the node steps as their own launches; 1 = dX in the edge backward's tail;
-# 2 = dX and the previous stage's step 1 in the tail
-FUSE_BWD = int(__import__("os").environ.get("NGACF_FUSE_BWD", "1"))
+# 2 (default) = dX and the previous stage's step 1 in the tail.  Measured: stand-alone a dense stage's
+# backward goes from 88 to 82 us (98 to 79 for the first stage, whose dX is the fp32 table's gradient); inside the two-chain
+# train step all three plans land within 1 % of each other -- the step is bound by its six edge backwards, not by what runs
+# between them.
+FUSE_BWD = int(__import__("os").environ.get("NGACF_FUSE_BWD", "2"))
 
 
 def can_fuse_bwd(plan, H_dtype, d, din, x_dtype, has_prev):
@@ -432,6 +435,31 @@ def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0, seed_de
                                        ptr(da), ptr(work), U, I, din, dout, heads,
                                        float(feat_drop_p), int(seed), _sd(seed_dev, dev), _stream()), "ngacf_transform_bwd")
     return dX, dW, da
+
+
+DW_BATCH_BLOCKS = int(__import__("os").environ.get("NGACF_DW_BATCH_BLOCKS", "192"))     # workgroups per job of the batched dW launch
+
+
+def transform_dw_batch(jobs, U, I, seed_dev=None):
+    """The weight halves of transform_bwd for several 64 -> 64 bf16 stages in one launch + one reduction
+    (ngacf_transform_dw_batch).  jobs: [(X, H, dH, dS, heads, feat_drop_p, seed, dW, da)] with dW float [2, 64, 64] and
+    da float [2, 64] given (they may have been handed out before this call fills them)."""
+    n = len(jobs)
+    if n == 0:
+        return
+    if n > _lib.DW_BATCH_MAX:
+        raise ValueError("transform_dw_batch: at most %d jobs" % _lib.DW_BATCH_MAX)
+    dev, N = jobs[0][0].device, U + I
+    arr = (_lib.DwJob * n)()
+    for k, (X, H, dH, dS, heads, p, seed, dW, da) in enumerate(jobs):
+        if X.dtype not in _DT or H.dtype != torch.bfloat16:
+            raise ValueError("transform_dw_batch: bf16 stages (X fp32 or bf16)")
+        arr[k] = _lib.DwJob(_chk(X, "X", None, N * 64, dev), _chk(H, "H", torch.bfloat16, N * 64, dev), _chk(dH, "dH", torch.bfloat16, N * 64, dev),
+                            _chk(dS, "dS", torch.float32, N * heads, dev), _chk(dW, "dW", torch.float32, 2 * 64 * 64, dev),
+                            _chk(da, "davec", torch.float32, 2 * 64, dev), _DT[X.dtype], 64, 64, int(heads), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF)
+    work = torch.empty(n, DW_BATCH_BLOCKS, 64 * 64 + 64, dtype=torch.float32, device=dev)
+    _lib.check(lib.ngacf_transform_dw_batch(arr, n, work.data_ptr(), DW_BATCH_BLOCKS, U, I, _sd(seed_dev, dev), _stream()),
+               "ngacf_transform_dw_batch")
 
 
 # ---------------------------------------------------------------------------------------------------------

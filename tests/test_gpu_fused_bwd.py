@@ -127,8 +127,10 @@ def test_fused_backward_stack_equals_unfused_backward_stack(dev, kind, sparse_la
     m.sparse_last_stage = sparse_last
     g = torch.Generator(device=dev); g.manual_seed(1)
     u, pi, ni = (torch.randint(0, k, (255,), device=dev, generator=g) for k in (U, I, I))
+    from ngacf_amd import functional as NF
     res = {}
-    was = ops.FUSE_BWD
+    was, was_sp = ops.FUSE_BWD, NF.FUSE_SPARSE
+    NF.FUSE_SPARSE = True                                     # (off by default: the stage of a scored batch; tested here)
     try:
         for fuse in (True, False):
             ops.FUSE_BWD = level if fuse else 0
@@ -141,7 +143,7 @@ def test_fused_backward_stack_equals_unfused_backward_stack(dev, kind, sparse_la
             torch.cuda.synchronize()
             res[fuse] = (float(loss.detach()), {n: p.grad.clone() for n, p in m.named_parameters()}, _count_dx_calls() - n0)
     finally:
-        ops.FUSE_BWD = was
+        ops.FUSE_BWD, NF.FUSE_SPARSE = was, was_sp
     L = 2 if kind == "spuigacf" else 3
     assert res[True][2] == 2 * L and res[False][2] == 0, (res[True][2], res[False][2])     # every stage of both chains took the fused launch
     assert res[True][0] == res[False][0]
@@ -169,3 +171,72 @@ def _spy_on_dx(monkeypatch):
         return real(*a, **k)
     monkeypatch.setattr(ops, "prop_bwd", spy)
     yield
+
+
+def test_batched_weight_gradients_equal_the_per_stage_launches(dev):
+    """ngacf_transform_dw_batch (three stages' dW / davec in one launch + one reduction; fp32 and bf16 inputs, 8 heads and 1, with
+    and without feature dropout) against ngacf_transform_bwd's weight half: the same per-workgroup arithmetic, a different number
+    of partial sums -> equal to fp32 summation noise."""
+    from ngacf_amd import ops
+    U, I = 3100, 2501
+    N = U + I
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    bf = torch.bfloat16
+    jobs, want = [], []
+    for x_dtype, heads, p in ((torch.float32, 8, 0.2), (bf, 8, 0.0), (bf, 1, 0.1), (bf, 8, 0.3)):
+        X = (rnd(N, 64) * 0.5).to(x_dtype)
+        W = rnd(2, 64, 64) * 0.2
+        H, dH = (rnd(N, 64) * 0.5).to(bf), (rnd(N, 64) * 0.1).to(bf)
+        dS = rnd(N, heads) * 0.1
+        _, dW, da = ops.transform_bwd(X, W, H, dH, dS, U, I, heads, p, 17, part="dw")
+        want.append((dW, da))
+        jobs.append((X, H, dH, dS, heads, p, 17, torch.empty(2, 64, 64, device=dev), torch.empty(2, 64, device=dev)))
+    ops.transform_dw_batch(jobs, U, I)
+    torch.cuda.synchronize()
+    for (dW, da), j in zip(want, jobs):
+        for a_, b_ in ((dW, j[7]), (da, j[8])):
+            assert float((a_.double() - b_.double()).norm() / a_.double().norm()) < 2e-6
+
+
+@pytest.mark.parametrize("level,sparse_fused", [(1, False), (2, False), (2, True)])
+def test_graphed_step_with_deferred_weight_gradients(dev, level, sparse_fused):
+    """GraphedBPRStep (two chains, gradient sinks: the weight gradients of the fused stages are left to one batched launch per
+    chain) against the same replayed steps with NGACF_FUSE_BWD = 0: same parameters after four Adam steps (no dropout, so that the
+    two captures see the same masks), to the noise of fp32 sums and of the score gradient's float atomics."""
+    import copy
+    import ngacf_amd
+    from ngacf_amd import ops
+    from ngacf_amd.graphs import GraphedBPRStep
+    from ngacf_amd.optim import Adam
+    U, I, B = 900, 700, 64
+    edge = torch.from_numpy(_graph(U, I, 30000, 2, hub=400)).to(dev)
+    torch.manual_seed(1)
+    m0 = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev)
+    with torch.no_grad():
+        m0.uEmbd.weight.mul_(30.0); m0.iEmbd.weight.mul_(30.0)
+    ngacf_amd.set_compute_dtype(m0, torch.bfloat16)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    upn = torch.stack([torch.randint(0, U, (B,), device=dev, generator=g), torch.randint(0, I, (B,), device=dev, generator=g),
+                       torch.randint(0, I, (B,), device=dev, generator=g)])
+    from ngacf_amd import functional as NF
+    res = {}
+    was, was_sp = ops.FUSE_BWD, NF.FUSE_SPARSE
+    NF.FUSE_SPARSE = sparse_fused
+    try:
+        for fuse in (level, 0):
+            ops.FUSE_BWD = fuse
+            m = copy.deepcopy(m0)
+            opt = Adam(m.parameters(), lr=1e-2, weight_decay=1e-5)
+            n0 = _count_dx_calls()
+            step = GraphedBPRStep(m, ngacf_amd.BPRLoss(), opt, edge, B, preserve_state=True)
+            losses = [float(step(upn)) for _ in range(4)]
+            torch.cuda.synchronize()
+            res[fuse] = (losses, {n: p.detach().clone() for n, p in m.named_parameters()}, _count_dx_calls() - n0)
+    finally:
+        ops.FUSE_BWD, NF.FUSE_SPARSE = was, was_sp
+    assert res[level][2] > 0 and res[0][2] == 0
+    assert np.allclose(res[level][0], res[0][0], rtol=1e-4, atol=1e-7), (res[level][0], res[0][0])
+    for n in res[0][1]:
+        a_, b_ = res[level][1][n].double(), res[0][1][n].double()
+        assert float((a_ - b_).norm() / b_.norm().clamp_min(1e-30)) < 1e-4, n
