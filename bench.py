@@ -86,6 +86,17 @@ def make_model(ng, torch, U, I, d, stages, droprate, dtype, dev):
     return m
 
 
+def stack_fuses_next(NF, ops, model, edge, U, I, seg_len):
+    """Does the forward run every later stage's transform in the previous traversal's epilogue (ngacf_prop_fwd_next)?  The model's
+    own rule (SPUIGACF._run), bf16 and fp32 storage alike."""
+    if not NF.FUSE_NEXT:
+        return False
+    plan = model.gat._plans.get(edge, U, I, seg_len)
+    shapes = model.gat.stage_shapes()
+    return all(ops.can_fuse_next(plan, model.gat.compute_dtype, shapes[s - 1][1], shapes[s - 1][2]) and shapes[s][0] == 64 and shapes[s][1] in (64, 128)
+               for s in range(1, len(shapes)))
+
+
 def stage_layer_names(model):
     """state_dict prefixes of the layers of every stage, in execution order."""
     return [["gat." + n for n in names] for names in model.gat.stage_layer_names()]
@@ -199,31 +210,37 @@ def roofline_of(BK, D, wl, dtype, U, I, E, dims, elem, prop_ms, n_timed, fused):
     regime = BK.gather_regime(N * d * elem, max(U, I) * d * elem)
     traffic, traffic_src = BK.traffic_from_profile(ROOT, wl, dtype, L, d)
     hit, hit_src = BK.l2_hit_from_profile(ROOT, wl, dtype)
-    blend = None
+    blend = l2blend = None
     if regime["regime"] == "HBM":
         bound, peak, peak_note = "hbm", BK.HBM_PEAK_GBS, "HBM3E spec peak"
     else:
+        # The ceiling is fixed by regime and dtype BEFORE anything is measured.  The guide's two row-gather rates (L2-resident
+        # 17.8 TB/s, Infinity-Cache 8.6 TB/s) are measured LOWER bounds of one loop over 1152-byte rows; blended by the kernel's L2
+        # hit rate they are the roof of the bf16 kernel (128-byte rows: one line per gathered row).  fp32's 256-byte rows (two
+        # lines per request burst) are known to exceed that blend, so their roof takes the L2's own peak (34.5 TB/s) for the hits.
+        # Both fractions are in the line whatever the dtype.
         bound = "l2+mall gather"
         if hit is not None:
-            # the guide's two measured row-gather rates (L2-resident 17.8 TB/s, Infinity-Cache 8.6 TB/s), blended by the kernel's hit rate
             blend = 1.0 / (hit / BK.ROOF_L2_GATHER_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
-            peak = blend
-            peak_note = ("1 / (hit / %.0f + miss / %.0f) GB/s at the kernel's L2 hit rate %.3f (%s)"
-                         % (BK.ROOF_L2_GATHER_GBS, BK.ROOF_MALL_GATHER_GBS, hit, hit_src))
-            if achieved > blend:
-                # those two rates are measured LOWER bounds of one loop over 1152-byte rows, not ceilings: with fp32's 256-byte rows
-                # (two lines per request burst) this kernel exceeds their blend.  The ceiling then is the L2's own peak for the hits.
-                peak = 1.0 / (hit / BK.L2_PEAK_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
-                peak_note = ("the guide's gather blend (%.0f GB/s) is exceeded -- its L2 figure is a measured lower bound; ceiling = "
-                             "1 / (hit / %.0f [L2 peak] + miss / %.0f) at hit rate %.3f (%s)"
-                             % (blend, BK.L2_PEAK_GBS, BK.ROOF_MALL_GATHER_GBS, hit, hit_src))
+            l2blend = 1.0 / (hit / BK.L2_PEAK_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
+            if elem == 2:
+                peak = blend
+                peak_note = ("bf16 rows: 1 / (hit / %.0f + miss / %.0f) GB/s (the guide's L2-resident and Infinity-Cache row-gather rates) at "
+                             "the kernel's L2 hit rate %.3f (%s)" % (BK.ROOF_L2_GATHER_GBS, BK.ROOF_MALL_GATHER_GBS, hit, hit_src))
+            else:
+                peak = l2blend
+                peak_note = ("fp32 rows: 1 / (hit / %.0f [the L2's own peak] + miss / %.0f) GB/s at the kernel's L2 hit rate %.3f (%s); "
+                             "chosen by dtype before measuring -- 256-byte rows exceed the guide's gather blend, a measured lower bound"
+                             % (BK.L2_PEAK_GBS, BK.ROOF_MALL_GATHER_GBS, hit, hit_src))
         else:
             peak, peak_note = regime["roof_GBps"], "no request-counter profile for this workload: the regime's row-gather rate"
-    out = {"bound": bound, "kernel": "prop_fwd_kernel (ngacf_prop_fwd%s)" % (": with the next stage's transform in its epilogue on all but the last stage" if fused else ""),
+    out = {"bound": bound, "kernel": "prop_fwd_kernel (ngacf_prop_fwd%s); traffic / l2_hit_rate: from_profile, not collected in this run"
+                                     % (": with the next stage's transform in its epilogue on all but the last stage" if fused else ""),
            "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s", "frac": round(achieved / peak, 4),
            "peak_note": peak_note, "traffic": traffic, "traffic_source": traffic_src,
            "frac_hbm_algorithmic": round(achieved / BK.HBM_PEAK_GBS, 4),
            "frac_of_guide_gather_blend": round(achieved / blend, 4) if blend else None,
+           "frac_of_l2_peak_blend": round(achieved / l2blend, 4) if l2blend else None,
            "counter_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
            "regime": regime["regime"], "regime_note": regime["note"], "l2_hit_rate": hit,
            "bytes_per_launch": int(avg_bytes), "avg_launch_us": round(avg_ms * 1e3, 2),
@@ -231,6 +248,61 @@ def roofline_of(BK, D, wl, dtype, U, I, E, dims, elem, prop_ms, n_timed, fused):
            "timing": "dispatch-packet timestamps (hipExtLaunchKernel start/stop events) of eager launches of the replayed graph's kernels",
            "edges_per_s_in_kernel": round(2 * E / (avg_ms * 1e-3), 1)}
     return out
+
+
+def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dims, elem, n_steps=10):
+    """`train_roofline`: the train step's dominant kernel -- the dense stages' edge backward (ngacf_prop_bwd / ngacf_prop_bwd_dx,
+    four launches per step, ~60 % of the backward) -- from its SURVEY.md 8(d) bytes, 2E (4 + 2 d T) + N (2 d T + 8), and its own
+    duration: dispatch-packet timestamps of eager train steps (launches one after the other; inside the replayed two-chain step
+    a launch shares the GPU with the other chain's and lasts 1.3-1.7 x as long: profiles/r04_trainstep_timeline.txt).  Roof as in
+    `roofline`: the cache-gather blend at the kernel's own L2 hit rate (profiles/r04_traffic_trainstep.json)."""
+    L = len(dims)
+    N, d = U + I, dims[0][1]
+    for _ in range(2):
+        eager_step()
+    torch.cuda.synchronize()
+    with ops.KernelTimer() as kt:
+        for _ in range(n_steps):
+            eager_step()
+        torch.cuda.synchronize()
+    ms = kt.durations_ms(kt.TAG_PROP_BWD)
+    if len(ms) != 2 * L * n_steps:
+        raise RuntimeError("expected %d edge-backward launches, timed %d" % (2 * L * n_steps, len(ms)))
+    sparse_last = bool(type(model).sparse_last_stage)
+    # autograd runs a chain's stages last to first: launch k of a step is stage L - 1 - (k mod L)
+    per_stage = [[ms[k] for k in range(len(ms)) if L - 1 - (k % L) == s_] for s_ in range(L)]
+    dense = [x for s_ in range(L) for x in per_stage[s_] if not (sparse_last and s_ == L - 1)]
+    avg_ms = sum(dense) / len(dense)
+    bytes_launch = 2 * E * (4 + 2 * d * elem) + N * (2 * d * elem + 8)
+    achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
+    hit, hit_src = BK.bwd_hit_from_profile(ROOT, wl, dtype)
+    regime = BK.gather_regime(2 * N * d * elem, 2 * max(U, I) * d * elem)          # two gathered tables (H and Gn)
+    blend = l2blend = None
+    if regime["regime"] == "HBM":
+        bound, peak, note = "hbm", BK.HBM_PEAK_GBS, "HBM3E spec peak"
+    elif hit is not None:
+        bound = "l2+mall gather"
+        blend = 1.0 / (hit / BK.ROOF_L2_GATHER_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
+        l2blend = 1.0 / (hit / BK.L2_PEAK_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
+        peak = blend if elem == 2 else l2blend
+        note = "as `roofline` (ceiling fixed by dtype), at the edge backward's own L2 hit rate %.3f (%s)" % (hit, hit_src)
+    else:
+        bound, peak, note = "l2+mall gather", regime["roof_GBps"], "no request-counter profile: the regime's row-gather rate"
+    from ngacf_amd import functional as NF
+    return {"bound": bound, "kernel": "prop_bwd_kernel, dense stages (NGACF_FUSE_BWD=%d: %s); l2_hit_rate: from_profile"
+                                      % (ops.FUSE_BWD, "with the stage's dX%s in its tail" % (" and the previous stage's node step" if ops.FUSE_BWD >= 2 else "")
+                                         if ops.FUSE_BWD and dtype == "bf16" else "edge backward alone"),
+            "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s", "frac": round(achieved / peak, 4), "peak_note": note,
+            "frac_hbm_algorithmic": round(achieved / BK.HBM_PEAK_GBS, 4),
+            "frac_of_guide_gather_blend": round(achieved / blend, 4) if blend else None,
+            "frac_of_l2_peak_blend": round(achieved / l2blend, 4) if l2blend else None,
+            "l2_hit_rate": hit, "bytes_per_launch": int(bytes_launch),
+            "bytes_note": "SURVEY.md 8(d) backward: 2E (4 + 2 d T) + N (2 d T + 8); the 4*heads-byte t gather and the fused tail's rows are not counted",
+            "avg_launch_us": round(avg_ms * 1e3, 2),
+            "per_stage_us": [round(1e3 * sum(x) / len(x), 2) for x in per_stage],
+            "last_stage_is_the_scored_batch_only": sparse_last and NF is not None,
+            "launches_timed": len(dense), "edges_per_s_in_kernel": round(2 * E / (avg_ms * 1e-3), 1),
+            "timing": "dispatch-packet timestamps of EAGER train steps (one launch at a time)"}
 
 
 def performed_train_traversals(torch, model, plan, ub, pb, nb_, L, E):
@@ -294,7 +366,7 @@ def worker(args):
     dims = model.gat.stage_shapes()
     L = len(dims)
     big = wl in D.BIG_WORKLOADS
-    fused = NF.FUSE_NEXT and args.dtype == "bf16"
+    fused = stack_fuses_next(NF, ops, model, edge, U, I, args.seg_len)
 
     def sync():
         torch.cuda.synchronize()
@@ -342,6 +414,7 @@ def worker(args):
             loss.backward()
             opt.step()
             return loss
+        eager_step = step
         if not args.eager:                      # whole step (2 fwd, loss, bwd, Adam) as one replayed hipGraph
             from ngacf_amd.graphs import GraphedBPRStep
             gstep = GraphedBPRStep(model, lossfn, opt, edge, B)
@@ -364,6 +437,11 @@ def worker(args):
             sync()
             return time.perf_counter() - t0, n, out
         t_tr, ksteps, loss = time_train(step)
+        train_rl = None
+        try:
+            train_rl = train_roofline_of(torch, BK, ops, eager_step, model, wl, args.dtype, U, I, E, dims, elem)
+        except Exception as e:                        # (a secondary figure must not cost the line)
+            print("[bench] train_roofline failed: %r" % (e,), file=sys.stderr, flush=True)
         plan = model.gat._plans.get(edge, U, I, args.seg_len)
         performed = performed_train_traversals(torch, model, plan, ub, pb, nb, L, E)
         train = {"bpr_pairs_per_s": round(B * ksteps / t_tr, 1), "train_ms_per_step": round(1e3 * t_tr / ksteps, 3),
@@ -371,7 +449,7 @@ def worker(args):
                  "train_traversals_per_step": {"performed": performed, "if_every_stage_ran_in_full": 4 * trav_per_pass,
                                                "note": "directed-edge gathers of one step (2 propagations, forward + backward); the last "
                                                        "stage of a scored batch walks the batch's rows only"},
-                 "train_traversals_per_s": round(performed * ksteps / t_tr, 1)}
+                 "train_traversals_per_s": round(performed * ksteps / t_tr, 1), "train_roofline": train_rl}
         if not args.eager and not big:
             # reported SEPARATELY: the opt-in mode that shares one propagation between the
             # positive and the negative scoring of a step -- not reference semantics, never the headline number
@@ -412,11 +490,14 @@ def worker(args):
         del model, edge
         torch.cuda.empty_cache()
         # north_star's roofline target is stated at Yelp scale: the same forward on the Yelp-scale graph, a short second region
-        try:
-            out["yelp_probe"] = yelp_probe(args, torch, ng, BK, D, NF, ops, dev)
-        except Exception as e:
-            print("[bench] yelp probe failed: %r" % (e,), file=sys.stderr, flush=True)
-            out["yelp_probe"] = {"error": repr(e)}
+        # in the reference's precision (fp32: BASELINE.md section 5, the dtype of north_star's 1e-4 bar) AND in bf16 storage; plus the
+        # headline graph's forward in fp32
+        for key, pwl, pdt in (("yelp_probe", "yelp", "fp32"), ("yelp_probe_bf16", "yelp", "bf16"), ("gowalla_fp32_probe", "gowalla", "fp32")):
+            try:
+                out[key] = forward_probe(args, torch, ng, BK, D, NF, ops, dev, pwl, pdt)
+            except Exception as e:
+                print("[bench] %s failed: %r" % (key, e), file=sys.stderr, flush=True)
+                out[key] = {"error": repr(e)}
         # the same forward on the 10^9-edge graph (BASELINE config 5) at this GPU count: the regime where the node partition
         # can pay; lets one `bench.py --gpus N` sweep yield a second strong-scaling curve (ngacf_amd.dist.scaling_probe)
         try:
@@ -483,24 +564,24 @@ def ingest_graph(D, wl, dev, args):
     return edge
 
 
-def yelp_probe(args, torch, ng, BK, D, NF, ops, dev):
-    """The headline measurement repeated at Yelp scale (BASELINE config 2's graph; north_star: ">= 50 % of the HBM roofline on
-    the attention-propagation kernel at Yelp scale on 1 GPU"): forward only, ~0.3 s timed region, its own roofline."""
-    wl = "yelp"
+def forward_probe(args, torch, ng, BK, D, NF, ops, dev, wl, dtype):
+    """The headline measurement repeated on another graph / in another storage type: forward only, ~0.3 s timed region, its own
+    roofline.  Yelp scale is BASELINE config 3's graph and north_star's roofline target (">= 50 % of the HBM roofline on the
+    attention-propagation kernel at Yelp scale on 1 GPU"); fp32 is the reference's precision."""
     U, I, _ = D.SHAPES[wl]
     torch.manual_seed(2019)
     edge = ingest_graph(D, wl, dev, args)
     E = int(edge.shape[1])
-    elem = 2 if args.dtype == "bf16" else 4
-    model = make_model(ng, torch, U, I, 64, 3, args.droprate, args.dtype, dev)
+    elem = 2 if dtype == "bf16" else 4
+    model = make_model(ng, torch, U, I, 64, 3, args.droprate, dtype, dev)
     dims = model.gat.stage_shapes()
     K = max(5, min(args.steps, 10))
     fm = measure_forward(torch, BK, ops, model, edge, K, 2, 0.3, 0, args.eager, 50)
     trav = len(dims) * 2 * E
-    rl = roofline_of(BK, D, wl, args.dtype, U, I, E, dims, elem, fm["prop_ms"], fm["n_timed"], NF.FUSE_NEXT and args.dtype == "bf16")
+    rl = roofline_of(BK, D, wl, dtype, U, I, E, dims, elem, fm["prop_ms"], fm["n_timed"], stack_fuses_next(NF, ops, model, edge, U, I, 256))
     return {"workload": "%s-scale bipartite graph U=%d I=%d E=%d, d=64, L=3, eval forward" % (wl, U, I, E),
             "value": round(trav * fm["R"] * K / fm["t"], 1), "unit": "edges/s", "ms_per_pass": round(1e3 * fm["t"] / K / fm["R"], 5),
-            "steps": K, "passes_per_step": fm["R"], "dtype": args.dtype, "roofline": rl}
+            "steps": K, "passes_per_step": fm["R"], "dtype": dtype, "roofline": rl}
 
 
 def main(argv=None):

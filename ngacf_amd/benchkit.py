@@ -187,7 +187,7 @@ def cpu_model_name():
     return "unknown"
 
 
-_ROUNDS = ("r03", "r02", "r01")
+_ROUNDS = ("r04", "r03", "r02", "r01")
 
 
 def traffic_from_profile(root, workload, dtype, stages, d):
@@ -226,4 +226,25 @@ def l2_hit_from_profile(root, workload, dtype):
                      if k.startswith("prop_fwd_kernel") and ", true, false, false" in k and "L2_hit_rate" in v.get("per_directed_edge", {})]
             if rates:
                 return round(sum(rates) / len(rates), 4), "from_profile: %s (rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum over tools/kbench.py)" % rel
+    return None, None
+
+
+def bwd_hit_from_profile(root, workload, dtype):
+    """(L2 hit rate of the dense edge backward, source): tools/traffic.py trainstep (r04: the kernels of the replayed train step
+    under rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum), or round 2's tools/reqcount.py passes over tools/kbench.py."""
+    for rnd in _ROUNDS:
+        rel = os.path.join("profiles", "%s_traffic_trainstep.json" % rnd)
+        p = os.path.join(root, rel)
+        if os.path.exists(p) and workload == "gowalla":
+            k = (json.load(open(p)).get("by_dtype", {}).get(dtype) or {}).get("kernels", {}).get("prop_bwd_kernel dense")
+            if k and k.get("l2_hit_rate") is not None:
+                return k["l2_hit_rate"], "from_profile: %s" % rel
+        rel = os.path.join("profiles", "%s_reqcount_%s_%s.json" % (rnd, workload, dtype))
+        p = os.path.join(root, rel)
+        if os.path.exists(p):
+            ks = json.load(open(p)).get("kernels", {})
+            rates = [v["per_directed_edge"]["L2_hit_rate"] for k, v in sorted(ks.items())
+                     if k.startswith("prop_bwd_kernel") and "L2_hit_rate" in v.get("per_directed_edge", {})]
+            if rates:
+                return round(sum(rates) / len(rates), 4), "from_profile: %s (tools/reqcount.py over tools/kbench.py, round 2's numbering)" % rel
     return None, None

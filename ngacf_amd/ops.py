@@ -27,8 +27,8 @@ def _stream():
 
 
 class KernelTimer:
-    """Opt-in per-KERNEL timing (bench.py's roofline leg): inside the block the traversal and transform launches of this host
-    thread carry start / stop events of their dispatch packets (ngacf_timing_begin / _end, hipExtLaunchKernel) -- the
+    """Opt-in per-KERNEL timing (bench.py's roofline leg): inside the block the traversal and transform launches of this
+    process (any host thread: autograd's backward runs on its own) carry start / stop events of their dispatch packets (ngacf_timing_begin / _end, hipExtLaunchKernel) -- the
     kernel's own duration, without the host's launch gaps; it is the number a rocprofv3 kernel trace reports (an event pair
     AROUND a launch call read 5-8 us longer in round 2).  Eager launches only (not inside a stream capture).
       with KernelTimer() as t: ...;   t.durations_ms(TAG_PROP_FWD) -> [ms per launch, in launch order]"""

@@ -436,8 +436,17 @@ def test_bench_prints_one_contract_line():
     assert 0.8 * kern_us < 1e3 * d["ms_per_pass"] < 1.25 * kern_us, (kern_us, d["ms_per_pass"])
     assert d["config"]["fused_next_stage_transform"] and d["config"]["launches_per_pass"] == 4
     assert d["train_traversals_per_step"]["performed"] < d["train_traversals_per_step"]["if_every_stage_ran_in_full"]
-    yp = d["yelp_probe"]
-    assert "error" not in yp and yp["value"] > 3e10 and yp["roofline"]["bound"] == "l2+mall gather" and yp["roofline"]["frac"] <= 1.0, yp
+    assert rf["frac_of_guide_gather_blend"] is not None and rf["frac_of_l2_peak_blend"] is not None        # both fixed fields, whatever the dtype
+    # north_star's target configuration in the reference's precision (fp32), the same in bf16 storage, and the headline graph in fp32
+    for key, dt, floor in (("yelp_probe", "fp32", 2.5e10), ("yelp_probe_bf16", "bf16", 3e10), ("gowalla_fp32_probe", "fp32", 2.5e10)):
+        yp = d[key]
+        assert "error" not in yp and yp["dtype"] == dt and yp["value"] > floor, (key, yp)
+        assert yp["roofline"]["bound"] == "l2+mall gather" and yp["roofline"]["frac"] <= 1.0 and yp["roofline"]["launches_timed"] >= 150, (key, yp)
+    tr = d["train_roofline"]                                             # the train leg's dominant kernel: the dense edge backward
+    assert tr["bound"] == "l2+mall gather" and 0.2 < tr["frac"] <= 1.0 and tr["launches_timed"] >= 40 and len(tr["per_stage_us"]) == 3, tr
+    assert abs(tr["frac"] - tr["achieved"] / tr["peak"]) < 1e-3 and tr["bytes_per_launch"] > d["roofline"]["bytes_per_launch"]
+    # an edge backward launched alone cannot last longer than its share of the two-chain step
+    assert 4 * tr["avg_launch_us"] < 1e3 * d["train_ms_per_step"], (tr["avg_launch_us"], d["train_ms_per_step"])
     pr = d["scaling_probe"]                                              # the same forward on the 10^9-edge graph, one GPU
     assert "error" not in pr and pr["n_gpus"] == 1 and pr["value"] > 3e10 and pr["prop_fwd_frac_of_hbm_peak"] > 0.7, pr
     assert pr["roofline"]["bound"] == "hbm" and pr["roofline"]["peak"] == 8000.0 and 0.5 < pr["roofline"]["frac"] <= 1.0, pr

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the round's bench / profile files under gpurun_out/refresh/ on the GPU box (copy what is wanted into profiles/).
 #   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh [tag] [part]'      part: all | bench | pmc | train | aux
-tag=${1:-r03}
+tag=${1:-r04}
 part=${2:-all}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -17,6 +17,8 @@ prof() {   # prof <name> <bench args...>: rocprofv3 kernel stats of a bench run
 if [ "$part" = all ] || [ "$part" = bench ]; then
 say "default bench (with the Yelp and 10^9-edge probes)"; timeout -k 10 600 python bench.py > $out/${tag}_bench_gowalla_bf16.json 2> $out/err.log || exit 1
 say "gowalla bf16 under rocprof";        prof gowalla_bf16 --steps 20 --warmup 5 --no-probe || exit 1
+say "yelp bf16 / fp32 under rocprof";    prof yelp_bf16 --workload yelp --steps 20 --warmup 5 --no-probe --no-train --no-cpu-baseline || exit 1
+prof yelp_fp32 --workload yelp --dtype fp32 --steps 20 --warmup 5 --no-probe --no-train --no-cpu-baseline || exit 1
 say "gowalla bf16, transforms as their own launches (A/B)"; NGACF_FUSE_NEXT=0 timeout -k 10 300 python bench.py --no-probe --no-cpu-baseline > $out/${tag}_bench_gowalla_bf16_unfused.json 2>> $out/err.log || exit 1
 for cfg in "yelp bf16" "yelp fp32" "gowalla fp32" "gowalla128 bf16" "gowalla128 fp32"; do
   set -- $cfg
@@ -31,13 +33,21 @@ say "PMC traffic + L2 hit rate: gowalla"; timeout -k 10 600 python tools/traffic
 say "PMC traffic + L2 hit rate: yelp";    timeout -k 10 600 python tools/traffic.py yelp bf16,fp32 > $out/traffic_yelp.log 2>&1 && cp gpurun_out/${tag}_traffic_yelp.json $out/
 say "PMC traffic: synthetic1b";           timeout -k 10 900 python tools/traffic.py synthetic1b bf16 > $out/traffic_1b.log 2>&1 && cp gpurun_out/${tag}_traffic_synthetic1b.json $out/
 say "PMC traffic: synthetic200m";         timeout -k 10 600 python tools/traffic.py synthetic200m bf16 > $out/traffic_200m.log 2>&1 && cp gpurun_out/${tag}_traffic_synthetic200m.json $out/
+say "PMC traffic + L2 hit rate: the kernels of the train step"; timeout -k 10 600 python tools/traffic.py trainstep bf16 > $out/traffic_trainstep.log 2>&1 && cp gpurun_out/${tag}_traffic_trainstep.json $out/
 fi
 if [ "$part" = all ] || [ "$part" = train ]; then
 say "train step breakdown";              timeout -k 10 300 python tools/train_profile.py --profile > $out/tp_refsem.log 2>&1 && cp gpurun_out/trainprof_refsem.txt $out/${tag}_trainstep_kernels_refsem.txt
+python tools/step_timeline.py gpurun_out/trainprof/t_kernel_trace.csv > $out/${tag}_trainstep_timeline.txt
+NGACF_FUSE_BWD=0 timeout -k 10 300 python tools/train_profile.py --profile > $out/tp_refsem0.log 2>&1 && cp gpurun_out/trainprof_refsem.txt $out/${tag}_trainstep_kernels_refsem_unfused.txt
+python tools/step_timeline.py gpurun_out/trainprof/t_kernel_trace.csv > $out/${tag}_trainstep_timeline_unfused.txt
 timeout -k 10 300 python tools/train_profile.py --profile --shared > $out/tp_shared.log 2>&1 && cp gpurun_out/trainprof_shared.txt $out/${tag}_trainstep_kernels_shared.txt
 timeout -k 10 200 python tools/train_profile.py > $out/${tag}_trainstep.jsonl 2>/dev/null; timeout -k 10 200 python tools/train_profile.py --shared >> $out/${tag}_trainstep.jsonl 2>/dev/null
 NGACF_SPARSE_LAST=0 timeout -k 10 200 python tools/train_profile.py >> $out/${tag}_trainstep.jsonl 2>/dev/null
 NGACF_FUSE_NEXT=0 timeout -k 10 200 python tools/train_profile.py >> $out/${tag}_trainstep.jsonl 2>/dev/null
+for f in 0 1; do NGACF_FUSE_BWD=$f timeout -k 10 200 python tools/train_profile.py >> $out/${tag}_trainstep.jsonl 2>/dev/null; done
+NGACF_FUSE_SPARSE=1 timeout -k 10 200 python tools/train_profile.py >> $out/${tag}_trainstep.jsonl 2>/dev/null
+NGACF_DEFER_DW=0 timeout -k 10 200 python tools/train_profile.py >> $out/${tag}_trainstep.jsonl 2>/dev/null
+timeout -k 10 200 python tools/bwd_probe.py > $out/${tag}_bwd_probe.log 2>&1; timeout -k 10 200 python tools/pair_probe.py > $out/${tag}_pair_probe.log 2>&1
 timeout -k 10 200 python tools/train_profile.py --torch-adam >> $out/${tag}_trainstep.jsonl 2>/dev/null
 say "epoch + evaluation";                timeout -k 10 300 python tools/eval_bench.py --epochs 3 > $out/${tag}_epoch_eval_gowalla.log 2>&1
 rm -rf gpurun_out/trainprof
