@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- propagation edges/s (+ BPR pairs/s) of the HIP path on N MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gowalla|yelp|gowalla128|synthetic200m|synthetic1b]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gowalla|yelp|gowalla128|synthetic200m|synthetic1b|gowalla_real|yelp_real]
+  (gowalla_real / yelp_real: the REAL interaction lists the reference ships -- its test halves, tests/golden/*_test_pairs.npz;
+  one GPU; the degree law of every workload's graph is printed in config.graph)
 
 N = 1 runs in this process.  N > 1 (or NGACF_BENCH_FORCE_DIST=1: the N > 1 code path rehearsed on one rank) without a
 torchrun environment: this process -- which imports no torch and makes no GPU call -- starts
@@ -26,7 +28,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = ["ml100k", "gowalla", "yelp", "gowalla128", "synthetic200m", "synthetic1b"]
+WORKLOADS = ["ml100k", "gowalla", "yelp", "gowalla128", "synthetic200m", "synthetic1b", "gowalla_real", "yelp_real"]
 
 
 def _benchkit():
@@ -95,6 +97,15 @@ def stack_fuses_next(NF, ops, model, edge, U, I, seg_len):
     shapes = model.gat.stage_shapes()
     return all(ops.can_fuse_next(plan, model.gat.compute_dtype, shapes[s - 1][1], shapes[s - 1][2]) and shapes[s][0] == 64 and shapes[s][1] in (64, 128)
                for s in range(1, len(shapes)))
+
+
+def graph_law(torch, model, edge, U, I, seg_len):
+    """the degree law of the benched graph and what the plan makes of it"""
+    plan = model.gat._plans.get(edge, U, I, seg_len)
+    du, di = torch.bincount(edge[0], minlength=U), torch.bincount(edge[1], minlength=I)
+    return {"max_degree_user": int(du.max()), "max_degree_item": int(di.max()), "isolated_items": int((di == 0).sum()),
+            "rows_over_64_edges": int((du > 64).sum() + (di > 64).sum()), "hub_rows_cut_into_slices": int(plan.nsplit),
+            "hub_slices": int(plan.nparts), "long_segments": int(plan.nseg), "short_rows": int(plan.nshort)}
 
 
 def stage_layer_names(model):
@@ -351,6 +362,8 @@ def worker(args):
     U, I, E_target = D.SHAPES[wl]
     elem = 2 if args.dtype == "bf16" else 4
 
+    if (world > 1 or force_dist) and wl in D.REAL_WORKLOADS:
+        raise SystemExit("--workload %s: one GPU (the real lists are a fifth of the size of the Gowalla-scale graph)" % wl)
     if world > 1 or force_dist:
         from ngacf_amd import dist as ND
         return ND.bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg)
@@ -468,8 +481,11 @@ def worker(args):
     out = {"metric": "propagation edges/sec (directed edge traversals, forward, all stages)", "value": round(value, 1),
            "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": "%s-scale bipartite graph U=%d I=%d E=%d, d=%d, L=%d stages (%s), 8 heads x 8 + 1 x %d"
-                                  % (wl, U, I, E, d, L, type(model).__name__, d),
+           "config": {"workload": "%s U=%d I=%d E=%d, d=%d, L=%d stages (%s), 8 heads x 8 + 1 x %d"
+                                  % (("the reference's data/%s_test.csv interaction list (real topology; the train half is a missing blob)"
+                                      % {"gowalla_real": "Gowalla/g", "yelp_real": "Yelp/y"}[wl]) if wl in D.REAL_WORKLOADS
+                                     else "%s-scale bipartite graph" % wl, U, I, E, d, L, type(model).__name__, d),
+                      "graph": graph_law(torch, model, edge, U, I, args.seg_len),
                       "passes_per_step": R, "edges_directed_per_pass": trav_per_pass, "edges_directed_per_step": trav_per_step,
                       "seg_len": args.seg_len, "parallelism": "1 GPU",
                       "launch": "eager" if args.eager else "hipGraph replay",

@@ -15,6 +15,9 @@ SHAPES = {          # (U, I, E) -- SURVEY.md §8
     "ml100k": (943, 1682, 100000),
     "gowalla": (29858, 40981, 1027370),
     "yelp": (45919, 45538, 1185065),
+    # the REAL interaction lists the reference ships (its test halves; the train halves are missing blobs): real_graph() below
+    "gowalla_real": (29858, 40981, 217242),
+    "yelp_real": (45918, 45538, 253578),                       # (one of the 45 919 users has no pair in the test half: dropped)
     "synthetic1b": (10_000_000, 5_000_000, 1_000_000_000),
     "synthetic200m": (10_000_000, 5_000_000, 200_000_000),     # same node tables (1.9 GB bf16: far beyond the 256 MB
 }                                                               # Infinity Cache), a fifth of the edges: true-HBM regime
@@ -127,12 +130,76 @@ def renumber(edge, perm_u, perm_i):
 
 
 BIG_WORKLOADS = ("synthetic200m", "synthetic1b")
+REAL_WORKLOADS = ("gowalla_real", "yelp_real")
+
+
+def real_pairs(name):
+    """(user int64[n], item int64[n], U, I): the interaction pairs of the reference's data/Gowalla/g_test.csv or data/Yelp/y_test.csv
+    (loader layout data/loadGowalla.py:35-45), from the data fixture oracle/gen_real_pairs.py wrote
+    (tests/golden/<name>_test_pairs.npz: two id columns, sorted row-major, unique = the coalesced ui_mat of :244-253)."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "%s_test_pairs.npz" % name)
+    z = np.load(path)
+    return z["user"].astype(np.int64), z["item"].astype(np.int64), int(z["U"]), int(z["I"])
+
+
+def real_graph(name, device, isolated_users="drop"):
+    """([2,E] indices, U, I) of the real test-half graph `gowalla_real` / `yelp_real`.  A user without a pair is what the
+    reference's layer asserts against (SPUIGACF.py:368; here: ValueError at plan build) -- the Yelp test half has one.
+    isolated_users = "drop": such users leave the id space (the others keep their order); "keep": the graph as the file has it
+    (building a plan on it raises).  Isolated ITEMS stay: the reference handles them (:389)."""
+    u, i, U, I = real_pairs(name[:-5] if name.endswith("_real") else name)
+    if isolated_users == "drop":
+        has = np.zeros(U, dtype=bool)
+        has[u] = True
+        if not has.all():
+            new = np.cumsum(has) - 1
+            u, U = new[u], int(has.sum())
+    elif isolated_users != "keep":
+        raise ValueError("isolated_users: 'drop' or 'keep'")
+    return torch.from_numpy(np.stack([u, i])).to(device), U, I
+
+
+def cluster_order(edge, U, I):
+    """(perm_u, perm_i), dataset id -> internal id: a locality order BEYOND the degree order -- items by degree (descending);
+    users by their most popular item (then by degree), so that users who share a hot item sit together; items then re-sorted by
+    their heaviest user's position (ties: by degree).  Real check-in data cluster (a city's users visit that city's places);
+    the generator's independent draws do not (tools/renumber_probe.py measures both)."""
+    dev = edge.device
+    du, di = torch.bincount(edge[0], minlength=U), torch.bincount(edge[1], minlength=I)
+    rank_i = torch.empty(I, dtype=torch.long, device=dev)
+    rank_i[torch.argsort(di, descending=True, stable=True)] = torch.arange(I, device=dev)
+    best = torch.full((U,), I, dtype=torch.long, device=dev).scatter_reduce(0, edge[0], rank_i[edge[1]], "amin")
+    order_u = torch.argsort(best * (int(du.max()) + 1) + (int(du.max()) - du), stable=True)       # by hottest item, then by degree
+    perm_u = torch.empty(U, dtype=torch.long, device=dev)
+    perm_u[order_u] = torch.arange(U, device=dev)
+    first = torch.full((I,), U, dtype=torch.long, device=dev).scatter_reduce(0, edge[1], perm_u[edge[0]], "amin")
+    order_i = torch.argsort(first * (int(di.max()) + 1) + (int(di.max()) - di), stable=True)
+    perm_i = torch.empty(I, dtype=torch.long, device=dev)
+    perm_i[order_i] = torch.arange(I, device=dev)
+    return perm_u, perm_i
+
+
+def rcm_order(edge, U, I):
+    """(perm_u, perm_i) from a reverse Cuthill-McKee order of the bipartite graph (scipy, host): neighbours get nearby numbers."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    u, i = edge[0].cpu().numpy(), edge[1].cpu().numpy() + U
+    N = U + I
+    a = sp.coo_matrix((np.ones(2 * len(u), dtype=np.int8), (np.concatenate([u, i]), np.concatenate([i, u]))), shape=(N, N)).tocsr()
+    order = reverse_cuthill_mckee(a, symmetric_mode=True).astype(np.int64)        # position -> node
+    pos = np.empty(N, dtype=np.int64)
+    pos[order] = np.arange(N)
+    perm_u = np.argsort(np.argsort(pos[:U], kind="stable"), kind="stable")
+    perm_i = np.argsort(np.argsort(pos[U:], kind="stable"), kind="stable")
+    return torch.from_numpy(perm_u).to(edge.device), torch.from_numpy(perm_i).to(edge.device)
 
 
 def workload_graph(name, device, seed=2019):
     """[2,E] indices of a named bench workload.  Gowalla / Yelp scale: synthetic_bipartite (the graphs of round 1);
     ml100k: the real file; synthetic200m / synthetic1b: the chunked generator (same graph at every GPU count)."""
     U, I, E = SHAPES[name]
+    if name in REAL_WORKLOADS:
+        return real_graph(name, device)[0]
     if name == "ml100k":
         u, i, _ = load_ml100k()
         return torch.from_numpy(ui_mat_indices(u, i, I)).to(device)

@@ -195,12 +195,18 @@ def test_bf16_train_mode_fixed_masks_vs_float64_oracle(dev):
 # ---------------------------------------------------------------------------------------------------------
 # (b) Gowalla / Yelp scale, full size, all three stages, forward + every gradient
 # ---------------------------------------------------------------------------------------------------------
-def _full_size_check(dev, workload, dt, d=64, stages=3):
+def _full_size_check(dev, workload, dt, d=64, stages=3, renumber=False):
     import ngacf_amd
     from ngacf_amd import data as D
     U, I, E = D.SHAPES[workload]
-    edge = D.synthetic_bipartite(U, I, E, seed=2019, device=dev)
-    assert abs(edge.shape[1] - E) < 0.01 * E
+    if workload in D.REAL_WORKLOADS:                   # the reference's own interaction lists (test halves), under the ingest's numbering
+        edge, U, I = D.real_graph(workload, dev)
+        if renumber:
+            edge = D.renumber(edge, *D.degree_order(edge, U, I))
+        assert edge.shape[1] == E and (U, I) == D.SHAPES[workload][:2]
+    else:
+        edge = D.synthetic_bipartite(U, I, E, seed=2019, device=dev)
+        assert abs(edge.shape[1] - E) < 0.01 * E
     torch.manual_seed(5)
     if stages == 3 and d == 64:
         m = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev).train()
@@ -260,6 +266,28 @@ def test_full_size_three_stage_stack_forward_and_gradients(dev, workload, dt):
     """BASELINE configs 1 and 2 at their full shapes: SPUIMultiGACF (L=3) propagation, B=2048 pair scores, BPR loss and
     the gradient of every parameter (both embedding tables, 3 x {W, a}) against the float64 statement + torch autograd."""
     _full_size_check(dev, workload, dt)
+
+
+@pytest.mark.parametrize("workload,renumber", [("gowalla_real", False), ("gowalla_real", True), ("yelp_real", True)])
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_real_topology_three_stage_stack_forward_and_gradients(dev, workload, renumber, dt):
+    """The same full-stack check on REAL topology: the interaction lists the reference ships (data/Gowalla/g_test.csv: 217 242
+    pairs, a 895-edge item, 2 435 isolated items; data/Yelp/y_test.csv: 253 578 pairs), fixtures tests/golden/*_test_pairs.npz --
+    real hubs, real isolated items, under the data set's ids and under the ingest's degree numbering."""
+    _full_size_check(dev, workload, dt, renumber=renumber)
+
+
+def test_real_yelp_test_half_has_a_user_without_a_pair_and_the_plan_refuses_it(dev):
+    """SPUIGACF.py:368 asserts that every user has an edge; the Yelp test half has one user without any.  Kept in the id space, the
+    plan build raises (the reference would fail its assert in the first layer); real_graph() drops such users by default."""
+    from ngacf_amd import data as D
+    from ngacf_amd.plan import build_plan
+    edge, U, I = D.real_graph("yelp_real", dev, isolated_users="keep")
+    assert U == 45919 and int(torch.bincount(edge[0], minlength=U).eq(0).sum()) == 1
+    with pytest.raises(ValueError):
+        build_plan(edge, U, I)
+    e2, U2, _ = D.real_graph("yelp_real", dev)
+    assert U2 == U - 1 and e2.shape == edge.shape and int(torch.bincount(e2[0], minlength=U2).min()) >= 1
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
