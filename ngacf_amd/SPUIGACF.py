@@ -518,6 +518,11 @@ class _CFBase(nn.Module):
         uidx, iidx, features = self.getFeatureMat()
         return self.gat(uidx, iidx, features, squeeze_mask(mask), needed, score)        # :42-46
 
+    def score_table(self, mask):
+        """The [U + I, w] table whose rows' dot products are the model's scores (SPUIGACF.py:49-52): the propagated features
+        (evaluation ranks every item against it once)."""
+        return self.propagate(mask)
+
     def _sparse_batch(self, userIdx, n_item_lists):
         """Does the batch list few enough rows for the rows-only last stage to pay?  (a host-side decision)"""
         _refuse_replica(self)
@@ -611,7 +616,8 @@ class SPUIGAGPCF(_CFBase):
             self._prop = StaticPropagation(r.to(dev), c.to(dev), v.to(dev).float(), self.userNum + self.itemNum)
         return self._prop
 
-    def forward(self, userIdx, itemIdx, mask):
+    def score_table(self, mask):
+        """SPUIGACF.py:160-167: the GAT's features and every GP layer's output side by side ([U + I, 64 + sum(layers)])."""
         features = self.propagate(mask).float()
         prop = self._propagation(features.device)
         final = [features]
@@ -620,7 +626,10 @@ class SPUIGAGPCF(_CFBase):
                 raise ValueError("GPLayer widths must be 64 or 128 on the accelerated path")
             features = torch.relu(aff(gp(features, prop, True)))          # :164-165
             final.append(features)
-        final = torch.cat(final, dim=1)                                   # :167
+        return torch.cat(final, dim=1)                                    # :167
+
+    def forward(self, userIdx, itemIdx, mask):
+        final = self.score_table(mask)
         return torch.sum(final[userIdx] * final[itemIdx + self.userNum], dim=1)
 
 

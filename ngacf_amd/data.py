@@ -224,8 +224,8 @@ def ui_mat_indices(user_ids, item_ids, I):
     return np.stack([key // I, key % I])
 
 
-def load_ml100k(path=None):
-    """(userId, itemId, rating) zero-based, in file order.  `path` may be the reference's
+def load_ml100k(path=None, with_time=False):
+    """(userId, itemId, rating[, timestamp]) zero-based, in file order.  `path` may be the reference's
     data/1K/u.data (tab separated, data/loadGowalla.py:19-21) or the committed fixture
     tests/golden/ml100k_interactions.npz (same rows, same order)."""
     if path is None:
@@ -233,9 +233,11 @@ def load_ml100k(path=None):
                             "tests", "golden", "ml100k_interactions.npz")
     if path.endswith(".npz"):
         d = np.load(path)
-        return d["userId"].astype(np.int64), d["itemId"].astype(np.int64), d["rating"].astype(np.int64)
+        r = (d["userId"].astype(np.int64), d["itemId"].astype(np.int64), d["rating"].astype(np.int64))
+        return r + (d["timestamp"].astype(np.int64),) if with_time else r
     raw = np.loadtxt(path, dtype=np.int64, delimiter="\t")
-    return raw[:, 0] - 1, raw[:, 1] - 1, raw[:, 2]
+    r = (raw[:, 0] - 1, raw[:, 1] - 1, raw[:, 2])
+    return r + (raw[:, 3],) if with_time else r
 
 
 def algorithmic_bytes_stage(U, I, E, din, dout, elem_bytes):

@@ -10,6 +10,13 @@
                                                of graphattention/metrics.py incl. the NDCG quirk
                                                (:63-73), sums divided by the number of *train* users (:283)
 
+  train_neg_sample  train_eval_Gowalla.py:36-88  --train_mode NegSampling: per train row its item (label 1) and 4 sampled
+                                               negatives (label 0) from item pool - ALL the user's positives
+                                               (loadGowalla.py:63-67,79-83); BCEWithLogitsLoss; total_loss / rows
+  eval_neg_sample   train_eval_Gowalla.py:193-259  --eval_mode SampledNeg: per test row its item and 99 sampled negatives,
+                                               top-10 of the 100 scores, HR / NDCG (graphattention/evaluation.py:4-13)
+  split_loo         data/loadGowalla.py:307-313   the leave-one-out split those two modes use on ml100k / ml1m
+
 What changes is where the work happens: the per-user negative `set`s (the 60-100 GB of README.md:19,25)
 become a sorted key array + rejection sampling on the device, and the evaluation computes the propagated
 embeddings once (the reference recomputes a bit-identical propagation for every 64 x 2048 score block).
@@ -66,6 +73,16 @@ class Interactions:
         self.test_ptr = torch.zeros(U + 1, dtype=torch.long, device=dev)
         self.test_ptr[1:] = torch.cumsum(torch.bincount(tu, minlength=U), 0)
         self.test_items = self.test_keys % I
+
+    def all_positives(self):
+        """CSR of every user's positives over train and test (positives_negtives(rt), data/loadGowalla.py:63-67): what the
+        NegSampling / SampledNeg modes draw their negatives away from.  (ptr int64 [U+1], items int32)"""
+        if getattr(self, "_allpos", None) is None:
+            key = torch.unique(torch.cat([self.train_keys, self.test_keys]))
+            ptr = torch.zeros(self.U + 1, dtype=torch.long, device=self.device)
+            ptr[1:] = torch.cumsum(torch.bincount(key // self.I, minlength=self.U), 0)
+            self._allpos = (ptr, (key % self.I).to(torch.int32))
+        return self._allpos
 
     def adjacency(self):
         """`ui_mat` indices over train ∪ test, coalesced (data/loadGowalla.py:184-253, run_Gowalla.py:82,94)."""
@@ -204,7 +221,7 @@ def eval_neg_all(model, batch_size, data, adj, user_batch=1 << 20, return_scores
     propagated table and the metric sums are added over the ranks (ngacf_amd/sharded_loop.py); topk: stand-in for
     ops.eval_topk with the same signature (the CPU tests of the loop logic; the product never passes it)."""
     model.eval()
-    F = model.propagate(adj).contiguous()                             # once: eval mode is deterministic
+    F = getattr(model, "score_table", model.propagate)(adj).contiguous()     # once: eval mode is deterministic
     U, I = data.U, data.I
     has_test = (data.test_ptr[1:] - data.test_ptr[:-1]) > 0
     has_train = (data.train_ptr[1:] - data.train_ptr[:-1]) > 0
@@ -214,7 +231,8 @@ def eval_neg_all(model, batch_size, data, adj, user_batch=1 << 20, return_scores
     n_norm = float(data.train_users.numel())
     res = {k: torch.zeros(len(KS), dtype=torch.double, device=data.device) for k in ("precision", "recall", "ndcg", "hit_ratio")}
     kept = []
-    rank_items = topk if topk is not None else ops.eval_topk
+    # (a table wider than the ranking kernel takes -- SPUIGAGPCF's concatenated stage outputs -- is ranked by the torch statement)
+    rank_items = topk if topk is not None else (ops.eval_topk if F.shape[1] in ops.SUPPORTED_D else topk_torch)
     for s in range(0, users.numel(), user_batch):
         ub = users[s:s + user_batch].contiguous()
         # scoring F_u . F_i^T on the matrix cores fused with the top-20 selection (ngacf_eval_topk): candidates =
@@ -242,6 +260,34 @@ def eval_neg_all(model, batch_size, data, adj, user_batch=1 << 20, return_scores
     return out
 
 
+def topk_torch(F, users, U, I, pool_mask, train_ptr, train_items, K=20, chunk=2048):
+    """ops.eval_topk's contract in torch ops (a GEMM, a mask, a stable sort): the K best candidates of every user, candidates =
+    pool - the user's train positives, ties to the lower item id, -1 where fewer than K exist.  Serves score tables of widths the
+    ranking kernel does not take (SPUIGAGPCF's 64 + sum(layers) columns); the headline models never come here."""
+    tops, vals = [], []
+    items = F[U:].float()
+    for s in range(0, users.numel(), chunk):
+        ub = users[s:s + chunk]
+        sc = F[ub].float() @ items.t()
+        sc = sc.masked_fill(~pool_mask.bool()[None, :], float("-inf"))
+        cnt = train_ptr[ub + 1] - train_ptr[ub]
+        rows = torch.repeat_interleave(torch.arange(ub.numel(), device=F.device), cnt)
+        sc[rows, _gather_rows(train_ptr, train_items.long(), ub)] = float("-inf")
+        v, ix = torch.sort(sc, dim=1, descending=True, stable=True)
+        v, ix = v[:, :K], ix[:, :K].to(torch.int32)
+        ix[torch.isinf(v) & (v < 0)] = -1
+        tops.append(ix)
+        vals.append(v)
+    return torch.cat(tops), torch.cat(vals)
+
+
+def _pair_scores(F, u, i, U):
+    """score[b] = F[u[b]] . F[U + i[b]]: ngacf_score_fwd for the widths it takes, the torch statement for wider tables"""
+    if F.shape[1] in ops.SUPPORTED_D and F.is_cuda:
+        return ops.score_fwd(F, u, i, U)
+    return (F[u].float() * F[U + i].float()).sum(1)
+
+
 def _gather_rows(ptr, items, rows):
     """Concatenate CSR rows `rows` without a Python loop."""
     beg, cnt = ptr[rows], ptr[rows + 1] - ptr[rows]
@@ -249,3 +295,120 @@ def _gather_rows(ptr, items, rows):
     start = torch.cumsum(cnt, 0) - cnt
     idx = torch.arange(total, device=ptr.device) - torch.repeat_interleave(start, cnt) + torch.repeat_interleave(beg, cnt)
     return items[idx]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# --train_mode NegSampling / --eval_mode SampledNeg (run_Gowalla.py:163-183; train_eval_Gowalla.py:36-88, :193-259)
+# ---------------------------------------------------------------------------------------------------------
+def split_loo(u, i, t):
+    """data/loadGowalla.py:307-313: per user the row with the latest timestamp is the test row, the others train -- ties go to
+    the row that comes first in the file (pandas rank(method='first', ascending=False)).  Returns (train rows, test rows), both
+    in file order, as index arrays."""
+    u, t = np.asarray(u), np.asarray(t)
+    order = np.lexsort((np.arange(len(u)), -t.astype(np.int64), u))          # by user, then time descending, then file order
+    first = np.ones(len(u), dtype=bool)
+    first[1:] = u[order][1:] != u[order][:-1]
+    test = np.zeros(len(u), dtype=bool)
+    test[order[first]] = True
+    return np.nonzero(~test)[0], np.nonzero(test)[0]
+
+
+def sample_negatives(data, users, k, seed, margin=None):
+    """[n, k] DISTINCT negatives per row, uniform over item pool - all positives of the row's user (random.sample(negative_items,
+    k), loadGowalla.py:81,102): ngacf_sample_pairs draws `margin` candidates per row in one launch (rejection against the user's
+    positives), the first k distinct ones are kept.  Rows that end with fewer than k (a user with fewer than k negatives) are
+    counted in the returned int tensor."""
+    dev = users.device
+    M = margin or (2 * k if k <= 8 else k + max(32, k // 2))
+    ptr, items32 = data.all_positives()
+    rep = users.repeat_interleave(M).contiguous()
+    upn, unres = ops.sample_pairs(rep, 0, rep.numel(), ptr, items32, data.pool_items32, seed)
+    c = upn[2].view(-1, M)
+    dup = torch.zeros_like(c, dtype=torch.bool)
+    for j in range(1, M):                                              # candidate j repeats an earlier one of its row
+        dup[:, j] = (c[:, :j] == c[:, j:j + 1]).any(1)
+    keep = ~dup
+    rank = torch.cumsum(keep, 1)
+    sel = keep & (rank <= k)
+    short = (rank[:, -1] < k).sum() + unres.sum()
+    pos = torch.argsort((~sel).to(torch.int8), dim=1, stable=True)[:, :k]      # the first k kept candidates, in draw order
+    return torch.gather(c, 1, pos), short
+
+
+def train_neg_sample(model, batch_size, data, adj, optim, lossfn=None, generator=None, negatives=None, log_every=0):
+    """One epoch of --train_mode NegSampling (train_eval_Gowalla.py:36-88): sequential batches of train rows; per row the
+    row's item with label 1 and 4 negatives with label 0; predictions = model(u x 5, items) in ONE propagation; BCEWithLogitsLoss
+    (torch's, as the reference's run_Gowalla.py:109; the mean over the 5 B logits); returns total_loss / len(train rows) (:88).
+    negatives: int [rows, 4] to use instead of sampling (tests: the draws a reference run recorded)."""
+    import torch.nn.functional as Fn
+    model.train()
+    n, B = data.train_u.numel(), batch_size
+    seed0 = _epoch_seed(generator, data.device) if negatives is None else 0
+    total = torch.zeros((), device=data.device, dtype=torch.float64)
+    short = torch.zeros((), device=data.device, dtype=torch.long)
+    n_batches = n // B + 1                                            # :48
+    for b in range(n_batches):
+        users, pos = data.train_u[b * B:(b + 1) * B], data.train_i[b * B:(b + 1) * B]
+        if users.numel() == 0:
+            continue
+        if negatives is None:
+            neg, sh = sample_negatives(data, users, 4, seed0 + b * SAMPLE_STRIDE)
+            short += sh
+        else:
+            neg = negatives[b * B:(b + 1) * B].to(data.device).long()
+        items = torch.cat([pos[:, None], neg], 1)                    # (rows, 5): the positive first (:66-68)
+        labels = torch.zeros_like(items, dtype=torch.float32)
+        labels[:, 0] = 1.0
+        u5 = users[:, None].expand_as(items).reshape(-1)             # every user 5 times (:75)
+        optim.zero_grad(set_to_none=True)
+        pred = model(u5.contiguous(), items.reshape(-1).contiguous(), adj)
+        loss = (lossfn or Fn.binary_cross_entropy_with_logits)(pred.float(), labels.reshape(-1))
+        loss.backward()
+        optim.step()
+        total += loss.detach().double()
+        if log_every and b % log_every == 0:
+            print("  batch %d/%d loss %.5f" % (b, n_batches, float(loss.detach())), flush=True)
+    if negatives is None and int(short) != 0:
+        raise RuntimeError("negative sampling: a user has fewer than 4 negatives, or the sampler did not converge")
+    if data.device.type == "cuda":
+        ops.raise_if_bad_indices(data.device)
+    return float(total) / n
+
+
+@torch.no_grad()
+def eval_neg_sample(model, batch_size, data, adj, top_k=10, generator=None, negatives=None):
+    """--eval_mode SampledNeg (train_eval_Gowalla.py:193-259): per test row the row's item and 99 sampled negatives; the row is a
+    hit when its item is among the top_k of the 100 scores, NDCG = 1 / log2(position + 2) (graphattention/evaluation.py:4-13);
+    returns (mean HR, mean NDCG) over the test rows.  The propagation runs ONCE (the reference: once per batch of
+    batch_size // 8 rows, bit-identical each time); the position of the row's item = the number of sampled negatives that score
+    higher (what torch.topk over the 100 scores yields, exact ties aside).
+    negatives: int [rows, 99] to use instead of sampling."""
+    model.eval()
+    F = getattr(model, "score_table", model.propagate)(adj).contiguous()
+    U = data.U
+    users, pos = data.test_u, data.test_i
+    n = users.numel()
+    seed0 = _epoch_seed(generator, data.device) if negatives is None else 0
+    hits = torch.zeros((), dtype=torch.float64, device=data.device)
+    ndcg = torch.zeros((), dtype=torch.float64, device=data.device)
+    short = torch.zeros((), device=data.device, dtype=torch.long)
+    B = max(batch_size // 8, 1)                                       # :197
+    for b in range(0, n, B):
+        ub, pb = users[b:b + B], pos[b:b + B]
+        if negatives is None:
+            neg, sh = sample_negatives(data, ub, 99, seed0 + (b // B) * SAMPLE_STRIDE)
+            short += sh
+        else:
+            neg = negatives[b:b + B].to(data.device).long()
+        items = torch.cat([pb[:, None], neg], 1)                     # (rows, 100)
+        u100 = ub[:, None].expand_as(items).reshape(-1).contiguous()
+        sc = _pair_scores(F, u100, items.reshape(-1).contiguous(), U).view(items.shape)      # ngacf_score_fwd: F_u . F_i
+        place = (sc[:, 1:] > sc[:, :1]).sum(1)                        # negatives ahead of the row's item
+        hit = place < top_k
+        hits += hit.double().sum()
+        ndcg += torch.where(hit, 1.0 / torch.log2(place.double() + 2.0), torch.zeros_like(place, dtype=torch.float64)).sum()
+    if negatives is None and int(short) != 0:
+        raise RuntimeError("negative sampling: a user has fewer than 99 negatives, or the sampler did not converge")
+    if data.device.type == "cuda":
+        ops.raise_if_bad_indices(data.device)
+    return float(hits) / n, float(ndcg) / n

@@ -277,9 +277,7 @@ def g9_g10_ml100k():
     adj = scipySP_torchSP(buildLaplacianMat(rt, U, I, "ui_mat")).coalesce()
     idx = adj.indices().numpy()
     digest = hashlib.sha256(np.ascontiguousarray(idx).tobytes()).hexdigest()
-    # raw interactions in file order (data, small ints) so the GPU box can rebuild everything
-    save("ml100k_interactions", userId=rt["userId"].values.astype(np.int16),
-         itemId=rt["itemId"].values.astype(np.int16), rating=rt["rating"].values.astype(np.int8))
+    ml100k_interactions()
     torch.manual_seed(2019)
     m = R.SPUIGACF(U, I, 64, [64, 64], 0.1, useCuda=False).eval()
     emb = (np.random.RandomState(2019).randn(U + I, 64) * 0.01).astype(np.float32)   # N(0, 0.01^2), :27-28
@@ -606,10 +604,92 @@ def g11_eval_neg_all():
          test_users_order=test_df["userId"].values.astype(np.int32), **out)
 
 
+def ml100k_interactions():
+    """the raw interaction table in file order (data, small ints) so the GPU box can rebuild everything; with the timestamps
+    (split_loo, data/loadGowalla.py:307-313, ranks a user's rows by them)"""
+    import pandas as pd
+    rt = pd.read_table(REF + "/data/1K/u.data", sep="\t", names=["userId", "itemId", "rating", "timestamp"])
+    save("ml100k_interactions", userId=(rt["userId"].values - 1).astype(np.int16), itemId=(rt["itemId"].values - 1).astype(np.int16),
+         rating=rt["rating"].values.astype(np.int8), timestamp=rt["timestamp"].values.astype(np.int32))
+
+
+def g18_neg_sampling_modes():
+    """The reference's OTHER runner modes on fixed score tables (run_Gowalla.py --train_mode NegSampling --eval_mode SampledNeg):
+    its own split_loo (data/loadGowalla.py:307-313), positives_negtives (:63-67), train_neg_sample (train_eval_Gowalla.py:36-88:
+    4 sampled negatives per train row, BCEWithLogitsLoss, total_loss / len(train_df)) and eval_neg_sample (:193-259: 99 sampled
+    negatives per test row, top-10 of the 100 scores, HR / NDCG of graphattention/evaluation.py:4-13) on the ml100k table.
+    The model is a stand-in returning S[u, i] (+ 0 * w, so that the loop's backward and optimizer step have something to do);
+    the negatives the reference's random.sample draws are RECORDED (wrappers around train_neg_sampling / test_neg_sampling), so
+    that another implementation can be fed the same samples.  Shims: Tensor.cuda -> identity, torch.cuda.empty_cache -> no-op,
+    torch.cuda.device_count -> 1, Tensor.backward(ones(1)) on the 0-dim loss -> backward()."""
+    import random
+    import pandas as pd
+    import train_eval_Gowalla as TE
+    from data.loadGowalla import load100KRatings, split_loo, positives_negtives
+    seed = 2019
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)                                     # (the reference leaves `random` unseeded; the draws are recorded anyway)
+    rt = load100KRatings(REF + "/data/1K")
+    U, I = int(rt["userId"].max()), int(rt["itemId"].max())
+    rt["userId"] = rt["userId"] - 1
+    rt["itemId"] = rt["itemId"] - 1
+    train_df, test_df = split_loo(rt)                     # run_Gowalla.py:77
+    pos_neg = positives_negtives(rt)                      # :90
+    A, B = g11_factors(U, I)["cont"]
+    table = (0.25 * (A @ B.T)).astype(np.float32)         # (logits of a few units: the BCE terms are neither 0 nor saturated)
+
+    class Table(torch.nn.Module):
+        def __init__(self, t):
+            super().__init__()
+            self.t = torch.from_numpy(t)
+            self.w = torch.nn.Parameter(torch.zeros(()))
+
+        def forward(self, u, i, adj):
+            return self.t[u, i] + 0.0 * self.w
+    rec = {"train": [], "test": []}
+    real_tr, real_te = TE.train_neg_sampling, TE.test_neg_sampling
+
+    def tr_wrap(df, pn):
+        out = real_tr(df, pn)
+        rec["train"].append(np.stack(out["neg_samples"].values).astype(np.int32))
+        assert (out["userId"].values == df["userId"].values).all() and (out["itemId"].values == df["itemId"].values).all()
+        return out
+
+    def te_wrap(df, pn):
+        out, n = real_te(df, pn)
+        rec["test"].append(np.stack(out["neg_samples"].values).astype(np.int32))
+        assert (out["userId"].values == df["userId"].values).all() and (out["itemId"].values == df["itemId"].values).all()
+        return out, n
+    real = (torch.Tensor.cuda, torch.cuda.empty_cache, torch.cuda.device_count, torch.Tensor.backward)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.empty_cache = lambda: None
+    torch.cuda.device_count = lambda: 1
+    torch.Tensor.backward = lambda self, gradient=None, *a, **k: real[3](self, None if (gradient is not None and self.dim() == 0) else gradient, *a, **k)
+    TE.train_neg_sampling, TE.test_neg_sampling = tr_wrap, te_wrap
+    try:
+        model = Table(table)
+        optim = torch.optim.Adam(model.parameters(), lr=1e-3)
+        train_loss = TE.train_neg_sample(model, 2048, train_df, pos_neg, np.zeros((2, 1), dtype=np.int64), optim, torch.nn.BCEWithLogitsLoss(), False)
+        HR, NDCG = TE.eval_neg_sample(model, 2048, test_df, pos_neg, np.zeros((2, 1), dtype=np.int64), 10, False)
+    finally:
+        torch.Tensor.cuda, torch.cuda.empty_cache, torch.cuda.device_count, torch.Tensor.backward = real
+        TE.train_neg_sampling, TE.test_neg_sampling = real_tr, real_te
+    save("g18_neg_sampling_modes", U=U, I=I, table_seed=7, table_scale=0.25,
+         train_rows=train_df.index.values.astype(np.int32), test_rows=test_df.index.values.astype(np.int32),
+         train_negs=np.concatenate(rec["train"]), test_negs=np.concatenate(rec["test"]),
+         train_loss=np.float64(train_loss), HR=np.float64(HR), NDCG=np.float64(NDCG), batch_size=2048)
+    print("g18: train rows %d, test rows %d, loss %.8f, HR %.6f, NDCG %.6f" % (len(train_df), len(test_df), train_loss, HR, NDCG))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-g11" in sys.argv:
         return g11_eval_neg_all()
+    if "--only-g18" in sys.argv:
+        return g18_neg_sampling_modes()
+    if "--only-ml100k-interactions" in sys.argv:
+        return ml100k_interactions()
     edge = toy_graph()
     U, I = 50, 40
     if "--only-g7c" in sys.argv:
@@ -642,6 +722,7 @@ def main():
     g15_spga_models(edge, U, I)
     g16_gacf_variants(edge, U, I)
     g17_gacf_mlp_heads(edge, U, I)
+    g18_neg_sampling_modes()
 
 
 if __name__ == "__main__":

@@ -509,3 +509,42 @@ def eval_all_items(score_rows, users, train_pos, test_pos, item_pool, n_norm, Ks
         for key in res:
             res[key] += p[key] / n_norm
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# --train_mode NegSampling / --eval_mode SampledNeg on a score table (pinned by fixture g18: the reference's own loops)
+# ---------------------------------------------------------------------------------------------------------
+def neg_sample_epoch_loss(S, users, pos, negs, batch_size):
+    """train_eval_Gowalla.py:36-88 with predictions = S[u, i]: per batch BCEWithLogitsLoss (mean over the rows' 5 logits: the row's
+    item with label 1, its 4 negatives with label 0), summed over the batches and divided by the number of rows (:88)."""
+    S = np.asarray(S, dtype=np.float64)
+    n, total = len(users), 0.0
+    for b in range(n // batch_size + 1):
+        sl = slice(b * batch_size, (b + 1) * batch_size)
+        if len(users[sl]) == 0:
+            continue
+        items = np.concatenate([np.asarray(pos[sl])[:, None], np.asarray(negs[sl])], 1)
+        x = S[np.asarray(users[sl])[:, None], items]
+        y = np.zeros_like(x)
+        y[:, 0] = 1.0
+        total += float(np.mean(np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))))       # BCEWithLogitsLoss, stable form
+    return total / n
+
+
+def sampled_hr_ndcg(S, users, pos, negs, top_k=10):
+    """train_eval_Gowalla.py:193-259 + graphattention/evaluation.py:4-13 with predictions = S[u, i]: the row's item among the
+    top_k of its 100 scores -> hit, NDCG = 1 / log2(index + 2); means over the rows."""
+    S = np.asarray(S, dtype=np.float64)
+    hr, nd = [], []
+    for u, p, ng in zip(users, pos, negs):
+        items = np.concatenate([[p], ng])
+        sc = S[u, items]
+        top = items[np.argsort(-sc, kind="stable")[:top_k]]          # torch.topk's order, exact ties aside
+        if p in top:
+            idx = int(np.nonzero(top == p)[0][0])
+            hr.append(1.0)
+            nd.append(1.0 / np.log2(idx + 2))
+        else:
+            hr.append(0.0)
+            nd.append(0.0)
+    return float(np.mean(hr)), float(np.mean(nd))

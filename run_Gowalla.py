@@ -1,6 +1,15 @@
 #!/usr/bin/env python3
 """Counterpart of the reference's run_Gowalla.py (:41-194) on the HIP path: same flags, same epoch /
-eval / checkpoint cadence, same scalar names.  Additions: --dtype, --stages, --data_root, --synthetic, --renumber.
+eval / checkpoint cadence, same tensorboard scalar names (written when tensorboardX or torch's tensorboard writer is installed:
+loss/train_loss, metrics@K/{precision,recall,ndcg,hit_ratio}, metrics/HR, metrics/NDCG -- :139,149-159).
+Additions: --dtype, --stages, --data_root, --synthetic, --renumber.
+
+Modes (:163-183): --train_mode PairSampling --eval_mode AllNeg (BPR, all-item ranking: the README's commands) and
+--train_mode NegSampling --eval_mode SampledNeg (BCE on 1 + 4 sampled items, HR / NDCG@10 on 1 + 99: ml100k is split leave-one-out,
+:77).  --model SPUIGACF | SPUIMultiGACF | SPUIGAGPCF.  --adj_type: the attention layers read (user, item) pairs, i.e. ui_mat
+(SPUIGACF.py:340-350); SPUIGAGPCF additionally propagates through a Laplacian -- the matrix --adj_type names (mean_adj when it says
+ui_mat).  (The reference's own createModels cannot build SPUIGAGPCF: :101-102 reads an `adj` that is not in scope, and its
+prepareData hands the model ONE index list for both uses.)
 
   python run_Gowalla.py --dataset ml100k --model SPUIGACF --adj_type ui_mat --train_mode PairSampling \
       --eval_mode AllNeg --epochs 2 --eval_every 1 --lr 0.002 --weight_decay 0.000001 --droprate 0.2
@@ -22,7 +31,7 @@ import torch
 
 import ngacf_amd
 from ngacf_amd import checkpoint as CK, data as D, sharded_loop as SL
-from ngacf_amd.train_eval import Interactions, eval_neg_all, train_bpr
+from ngacf_amd.train_eval import Interactions, eval_neg_all, eval_neg_sample, split_loo, train_bpr, train_neg_sample
 
 
 def prepare_data(args, dev):
@@ -35,8 +44,11 @@ def prepare_data(args, dev):
         split = True
     elif args.dataset == "ml100k":
         path = os.path.join(args.data_root, "1K", "u.data") if args.data_root else None
-        u, i, _ = D.load_ml100k(path if path and os.path.exists(path) else None)
+        u, i, _, t = D.load_ml100k(path if path and os.path.exists(path) else None, with_time=True)
         U, I = int(u.max()) + 1, int(i.max()) + 1
+        if args.train_mode == "NegSampling":           # leave-one-out: a user's latest row is the test row (:77, loadGowalla.py:307-313)
+            tr, te = split_loo(u, i, t)
+            return Interactions(u[tr], i[tr], u[te], i[te], U, I, dev, renumber=args.renumber)
         split = True
     elif args.dataset in ("Gowalla", "Yelp"):
         pre = {"Gowalla": "g", "Yelp": "y"}[args.dataset]
@@ -59,7 +71,14 @@ def prepare_data(args, dev):
         return Interactions(u[tr], i[tr], u[te], i[te], U, I, dev, renumber=args.renumber)
 
 
-def create_model(args, U, I, dev):
+def laplacian(args, adj, U, I):
+    """the matrix SPUIGAGPCF's GPLayers propagate through (data/loadGowalla.py:184-227), as COO over the U + I nodes"""
+    from ngacf_amd import spmm
+    kind = "mean_adj" if args.adj_type == "ui_mat" else args.adj_type
+    return {"mean_adj": spmm.mean_adj_coo, "norm_adj": spmm.norm_adj_coo, "plain_adj": spmm.plain_adj_coo}[kind](adj, U, I)
+
+
+def create_model(args, U, I, dev, adj=None):
     kw = dict(embedSize=args.embedSize, layers=args.layers, droprate=args.droprate)
     if args.stages:
         m = ngacf_amd.SPUIStackedGACF(U, I, stages=args.stages, **kw)
@@ -67,6 +86,8 @@ def create_model(args, U, I, dev):
         m = ngacf_amd.SPUIGACF(U, I, **kw)
     elif args.model == "SPUIMultiGACF":
         m = ngacf_amd.SPUIMultiGACF(U, I, **kw)
+    elif args.model == "SPUIGAGPCF":                   # (:101-102)
+        m = ngacf_amd.SPUIGAGPCF(U, I, laplacian(args, adj, U, I), **kw)
     else:
         raise SystemExit("model %s is not on the accelerated path" % args.model)
     m = m.to(dev)
@@ -99,9 +120,11 @@ def main(args):
                "peer stores (NGACF_PEER_GATHER=1)" if model.comm.peer_store else "all-gather"))
         train_fn, eval_fn, save_fn, load_fn = SL.train_bpr, SL.eval_neg_all, SL.save_checkpoint, SL.load_checkpoint
     else:
-        model = create_model(args, data.U, data.I, dev)
+        model = create_model(args, data.U, data.I, dev, adj)
         train_fn, eval_fn, save_fn, load_fn = train_bpr, eval_neg_all, CK.save_checkpoint, CK.load_checkpoint
-    lossfn = ngacf_amd.BPRLoss()
+    pair_mode = args.train_mode == "PairSampling"
+    lossfn = ngacf_amd.BPRLoss() if pair_mode else torch.nn.BCEWithLogitsLoss()      # :104-113
+    writer = summary_writer(args) if rank == 0 else None
     # torch.optim.Adam's arithmetic and state_dict; its step() is one ngacf_adam_step launch with the step counters on the
     # device, so the optimizer step is part of the replayed hipGraph of a batch (train_bpr(graph=True))
     optim = ngacf_amd.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
@@ -120,22 +143,54 @@ def main(args):
     graph = (not args.eager) if not sharded else args.sharded_graph
     for epoch in range(args.resume_from, args.epochs):
         t0 = time.time()
-        loss = train_fn(model, args.batch_size, data, adj, optim, lossfn, gen, graph=graph)
+        if pair_mode:
+            loss = train_fn(model, args.batch_size, data, adj, optim, lossfn, gen, graph=graph and args.model != "SPUIGAGPCF")
+        else:
+            loss = train_neg_sample(model, args.batch_size, data, adj, optim, lossfn, gen)
         torch.cuda.synchronize()
+        if writer is not None:
+            writer.add_scalar("loss/train_loss", loss, epoch)                    # :139
         say("------epoch:{}, train_loss:{:5f}, time consuming:{:.2f}s".format(epoch, loss, time.time() - t0), flush=True)
         if (epoch + 1) % args.save_every == 0:
             save_fn("ckpts/{}_{}_{:03d}.pkl".format(args.model, args.dataset, epoch + 1), model, optim, perm=perm)
         if (epoch + 1) % args.eval_every == 0:
             t0 = time.time()
-            m = eval_fn(model, args.batch_size, data, adj)
-            say("epoch:{} metrics:{}".format(epoch, {k: np.round(v, 5).tolist() if k != "auc" else v for k, v in m.items()}))
+            if args.eval_mode == "AllNeg":
+                m = eval_fn(model, args.batch_size, data, adj)
+                say("epoch:{} metrics:{}".format(epoch, {k: np.round(v, 5).tolist() if k != "auc" else v for k, v in m.items()}))
+                if writer is not None:
+                    for k_i, K in enumerate([1, 5, 10, 20]):                     # :149-154
+                        for name in ("precision", "recall", "ndcg", "hit_ratio"):
+                            writer.add_scalar("metrics@{}/{}".format(K, name), float(m[name][k_i]), epoch)
+            else:
+                HR, NDCG = eval_neg_sample(model, args.batch_size, data, adj, 10, gen)    # :156
+                say("epoch:{}, HR:{:5f}, NDCG:{:5f}".format(epoch, HR, NDCG))
+                if writer is not None:
+                    writer.add_scalar("metrics/HR", HR, epoch)                   # :158-159
+                    writer.add_scalar("metrics/NDCG", NDCG, epoch)
+                m = {"HR": HR, "NDCG": NDCG}
             say("The time of evaluate epoch {:03d} is: {:.2f}s".format(epoch, time.time() - t0), flush=True)
             history.append((epoch, loss, m))
+    if writer is not None:
+        writer.close()
     if sharded:
         import torch.distributed as dist
         model.comm.check()                            # (peer-store transport: no wait ever timed out)
         dist.barrier()
     return history
+
+
+def summary_writer(args):
+    """The reference's SummaryWriter (run_Gowalla.py:120-122: results under ./runs) when a tensorboard writer is installed; None
+    otherwise (tensorboardX is not a dependency of the accelerated path)."""
+    comment = "_DS:{}_M:{}_E:{}_L:{}_lr:{}_wd:{}_dp:{}_rs:{}_parallel:{}".format(
+        args.dataset, args.model, args.embedSize, args.layers, args.lr, args.weight_decay, args.droprate, args.seed, args.parallel)
+    for mod in ("tensorboardX", "torch.utils.tensorboard"):
+        try:
+            return __import__(mod, fromlist=["SummaryWriter"]).SummaryWriter(comment=comment)
+        except Exception:
+            continue
+    return None
 
 
 def parse(argv=None):
@@ -175,8 +230,17 @@ def parse(argv=None):
         import sys
         raise SystemExit("--parallel True (nn.DataParallel replicas, every GPU redoing the whole propagation) is replaced by a node "
                          "partition with one process per GPU.  Run:\n  " + SL.torchrun_command(sys.argv[1:] if argv is None else argv))
-    if a.adj_type != "ui_mat" or a.train_mode != "PairSampling" or a.eval_mode != "AllNeg":
-        raise SystemExit("the accelerated path is --adj_type ui_mat --train_mode PairSampling --eval_mode AllNeg (README.md:13-29)")
+    modes = (a.train_mode, a.eval_mode)
+    if modes not in (("PairSampling", "AllNeg"), ("NegSampling", "SampledNeg")):
+        raise SystemExit("--train_mode / --eval_mode: PairSampling + AllNeg or NegSampling + SampledNeg (the two combinations the "
+                         "reference's prepareData serves, run_Gowalla.py:84-92)")
+    if a.adj_type not in ("ui_mat", "plain_adj", "norm_adj", "mean_adj"):
+        raise SystemExit("--adj_type: ui_mat, plain_adj, norm_adj or mean_adj")
+    if a.adj_type != "ui_mat" and a.model != "SPUIGAGPCF":
+        raise SystemExit("--adj_type %s: the attention layers of %s read (user, item) pairs, i.e. ui_mat (SPUIGACF.py:340-350); the "
+                         "Laplacian variants feed SPUIGAGPCF's static-weight layers" % (a.adj_type, a.model))
+    if SL.in_torchrun() and (modes[0] != "PairSampling" or a.model == "SPUIGAGPCF"):
+        raise SystemExit("under torchrun (node partition): --model SPUIGACF | SPUIMultiGACF with PairSampling + AllNeg")
     return a
 
 

@@ -695,3 +695,86 @@ def test_a_renumbered_run_evaluates_the_same_model_to_the_same_metrics(tmp_path)
         ta, tb = a.eval().propagate(plain.adjacency()), b.eval().propagate(ren.adjacency())
     assert float((tb[:U][ren.perm_u] - ta[:U]).abs().max()) < 2e-5 * float(ta.abs().max())
     assert float((tb[U:][ren.perm_i] - ta[U:]).abs().max()) < 2e-5 * float(ta.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# --train_mode NegSampling / --eval_mode SampledNeg, --model SPUIGAGPCF (run_Gowalla.py:163-183)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_neg_sampling_modes_match_the_references_own_loops_on_a_fixed_score_table():
+    """train_eval.train_neg_sample / eval_neg_sample on the device against the REFERENCE's own train_neg_sample /
+    eval_neg_sample run (fixture g18: its split_loo split of ml100k, a fixed rank-64 score table, the negatives its
+    random.sample drew): the epoch loss and HR / NDCG@10."""
+    from test_oracle_golden import g18_split, g18_table
+    from ngacf_amd.train_eval import Interactions, eval_neg_sample, train_neg_sample
+    dev = torch.device("cuda:0")
+    u, i, t, tr, te, g = g18_split()
+    U, I = int(g["U"]), int(g["I"])
+    A, B, S = g18_table(g)
+    data = Interactions(u[tr], i[tr], u[te], i[te], U, I, dev)
+    St = torch.from_numpy(S).to(dev)
+
+    class Table(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros((), device=dev))
+
+        def forward(self, uu, ii, adj):
+            return St[uu, ii] + 0.0 * self.w
+
+        def propagate(self, adj):                  # the same scores as a table of "propagated embeddings": F_u . F_i = S[u, i]
+            return torch.from_numpy(np.concatenate([A, B]) * np.sqrt(float(g["table_scale"]))).to(dev).float()
+    m = Table()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    loss = train_neg_sample(m, int(g["batch_size"]), data, data.adjacency(), opt, torch.nn.BCEWithLogitsLoss(),
+                            negatives=torch.from_numpy(g["train_negs"]))
+    assert abs(loss - float(g["train_loss"])) < 2e-6 * abs(float(g["train_loss"])), (loss, float(g["train_loss"]))
+    hr, nd = eval_neg_sample(m, int(g["batch_size"]), data, data.adjacency(), 10, negatives=torch.from_numpy(g["test_negs"]))
+    assert abs(hr - float(g["HR"])) < 1e-9 and abs(nd - float(g["NDCG"])) < 1e-6, (hr, nd, float(g["HR"]), float(g["NDCG"]))
+
+
+@pytest.mark.gpu
+def test_sampled_negatives_are_distinct_pool_items_outside_the_users_positives():
+    """sample_negatives (ngacf_sample_pairs candidates, first k distinct kept) = random.sample(negative_items, k) of
+    data/loadGowalla.py:79-83,100-104: k distinct items per row, from the item pool, none of them a positive of the row's user
+    (train or test), different rows / seeds different draws."""
+    from test_oracle_golden import g18_split
+    from ngacf_amd.train_eval import Interactions, sample_negatives
+    dev = torch.device("cuda:0")
+    u, i, t, tr, te, g = g18_split()
+    U, I = int(g["U"]), int(g["I"])
+    data = Interactions(u[tr], i[tr], u[te], i[te], U, I, dev)
+    users = data.test_u[:300]
+    allpos = set(zip(u.tolist(), i.tolist()))
+    for k in (4, 99):
+        neg, short = sample_negatives(data, users, k, 12345)
+        assert int(short) == 0 and neg.shape == (300, k)
+        n = neg.cpu().numpy()
+        assert all(len(set(r.tolist())) == k for r in n)
+        assert bool(data.pool_mask[neg.reshape(-1)].all())
+        assert not any((int(uu), int(x)) in allpos for uu, r in zip(users.cpu().tolist(), n) for x in r)
+        neg2, _ = sample_negatives(data, users, k, 12346)
+        assert not torch.equal(neg, neg2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [["--train_mode", "NegSampling", "--eval_mode", "SampledNeg", "--model", "SPUIGACF"],
+                                   ["--train_mode", "PairSampling", "--eval_mode", "AllNeg", "--model", "SPUIGAGPCF", "--adj_type", "norm_adj"],
+                                   ["--train_mode", "NegSampling", "--eval_mode", "SampledNeg", "--model", "SPUIGAGPCF"]])
+def test_runner_reaches_the_references_other_modes(flags, tmp_path, monkeypatch):
+    """run_Gowalla.py through the modes the reference's argument parser offers beside the README's (run_Gowalla.py:163-183): two
+    ml100k epochs each -- the loss falls, the metrics are those of a model that has learnt something (HR@10 of a random ranking of
+    1 + 99 items is 0.1; Recall@20 of a random ranking of ~1600 items ~0.012)."""
+    import run_Gowalla as RG
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(2019); np.random.seed(2019)
+    args = RG.parse(["--dataset", "ml100k", "--epochs", "2", "--eval_every", "2", "--save_every", "100", "--lr", "0.002",
+                     "--weight_decay", "0.000001", "--droprate", "0.1"] + flags)
+    hist = RG.main(args)
+    assert len(hist) == 1
+    epoch, loss, m = hist[0]
+    assert np.isfinite(loss) and loss > 0
+    if "SampledNeg" in flags:
+        assert 0.25 < m["HR"] <= 1.0 and 0.1 < m["NDCG"] <= m["HR"], m
+    else:
+        assert m["recall"][3] > 0.05 and m["ndcg"][3] > 0.1, m

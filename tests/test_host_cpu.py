@@ -524,3 +524,27 @@ def test_degree_renumbering_is_a_relabelling_and_checkpoints_keep_the_data_sets_
         assert torch.equal(a, b), k
     assert torch.equal(opt2.state[m2.uEmbd.weight]["exp_avg"], opt.state[m.uEmbd.weight]["exp_avg"])
     assert torch.equal(opt2.state[m2.iEmbd.weight]["exp_avg_sq"], opt.state[m.iEmbd.weight]["exp_avg_sq"])
+
+
+def test_runner_flag_combinations_follow_the_references_prepare_data():
+    """run_Gowalla.py's parser: the two mode pairs the reference's prepareData serves (run_Gowalla.py:84-92) are accepted, mixed
+    pairs and Laplacian adjacencies for the attention-only models are refused with a message, SPUIGAGPCF takes every --adj_type."""
+    import run_Gowalla as RG
+    ok = RG.parse(["--train_mode", "NegSampling", "--eval_mode", "SampledNeg"])
+    assert ok.train_mode == "NegSampling" and ok.model == "SPUIGACF"
+    assert RG.parse(["--model", "SPUIGAGPCF", "--adj_type", "mean_adj"]).adj_type == "mean_adj"
+    assert RG.parse(["--model", "SPUIGAGPCF"]).adj_type == "ui_mat"
+    for bad in (["--train_mode", "NegSampling"], ["--eval_mode", "SampledNeg"], ["--adj_type", "norm_adj"], ["--adj_type", "nope"]):
+        with pytest.raises(SystemExit):
+            RG.parse(bad)
+
+
+def test_split_loo_keeps_file_order_and_breaks_timestamp_ties_by_position():
+    """data/loadGowalla.py:307-313: rank(method='first', ascending=False) -- the latest row of a user is the test row; among equal
+    timestamps the row that comes first in the file."""
+    from ngacf_amd.train_eval import split_loo
+    u = np.array([0, 1, 0, 1, 0, 2])
+    i = np.array([5, 6, 7, 8, 9, 1])
+    t = np.array([10, 3, 30, 3, 30, 7])
+    tr, te = split_loo(u, i, t)
+    assert te.tolist() == [1, 2, 5] and tr.tolist() == [0, 3, 4]

@@ -286,3 +286,32 @@ def test_g17_gacfv6_and_gacfv3x():
         got = O.gacf_mlp_scores(p, Lk, g14["u"], g14["item"], U, I, kind)
         ref = g[kind + "_scores"]
         assert np.abs(got - ref).max() < 2e-5 * max(np.abs(ref).max(), 1.0), (kind, np.abs(got - ref).max())
+
+
+def g18_split():
+    """(u, i, t of ml100k in file order, train rows, test rows, fixture) of the reference's own split_loo run."""
+    from ngacf_amd import data as D
+    g = load_golden("g18_neg_sampling_modes")
+    u, i, _, t = D.load_ml100k(with_time=True)
+    return u, i, t, g["train_rows"].astype(np.int64), g["test_rows"].astype(np.int64), g
+
+
+def g18_table(g):
+    A, B = _g11_factors(int(g["U"]), int(g["I"]))["cont"]
+    return A, B, (float(g["table_scale"]) * (A @ B.T)).astype(np.float32)
+
+
+def test_g18_neg_sampling_and_sampled_eval_match_the_references_own_loops():
+    """--train_mode NegSampling / --eval_mode SampledNeg (run_Gowalla.py:163-183): the leave-one-out split (data/loadGowalla.py:
+    307-313), the epoch loss of train_neg_sample (train_eval_Gowalla.py:36-88) and HR / NDCG@10 of eval_neg_sample (:193-259) on a
+    fixed score table and the negatives the reference's run drew -- against the numbers that run printed (fixture g18)."""
+    from ngacf_amd.train_eval import split_loo
+    u, i, t, tr, te, g = g18_split()
+    got_tr, got_te = split_loo(u, i, t)
+    assert np.array_equal(got_tr, tr) and np.array_equal(got_te, te)           # the same rows, in file order
+    _, _, S = g18_table(g)
+    assert g["train_negs"].shape == (len(tr), 4) and g["test_negs"].shape == (len(te), 99)
+    loss = O.neg_sample_epoch_loss(S, u[tr], i[tr], g["train_negs"], int(g["batch_size"]))
+    assert abs(loss - float(g["train_loss"])) < 1e-9 * abs(float(g["train_loss"])) + 1e-12, (loss, float(g["train_loss"]))
+    hr, nd = O.sampled_hr_ndcg(S, u[te], i[te], g["test_negs"], 10)
+    assert abs(hr - float(g["HR"])) < 1e-12 and abs(nd - float(g["NDCG"])) < 1e-12, (hr, nd)
