@@ -420,7 +420,8 @@ int ngacf_timing_end(float* ms, int32_t* tags, int cap);
  * replicate / scatter / gather, parallel.py:94-196): a rank writes its block of a half-table straight into its peers' copies
  * (device pointers mapped through hipIpc) and publishes a counter in each peer's flag word; a consumer waits on its own flag
  * words in front of its traversal.  No collective launch; the epochs live in device memory, so captured graphs replay.
- *   ngacf_peer_alloc / _free      zero-filled device memory owned by the library (hipMalloc): tables and flag words
+ *   ngacf_peer_alloc / _free      zero-filled device memory owned by the library (hipMalloc): the tables
+ *   ngacf_peer_alloc_ctrl         the same, uncached / fine-grained (hipExtMallocWithFlags): the flag words
  *   ngacf_peer_export / _import   64-byte hipIpc handle of such an allocation / the peer's mapping of it (_close unmaps)
  *   ngacf_peer_push   copy every region's src (this rank's block) to dst[0..npeers) (the same block inside each peer's table)
  *                     with system-scope write-through stores; when every workgroup has seen its stores acknowledged, the last
@@ -437,6 +438,9 @@ typedef struct {
     void* dst[NGACF_MAX_PEERS];
 } ngacf_peer_region;
 int ngacf_peer_alloc(uint64_t bytes, void** ptr);
+/* the same as uncached (fine-grained) device memory: the control block -- flag / epoch words that other agents write while this
+ * agent's kernels poll them (coarse-grained memory has no coherence guarantee against remote writes during a kernel) */
+int ngacf_peer_alloc_ctrl(uint64_t bytes, void** ptr);
 int ngacf_peer_free(void* ptr);
 int ngacf_peer_export(const void* ptr, void* handle);
 int ngacf_peer_import(const void* handle, void** ptr);

@@ -105,6 +105,17 @@ extern "C" int ngacf_peer_alloc(uint64_t bytes, void** ptr) {
     return e == hipSuccess ? 0 : static_cast<int>(e);
 }
 
+// The control block (flag words polled by running kernels, written by other agents): fine-grained, uncached device memory --
+// coarse-grained hipMalloc memory has no coherence guarantee against a remote agent's writes while a kernel runs.
+extern "C" int ngacf_peer_alloc_ctrl(uint64_t bytes, void** ptr) {
+    if (!ptr || bytes == 0) return NGACF_E_ARG;
+    hipError_t e = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) return static_cast<int>(e);
+    e = hipMemset(*ptr, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return e == hipSuccess ? 0 : static_cast<int>(e);
+}
+
 extern "C" int ngacf_peer_free(void* ptr) {
     if (!ptr) return NGACF_E_ARG;
     const hipError_t e = hipFree(ptr);

@@ -15,6 +15,8 @@ What has to hold for that, and how it is kept:
                      or, for s = 0, after it has finished pass k, whose last stage needed a block that I sent AFTER my own
                      stage-0 traversals of pass k: with at least two stages a table is never written while its previous
                      content is still being read.  One-stage stacks are refused.
+  control block      the flag / epoch words live in uncached (fine-grained) device memory (ngacf_peer_alloc_ctrl): they are polled
+                     by running kernels while other agents write them.
   visibility         push: system-scope write-through stores -> vmcnt(0) -> last-workgroup ticket -> system-scope store of the
                      epoch per peer (no cache-wide write-back: it would flush the L2 under the traversal running beside it);
                      wait: system-scope loads of the flag words; the traversal is a NEW kernel (its start drops what its caches
@@ -35,6 +37,7 @@ in line on the current stream, no fork); join() brings it back before a pass end
 tools/peer_probe.py); between GPUs it has never run: opt-in (NGACF_PEER_GATHER=1 / peer_store=True).
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -70,32 +73,64 @@ class _Lease:
             b.busy = False
         self.bufs = []
 
-    def __del__(self):
-        self.release()
+    # No __del__: "the k-th acquisition of a key is the k-th buffer on every rank" holds only while buffers return to the pool at
+    # the SAME program points on every rank.  release() is called at such points (the end of a no-grad forward, the backward of
+    # the node that leased them); a lease that is dropped without it (a forward whose backward never runs) keeps its buffers --
+    # a garbage collector returning them at a rank-dependent moment would let ranks pick different buffers, and a peer would
+    # then write into a table that is still being read.  An abandoned lease costs memory and, in a loop, ends in the pool's
+    # "out of flag slots" error: loud, never a silent wrong answer.
 
 
 class PeerComm(Comm):
     peer_store = True
 
-    def __init__(self, part, group=None, device=None, timeout_s=5.0):
+    def __init__(self, part, group=None, device=None, timeout_s=None):
         super().__init__(part, group)
         if part.P - 1 > _lib.MAX_PEERS:
             raise ValueError("peer-store all-gather: at most %d ranks" % (_lib.MAX_PEERS + 1))
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.rank, self.W = part.rank, part.P
+        if timeout_s is None:       # a straggler's plan build, a checkpoint write or a GC pause must not read as "peer lost"
+            timeout_s = float(os.environ.get("NGACF_PEER_TIMEOUT_S", "60"))
+        self._refuse_unvalidated_topology()
         self.others = [r for r in range(self.W) if r != self.rank]
         self.side = torch.cuda.Stream(self.device)
         self.timeout_ticks = int(timeout_s * 100e6)           # s_memrealtime: 100 MHz
         self._bufs, self._pool, self._by_ptr, self._ar = [], {}, {}, {}
         # control block: flags[SLOTS][W] (written by the peers) | sent[SLOTS] | expect[SLOTS] | ticket[SLOTS] | err
-        self._ctrl = self._symmetric(4 * (SLOTS * self.W + 3 * SLOTS + 1))
+        self._ctrl = self._symmetric(4 * (SLOTS * self.W + 3 * SLOTS + 1), ctrl=True)
         self.pushes = 0
+        if self.W > 1:
+            dist.barrier(group=self.group)                    # nobody pushes before every rank has mapped every control block
+
+    def _refuse_unvalidated_topology(self):
+        """The transport has only ever run as several processes on ONE GPU (one L2 serves all writers).  Between GPUs the flag
+        polls and the traversals' reads of peer-written tables rest on memory-model behaviour that is not validated here (xGMI
+        write acknowledgement order; a GPU's L2 against a peer's stores): refused until a two-GPU run of tools/peer_soak.py has
+        passed on the machine -- NGACF_PEER_ALLOW_MULTI_GPU=1 is that operator's statement."""
+        if self.W <= 1:
+            return
+        props = torch.cuda.get_device_properties(self.device)
+        me = (os.uname().nodename, str(getattr(props, "uuid", "")) or "%s/%d" % (props.name, self.device.index))
+        ids = [None] * self.W
+        dist.all_gather_object(ids, me, group=self.group)
+        if len(set(ids)) > 1 and os.environ.get("NGACF_PEER_ALLOW_MULTI_GPU") != "1":
+            raise RuntimeError("peer-store all-gather between different GPUs (%d distinct devices among %d ranks) is not validated: "
+                               "run `python tools/peer_soak.py --world 2` with one rank per GPU on this machine first, then set "
+                               "NGACF_PEER_ALLOW_MULTI_GPU=1; the default transport (RCCL all-gather) needs nothing"
+                               % (len(set(ids)), self.W))
 
     # ---- symmetric memory -------------------------------------------------------------------------------------------------
-    def _symmetric(self, nbytes):
-        """nbytes of zeroed device memory on every rank, each rank holding a mapping of every peer's (collective, host side)."""
+    def _symmetric(self, nbytes, ctrl=False):
+        """nbytes of zeroed device memory on every rank, each rank holding a mapping of every peer's (collective, host side).
+        ctrl: the control block -- uncached (fine-grained) memory, polled by running kernels while peers write it."""
+        if 2 * len(self._bufs) + 1 >= SLOTS:                  # (every buffer owns two flag slots: 2 * index, 2 * index + 1)
+            raise RuntimeError("peer-store pool: out of flag slots (%d buffers; leases dropped without release()?)" % len(self._bufs))
         ptr = ctypes.c_void_p()
-        _lib.check(_lib.lib.ngacf_peer_alloc(nbytes, ctypes.byref(ptr)), "ngacf_peer_alloc")
+        if ctrl:
+            _lib.check(_lib.lib.ngacf_peer_alloc_ctrl(nbytes, ctypes.byref(ptr)), "ngacf_peer_alloc_ctrl")
+        else:
+            _lib.check(_lib.lib.ngacf_peer_alloc(nbytes, ctypes.byref(ptr)), "ngacf_peer_alloc")
         peers = {}
         if self.W > 1:
             h = ctypes.create_string_buffer(_lib.PEER_HANDLE_BYTES)
@@ -134,8 +169,6 @@ class PeerComm(Comm):
         else:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("peer-store table %r first needed inside a stream capture: run one eager pass first" % (key,))
-            if 2 * len(self._bufs) + 1 >= SLOTS:
-                raise RuntimeError("peer-store pool: out of flag slots")
             b = self._symmetric(max(nbytes, 16))
             self._pool[key].append(b)
             self._by_ptr[b.ptr] = b

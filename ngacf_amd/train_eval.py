@@ -36,9 +36,12 @@ class Interactions:
     item pool: the distinct items of train ∪ test (`rt`, run_Gowalla.py:46,85)."""
 
     def __init__(self, train_u, train_i, test_u, test_i, U, I, device, renumber=None):
-        """renumber="degree": users and items get internal ids by degree over train + test (ngacf_amd.data.degree_order) -- every
-        tensor of this object, the adjacency it hands out and hence the model speak the internal numbering; perm_u / perm_i
-        (data set id -> internal id) are kept for whoever has to speak the data set's (checkpoints)."""
+        """renumber="degree": users and items get internal ids by their degree in the TRAIN interactions (ngacf_amd.data.degree_order;
+        the test half must not shape anything the ranking sees: ngacf_eval_topk breaks exact score ties toward the lower internal
+        item id, i.e. toward the item with more train interactions, then the lower data-set id -- the reference breaks them in its
+        sets' iteration order; exact ties need equal fp32 / bf16 dot products) -- every tensor of this object, the adjacency it
+        hands out and hence the model speak the internal numbering; perm_u / perm_i (data set id -> internal id) are kept for
+        whoever has to speak the data set's (checkpoints)."""
         dev = torch.device(device)
         t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.long, device=dev)
         self.U, self.I, self.device = U, I, dev
@@ -47,8 +50,7 @@ class Interactions:
         self.perm_u = self.perm_i = None
         if renumber == "degree":
             from .data import degree_order
-            allp = torch.stack([torch.cat([self.train_u, self.test_u]), torch.cat([self.train_i, self.test_i])])
-            key = torch.unique(allp[0] * I + allp[1])
+            key = torch.unique(self.train_u * I + self.train_i)
             self.perm_u, self.perm_i = degree_order(torch.stack([key // I, key % I]), U, I)
             self.train_u, self.train_i = self.perm_u[self.train_u], self.perm_i[self.train_i]
             self.test_u, self.test_i = self.perm_u[self.test_u], self.perm_i[self.test_i]

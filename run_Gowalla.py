@@ -148,6 +148,8 @@ def main(args):
         else:
             loss = train_neg_sample(model, args.batch_size, data, adj, optim, lossfn, gen)
         torch.cuda.synchronize()
+        if sharded:
+            model.comm.check()                        # (peer-store transport: a timed-out wait means stale rows -- stop before saving / evaluating)
         if writer is not None:
             writer.add_scalar("loss/train_loss", loss, epoch)                    # :139
         say("------epoch:{}, train_loss:{:5f}, time consuming:{:.2f}s".format(epoch, loss, time.time() - t0), flush=True)
@@ -157,6 +159,8 @@ def main(args):
             t0 = time.time()
             if args.eval_mode == "AllNeg":
                 m = eval_fn(model, args.batch_size, data, adj)
+                if sharded:
+                    model.comm.check()
                 say("epoch:{} metrics:{}".format(epoch, {k: np.round(v, 5).tolist() if k != "auc" else v for k, v in m.items()}))
                 if writer is not None:
                     for k_i, K in enumerate([1, 5, 10, 20]):                     # :149-154

@@ -490,10 +490,12 @@ def test_degree_renumbering_is_a_relabelling_and_checkpoints_keep_the_data_sets_
     assert sorted(pu.tolist()) == list(range(U)) and sorted(pi.tolist()) == list(range(I))
     adj, adj_r = plain.adjacency(), ren.adjacency()
     assert torch.equal(adj_r, D.renumber(adj, pu, pi))                                   # the same graph, relabelled, sorted
-    for ids, m in ((adj_r[0], U), (adj_r[1], I)):
+    # hot rows first -- by the degree in the TRAIN interactions: the test half shapes nothing the ranking could see
+    tk = torch.unique(ren.train_u * I + ren.train_i)
+    for ids, m in ((tk // I, U), (tk % I, I)):
         deg = torch.bincount(ids, minlength=m)
-        assert bool((deg[:-1] >= deg[1:]).all())                                         # hot rows first
-    du = torch.bincount(adj[0], minlength=U)
+        assert bool((deg[:-1] >= deg[1:]).all())
+    du = torch.bincount(torch.unique(plain.train_u * I + plain.train_i) // I, minlength=U)
     inv_u = CK._inverse(pu)
     same = du[inv_u][:-1] == du[inv_u][1:]
     assert bool((inv_u[:-1][same] < inv_u[1:][same]).all())                              # ties keep the data set's order
