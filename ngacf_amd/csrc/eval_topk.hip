@@ -5,17 +5,19 @@
 // written to memory: a wave keeps the running top-K of its 32 users and only scores that beat a user's current
 // K-th best leave the accumulator registers.
 //
-//   workgroup = 32 users x all items, 4 waves; wave w takes the 32-item tiles t = w (mod 4)
+//   workgroup = 32 users x all items, NW waves (1 when the user groups alone fill the chip, else 4); wave w takes the 32-item
+//               tiles t = w (mod NW)
 //   tile      = S[32 users][32 items] by v_mfma_f32_32x32x2_f32 (fp32 table: exact products, fp32 accumulate)
 //               or v_mfma_f32_32x32x16_bf16 (bf16 table: products of bf16 values are exact in fp32 too)
 //   select    = per accumulator register (one user per 32-lane half): score > tau_user; the rare survivors
 //               append THEMSELVES to the user's LDS buffer (K live entries + slack; slot by LDS atomic, no
 //               wave-serial work); when a buffer overflows the wave compacts it: train positives of the user out (first 64 cached in LDS), every entry
 //               ranked against the others in registers, the K best rewritten in order, tau_user raised
-//   finish    = the 4 waves' lists of a user are merged by rank ((score desc, item asc) is a total order)
+//   finish    = the NW waves' lists of a user are merged by rank ((score desc, item asc) is a total order)
 //
 // Items stream in ascending id order inside a wave, so "score > tau" (strict) is exactly the stable descending
 // sort's tie rule; the cross-wave merge compares ids explicitly.
+#include <stdlib.h>
 #include "ngacf_common.hpp"
 
 namespace ngacf {
@@ -24,7 +26,7 @@ typedef __attribute__((ext_vector_type(16))) float tk_f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 tk_bf16x8;
 
 constexpr int TK_MAXK = 32;          // largest K
-constexpr int TK_CAP = 48;           // buffer entries per (wave, user): K live + slack between compactions
+constexpr int TK_CAP = 64;           // buffer entries per (wave, user): K live + slack between compactions (one per lane of the compacting wave)
 constexpr int TK_CACHE = 64;          // train items of a user kept in LDS
 constexpr float TK_NEG = -3.402823466e38f;
 
@@ -52,16 +54,19 @@ __device__ __forceinline__ int64_t tk_user(const TopkArgs& a, int ub) {
     return u < 0 ? 0 : (u >= a.U ? (int64_t)a.U - 1 : u);
 }
 
-template <typename T, int D>
-__global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
+// NW = waves that share one group of 32 users, each taking every NW-th item tile and keeping its own lists (merged at the end).
+// More waves per group = more parallelism per user, but every list pays its own warm-up (the first ~K ln(n / K) items it sees
+// all pass): 4 waves insert ~860 scores per user and compact their lists ~24 times, one wave ~260 and ~8.
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(64 * NW) void eval_topk_kernel(const TopkArgs a) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int NA = BF ? D / 16 : D / 2;        // operand registers (bf16x8 fragments / floats) per row
     // plain (not volatile) LDS arrays: volatile accesses are emitted as system-coherent flat_load/flat_store, an order
     // of magnitude slower than ds_read/ds_write.  In-wave ordering needs nothing more: LDS executes a wave's
     // operations in order and the compiler keeps may-aliasing accesses to one array in program order.
-    __shared__ float l_score[4][32][TK_CAP];
-    __shared__ int l_item[4][32][TK_CAP];
-    __shared__ int l_cnt[4][32];
+    __shared__ float l_score[NW][32][TK_CAP + 1];         // (+1: the 32 users' rows start on different banks)
+    __shared__ int l_item[NW][32][TK_CAP + 1];
+    __shared__ int l_cnt[NW][32];
     __shared__ int c_item[32][TK_CACHE];
     __shared__ int c_deg[32];
     // best K-th-best any of the 4 waves holds for a user, stored one ulp lower: another wave's candidate with exactly
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
     // ---- per-user state: empty lists, the first TK_CACHE train items ---------------------------------------
     if (lane < 32) l_cnt[wave][lane] = 0;
     if (tid < 32) g_tau[tid] = TK_NEG;
-    for (int i = wave; i < 32; i += 4) {
+    for (int i = wave; i < 32; i += NW) {
         const int ub = u0 + i;
         int deg = 0;
         if (ub < a.B) {
@@ -135,12 +140,26 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
         }
         const bool valid = live && !member;
         const unsigned long long vm = __ballot(valid);
+        // rank = entries that beat this one.  Scores first, straight-line over all buffer slots (an entry that does not count
+        // carries the lowest score and outranks nobody: no branch per slot, one v_readlane + compare + add each); equal scores
+        // are rare and settled by item id in a second pass only when some lane saw one.  (The first form -- a loop with a
+        // branch and two v_readlane per slot -- took 2.3 us per compaction, three quarters of the selection's time.)
+        const float s_v = valid ? s_t : TK_NEG;
         int rank = 0;
-        for (int t = 0; t < n; ++t) {
-            if (!((vm >> t) & 1ull)) continue;
-            const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s_t), t));
-            const int i2 = __builtin_amdgcn_readlane(i_t, t);
-            rank += (s2 > s_t || (s2 == s_t && i2 < i_t)) ? 1 : 0;
+        bool tie = false;
+#pragma unroll
+        for (int t = 0; t < TK_CAP; ++t) {
+            const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s_v), t));
+            rank += s2 > s_v ? 1 : 0;
+            tie |= s2 == s_v && t != lane;
+        }
+        if (__ballot(tie && valid) != 0ull) {
+            for (int t = 0; t < n; ++t) {
+                if (!((vm >> t) & 1ull)) continue;
+                const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s_t), t));
+                const int i2 = __builtin_amdgcn_readlane(i_t, t);
+                rank += (s2 == s_t && i2 < i_t) ? 1 : 0;
+            }
         }
         const int nvalid = __popcll(vm);
         const int ncnt = nvalid < K ? nvalid : K;
@@ -155,47 +174,89 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
         return ncnt;
     };
 
-#pragma unroll 1
-    for (int tile = wave; tile < ntiles; tile += 4) {
-        const int j = tile * 32 + col;
-        const bool jv = j < a.I;
-        const int jj = jv ? j : a.I - 1;
+    // The item rows of the wave's NEXT tile are requested before the current tile is multiplied and sifted: the loop used to
+    // issue its loads, wait a full L2 round trip, and only then compute -- with two waves per SIMD (the lists' LDS) nothing hid
+    // that wait, and a tile cost ~5 us of wall time against ~0.3 us of matrix-core and vector work.
+    struct TileOps {
+        tk_bf16x8 bb[BF ? NA : 1];
+        float bfv[BF ? 1 : NA];
+        int j;
+        bool cand;
+    };
+    auto fetch = [&](int tile, TileOps& t) {
+        t.j = tile * 32 + col;
+        const bool jv = t.j < a.I;
+        const int jj = jv ? t.j : a.I - 1;
         const T* irow = items + (size_t)jj * D;
-        const bool cand = jv && a.pool[jj] != 0;
-        tk_f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        t.cand = jv && a.pool[jj] != 0;
         if constexpr (BF) {
-            tk_bf16x8 bb[NA];
 #pragma unroll
-            for (int s = 0; s < NA; ++s) bb[s] = *reinterpret_cast<const tk_bf16x8*>(reinterpret_cast<const uint16_t*>(irow) + 16 * s + 8 * kh);
-#pragma unroll
-            for (int s = 0; s < NA; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[s], bb[s], acc, 0, 0, 0);
+            for (int s = 0; s < NA; ++s) t.bb[s] = *reinterpret_cast<const tk_bf16x8*>(reinterpret_cast<const uint16_t*>(irow) + 16 * s + 8 * kh);
         } else {
-            float bfv[NA];
 #pragma unroll
             for (int s = 0; s < NA; s += 4) {
                 const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(irow) + kh * (D / 2) + s);
-                bfv[s] = v.x; bfv[s + 1] = v.y; bfv[s + 2] = v.z; bfv[s + 3] = v.w;
+                t.bfv[s] = v.x; t.bfv[s + 1] = v.y; t.bfv[s + 2] = v.z; t.bfv[s + 3] = v.w;
             }
+        }
+    };
+    // Software pipeline, two tiles deep: while tile k is sifted (vector and LDS work), tile k+1 is on the matrix cores (its
+    // accumulator is not read before the next turn) and tile k+2's rows are on their way from L2.
+    auto multiply = [&](const TileOps& t) -> tk_f32x16 {
+        tk_f32x16 r;
 #pragma unroll
-            for (int s = 0; s < NA; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bfv[s], acc, 0, 0, 0);
+        for (int e = 0; e < 16; ++e) r[e] = 0.f;
+        if constexpr (BF) {
+#pragma unroll
+            for (int s = 0; s < NA; ++s) r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[s], t.bb[s], r, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < NA; ++s) r = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], t.bfv[s], r, 0, 0, 0);
+        }
+        return r;
+    };
+    TileOps ops1, ops2;                                       // operands of tile k+1 (loaded) and k+2 (in flight)
+    ops1.j = 0; ops1.cand = false; ops2.j = 0; ops2.cand = false;
+    if (wave < ntiles) fetch(wave, ops1);
+    if (wave + NW < ntiles) fetch(wave + NW, ops2);
+    tk_f32x16 acc_n = multiply(ops1);
+    int j_n = ops1.j;
+    bool cand_n = ops1.cand;
+#pragma unroll 1
+    for (int tile = wave; tile < ntiles; tile += NW) {
+        const tk_f32x16 acc = acc_n;
+        const int j = j_n;
+        const bool cand = cand_n;
+        ops1 = ops2;
+        if (tile + 2 * NW < ntiles) fetch(tile + 2 * NW, ops2);
+        if (tile + NW < ntiles) {
+            acc_n = multiply(ops1);
+            j_n = ops1.j;
+            cand_n = ops1.cand;
         }
 
         // acc[e] in lane (col, kh) = score(user (e&3) + 8(e>>2) + 4kh, item tile*32 + col)
-        if (((tile - wave) & 28) == 0) {                   // every 8th tile of this wave: what the other waves found
+        if (NW > 1 && (((tile - wave) / NW) & 7) == 0) {   // every 8th tile of this wave: what the other waves found
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int e = 0; e < 16; ++e) tau[e] = fmaxf(tau[e], g_tau[(e & 3) + 8 * (e >> 2) + 4 * kh]);
         }
-        // survivors append themselves to their user's buffer: one LDS atomic for the slot, no wave-serial work
-        unsigned int pend = 0u;                            // bit e: this lane's score of register e found the buffer full
+        // Which of this lane's 16 scores beat their user's threshold?  One bit per register; a tile in which nobody's does (most
+        // tiles, once the lists have filled) is dropped with ONE ballot.
+        unsigned int todo = 0u;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float v = cand ? acc[e] : TK_NEG;
-            const bool pass = v > tau[e];
-            if (__ballot(pass) == 0ull) continue;
-            if (pass) {
+        for (int e = 0; e < 16; ++e) todo |= (acc[e] > tau[e] ? 1u : 0u) << e;
+        if (!cand) todo = 0u;
+        // Survivors append themselves to their user's buffer: one LDS atomic for the slot.  The wave makes as many rounds as its
+        // busiest lane has survivors (one or two), not sixteen: every lane takes its lowest pending register per round.
+        unsigned int pend = 0u;                            // bit e: this lane's score of register e found the buffer full
+        while (__ballot(todo != 0u) != 0ull) {
+            if (todo != 0u) {
+                const int e = __builtin_ctz(todo);
+                todo &= todo - 1u;
+                float v = acc[0];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) v = e == k ? acc[k] : v;
                 const int ui = (e & 3) + 8 * (e >> 2) + 4 * kh;
                 const int pos = atomicAdd(&l_cnt[wave][ui], 1);
                 if (pos < TK_CAP) {
@@ -225,7 +286,7 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 if (!(pend & (1u << e))) continue;
-                const float v = cand ? acc[e] : TK_NEG;
+                const float v = acc[e];                    // (cand holds: the bit was set)
                 pend &= ~(1u << e);
                 if (v > tau[e]) {
                     const int ui = (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -250,7 +311,7 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
     __syncthreads();
 
     // ---- merge the 4 waves' lists of each user by rank ----------------------------------------------------------
-    for (int ui = wave; ui < 32; ui += 4) {
+    for (int ui = wave; ui < 32; ui += NW) {
         const int ub = u0 + ui;
         if (ub >= a.B) continue;
         const int64_t uraw = a.users[ub];
@@ -264,15 +325,15 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const TopkArgs a) {
         }
         int total = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) total += l_cnt[w][ui];
+        for (int w = 0; w < NW; ++w) total += l_cnt[w][ui];
 #pragma unroll 1
-        for (int c = lane; c < 4 * TK_MAXK; c += 64) {
+        for (int c = lane; c < NW * TK_MAXK; c += 64) {
             const int w = c / TK_MAXK, p = c % TK_MAXK;     // compacted lists hold at most K <= TK_MAXK entries
             if (p >= l_cnt[w][ui]) continue;
             const float s = l_score[w][ui][p];
             const int it = l_item[w][ui][p];
             int rank = 0;
-            for (int w2 = 0; w2 < 4; ++w2) {
+            for (int w2 = 0; w2 < NW; ++w2) {
                 const int n2 = l_cnt[w2][ui];
                 for (int p2 = 0; p2 < n2; ++p2) {
                     const float s2 = l_score[w2][ui][p2];
@@ -307,12 +368,25 @@ extern "C" int ngacf_eval_topk(const void* F, int dtype, const int64_t* users, i
     a.F = F; a.users = users; a.pool = pool_mask; a.train_ptr = train_ptr; a.train_items = train_items;
     a.top_items = top_items; a.top_scores = top_scores; a.bad = bad_index; a.B = B; a.U = U; a.I = I; a.K = K;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((B + 31) / 32), block(256);
-    if (dtype == NGACF_F32 && d == 64) hipLaunchKernelGGL((eval_topk_kernel<float, 64>), grid, block, 0, st, a);
-    else if (dtype == NGACF_F32 && d == 128) hipLaunchKernelGGL((eval_topk_kernel<float, 128>), grid, block, 0, st, a);
-    else if (dtype == NGACF_BF16 && d == 64) hipLaunchKernelGGL((eval_topk_kernel<bf16_t, 64>), grid, block, 0, st, a);
-    else if (dtype == NGACF_BF16 && d == 128) hipLaunchKernelGGL((eval_topk_kernel<bf16_t, 128>), grid, block, 0, st, a);
+    static const int nw_env = getenv("NGACF_TOPK_WAVES") ? atoi(getenv("NGACF_TOPK_WAVES")) : 0;
+    // waves per group of 32 users: one list per user (1) as long as the groups alone fill the chip's 1024 SIMDs; small user
+    // batches split every group's items over 2 or 4 waves instead
+    const int groups = (B + 31) / 32;
+    // (measured, 29 858 users x 40 981 items, bf16 / fp32: 4 waves 2.18 / 3.33 ms, 2 waves 2.63 / 4.83 ms, 1 wave 1.85 / 2.99 ms)
+    const int nw = nw_env == 1 || nw_env == 2 || nw_env == 4 ? nw_env : (groups >= 768 ? 1 : 4);
+    const dim3 grid(groups), block(64 * nw);
+#define NGACF_TK(T, D)                                                                                        \
+    do {                                                                                                      \
+        if (nw == 1) hipLaunchKernelGGL((eval_topk_kernel<T, D, 1>), grid, block, 0, st, a);                  \
+        else if (nw == 2) hipLaunchKernelGGL((eval_topk_kernel<T, D, 2>), grid, block, 0, st, a);             \
+        else hipLaunchKernelGGL((eval_topk_kernel<T, D, 4>), grid, block, 0, st, a);                          \
+    } while (0)
+    if (dtype == NGACF_F32 && d == 64) NGACF_TK(float, 64);
+    else if (dtype == NGACF_F32 && d == 128) NGACF_TK(float, 128);
+    else if (dtype == NGACF_BF16 && d == 64) NGACF_TK(bf16_t, 64);
+    else if (dtype == NGACF_BF16 && d == 128) NGACF_TK(bf16_t, 128);
     else return NGACF_E_SHAPE;
+#undef NGACF_TK
     NGACF_CHECK_LAUNCH();
     return 0;
 }
