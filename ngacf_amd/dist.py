@@ -706,6 +706,14 @@ def scaling_probe(args, world, rank, dev, d=64):
         except Exception as e:                                     # the eager number stands
             import sys
             print("[bench] probe capture not used: %r" % (e,), file=sys.stderr, flush=True)
+    ag = None
+    if world > 1:                                       # the measured all-gather receive rate beside the 340 GB/s that >= 6 x needs
+        try:
+            with torch.no_grad():
+                ag = allgather_summary(allgather_timing(model, fwd, 2, not args.no_overlap), "RCCL all-gather (in place)")
+        except Exception as e:                          # (a secondary figure must not cost the probe)
+            import sys
+            print("[bench] probe all-gather timing failed: %r" % (e,), file=sys.stderr, flush=True)
     stage_ms = sum(durs) / 3 / L
     bytes_stage = local_edges * (4 + d * elem) + n_local * (2 * d * elem + 8)
     achieved = -allmax(-bytes_stage / (stage_ms * 1e-3) / 1e9)
@@ -725,7 +733,37 @@ def scaling_probe(args, world, rank, dev, d=64):
             "launch": launch, "ms_per_pass_eager": round(1e3 * t_eager / K, 3), "dtype": args.dtype,
             "prop_fwd_GBps_slowest_rank": round(achieved, 1), "prop_fwd_frac_of_hbm_peak": round(achieved / BK.HBM_PEAK_GBS, 4),
             "stage_kernel_ms": round(stage_ms, 3), "local_directed_edges": int(local_edges), "setup_s": round(setup_s, 1),
+            "allgather": ag,
             "schedule": "1 GPU" if world == 1 else ("pipelined half-table all-gathers" if not args.no_overlap else "serial all-gathers")}
+
+
+NEEDED_RECEIVE_GBPS_FOR_6X = 340.0        # DESIGN.md section 6: >= 6 x at 8 GPUs on the 10^9-edge graph needs this all-gather receive rate per GPU
+
+
+def allgather_timing(model, fwd, n_passes, restore_overlap):
+    """[(ms from start to wait, bytes this rank received)] of every half-table all-gather of `n_passes` SERIAL forward passes
+    (each gather waited for right behind its start: Comm.timer) -- the measured receive rate the multi-GPU projection rests on."""
+    comm = model.comm
+    comm.overlap, comm.timer = False, []
+    try:
+        for _ in range(n_passes):
+            fwd()
+        torch.cuda.synchronize()
+        return [(a.elapsed_time(b), nb) for a, b, nb in comm.timer]
+    finally:
+        comm.overlap, comm.timer = restore_overlap, None
+
+
+def allgather_summary(ag, transport):
+    """the `allgather` sub-dict of a bench line from allgather_timing()'s records"""
+    if not ag:
+        return None
+    ms = sum(x for x, _ in ag) / len(ag)
+    nb = sum(b for _, b in ag) / len(ag)
+    rate = nb / max(ms * 1e-3, 1e-12) / 1e9
+    return {"avg_us_serial": round(ms * 1e3, 2), "avg_bytes_received_per_rank": int(nb), "GBps_received_per_rank": round(rate, 1),
+            "needed_GBps_for_6x_at_8_gpus_on_1e9_edges": NEEDED_RECEIVE_GBPS_FOR_6X, "transport": transport,
+            "note": "one async all-gather per half-table per stage; serial-pass duration start -> wait on this rank"}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -806,12 +844,7 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
                 fwd()
             torch.cuda.synchronize()
         durs = kt.durations_ms()
-        model.comm.overlap, model.comm.timer = False, []
-        for _ in range(n_probe):
-            fwd()
-        torch.cuda.synchronize()
-        ag = [(a.elapsed_time(b), nb) for a, b, nb in model.comm.timer]
-        model.comm.overlap, model.comm.timer = not args.no_overlap, None
+        ag = allgather_timing(model, fwd, n_probe, not args.no_overlap)
     n_launch = len(durs) // n_probe                                          # 2 half-launches per stage
     stage_ms = sum(durs) / n_probe / L                                       # both halves of a stage
     local_edges = plan.n_edges_directed
@@ -826,13 +859,10 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
                 "applicable_roof_GBps": regime["roof_GBps"], "frac_of_applicable_roof": round(achieved / regime["roof_GBps"], 4),
                 "bytes_per_stage_per_rank": int(bytes_stage), "avg_stage_kernel_us": round(stage_ms * 1e3, 2),
                 "launches_per_forward": n_launch, "local_directed_edges": int(local_edges),
-                "allgather": {"per_forward": launches_fwd, "avg_us_serial": round(ag_ms * 1e3, 2),
-                              "avg_bytes_received_per_rank": int(ag_bytes),
-                              "GBps_received_per_rank": round(ag_bytes / max(ag_ms * 1e-3, 1e-12) / 1e9, 1) if ag else None,
-                              "transport": "peer stores through hipIpc-mapped tables + flag words (NGACF_PEER_GATHER=1)"
-                                           if model.comm.peer_store else "RCCL all-gather (in place)",
-                              "note": "one async all-gather per half-table per stage; serial-pass duration start -> wait, "
-                                      "rank 0 (collective transport only)"}}
+                "allgather": dict(allgather_summary(ag, "peer stores through hipIpc-mapped tables + flag words (NGACF_PEER_GATHER=1)"
+                                                         if model.comm.peer_store else "RCCL all-gather (in place)") or
+                                  {"avg_us_serial": round(ag_ms * 1e3, 2), "avg_bytes_received_per_rank": int(ag_bytes), "GBps_received_per_rank": None},
+                                  per_forward=launches_fwd)}
     extra = {"ms_per_pass_eager": round(1e3 * t_eager / args.steps / R, 5), "roofline": roofline}
     model.comm.check()                            # (peer stores: no wait has timed out so far)
 
