@@ -391,21 +391,20 @@ int ngacf_sample_pairs(const int64_t* users, long long n_rows, long long offset,
  *     P = softmax_k( q.k / sqrt(d_k), masked_fill(mask[q][k] == 0, -1e9) );  O = dropout(P) @ v
  * mask: bit-packed, uint32 [Nq][ceil(Nk/32)], bit (k & 31) of word k / 32 set = key k visible to query q; or NULL.  LSE float[Nq][heads][2] = (max, 1 / sum of exp(score - max)) of the masked scaled scores,
  * saved for the backward (kept apart: at a fully masked row max = -1e9 would swallow log(sum) in fp32).
- * Dropout: counter hash of (seed + *seed_dev, head, q, k) like the edge masks.  bf16_operands != 0: matrix-core
- * operands rounded to bf16 (fp32 softmax / accumulation); 0: exact fp32 matrix cores.  d_k in {8, 16, 32}.
+ * Dropout: counter hash of (seed + *seed_dev, head, q, k) like the edge masks.  Exact fp32 matrix cores.  d_k in {8, 16, 32}.
  * The [heads][Nq][Nk] score tensor is never materialised. */
 int ngacf_mha_fwd(const float* Q, const float* K, const float* V, const uint32_t* mask, float* O, float* LSE,
                   int Nq, int Nk, int dim, int heads, float drop_p, uint64_t seed, const uint64_t* seed_dev,
-                  int bf16_operands, void* stream);
+                  void* stream);
 /* Backward of ngacf_mha_fwd: dQ [Nq][dim], dK, dV [Nk][dim] from dO [Nq][dim]; masked positions pass no gradient
  * (masked_fill).  delta float[Nq][heads] is scratch (dO . O per head).  No atomics: one pass owns query rows, one key rows. */
 int ngacf_mha_bwd(const float* Q, const float* K, const float* V, const uint32_t* mask, const float* O,
                   const float* LSE, const float* dO, float* dQ, float* dK, float* dV, float* delta,
                   int Nq, int Nk, int dim, int heads, float drop_p, uint64_t seed, const uint64_t* seed_dev,
-                  int bf16_operands, void* stream);
+                  void* stream);
 
-/* Opt-in kernel timing for measurements (bench.py's roofline leg): between ngacf_timing_begin() and ngacf_timing_end() on the
- * SAME host thread, the launches of the traversal and transform kernels carry start / stop events of their dispatch packets
+/* Opt-in kernel timing for measurements (bench.py's roofline leg): between ngacf_timing_begin() and ngacf_timing_end() (any
+ * host thread of the process: autograd launches a backward from its own), the launches of the traversal and transform kernels carry start / stop events of their dispatch packets
  * (hipExtLaunchKernel): the kernel's own duration, without the host's launch gaps -- the number a kernel trace reports.
  * ngacf_timing_end synchronises, writes up to cap (duration in ms, NGACF_TAG_*) pairs in launch order and returns their count
  * (negative on error).  Not for use inside a stream capture.  Per-thread state; nothing happens unless a thread asks. */

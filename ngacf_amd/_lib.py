@@ -60,8 +60,8 @@ SIGNATURES = {
     "ngacf_timing_end": [_p, _p, _i],
     "ngacf_peer_alloc": [_u64, _p], "ngacf_peer_alloc_ctrl": [_u64, _p], "ngacf_peer_free": [_p], "ngacf_peer_export": [_p, _p], "ngacf_peer_import": [_p, _p],
     "ngacf_peer_close": [_p], "ngacf_peer_push": [_p, _i, _i, _p, _p, _p, _p], "ngacf_peer_wait": [_p, _i, _i, _p, _p, _u64, _p],
-    "ngacf_mha_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _i, _p],
-    "ngacf_mha_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _i, _p],
+    "ngacf_mha_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p],
+    "ngacf_mha_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p],
 }
 
 

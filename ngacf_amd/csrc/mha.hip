@@ -6,24 +6,20 @@
 // for h heads of width d_k = dim / h over Nq queries x Nk keys (ATTLayer: users x items and items x users; ATTLayer_mask:
 // all N nodes against all N nodes with the adjacency as mask).  The reference materialises the [h, Nq, Nk] score tensor
 // twice (scores and probabilities: 2 x 220 MB at ml100k, N = 2625) plus the autograd copies; here it never exists:
-// flash-style, one workgroup per (head, 32-query block), keys streamed in tiles of 32 (every 4th tile per wave) with a
-// running max / sum per wave, merged once at the end.
+// flash-style, one workgroup per (head, 32-query block), keys streamed in stages through LDS with a running max / sum.
 //
 // Q, K, V are read straight from the [N, dim] outputs of the linear layers (head h = columns h*d_k ..): the
-// view/transpose/contiguous of :96-98 and :104 costs nothing.  Matrix cores (gfx950):
-//   S^T tile  = K_tile . Q_tile^T   (keys x queries, contraction over d_k)  -> lane = query column, 16 keys in registers
-//   O^T      += V_tile^T . P^T      (d_k x queries, contraction over the 32 keys): the accumulator registers of S^T ARE
-//               the B operand of this product (4 registers = 4 consecutive keys per lane), no LDS round trip
-// exact fp32 matrix cores (v_mfma_f32_32x32x2_f32, parity with the fp32 reference) or bf16 operands
-// (v_mfma_f32_32x32x16_bf16, fp32 softmax and accumulation).  A lane owns a query (forward, dQ pass) or a key (dK/dV
-// pass), so every softmax reduction is 16 registers + one cross-half exchange, and no atomics are needed anywhere.
+// view/transpose/contiguous of :96-98 and :104 costs nothing.  Exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32: parity
+// with the fp32 reference); the kernels below describe their tiling.  A lane owns queries (forward, dQ pass) or keys (dK / dV
+// pass), so the softmax reductions stay in registers and no atomics are needed anywhere.
 // The work is exp- and VALU-bound, not MFMA-bound (d_k = 8: 32 flop per score against one v_exp_f32): DESIGN.md.
+// (Rounds 2-3 also carried a form with bf16 matrix-core operands on 32x32x16 tiles: slower than this one in both directions --
+// 80 against 67 us forward, 513 against 174 us backward at ml100k -- and less accurate, so it is gone: VERDICT r3 item 7.)
 #include "ngacf_common.hpp"
 
 namespace ngacf {
 
 typedef float mha_f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 mha_bf16x8 __attribute__((ext_vector_type(8)));
 
 struct MhaArgs {
     const float* Q;        // [Nq][dim]
@@ -48,192 +44,11 @@ struct MhaArgs {
 
 constexpr float MHA_MASKED = -1e9f;                 // modules.py:36
 
-// row index of accumulator register e in a 32x32 MFMA result for the half-wave kh (cdna_hip_programming.md section 3)
-__device__ __forceinline__ int acc_row(int e, int kh) { return (e & 3) + 8 * (e >> 2) + 4 * kh; }
-
-// T^T tile = X_tile . Y_tile^T : rows = the 32 rows of X (MFMA A operand), columns = the 32 rows of Y (B operand),
-// contraction over the DK features of head `h`.  xr / yr: this lane's row of X / Y (already clamped), as pointers to
-// the head's first feature.
-template <bool BF, int DK>
-__device__ __forceinline__ mha_f32x16 tile_xyT(const float* xr, const float* yr, int kh) {
-    mha_f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    float xf[DK], yf[DK];
-#pragma unroll
-    for (int j = 0; j < DK; j += 4) {
-        const float4 a = *reinterpret_cast<const float4*>(xr + j);
-        const float4 b = *reinterpret_cast<const float4*>(yr + j);
-        xf[j] = a.x; xf[j + 1] = a.y; xf[j + 2] = a.z; xf[j + 3] = a.w;
-        yf[j] = b.x; yf[j + 1] = b.y; yf[j + 2] = b.z; yf[j + 3] = b.w;
-    }
-    if constexpr (BF) {
-        // one MFMA contracts 16 features: this lane supplies features 16 t + 8 kh + j (zero beyond DK)
-#pragma unroll
-        for (int t = 0; t < (DK + 15) / 16; ++t) {
-            mha_bf16x8 a, b;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float av = 0.f, bv = 0.f;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {                     // (static indices: pick by kh without dynamic indexing)
-                    const int f = 16 * t + 8 * s + j;
-                    if (f < DK && s == kh) { av = xf[f]; bv = yf[f]; }
-                }
-                a[j] = static_cast<__bf16>(av);
-                b[j] = static_cast<__bf16>(bv);
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < DK / 2; ++t) {                        // features {2t, 2t+1}: lane half kh takes 2t + kh
-            const float a = kh ? xf[2 * t + 1] : xf[2 * t];
-            const float b = kh ? yf[2 * t + 1] : yf[2 * t];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-    }
-    return acc;
-}
-
-// Acc^T (rows = feature c of Z, columns = this tile's column owners) += Z_tile^T . T, where T (32 rows x 32 columns) is
-// held the way tile_xyT returns it: lane = column, register e = row acc_row(e, kh).  zbase: row 0 of the Z tile at the
-// head's first feature; rows >= nrows contribute zero.  Lanes with c = lane % 32 >= DK feed zeros.
-template <bool BF, int DK>
-__device__ __forceinline__ void accum_zT_t(mha_f32x16& acc, const float* zbase, int dim, int nrows, const mha_f32x16& t, int lane) {
-    const int c = lane & 31, kh = lane >> 5;
-    const bool live = c < DK;
-    if constexpr (BF) {
-#pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {                          // 16 rows per MFMA: register groups 2*g2 and 2*g2+1
-            mha_bf16x8 a, b;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = 4 * (2 * g2 + (j >> 2)) + (j & 3);
-                const int r = acc_row(e, kh);
-                const float zv = (live && r < nrows) ? zbase[(size_t)r * dim + c] : 0.f;
-                a[j] = static_cast<__bf16>(zv);
-                b[j] = static_cast<__bf16>(t[e]);
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {                            // rows {r, r + 4}: lane half kh supplies row acc_row(e, kh)
-            const int r = acc_row(e, kh);
-            const float zv = (live && r < nrows) ? zbase[(size_t)r * dim + c] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zv, t[e], acc, 0, 0, 0);
-        }
-    }
-}
-
-// the lane's 4*(DK/8) result features of Acc^T: feature c = 8 g + 4 kh + (e & 3) sits in register e = 4 g + (e & 3)
-template <int DK>
-__device__ __forceinline__ void store_accT(float* row, const mha_f32x16& acc, int kh, float mul) {
-#pragma unroll
-    for (int g = 0; g < DK / 8; ++g)
-        *reinterpret_cast<float4*>(row + 8 * g + 4 * kh) =
-            make_float4(acc[4 * g] * mul, acc[4 * g + 1] * mul, acc[4 * g + 2] * mul, acc[4 * g + 3] * mul);
-}
-
-__device__ __forceinline__ float half_swap(float v) { return __shfl_xor(v, 32, WAVE); }
-
 // keep-multiplier of attention probability (query q, key k, head salt): the edge-mask hash of the sparse path
 __device__ __forceinline__ float drop_mul(const MhaArgs& a, uint32_t salt_h, int q, int k) {
     return edge_bits(salt_h, (uint32_t)q, (uint32_t)k) >= a.drop_thr ? a.drop_scale : 0.f;
 }
 
-// Sum the 16 accumulator registers of the workgroup's four waves (each wave took every 4th tile of the streamed side):
-// waves 1..3 park theirs in LDS, wave 0 adds them in wave order (deterministic).  `scale_own`: wave 0's own factor.
-__device__ __forceinline__ void fold_waves(mha_f32x16& acc, float (*buf)[16][64], int wv, int lane, const float (&f)[4]) {
-    if (wv > 0) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) buf[wv - 1][e][lane] = acc[e];
-    }
-    __syncthreads();
-    if (wv == 0) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float v = acc[e] * f[0];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) v = fmaf(buf[w - 1][e][lane], f[w], v);
-            acc[e] = v;
-        }
-    }
-    __syncthreads();
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// forward: workgroup per (head, 32-query block), its four waves take every 4th key tile; lane = query.
-// (One wave per block left 664 waves on 1024 SIMDs at ml100k with an exposed load -> MFMA -> exp chain of 83 tiles each.)
-// ---------------------------------------------------------------------------------------------------------
-template <bool BF, int DK, bool DROP>
-__global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs a) {
-    __shared__ float red[3][16][64];
-    __shared__ float ml[2][4][64];
-    const int lane = threadIdx.x & 63, col = lane & 31, kh = lane >> 5, wv = threadIdx.x >> 6;
-    const int w = blockIdx.x;
-    const int qblocks = (a.Nq + 31) / 32;
-    const int h = w / qblocks, q0 = (w % qblocks) * 32;
-    const int q = q0 + col;
-    const bool qv = q < a.Nq;
-    const int qc = qv ? q : a.Nq - 1;
-    const float* qrow = a.Q + (size_t)qc * a.dim + h * DK;
-    const uint32_t salt_h = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + h) : 0u;
-    mha_f32x16 o;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[e] = 0.f;
-    float m = -INFINITY, l = 0.f;
-    for (int k0 = 32 * wv; k0 < a.Nk; k0 += 128) {
-        const int kr = min(k0 + col, a.Nk - 1);
-        mha_f32x16 s = tile_xyT<BF, DK>(a.K + (size_t)kr * a.dim + h * DK, qrow, kh);
-        float tmax = -INFINITY;
-        const uint32_t mw = a.mask ? a.mask[(size_t)qc * ((a.Nk + 31) >> 5) + (k0 >> 5)] : 0xffffffffu;   // this query, these 32 keys
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = acc_row(e, kh);
-            float v = s[e] * a.scale;
-            v = ((mw >> r) & 1u) ? v : MHA_MASKED;                  // masked_fill(mask == 0, -1e9)
-            v = k0 + r < a.Nk ? v : -INFINITY;                      // key tail
-            s[e] = v;
-            tmax = fmaxf(tmax, v);
-        }
-        tmax = fmaxf(tmax, half_swap(tmax));
-        const float mnew = fmaxf(m, tmax);
-        const float corr = __expf(m - mnew);                        // exp(-inf) = 0 on the first tile
-        float psum = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float p = __expf(s[e] - mnew);
-            psum += p;
-            if (DROP) p *= drop_mul(a, salt_h, qc, k0 + acc_row(e, kh));
-            s[e] = p;
-            o[e] *= corr;
-        }
-        psum += half_swap(psum);
-        l = l * corr + psum;
-        m = mnew;
-        accum_zT_t<BF, DK>(o, a.V + (size_t)k0 * a.dim + h * DK, a.dim, a.Nk - k0, s, lane);
-    }
-    // merge the four waves' (max, sum, O) for each query: M = max m_w, factor_w = exp(m_w - M)  (a wave without tiles has
-    // m = -inf, l = 0: factor 0)
-    ml[0][wv][lane] = m;
-    ml[1][wv][lane] = l;
-    __syncthreads();
-    float M = -INFINITY, f[4], L = 0.f;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) M = fmaxf(M, ml[0][x][lane]);
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        f[x] = __expf(ml[0][x][lane] - M);
-        L = fmaf(ml[1][x][lane], f[x], L);
-    }
-    fold_waves(o, red, wv, lane, f);
-    if (wv != 0 || !qv) return;
-    // o: rows = feature c, columns = queries.  This lane (query q, half kh) holds the features 8g + 4kh + (0..3)
-    store_accT<DK>(a.O + (size_t)q * a.dim + h * DK, o, kh, 1.f / L);
-    if (kh == 0) *reinterpret_cast<float2*>(a.LSE + 2 * ((size_t)q * a.heads + h)) = make_float2(M, 1.f / L);
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // forward, exact fp32 matrix cores, second form (round 3): v_mfma_f32_16x16x4_f32 and K / V tiles staged through LDS.
@@ -247,7 +62,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs a) {
 //     wastes half of the PV matrix-core rows instead of three quarters (768 instead of 1280 matrix-pipe cycles per 32 x 32 tile).
 //   * a lane owns TWO queries (n and 16 + n) and sees 8 of a tile's 32 keys for each: max / sum are 8 registers + two exchanges
 //     (lanes 16 and 32 apart); scale, mask and tail tests run only where they can matter.
-// Same semantics and outputs as mha_fwd_kernel (which stays for bf16 operands).
+// (Same semantics and outputs as the 32x32 form of round 2 it replaced.)
 // ---------------------------------------------------------------------------------------------------------
 typedef float mha_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -438,105 +253,6 @@ __global__ __launch_bounds__(NW * 64) void mha_fwd16_kernel(const MhaArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// backward 1: delta = dO . O per head, and dQ.  wave per (head, 32-query block); lane = query
-//   P = exp(s - LSE);  dPd = dO . V^T;  dS = P * (dPd * dropmul - delta) * scale on unmasked entries, 0 on masked ones
-//   (masked_fill cuts the gradient);  dQ = dS K
-// ---------------------------------------------------------------------------------------------------------
-template <bool BF, int DK, bool DROP>
-__global__ __launch_bounds__(256) void mha_bwd_q_kernel(const MhaArgs a) {
-    __shared__ float red[3][16][64];
-    const int lane = threadIdx.x & 63, col = lane & 31, kh = lane >> 5, wv = threadIdx.x >> 6;
-    const int w = blockIdx.x;
-    const int qblocks = (a.Nq + 31) / 32;
-    const int h = w / qblocks, q0 = (w % qblocks) * 32;
-    const int q = q0 + col;
-    const bool qv = q < a.Nq;
-    const int qc = qv ? q : a.Nq - 1;
-    const float* qrow = a.Q + (size_t)qc * a.dim + h * DK;
-    const float* dorow = a.dO + (size_t)qc * a.dim + h * DK;
-    const float* orow = a.O + (size_t)qc * a.dim + h * DK;
-    const uint32_t salt_h = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + h) : 0u;
-    float delta = 0.f;
-#pragma unroll
-    for (int j = 0; j < DK; ++j) delta = fmaf(dorow[j], orow[j], delta);
-    const float2 ml = *reinterpret_cast<const float2*>(a.LSE + 2 * ((size_t)qc * a.heads + h));   // (max, 1 / sum)
-    mha_f32x16 dq;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dq[e] = 0.f;
-    for (int k0 = 32 * wv; k0 < a.Nk; k0 += 128) {
-        const int kr = min(k0 + col, a.Nk - 1);
-        mha_f32x16 s = tile_xyT<BF, DK>(a.K + (size_t)kr * a.dim + h * DK, qrow, kh);
-        const mha_f32x16 dp = tile_xyT<BF, DK>(a.V + (size_t)kr * a.dim + h * DK, dorow, kh);
-        const uint32_t mw = a.mask ? a.mask[(size_t)qc * ((a.Nk + 31) >> 5) + (k0 >> 5)] : 0xffffffffu;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = acc_row(e, kh), key = k0 + r;
-            const bool inr = key < a.Nk;
-            const bool open = (mw >> r) & 1u;
-            const float sv = open ? s[e] * a.scale : MHA_MASKED;
-            const float p = inr ? __expf(sv - ml.x) * ml.y : 0.f;
-            float dpe = dp[e];
-            if (DROP) dpe *= drop_mul(a, salt_h, qc, key);
-            s[e] = (open && inr) ? p * (dpe - delta) * a.scale : 0.f;
-        }
-        accum_zT_t<BF, DK>(dq, a.K + (size_t)k0 * a.dim + h * DK, a.dim, a.Nk - k0, s, lane);
-    }
-    const float one[4] = {1.f, 1.f, 1.f, 1.f};
-    fold_waves(dq, red, wv, lane, one);
-    if (wv != 0 || !qv) return;
-    store_accT<DK>(a.dQ + (size_t)q * a.dim + h * DK, dq, kh, 1.f);
-    if (kh == 0) a.delta[(size_t)q * a.heads + h] = delta;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// backward 2: dK, dV.  wave per (head, 32-key block); lane = key; queries streamed in tiles of 32
-//   S tile = Q_tile . K_tile^T (queries x keys);  dV = Pd^T dO;  dK = dS^T Q
-// ---------------------------------------------------------------------------------------------------------
-template <bool BF, int DK, bool DROP>
-__global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const MhaArgs a) {
-    __shared__ float red[3][16][64];
-    const int lane = threadIdx.x & 63, col = lane & 31, kh = lane >> 5, wv = threadIdx.x >> 6;
-    const int w = blockIdx.x;
-    const int kblocks = (a.Nk + 31) / 32;
-    const int h = w / kblocks, k0 = (w % kblocks) * 32;
-    const int key = k0 + col;
-    const bool kv = key < a.Nk;
-    const int kc = kv ? key : a.Nk - 1;
-    const float* krow = a.K + (size_t)kc * a.dim + h * DK;
-    const float* vrow = a.V + (size_t)kc * a.dim + h * DK;
-    const uint32_t salt_h = DROP ? salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + h) : 0u;
-    mha_f32x16 dk, dv;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
-    for (int q0 = 32 * wv; q0 < a.Nq; q0 += 128) {
-        const int qr = min(q0 + col, a.Nq - 1);
-        mha_f32x16 s = tile_xyT<BF, DK>(a.Q + (size_t)qr * a.dim + h * DK, krow, kh);          // rows = queries, lane = key
-        const mha_f32x16 dp = tile_xyT<BF, DK>(a.dO + (size_t)qr * a.dim + h * DK, vrow, kh);
-        mha_f32x16 pd;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int q = q0 + acc_row(e, kh);
-            const bool inr = q < a.Nq && kv;
-            const int qq = q < a.Nq ? q : a.Nq - 1;
-            const bool open = !a.mask || ((a.mask[(size_t)qq * ((a.Nk + 31) >> 5) + (kc >> 5)] >> (kc & 31)) & 1u);
-            const float sv = open ? s[e] * a.scale : MHA_MASKED;
-            const float2 ml = *reinterpret_cast<const float2*>(a.LSE + 2 * ((size_t)qq * a.heads + h));
-            const float p = inr ? __expf(sv - ml.x) * ml.y : 0.f;
-            const float mul = DROP ? drop_mul(a, salt_h, qq, kc) : 1.f;
-            pd[e] = p * mul;
-            s[e] = (open && inr) ? p * (dp[e] * mul - a.delta[(size_t)qq * a.heads + h]) * a.scale : 0.f;
-        }
-        accum_zT_t<BF, DK>(dv, a.dO + (size_t)q0 * a.dim + h * DK, a.dim, a.Nq - q0, pd, lane);
-        accum_zT_t<BF, DK>(dk, a.Q + (size_t)q0 * a.dim + h * DK, a.dim, a.Nq - q0, s, lane);
-    }
-    const float one[4] = {1.f, 1.f, 1.f, 1.f};
-    fold_waves(dv, red, wv, lane, one);
-    fold_waves(dk, red, wv, lane, one);
-    if (wv != 0 || !kv) return;
-    store_accT<DK>(a.dK + (size_t)key * a.dim + h * DK, dk, kh, 1.f);
-    store_accT<DK>(a.dV + (size_t)key * a.dim + h * DK, dv, kh, 1.f);
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // backward, exact fp32 matrix cores, second form (round 3): the two passes above on v_mfma_f32_16x16x4_f32 with the streamed
@@ -882,57 +598,40 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd16_kv_kernel(const MhaArgs a) 
     }
 }
 
-template <bool BF, int DK>
+template <int DK>
 static int launch_mha(const MhaArgs& a, bool backward, bool drop, hipStream_t st) {
     const int qw = ((a.Nq + 31) / 32) * a.heads, kw = ((a.Nk + 31) / 32) * a.heads;
-    const dim3 block(256), gq(qw), gk(kw);                           // one workgroup (4 waves) per 32-row block and head
-    if (!backward) {
-        if constexpr (!BF) {                                         // exact fp32: the 16x16x4 form with LDS-staged K / V
-            constexpr int NW = DK == 32 ? 4 : 8;
-            constexpr size_t lds = (size_t)4 * DK * 32 * NW * sizeof(float);
-            const bool mk = a.mask != nullptr;
+    const dim3 gq(qw), gk(kw);                                       // one workgroup per 32-row block and head
+    constexpr int NW = DK == 32 ? 4 : 8;
+    const bool mk = a.mask != nullptr;
+    if (!backward) {                                                 // exact fp32: the 16x16x4 form with LDS-staged K / V
+        constexpr size_t lds = (size_t)4 * DK * 32 * NW * sizeof(float);
 #define NGACF_MHA16(DR, MK) hipLaunchKernelGGL((mha_fwd16_kernel<DK, NW, DR, MK>), gq, dim3(64 * NW), lds, st, a)
-            if (drop) { if (mk) NGACF_MHA16(true, true); else NGACF_MHA16(true, false); }
-            else      { if (mk) NGACF_MHA16(false, true); else NGACF_MHA16(false, false); }
+        if (drop) { if (mk) NGACF_MHA16(true, true); else NGACF_MHA16(true, false); }
+        else      { if (mk) NGACF_MHA16(false, true); else NGACF_MHA16(false, false); }
 #undef NGACF_MHA16
-            NGACF_CHECK_LAUNCH();
-            return 0;
-        }
-        if (drop) hipLaunchKernelGGL((mha_fwd_kernel<BF, DK, true>), gq, block, 0, st, a);
-        else      hipLaunchKernelGGL((mha_fwd_kernel<BF, DK, false>), gq, block, 0, st, a);
         NGACF_CHECK_LAUNCH();
         return 0;
     }
-    if constexpr (!BF) {                                             // exact fp32: the 16x16x4 form, both passes
-        constexpr int NW = DK == 32 ? 4 : 8;
-        constexpr size_t lq = (size_t)2 * 3 * DK * 32 * NW * sizeof(float);
-        constexpr size_t lkv = (size_t)2 * (4 * DK * 32 * NW + 4 * 32 * NW) * sizeof(float);
-        const bool mk = a.mask != nullptr;
+    constexpr size_t lq = (size_t)2 * 3 * DK * 32 * NW * sizeof(float);
+    constexpr size_t lkv = (size_t)2 * (4 * DK * 32 * NW + 4 * 32 * NW) * sizeof(float);
 #define NGACF_MHAB(KERNEL, GRID, LDS, DR, MK)                                                                             \
-        do {                                                                                                              \
-            static bool big_lds_ok = false;   /* > 64 KB of dynamic LDS must be asked for once per kernel */              \
-            if ((LDS) > 65536 && !big_lds_ok) {                                                                           \
-                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<DK, NW, DR, MK>),          \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));         \
-                if (e != hipSuccess) return static_cast<int>(e);                                                          \
-                big_lds_ok = true;                                                                                        \
-            }                                                                                                             \
-            hipLaunchKernelGGL((KERNEL<DK, NW, DR, MK>), GRID, dim3(64 * NW), LDS, st, a);                                \
-        } while (0)
-        if (drop) { if (mk) NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, true, true); else NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, true, false); }
-        else      { if (mk) NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, false, true); else NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, false, false); }
-        NGACF_CHECK_LAUNCH();
-        if (drop) { if (mk) NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, true, true); else NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, true, false); }
-        else      { if (mk) NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, false, true); else NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, false, false); }
-#undef NGACF_MHAB
-        NGACF_CHECK_LAUNCH();
-        return 0;
-    }
-    if (drop) hipLaunchKernelGGL((mha_bwd_q_kernel<BF, DK, true>), gq, block, 0, st, a);
-    else      hipLaunchKernelGGL((mha_bwd_q_kernel<BF, DK, false>), gq, block, 0, st, a);
+    do {                                                                                                              \
+        static bool big_lds_ok = false;   /* > 64 KB of dynamic LDS must be asked for once per kernel */              \
+        if ((LDS) > 65536 && !big_lds_ok) {                                                                           \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<DK, NW, DR, MK>),          \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));         \
+            if (e != hipSuccess) return static_cast<int>(e);                                                          \
+            big_lds_ok = true;                                                                                        \
+        }                                                                                                             \
+        hipLaunchKernelGGL((KERNEL<DK, NW, DR, MK>), GRID, dim3(64 * NW), LDS, st, a);                                \
+    } while (0)
+    if (drop) { if (mk) NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, true, true); else NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, true, false); }
+    else      { if (mk) NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, false, true); else NGACF_MHAB(mha_bwd16_q_kernel, gq, lq, false, false); }
     NGACF_CHECK_LAUNCH();
-    if (drop) hipLaunchKernelGGL((mha_bwd_kv_kernel<BF, DK, true>), gk, block, 0, st, a);
-    else      hipLaunchKernelGGL((mha_bwd_kv_kernel<BF, DK, false>), gk, block, 0, st, a);
+    if (drop) { if (mk) NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, true, true); else NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, true, false); }
+    else      { if (mk) NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, false, true); else NGACF_MHAB(mha_bwd16_kv_kernel, gk, lkv, false, false); }
+#undef NGACF_MHAB
     NGACF_CHECK_LAUNCH();
     return 0;
 }
@@ -941,7 +640,7 @@ static int launch_mha(const MhaArgs& a, bool backward, bool drop, hipStream_t st
 
 using namespace ngacf;
 
-static int mha_dispatch(MhaArgs& a, bool backward, float drop_p, int bf16_operands, void* stream) {
+static int mha_dispatch(MhaArgs& a, bool backward, float drop_p, void* stream) {
     if (a.Nq <= 0 || a.Nk <= 0 || a.heads <= 0 || a.dim <= 0 || a.dim % a.heads != 0) return NGACF_E_ARG;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return NGACF_E_ARG;
     const int dk = a.dim / a.heads;
@@ -951,7 +650,7 @@ static int mha_dispatch(MhaArgs& a, bool backward, float drop_p, int bf16_operan
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define NGACF_CASE(DKV)                                                                                  \
-    if (dk == DKV) return bf16_operands ? launch_mha<true, DKV>(a, backward, drop, st) : launch_mha<false, DKV>(a, backward, drop, st)
+    if (dk == DKV) return launch_mha<DKV>(a, backward, drop, st)
     NGACF_CASE(8);
     NGACF_CASE(16);
     NGACF_CASE(32);
@@ -961,22 +660,22 @@ static int mha_dispatch(MhaArgs& a, bool backward, float drop_p, int bf16_operan
 
 extern "C" int ngacf_mha_fwd(const float* Q, const float* K, const float* V, const uint32_t* mask, float* O, float* LSE,
                              int Nq, int Nk, int dim, int heads, float drop_p, uint64_t seed, const uint64_t* seed_dev,
-                             int bf16_operands, void* stream) {
+                             void* stream) {
     if (!Q || !K || !V || !O || !LSE) return NGACF_E_ARG;
     MhaArgs a{};
     a.Q = Q; a.K = K; a.V = V; a.mask = mask; a.O = O; a.LSE = LSE; a.Nq = Nq; a.Nk = Nk; a.dim = dim; a.heads = heads;
     a.seed = seed; a.seed_dev = seed_dev;
-    return mha_dispatch(a, false, drop_p, bf16_operands, stream);
+    return mha_dispatch(a, false, drop_p, stream);
 }
 
 extern "C" int ngacf_mha_bwd(const float* Q, const float* K, const float* V, const uint32_t* mask, const float* O,
                              const float* LSE, const float* dO, float* dQ, float* dK, float* dV, float* delta,
                              int Nq, int Nk, int dim, int heads, float drop_p, uint64_t seed, const uint64_t* seed_dev,
-                             int bf16_operands, void* stream) {
+                             void* stream) {
     if (!Q || !K || !V || !O || !LSE || !dO || !dQ || !dK || !dV || !delta) return NGACF_E_ARG;
     MhaArgs a{};
     a.Q = Q; a.K = K; a.V = V; a.mask = mask; a.O = const_cast<float*>(O); a.LSE = const_cast<float*>(LSE); a.dO = dO;
     a.dQ = dQ; a.dK = dK; a.dV = dV; a.delta = delta; a.Nq = Nq; a.Nk = Nk; a.dim = dim; a.heads = heads;
     a.seed = seed; a.seed_dev = seed_dev;
-    return mha_dispatch(a, true, drop_p, bf16_operands, stream);
+    return mha_dispatch(a, true, drop_p, stream);
 }

@@ -27,19 +27,19 @@ class _MHACore(torch.autograd.Function):
     """softmax(q k^T / sqrt(d_k) [masked]) -> dropout -> @ v for all heads, on [N, dim] projections."""
 
     @staticmethod
-    def forward(ctx, Q, K, V, mask_u8, heads, drop_p, seed, bf16_operands):
+    def forward(ctx, Q, K, V, mask_u8, heads, drop_p, seed):
         Q, K, V = Q.contiguous().float(), K.contiguous().float(), V.contiguous().float()
-        O, LSE = ops.mha_fwd(Q, K, V, heads, mask_u8, drop_p, seed, None, bf16_operands)
+        O, LSE = ops.mha_fwd(Q, K, V, heads, mask_u8, drop_p, seed, None)
         ctx.save_for_backward(Q, K, V, O, LSE)
-        ctx.cfg = (mask_u8, heads, drop_p, seed, bf16_operands)
+        ctx.cfg = (mask_u8, heads, drop_p, seed)
         return O
 
     @staticmethod
     def backward(ctx, dO):
         Q, K, V, O, LSE = ctx.saved_tensors
-        mask_u8, heads, drop_p, seed, bf16_operands = ctx.cfg
-        dQ, dK, dV = ops.mha_bwd(Q, K, V, O, LSE, dO.contiguous().float(), heads, mask_u8, drop_p, seed, None, bf16_operands)
-        return dQ, dK, dV, None, None, None, None, None
+        mask_u8, heads, drop_p, seed = ctx.cfg
+        dQ, dK, dV = ops.mha_bwd(Q, K, V, O, LSE, dO.contiguous().float(), heads, mask_u8, drop_p, seed, None)
+        return dQ, dK, dV, None, None, None, None
 
 
 class _MaskCache:
@@ -81,7 +81,6 @@ class MultiHeadAttention(nn.Module):
         for lin in (self.q_linear, self.v_linear, self.k_linear, self.out):       # modules.py:80-91
             nn.init.xavier_uniform_(lin.weight)
             lin.bias.data.zero_()
-        self.bf16_operands = False          # True: matrix-core operands rounded to bf16 (fp32 softmax / accumulation)
         self._masks = _MaskCache()
 
     def forward(self, q, k, v, mask=None):
@@ -89,7 +88,7 @@ class MultiHeadAttention(nn.Module):
         Q, K, V = self.q_linear(q), self.k_linear(k), self.v_linear(v)
         p = self.dropout.p if self.training else 0.0
         m8 = None if mask is None else self._masks.get(mask)
-        concat = _MHACore.apply(Q, K, V, m8, self.h, p, _fresh_seed() if p > 0 else 0, self.bf16_operands)
+        concat = _MHACore.apply(Q, K, V, m8, self.h, p, _fresh_seed() if p > 0 else 0)
         return self.out(concat)                                                   # :104-106
 
 

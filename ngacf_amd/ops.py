@@ -613,7 +613,7 @@ def _mask_bits(mask, Nq, Nk, dev):
     return _chk(mask, "mask bits", torch.int32, Nq * ((Nk + 31) // 32), dev, align=4), mask
 
 
-def mha_fwd(Q, K, V, heads, mask=None, drop_p=0.0, seed=0, seed_dev=None, bf16_operands=False):
+def mha_fwd(Q, K, V, heads, mask=None, drop_p=0.0, seed=0, seed_dev=None):
     """O [Nq,dim], LSE [Nq,heads,2] = ngacf_mha_fwd(Q [Nq,dim], K [Nk,dim], V [Nk,dim], mask).  mask: None, the packed
     int32 words of pack_mask_bits, or any [Nq, Nk] tensor (packed here, per call: cache the packed form for repeated use)."""
     dev, (Nq, dim), Nk = Q.device, Q.shape, K.shape[0]
@@ -627,11 +627,11 @@ def mha_fwd(Q, K, V, heads, mask=None, drop_p=0.0, seed=0, seed_dev=None, bf16_o
     LSE = torch.empty(Nq, heads, 2, dtype=torch.float32, device=dev)
     if Nq and Nk:
         _lib.check(lib.ngacf_mha_fwd(qp, kp, vp, mp, O.data_ptr(), LSE.data_ptr(), Nq, Nk, dim, heads,
-                          float(drop_p), int(seed), _sd(seed_dev, dev), int(bool(bf16_operands)), _stream()), "ngacf_mha_fwd")
+                          float(drop_p), int(seed), _sd(seed_dev, dev), _stream()), "ngacf_mha_fwd")
     return O, LSE
 
 
-def mha_bwd(Q, K, V, O, LSE, dO, heads, mask=None, drop_p=0.0, seed=0, seed_dev=None, bf16_operands=False):
+def mha_bwd(Q, K, V, O, LSE, dO, heads, mask=None, drop_p=0.0, seed=0, seed_dev=None):
     """dQ, dK, dV of ngacf_mha_fwd."""
     dev, (Nq, dim), Nk = Q.device, Q.shape, K.shape[0]
     qp = _chk(Q, "Q", torch.float32, Nq * dim, dev)
@@ -645,7 +645,7 @@ def mha_bwd(Q, K, V, O, LSE, dO, heads, mask=None, drop_p=0.0, seed=0, seed_dev=
     delta = torch.empty(Nq, heads, dtype=torch.float32, device=dev)
     if Nq and Nk:
         _lib.check(lib.ngacf_mha_bwd(qp, kp, vp, mp, op, lp, gp, dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), delta.data_ptr(),
-                                     Nq, Nk, dim, heads, float(drop_p), int(seed), _sd(seed_dev, dev), int(bool(bf16_operands)),
+                                     Nq, Nk, dim, heads, float(drop_p), int(seed), _sd(seed_dev, dev),
                                      _stream()), "ngacf_mha_bwd")
     return dQ, dK, dV
 

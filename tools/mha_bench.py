@@ -2,7 +2,7 @@
 all nodes under the adjacency mask (ATTLayer_mask), and users x items / items x users (ATTLayer).  Reports time, flop/s
 against the dense matrix-core peak of the operand type, and exponentials/s against the v_exp_f32 issue rate -- the bound
 that actually applies at d_k = 8 (32 flop per score against one exp + ~10 VALU of scale/mask/max/sum).
-    python tools/mha_bench.py [--dim 64] [--bf16]"""
+    python tools/mha_bench.py [--dim 64]"""
 import argparse
 import json
 import os
@@ -36,7 +36,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--heads", type=int, default=8)
-    ap.add_argument("--bf16", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     u, i, _ = D.load_ml100k()
@@ -54,12 +53,12 @@ def main():
     for name, (q, k, m) in {"all x all, adjacency mask (ATTLayer_mask)": (X, X, mask), "all x all, no mask": (X, X, None),
                             "items x users (ATTLayer)": (X[U:].contiguous(), X[:U].contiguous(), None)}.items():
         Nq, Nk = q.shape[0], k.shape[0]
-        O, LSE = ops.mha_fwd(q, k, k, a.heads, m, bf16_operands=a.bf16)
-        tf = timeit(lambda: ops.mha_fwd(q, k, k, a.heads, m, bf16_operands=a.bf16))
-        tb = timeit(lambda: ops.mha_bwd(q, k, k, O, LSE, G[:Nq].contiguous(), a.heads, m, bf16_operands=a.bf16))
+        O, LSE = ops.mha_fwd(q, k, k, a.heads, m)
+        tf = timeit(lambda: ops.mha_fwd(q, k, k, a.heads, m))
+        tb = timeit(lambda: ops.mha_bwd(q, k, k, O, LSE, G[:Nq].contiguous(), a.heads, m))
         fl, ex = attention_flops(Nq, Nk, a.dim), attention_exps(Nq, Nk, a.heads)
-        peak = MFMA_PEAK["bf16" if a.bf16 else "fp32"]
-        out.append({"case": name, "Nq": Nq, "Nk": Nk, "dim": a.dim, "heads": a.heads, "operands": "bf16" if a.bf16 else "fp32",
+        peak = MFMA_PEAK["fp32"]
+        out.append({"case": name, "Nq": Nq, "Nk": Nk, "dim": a.dim, "heads": a.heads, "operands": "fp32",
                     "fwd_us": round(tf * 1e6, 1), "bwd_us": round(tb * 1e6, 1),
                     "fwd_TFLOPs": round(fl / tf / 1e12, 2), "fwd_frac_of_mfma_peak": round(fl / tf / peak, 5),
                     "fwd_Gexp_per_s": round(ex / tf / 1e9, 1), "fwd_frac_of_exp_issue_peak": round(ex / tf / EXP_PEAK, 4),

@@ -54,7 +54,7 @@ rm -rf gpurun_out/trainprof
 fi
 if [ "$part" = all ] || [ "$part" = aux ]; then
 say "dense attention (N4)"; : > $out/${tag}_mha_bench_ml100k.jsonl
-for fl in "" "--dim 128" "--dim 256" "--bf16"; do timeout -k 10 200 python tools/mha_bench.py $fl >> $out/${tag}_mha_bench_ml100k.jsonl 2>> $out/err.log || exit 1; done
+for fl in "" "--dim 128" "--dim 256"; do timeout -k 10 200 python tools/mha_bench.py $fl >> $out/${tag}_mha_bench_ml100k.jsonl 2>> $out/err.log || exit 1; done
 say "node numbering probe"; : > $out/${tag}_renumber_probe.jsonl
 for w in gowalla yelp synthetic200m; do timeout -k 10 400 python tools/renumber_probe.py --workload $w >> $out/${tag}_renumber_probe.jsonl 2>> $out/err.log || exit 1; done
 say "stand-alone transform at 70 k and 15 M rows"; timeout -k 10 200 python tools/transform_probe.py > $out/${tag}_transform_probe.jsonl 2>> $out/err.log || exit 1
