@@ -64,7 +64,7 @@ def attention(q, k, v, d_k, mask=None, dropout=None):
     flat = lambda t: t.transpose(0, 1).reshape(t.shape[1], h * dk)
     p = dropout.p if (dropout is not None and dropout.training) else 0.0
     m8 = None if mask is None else ops.pack_mask_bits(mask)
-    O = _MHACore.apply(flat(q), flat(k), flat(v), m8, h, p, _fresh_seed() if p > 0 else 0, False)
+    O = _MHACore.apply(flat(q), flat(k), flat(v), m8, h, p, _fresh_seed() if p > 0 else 0)
     return O.view(Nq, h, dk).transpose(0, 1)
 
 
