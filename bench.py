@@ -60,7 +60,8 @@ def parse(argv=None):
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: serial all-gather -> traversal schedule")
     ap.add_argument("--renumber", default="degree", choices=["degree", "none"],
                     help="node numbering at ingest (run_Gowalla.py --renumber): by degree, descending, or the generator's ids")
-    ap.add_argument("--no-probe", action="store_true", help="skip the 10^9-edge scaling probe of the default (gowalla) line")
+    ap.add_argument("--no-probe", action="store_true", help="skip the secondary legs: the Yelp / fp32 / 10^9-edge probes of the default "
+                    "(gowalla) line and the two-passes-in-flight figure")
     a = ap.parse_args(argv)
     if not a.stages:
         a.stages = 4 if a.workload == "gowalla128" else 3
@@ -401,7 +402,9 @@ def worker(args):
     fwd_bytes = sum(sum(D.algorithmic_bytes_stage(U, I, E, din, dout, elem)) for din, dout, _ in dims)
 
     tif = None
-    if not args.eager and not big:                # (before the train leg: the freshly initialised model, like the headline)
+    if not args.eager and not big and not args.no_probe:      # (before the train leg: the freshly initialised model, like the headline;
+                                                              #  --no-probe skips it: a kernel trace of that run must not average
+                                                              #  overlapped launches into the traversal kernel's row)
         try:
             tif = two_in_flight(torch, model, edge, E, L)
         except Exception as e:                    # (a secondary figure must not cost the line)
