@@ -47,7 +47,8 @@ def run(args):
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / args.steps
     print(json.dumps({"train_ms_per_step": round(ms, 4), "steps": args.steps, "shared": args.shared, "batch": B,
-                      "sparse_last_stage": type(model).sparse_last_stage}), flush=True)
+                      "sparse_last_stage": type(model).sparse_last_stage, "torch_adam": bool(args.torch_adam),
+                      "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("NGACF_")}}), flush=True)
 
 
 def profile(args):
