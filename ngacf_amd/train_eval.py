@@ -326,9 +326,8 @@ def sample_negatives(data, users, k, seed, margin=None):
     rep = users.repeat_interleave(M).contiguous()
     upn, unres = ops.sample_pairs(rep, 0, rep.numel(), ptr, items32, data.pool_items32, seed)
     c = upn[2].view(-1, M)
-    dup = torch.zeros_like(c, dtype=torch.bool)
-    for j in range(1, M):                                              # candidate j repeats an earlier one of its row
-        dup[:, j] = (c[:, :j] == c[:, j:j + 1]).any(1)
+    earlier = torch.ones(M, M, dtype=torch.bool, device=dev).tril(-1)         # [j, i]: i < j
+    dup = ((c[:, :, None] == c[:, None, :]) & earlier).any(2)                 # candidate j repeats an earlier one of its row
     keep = ~dup
     rank = torch.cumsum(keep, 1)
     sel = keep & (rank <= k)
