@@ -264,7 +264,8 @@ def roofline_of(BK, D, wl, dtype, U, I, E, dims, elem, prop_ms, n_timed, fused):
 
 def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dims, elem, n_steps=10):
     """`train_roofline`: the train step's dominant kernel -- the dense stages' edge backward (ngacf_prop_bwd / ngacf_prop_bwd_dx,
-    four launches per step, ~60 % of the backward) -- from its SURVEY.md 8(d) bytes, 2E (4 + 2 d T) + N (2 d T + 8), and its own
+    four launches per step, the bulk of the backward) -- from its algorithmic bytes, 2E (4 + d T + 8 heads) + N (2 d T + 8) (the
+    split-sign form gathers ONE row and a (S, t) pair per head per edge: include/ngacf.h; SURVEY.md 8(d)'s form had 2 d T), and its own
     duration: dispatch-packet timestamps of eager train steps (launches one after the other; inside the replayed two-chain step
     a launch shares the GPU with the other chain's and lasts 1.3-1.7 x as long: profiles/r04_trainstep_timeline.txt).  Roof as in
     `roofline`: the cache-gather blend at the kernel's own L2 hit rate (profiles/r04_traffic_trainstep.json)."""
@@ -285,10 +286,12 @@ def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dim
     per_stage = [[ms[k] for k in range(len(ms)) if L - 1 - (k % L) == s_] for s_ in range(L)]
     dense = [x for s_ in range(L) for x in per_stage[s_] if not (sparse_last and s_ == L - 1)]
     avg_ms = sum(dense) / len(dense)
-    bytes_launch = 2 * E * (4 + 2 * d * elem) + N * (2 * d * elem + 8)
+    heads_dense = int(dims[0][2]) if len(dims[0]) > 2 else d // 8
+    bytes_launch = 2 * E * (4 + d * elem + 8 * heads_dense) + N * (2 * d * elem + 8)
+    bytes_survey = 2 * E * (4 + 2 * d * elem) + N * (2 * d * elem + 8)
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
     hit, hit_src = BK.bwd_hit_from_profile(ROOT, wl, dtype)
-    regime = BK.gather_regime(2 * N * d * elem, 2 * max(U, I) * d * elem)          # two gathered tables (H and Gn)
+    regime = BK.gather_regime(N * (d * elem + 8 * heads_dense), max(U, I) * (d * elem + 8 * heads_dense))   # gathered: Gn rows and (S, t) pairs
     blend = l2blend = None
     if regime["regime"] == "HBM":
         bound, peak, note = "hbm", BK.HBM_PEAK_GBS, "HBM3E spec peak"
@@ -309,7 +312,8 @@ def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dim
             "frac_of_guide_gather_blend": round(achieved / blend, 4) if blend else None,
             "frac_of_l2_peak_blend": round(achieved / l2blend, 4) if l2blend else None,
             "l2_hit_rate": hit, "bytes_per_launch": int(bytes_launch),
-            "bytes_note": "SURVEY.md 8(d) backward: 2E (4 + 2 d T) + N (2 d T + 8); the 4*heads-byte t gather and the fused tail's rows are not counted",
+            "bytes_note": "2E (4 + d T + 8 heads) + N (2 d T + 8): one gathered row and a (S, t) pair per head per edge (split-sign backward); the fused tail's rows are not counted",
+            "GBps_if_counted_in_the_two_row_form_of_SURVEY_8d": round(bytes_survey / (avg_ms * 1e-3) / 1e9, 1),
             "avg_launch_us": round(avg_ms * 1e3, 2),
             "per_stage_us": [round(1e3 * sum(x) / len(x), 2) for x in per_stage],
             "last_stage_is_the_scored_batch_only": sparse_last and NF is not None,

@@ -109,9 +109,13 @@ int ngacf_transform_fwd_rows(const void* X, int x_dtype, const float* W, const f
  * the two numerator sparse.mm, div, NaN->0, residual) plus the ELU of :397/:214.
  *   H      [N,d] dtype     S_dst,S_src float[N][heads] (may alias; S_src unused with NGACF_SCORE_ROW)
  *   avec   float[2][d]     (as in ngacf_transform_fwd; used only with NGACF_SCORE_ROW)
- *   out    [N,d] dtype     agg [N,d] dtype / R float[N][heads]: normalised aggregate (in the storage type, like
- *                          every other table of the stage) and denominators, saved for the backward (both may be NULL)
- *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows
+ *   out    [N,d] dtype     agg [2][N][d] dtype / R float[2][N][heads], saved for the backward (both NULL, or both given =
+ *                          a train-mode forward): plane 0 = the normalised aggregate (in the storage type, like every other
+ *                          table of the stage) and the denominators; plane 1 = the same sums restricted to the edges whose
+ *                          score s = S[dst] + S[src] is not positive (aggn = sum m e H[src] / R, Rn = sum e over them), which
+ *                          make the "own gradient" half of the backward's dS row-local (ngacf_prop_bwd)
+ *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows; with agg / R given a slot holds both
+ *                          planes: float[nparts][2][d], float[nparts][2][heads]
  *   part_split int32[nparts] (hub row of every slot), tickets int32[nsplit] (all zero on entry, left all zero):
  *       with both given, the last-arriving slice of a hub row finishes it inside the launch (write-through stores,
  *       an agent-scope ticket, agent-scope atomic loads; no fence, no waiting); with NULL a small second kernel does (same
@@ -176,24 +180,31 @@ int ngacf_prop_fwd_next(const int32_t* segs, int nseg, const int32_t* split, int
                         float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
                         const ngacf_next_stage* next, void* stream);
 
-/* Backward of ngacf_prop_fwd (autograd of SPUIGACF.py:359-397; formulas SURVEY.md §8(a) A4b).
- * Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  t[n,h] = (g . agg)_h / R   (ST below = this t table)
- * Step 2 (per edge, pull):  dH[n] = g[n] + sum_src m e Gn[src] + dS[n,h] * avec[type(n)]
- *                           dS[n,h] = sum_src -e * lrelu'(s) * (m (Gn[n].H[src] + Gn[src].H[n])_h - t[n] - t[src])
+/* Backward of ngacf_prop_fwd (autograd of SPUIGACF.py:359-397; formulas SURVEY.md §8(a) A4b, regrouped).
+ *   With e = exp(-lrelu(s)), s = S[n] + S[c], m the edge's dropout multiplier, the gradient of a score is
+ *       ds(n,c) = -lrelu'(s) e (m (Gn[n].H[c] + Gn[c].H[n])_h - t[n] - t[c])
+ *   and dS[n,h] = sum_c ds(n,c) is computed as P1[n,h] + the edge sums below, where the part that carries the row's own gradient,
+ *       P1[n,h] = sum_c -lrelu'(s) e (m Gn[n].H[c] - t[n]) = (1 - alpha) (R (Gn[n].aggn[n])_h - Rn t[n]),
+ *   is row-local thanks to the forward's second planes (lrelu' = 1 where s > 0, alpha elsewhere; the s > 0 terms cancel).
+ * Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  t[n,h] = (Gn . agg)_h;  ST[n,h] = (S[n,h], t[n,h]);  dS[n,h] = P1[n,h]
+ * Step 2 (per edge, pull):  dH[n] = g[n] + sum_c m e Gn[c] + dS[n,h] * avec[type(n)]
+ *                           dS[n,h] += sum_c -e * lrelu'(s) * (m (Gn[c].H[n])_h - t[c])
+ *   so an edge gathers ONE row (Gn[c]) and 8 bytes per head (ST[c,h]) -- not H[c] as well.
  *   gout [N,d] dtype (the gradient arrives in the storage type of `out`)   out [N,d] dtype (forward output)
- *   agg, R: as saved by the forward
- *   G float[N][d], Gn [N][d] dtype, ST float[N][heads] (the t table): workspace    dH [N][d] dtype (H's storage type), dS float[N][heads]: results
+ *   agg [2][N][d], R float[2][N][heads]: as saved by the forward;  S_src float[N][heads]: the scores (step 1 copies them into ST)
+ *   G float[N][d], Gn [N][d] dtype, ST float[N][heads][2] (pairs (S, t)): workspace
+ *   dH [N][d] dtype (H's storage type), dS float[N][heads]: results (dS is written by step 1 and finished by step 2: with
+ *   NGACF_SKIP_NODE it is an INPUT too, holding P1)
  *   G may be NULL when gout and out are given as global-row tables: step 2 then recomputes g from gout and out, bit for bit,
- *   and the 4-byte-per-element table is neither written nor read back (also with NGACF_SKIP_NODE, when Gn / ST come from elsewhere)
+ *   and the 4-byte-per-element table is neither written nor read back (also with NGACF_SKIP_NODE, when Gn / ST / P1 come from elsewhere)
  *   part_acc float[nparts][d], part_r float[nparts][heads]: workspace for hub rows; part_split / tickets: as in ngacf_prop_fwd
  *   (both given: the last-arriving slice of a hub row finishes it inside the launch; NULL: a second kernel does)
- *   needed / rows / nrows / short_max (NULL / NULL / 0 / 0, or the forward's): the forward ran with these flags, i.e. gout is
- *   zero outside the flagged rows (and out / agg / R are not valid there).  Then Gn and t vanish outside, and an edge with
- *   both ends outside contributes exactly zero.  Step 1 runs over the list only (Gn / t exist for the batch's rows).  The
- *   batch's short rows are walked from the list, a wave each (all their edges; Gn / t of a neighbour outside the batch
- *   count as zero); every other row tests one flag bit per edge, queues the columns that are in the batch (LDS) and
- *   gathers only those -- still UNROLL edges at a time.  Equal to the unflagged call on a gout that is zero outside, up to
- *   the order of the additions.  With NGACF_GOUT_F32 gout is float[N][d] (only the batch's rows are read). */
+ *   needed / rows / nrows (NULL / NULL / 0, or the forward's): the forward ran with these flags, i.e. gout is zero outside the
+ *   flagged rows (and out / agg / R are not valid there).  Then Gn, t and P1 vanish outside and only edges whose SOURCE is
+ *   flagged contribute anything -- to any row, flagged or not.  Step 1 runs over the list only; in step 2 every row tests one flag
+ *   bit per edge, queues the columns that are in the batch (LDS) and gathers only those.  Equal to the unflagged call on a gout
+ *   that is zero outside, bit for bit (terms that are exactly zero are left out).  With NGACF_GOUT_F32 gout is float[N][d]
+ *   (only the batch's rows are read).  S_dst == S_src in every caller (one score table); avec is the node's own attention vector. */
 int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                    const int32_t* srow, int nshort, int nseg_user, int nshort_user,
                    const int32_t* hrow, int nhub, int nhub_user, const int32_t* rowptr,
@@ -202,7 +213,7 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    const void* out, const void* agg, const float* R, const void* gout,
                    float* G, void* Gn, float* ST, void* dH, float* dS,
                    float* part_acc, float* part_r, const int32_t* part_split, int32_t* tickets,
-                   const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
+                   const uint32_t* needed, const int32_t* rows, int nrows,
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
 
@@ -210,17 +221,18 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  * stage's backward on the result -- the mirror image of ngacf_prop_fwd_next (autograd of SPUIGACF.py:356-357 chained through
  * :207-215; the reference's autograd runs these as separate ATen kernels):
  *   dX[n, :] = mask * (dH[n, :] @ W[type(n)]^T)      what ngacf_transform_bwd's dX half computes from the stored dH, bit for bit
- *   and with prev_*: g = dX * ELU'(prev_out);  prev_Gn = g / prev_R;  prev_T[n, h] = (prev_Gn . prev_agg)_h
+ *   and with prev_*: step 1 of the previous stage on gout = dX (prev_Gn, prev_ST, prev_dS = its Gn, ST and P1)
  *                                                    what ngacf_prop_bwd_node computes from the stored dX, bit for bit
- * so the previous stage's backward is then called with NGACF_SKIP_NODE, gout = dX, Gn = prev_Gn, ST = prev_T.
+ * so the previous stage's backward is then called with NGACF_SKIP_NODE, gout = dX, Gn = prev_Gn, ST = prev_ST, dS = prev_dS.
  *   panel   bf16 A fragments of W[type]^T: ngacf_transform_fwd_pack with pack_kind 1 (2 * din * d * 2 bytes)
  *   dX      [N][din], NGACF_BF16 or NGACF_F32 (X's type); with prev_* NGACF_BF16 (dX is the gradient of the previous stage's bf16
  *           output); NGACF_F32 e.g. for the first stage (the gradient of the fp32 embedding table)
  *   feat_drop_p, seed: the stage's feature dropout (the mask of ngacf_transform_fwd)
- *   prev_out, prev_agg [N][din] bf16, prev_R float[N][din/8]: as the previous stage's forward saved them (8-column heads);
- *   prev_Gn [N][din] bf16, prev_T float[N][din/8]: results;   prev_flags: NGACF_ELU of the previous stage
+ *   prev_out [N][din] bf16, prev_agg [2][N][din] bf16, prev_R float[2][N][din/8]: as the previous stage's forward saved them
+ *   (8-column heads); prev_S float[N][din/8]: that stage's scores; prev_alpha: its leaky-relu slope;
+ *   prev_Gn [N][din] bf16, prev_ST float[N][din/8][2], prev_dS float[N][din/8]: results;   prev_flags: NGACF_ELU of the previous stage
  * dH and dS are written as by ngacf_prop_bwd (the weights' gradient still needs them: ngacf_transform_bwd with dX == NULL).
- * Restrictions: dtype == NGACF_BF16, d == 64, din == 64, NGACF_SCORE_ROW, G == NULL, nhub == 0, hub rows finished in-kernel
+ * Restrictions: dtype == NGACF_BF16, d == 64, din == 64, G == NULL, nhub == 0, hub rows finished in-kernel
  * (part_split + tickets) or absent.  dx == NULL: exactly ngacf_prop_bwd. */
 typedef struct ngacf_bwd_dx {
     const void* panel;
@@ -231,11 +243,12 @@ typedef struct ngacf_bwd_dx {
     const void* prev_out;
     const void* prev_agg;
     const float* prev_R;
+    const float* prev_S;
     void* prev_Gn;
-    float* prev_T;
+    float* prev_ST;
+    float* prev_dS;
+    float prev_alpha;
     int32_t prev_flags;
-    int32_t rows_user;    /* with `needed`: how many leading entries of `rows` are user rows (ngacf_mark_rows lists the users first); a
-                             hint for which node type's panel a workgroup fetches first -- results do not depend on it */
 } ngacf_bwd_dx;
 int ngacf_prop_bwd_dx(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                       const int32_t* srow, int nshort, int nseg_user, int nshort_user,
@@ -245,7 +258,7 @@ int ngacf_prop_bwd_dx(const int32_t* segs, int nseg, const int32_t* split, int n
                       const void* out, const void* agg, const float* R, const void* gout,
                       float* G, void* Gn, float* ST, void* dH, float* dS,
                       float* part_acc, float* part_r, const int32_t* part_split, int32_t* tickets,
-                      const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
+                      const uint32_t* needed, const int32_t* rows, int nrows,
                       int U, int N, int d, int heads, float alpha,
                       float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
                       const ngacf_bwd_dx* dx, void* stream);
@@ -307,10 +320,11 @@ int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float* W, const v
                              float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* Step 1 of ngacf_prop_bwd alone, over row windows; gout holds only the window rows when gout_local != 0.
- * Lets a node-partitioned run all-gather Gn/ST between the two steps (then ngacf_prop_bwd with NGACF_SKIP_NODE). */
+ * Lets a node-partitioned run all-gather Gn / ST between the two steps (then ngacf_prop_bwd with NGACF_SKIP_NODE; P1 in dS is
+ * needed for the rank's own rows only).  All tables are indexed by global row: agg [2][N][d], R float[2][N][heads]. */
 int ngacf_prop_bwd_node(const void* out, int dtype, const void* agg, const float* R, const void* gout,
-                        const float* S_src, float* G, void* Gn, float* ST,
-                        int U, int N, int d, int heads, int flags,
+                        const float* S_src, float* G, void* Gn, float* ST, float* dS,
+                        int U, int N, int d, int heads, float alpha, int flags,
                         int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream);
 
 /* Pair scoring: score[b] = sum_c F[u[b],c] * F[U + i[b],c]   (SPUIGACF.py:49-52).

@@ -35,9 +35,9 @@ SIGNATURES = {
                             _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p, _p],
     "ngacf_transform_fwd_pack": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _i, _p, _p, _p, _p, _p, _p],
     "ngacf_prop_bwd": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
-                       _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p],
+                       _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p],
     "ngacf_prop_bwd_dx": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
-                          _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p, _p],
+                          _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p, _p],
     "ngacf_transform_dw_batch": [_p, _i, _p, _i, _i, _i, _p, _p],
     "ngacf_adam_step": [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p],
     "ngacf_bpr_fwd_bwd": [_p, _p, _p, _p, _p, _i, _p],
@@ -47,7 +47,7 @@ SIGNATURES = {
     "ngacf_transform_fwd_rows": [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _p, _p],
     "ngacf_transform_bwd_rows": [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                  _f, _u64, _p, _p],
-    "ngacf_prop_bwd_node": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ngacf_prop_bwd_node": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p],
     "ngacf_score_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ngacf_score_bwd": [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ngacf_bpr_fwd": [_p, _p, _p, _i, _p],
@@ -83,7 +83,8 @@ class DwJob(ctypes.Structure):
 class BwdDx(ctypes.Structure):
     """ngacf_bwd_dx of include/ngacf.h"""
     _fields_ = [("panel", _p), ("dX", _p), ("din", ctypes.c_int32), ("dx_dtype", ctypes.c_int32), ("feat_drop_p", _f), ("seed", _u64),
-                ("prev_out", _p), ("prev_agg", _p), ("prev_R", _p), ("prev_Gn", _p), ("prev_T", _p), ("prev_flags", ctypes.c_int32), ("rows_user", ctypes.c_int32)]
+                ("prev_out", _p), ("prev_agg", _p), ("prev_R", _p), ("prev_S", _p), ("prev_Gn", _p), ("prev_ST", _p), ("prev_dS", _p),
+                ("prev_alpha", _f), ("prev_flags", ctypes.c_int32)]
 
 
 MAX_PEERS, PEER_MAX_REGIONS, PEER_HANDLE_BYTES = 15, 2, 64       # NGACF_MAX_PEERS, NGACF_PEER_MAX_REGIONS, NGACF_PEER_HANDLE_BYTES

@@ -100,9 +100,21 @@ __device__ __forceinline__ int slot_bcast(int v) {
     return __builtin_amdgcn_ds_swizzle(v, (J << 5) | and_mask);
 }
 
-template <typename T, int D, int HEADS>
+// The negative-side sums a train-mode forward keeps for the backward (SAVE instantiations; propagate_bwd.hip, "split-sign"
+// form): over the edges whose score s = S[dst] + S[src] is not positive,
+//     accn = sum m e H[src],   rneg = sum e          (agg_neg = accn / R is stored behind agg, rneg behind R)
+// With them the half of dS[n] that multiplies the row's OWN gradient is row-local in the backward,
+//     sum_src -lrelu'(s) e (m Gn[n].H[src] - t[n]) = (1 - alpha) (R Gn[n].agg_neg[n] - rneg t[n]),
+// and the edge backward gathers one row (Gn[src]) and 8 bytes per head (S[src], t[src]) per edge instead of two rows and 4.
+template <int VEC>
+struct NegSums {
+    float accn[VEC];
+    float rneg;
+};
+
+template <typename T, int D, int HEADS, bool SAVE>
 __device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum,
-                                           float (&o)[Slice<T>::VEC]) {
+                                           NegSums<Slice<T>::VEC>& ng, float (&o)[Slice<T>::VEC]) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC;
     float own[VEC];
@@ -117,12 +129,19 @@ __device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, in
     if (a.out) Slice<T>::store(static_cast<T*>(a.out) + (size_t)row * D + q * VEC, o);     // (NULL: only the next stage's operands are wanted)
     if (a.agg) Slice<T>::store(static_cast<T*>(a.agg) + (size_t)row * D + q * VEC, acc);    // (bf16 storage: 128 B per row instead of 256)
     if (a.R && (q * VEC) % SH::HW == 0) a.R[(size_t)row * HEADS + head] = rsum;
+    if constexpr (SAVE) {                                 // second planes of agg / R: the negative-side aggregate and denominator
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) ng.accn[j] *= inv;
+        Slice<T>::store(static_cast<T*>(a.agg) + ((size_t)a.N + row) * D + q * VEC, ng.accn);
+        if ((q * VEC) % SH::HW == 0) a.R[((size_t)a.N + row) * HEADS + head] = ng.rneg;
+    }
 }
 
-template <typename T, int D, int HEADS>
-__device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum) {
+template <typename T, int D, int HEADS, bool SAVE>
+__device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum,
+                                           NegSums<Slice<T>::VEC>& ng) {
     float o[Slice<T>::VEC];
-    finish_row<T, D, HEADS>(a, row, q, head, acc, rsum, o);
+    finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, o);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -212,10 +231,11 @@ __device__ __forceinline__ void next_transform_tail_f32(const PropArgs& a, float
 }
 
 // one edge: score, exp(-leakyrelu), optional dropout, accumulate
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SAVE>
 __device__ __forceinline__ void edge_step(const PropArgs& a, const float (&hv)[Slice<T>::VEC], float s_src, bool ok, int c,
                                           float s_dst, const float (&av)[Slice<T>::VEC], bool dst_is_user,
-                                          uint32_t row_key, uint32_t salt_h, float (&acc)[Slice<T>::VEC], float& rsum) {
+                                          uint32_t row_key, uint32_t salt_h, float (&acc)[Slice<T>::VEC], float& rsum,
+                                          NegSums<Slice<T>::VEC>& ng) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC;
     float s;
@@ -231,17 +251,23 @@ __device__ __forceinline__ void edge_step(const PropArgs& a, const float (&hv)[S
     const float lr = fmaxf(s, a.alpha * s);               // leaky relu, 0 < alpha < 1
     float ev = ok ? __expf(-lr) : 0.f;
     rsum += ev;
+    if constexpr (SAVE) ng.rneg += s > 0.f ? 0.f : ev;    // (the backward's lrelu' takes alpha exactly where s > 0 is false)
     if (DROP) {
         const uint32_t other = dst_is_user ? (uint32_t)c * RNG_K2 + salt_h : (uint32_t)c * RNG_K1;
         ev = lowbias32(row_key ^ other) >= a.drop_thr ? ev * a.drop_scale : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = fmaf(ev, hv[j], acc[j]);
+    if constexpr (SAVE) {
+        const float evn = s > 0.f ? 0.f : ev;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) ng.accn[j] = fmaf(evn, hv[j], ng.accn[j]);
+    }
 }
 
 // The traversal of one wave's work item(s).  NEXT (the fused form, ngacf_prop_fwd_next): the finished row of this lane's group
 // is also handed back (rvalid, rrow, ro) for the workgroup's transform tail, and no path leaves before it.
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, bool NEXT>
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, bool NEXT, bool SAVE>
 __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int widx, int wend, bool& rvalid, int& rrow,
                                               float (&ro)[Slice<T>::VEC]) {
     using SH = Shape<T, D, HEADS>;
@@ -253,13 +279,18 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     float rsum = 0.f;
+    NegSums<VEC> ng;                                      // (SAVE only: dead code otherwise)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) ng.accn[j] = 0.f;
+    ng.rneg = 0.f;
+    constexpr int NP = SAVE ? 2 : 1;                      // planes of a hub row's partial sums: (acc, rsum) and, SAVE, (accn, rneg)
     float av[VEC];
     if (kind == WORK_HUB) {
         // ------------------------------------------------------------------ hub rows: workgroup per row
         // The four waves stride over the row's edges (EPI * UNROLL per wave and step); slots fold inside each wave,
         // waves through LDS in wave order (deterministic); wave 0 finishes the row.  No partial sums in memory.
-        __shared__ float hub_acc[3][D];
-        __shared__ float hub_r[3][HEADS];
+        __shared__ float hub_acc[3][NP * D];
+        __shared__ float hub_r[3][NP * HEADS];
         const int wv = threadIdx.x >> 6;
         const int row = uniform(a.hrow[widx]);
         if (SPARSE && !flagged(a.needed, row)) return;                // (block-uniform: no wave reaches the barrier below)
@@ -293,15 +324,25 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                edge_step<T, D, HEADS, FROM_ROW, DROP>(a, hv[u], ss[u], ok[u], c[u], s_dst, av, dst_is_user, row_key, salt_h, acc, rsum);
+                edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE>(a, hv[u], ss[u], ok[u], c[u], s_dst, av, dst_is_user, row_key, salt_h, acc, rsum, ng);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
         rsum = group_sum<LPR, WAVE>(rsum);
+        if constexpr (SAVE) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) ng.accn[j] = group_sum<LPR, WAVE>(ng.accn[j]);
+            ng.rneg = group_sum<LPR, WAVE>(ng.rneg);
+        }
         if (wv > 0 && slot == 0) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) hub_acc[wv - 1][q * VEC + j] = acc[j];
             if ((q * VEC) % SH::HW == 0) hub_r[wv - 1][head] = rsum;
+            if constexpr (SAVE) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) hub_acc[wv - 1][D + q * VEC + j] = ng.accn[j];
+                if ((q * VEC) % SH::HW == 0) hub_r[wv - 1][HEADS + head] = ng.rneg;
+            }
         }
         __syncthreads();
         if (wv == 0 && slot == 0) {
@@ -310,8 +351,13 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc[j] += hub_acc[x][q * VEC + j];
                 rsum += hub_r[x][head];
+                if constexpr (SAVE) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) ng.accn[j] += hub_acc[x][D + q * VEC + j];
+                    ng.rneg += hub_r[x][HEADS + head];
+                }
             }
-            finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+            finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
         }
         return;
     }
@@ -358,14 +404,14 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
-                    edge_step<T, D, HEADS, FROM_ROW, DROP>(a, hv[u], ss[u], k0 + h0 + u < deg, c[h0 + u], s_dst, av,
-                                                           dst_is_user, row_key, salt_h, acc, rsum);
+                    edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE>(a, hv[u], ss[u], k0 + h0 + u < deg, c[h0 + u], s_dst, av,
+                                                                 dst_is_user, row_key, salt_h, acc, rsum, ng);
             }
             colv = coln;
         }
         if (live) {
-            if constexpr (NEXT) { finish_row<T, D, HEADS>(a, row, q, head, acc, rsum, ro); rvalid = true; rrow = row; }
-            else finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+            if constexpr (NEXT) { finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro); rvalid = true; rrow = row; }
+            else finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
         }
         return;
     }
@@ -414,25 +460,36 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
-            edge_step<T, D, HEADS, FROM_ROW, DROP>(a, hv[u], ss[u], ok[u], c[u], s_dst, av, dst_is_user, row_key, salt_h, acc, rsum);
+            edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE>(a, hv[u], ss[u], ok[u], c[u], s_dst, av, dst_is_user, row_key, salt_h, acc, rsum, ng);
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     rsum = group_sum<LPR, WAVE>(rsum);
+    if constexpr (SAVE) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) ng.accn[j] = group_sum<LPR, WAVE>(ng.accn[j]);
+        ng.rneg = group_sum<LPR, WAVE>(ng.rneg);
+    }
     if (part < 0) {
         if (slot == 0) {                                      // one finished row per wave, in lane group 0
-            if constexpr (NEXT) { finish_row<T, D, HEADS>(a, row, q, head, acc, rsum, ro); rvalid = true; rrow = row; }
-            else finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+            if constexpr (NEXT) { finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro); rvalid = true; rrow = row; }
+            else finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
         }
         return;
     }
-    // slice of a hub row: leave the partial sums in slot `part`
+    // slice of a hub row: leave the partial sums in slot `part` (SAVE: a slot is [2][D] / [2][HEADS], the negative-side sums second)
     if (a.tickets == nullptr) {                            // prop_fwd_split_kernel finishes the row
         if (slot == 0) {
-            float* pa = a.part_acc + (size_t)part * D + q * VEC;
+            float* pa = a.part_acc + (size_t)part * NP * D + q * VEC;
 #pragma unroll
             for (int j = 0; j < VEC; j += 4) *reinterpret_cast<float4*>(pa + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
-            if ((q * VEC) % SH::HW == 0) a.part_r[(size_t)part * HEADS + head] = rsum;
+            if ((q * VEC) % SH::HW == 0) a.part_r[(size_t)part * NP * HEADS + head] = rsum;
+            if constexpr (SAVE) {
+#pragma unroll
+                for (int j = 0; j < VEC; j += 4)
+                    *reinterpret_cast<float4*>(pa + D + j) = make_float4(ng.accn[j], ng.accn[j + 1], ng.accn[j + 2], ng.accn[j + 3]);
+                if ((q * VEC) % SH::HW == 0) a.part_r[(size_t)part * NP * HEADS + HEADS + head] = ng.rneg;
+            }
         }
         return;
     }
@@ -441,15 +498,25 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
     // acquire -> plain loads.  No release fence (a buffer_wbl2 per slice tripled the kernel time), no wave ever waits on
     // another one.  Partials are added in slot order, so the result does not depend on which slice came last.
     if (slot == 0) {
-        unsigned long long* pa = reinterpret_cast<unsigned long long*>(a.part_acc + (size_t)part * D + q * VEC);
+        unsigned long long* pa = reinterpret_cast<unsigned long long*>(a.part_acc + (size_t)part * NP * D + q * VEC);
 #pragma unroll
         for (int j = 0; j < VEC; j += 2) {
             const unsigned long long bits = (unsigned long long)__float_as_uint(acc[j]) | ((unsigned long long)__float_as_uint(acc[j + 1]) << 32);
             __hip_atomic_store(pa + j / 2, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if ((q * VEC) % SH::HW == 0)
-            __hip_atomic_store(reinterpret_cast<unsigned*>(a.part_r + (size_t)part * HEADS + head), __float_as_uint(rsum),
+            __hip_atomic_store(reinterpret_cast<unsigned*>(a.part_r + (size_t)part * NP * HEADS + head), __float_as_uint(rsum),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (SAVE) {
+#pragma unroll
+            for (int j = 0; j < VEC; j += 2) {
+                const unsigned long long bits = (unsigned long long)__float_as_uint(ng.accn[j]) | ((unsigned long long)__float_as_uint(ng.accn[j + 1]) << 32);
+                __hip_atomic_store(pa + (D + j) / 2, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if ((q * VEC) % SH::HW == 0)
+                __hip_atomic_store(reinterpret_cast<unsigned*>(a.part_r + (size_t)part * NP * HEADS + HEADS + head), __float_as_uint(ng.rneg),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int si = uniform(a.part_split[part]);
@@ -462,31 +529,47 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
     // at the coherent level, where the other slices' write-through stores are, whatever this L2 holds).
     if (lane == 0) __hip_atomic_store(a.tickets + si, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int j = 0; j < VEC; ++j) { acc[j] = 0.f; ng.accn[j] = 0.f; }
     rsum = 0.f;
+    ng.rneg = 0.f;
 #pragma unroll 4
     for (int p = p0 + slot; p < p0 + np; p += EPI) {
-        unsigned long long* pa = reinterpret_cast<unsigned long long*>(a.part_acc + (size_t)p * D + q * VEC);
+        unsigned long long* pa = reinterpret_cast<unsigned long long*>(a.part_acc + (size_t)p * NP * D + q * VEC);
 #pragma unroll
         for (int j = 0; j < VEC; j += 2) {
             const unsigned long long bits = __hip_atomic_load(pa + j / 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             acc[j] += __uint_as_float((unsigned)bits); acc[j + 1] += __uint_as_float((unsigned)(bits >> 32));
         }
-        rsum += __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(a.part_r + (size_t)p * HEADS + head), __ATOMIC_RELAXED,
+        rsum += __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(a.part_r + (size_t)p * NP * HEADS + head), __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT));
+        if constexpr (SAVE) {
+#pragma unroll
+            for (int j = 0; j < VEC; j += 2) {
+                const unsigned long long bits = __hip_atomic_load(pa + (D + j) / 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ng.accn[j] += __uint_as_float((unsigned)bits); ng.accn[j + 1] += __uint_as_float((unsigned)(bits >> 32));
+            }
+            ng.rneg += __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(a.part_r + (size_t)p * NP * HEADS + HEADS + head),
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     rsum = group_sum<LPR, WAVE>(rsum);
+    if constexpr (SAVE) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) ng.accn[j] = group_sum<LPR, WAVE>(ng.accn[j]);
+        ng.rneg = group_sum<LPR, WAVE>(ng.rneg);
+    }
     if (slot == 0) {
-        if constexpr (NEXT) { finish_row<T, D, HEADS>(a, row, q, head, acc, rsum, ro); rvalid = true; rrow = row; }
-        else finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+        if constexpr (NEXT) { finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro); rvalid = true; rrow = row; }
+        else finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
     }
 }
 
 // NEXT > 0 (= the next stage's output width; NONE: that stage has ONE head): the fused form of ngacf_prop_fwd_next.
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int NEXT = 0, bool NONE = false, bool STAGE_OUT = false>
-__global__ __launch_bounds__(256, NEXT == 64 ? 5 : NEXT == 128 ? 4 : (sizeof(T) == 2 && D == 64 && !SPARSE ? 6 : 1)) void prop_fwd_kernel(const PropArgs a) {
+// SAVE: a train-mode forward (agg / R given): also the negative-side sums the backward wants (NegSums above).
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int NEXT = 0, bool NONE = false, bool STAGE_OUT = false, bool SAVE = false>
+__global__ __launch_bounds__(256, NEXT == 64 ? (SAVE ? 4 : 5) : NEXT == 128 ? 4 : (sizeof(T) == 2 && D == 64 && !SPARSE ? (SAVE ? 5 : 6) : 1)) void prop_fwd_kernel(const PropArgs a) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC, EPI = SH::EPI;
     static_assert(NEXT == 0 || (D == 64 && !SPARSE), "fused next-stage transform: rows of 64 columns");
@@ -515,7 +598,7 @@ __global__ __launch_bounds__(256, NEXT == 64 ? 5 : NEXT == 128 ? 4 : (sizeof(T) 
                                              (__attribute__((address_space(3))) void*)avec_lds, 16, 0, 0);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) ro[j] = 0.f;
-        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true>(a, kind, widx, wend, rvalid, rrow, ro);
+        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true, SAVE>(a, kind, widx, wend, rvalid, rrow, ro);
         next_transform_tail<D, NEXT, NONE, STAGE_OUT>(a, xtile_lds, xmeta_lds, panel_lds, reinterpret_cast<const float*>(avec_lds), rvalid, rrow,
                                            lane / SH::LPR, lane % SH::LPR, ro);
     } else if constexpr (NEXT > 0) {
@@ -535,19 +618,19 @@ __global__ __launch_bounds__(256, NEXT == 64 ? 5 : NEXT == 128 ? 4 : (sizeof(T) 
                                              (__attribute__((address_space(3))) void*)avec_f32, 16, 0, 0);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) ro[j] = 0.f;
-        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true>(a, kind, widx, wend, rvalid, rrow, ro);
+        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true, SAVE>(a, kind, widx, wend, rvalid, rrow, ro);
         next_transform_tail_f32<D, NEXT, NONE>(a, xtile_f32, xmeta_f32, panel_f32, avec_f32, sx_f32, rvalid, rrow, lane / SH::LPR,
                                                lane % SH::LPR, ro);
     } else {
-        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, false>(a, kind, widx, wend, rvalid, rrow, ro);
+        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, false, SAVE>(a, kind, widx, wend, rvalid, rrow, ro);
     }
 }
 
 // Hub rows: add the partial sums of the row's slices (slots take interleaved slices, fixed order) and finish.
-template <typename T, int D, int HEADS>
+template <typename T, int D, int HEADS, bool SAVE>
 __global__ __launch_bounds__(256) void prop_fwd_split_kernel(const PropArgs a, const int* __restrict__ split, int nsplit) {
     using SH = Shape<T, D, HEADS>;
-    constexpr int VEC = SH::VEC, LPR = SH::LPR, EPI = SH::EPI;
+    constexpr int VEC = SH::VEC, LPR = SH::LPR, EPI = SH::EPI, NP = SAVE ? 2 : 1;
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= nsplit) return;
@@ -555,29 +638,44 @@ __global__ __launch_bounds__(256) void prop_fwd_split_kernel(const PropArgs a, c
     if (a.needed && !flagged(a.needed, row)) return;
     const int slot = lane / LPR, q = lane % LPR, head = (q * VEC) / SH::HW;
     float acc[VEC];
+    NegSums<VEC> ng;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int j = 0; j < VEC; ++j) { acc[j] = 0.f; ng.accn[j] = 0.f; }
     float rsum = 0.f;
+    ng.rneg = 0.f;
 #pragma unroll 4
     for (int p = p0 + slot; p < p0 + np; p += EPI) {
-        const float* pa = a.part_acc + (size_t)p * D + q * VEC;
+        const float* pa = a.part_acc + (size_t)p * NP * D + q * VEC;
 #pragma unroll
         for (int j = 0; j < VEC; j += 4) {
             const float4 v = *reinterpret_cast<const float4*>(pa + j);
             acc[j] += v.x; acc[j + 1] += v.y; acc[j + 2] += v.z; acc[j + 3] += v.w;
         }
-        rsum += a.part_r[(size_t)p * HEADS + head];
+        rsum += a.part_r[(size_t)p * NP * HEADS + head];
+        if constexpr (SAVE) {
+#pragma unroll
+            for (int j = 0; j < VEC; j += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(pa + D + j);
+                ng.accn[j] += v.x; ng.accn[j + 1] += v.y; ng.accn[j + 2] += v.z; ng.accn[j + 3] += v.w;
+            }
+            ng.rneg += a.part_r[(size_t)p * NP * HEADS + HEADS + head];
+        }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     rsum = group_sum<LPR, WAVE>(rsum);
+    if constexpr (SAVE) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) ng.accn[j] = group_sum<LPR, WAVE>(ng.accn[j]);
+        ng.rneg = group_sum<LPR, WAVE>(ng.rneg);
+    }
     if (slot != 0) return;
-    finish_row<T, D, HEADS>(a, row, q, head, acc, rsum);
+    finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
 }
 
-template <typename T, int D, int HEADS>
-static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st, int next_dout = 0, bool next_one = false,
-                      bool next_staged = false) {
+template <typename T, int D, int HEADS, bool SAVE>
+static int launch_fwd_s(PropArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st, int next_dout, bool next_one,
+                        bool next_staged) {
     constexpr int EPI = Shape<T, D, HEADS>::EPI;
     int nb = 0;
     a.order = make_order(a.nseg, a.order.nseg_u, a.nshort, a.order.nshort_u, a.order.nhub, a.order.nhub_u, EPI, &nb);
@@ -587,8 +685,8 @@ static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, b
             const dim3 grid(nb), block(256);
 #define NGACF_NEXT(ND, ONE, STG)                                                                                         \
             do {                                                                                                         \
-                if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, true, false, ND, ONE, STG>, grid, block, 0, st, a);   \
-                else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, false, ND, ONE, STG>, grid, block, 0, st, a);  \
+                if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, true, false, ND, ONE, STG, SAVE>, grid, block, 0, st, a);   \
+                else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, false, ND, ONE, STG, SAVE>, grid, block, 0, st, a);  \
             } while (0)
             constexpr bool B16 = sizeof(T) == 2;             // (the staged form exists for bf16 storage only)
             if (B16 && next_staged) {
@@ -612,22 +710,30 @@ static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, b
     if (nb > 0) {
         const dim3 grid(nb), block(256);
         if (a.needed) {                 // (only with NGACF_SCORE_ROW: checked by the caller)
-            if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, true, true>, grid, block, 0, st, a);
-            else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, true>, grid, block, 0, st, a);
+            if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, true, true, 0, false, false, SAVE>, grid, block, 0, st, a);
+            else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, true, 0, false, false, SAVE>, grid, block, 0, st, a);
         } else if (from_row) {
-            if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, true, false>, grid, block, 0, st, a);
-            else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, false>, grid, block, 0, st, a);
+            if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, true, false, 0, false, false, SAVE>, grid, block, 0, st, a);
+            else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, false, 0, false, false, SAVE>, grid, block, 0, st, a);
         } else {
-            if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, false, true, false>, grid, block, 0, st, a);
-            else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, false, false, false>, grid, block, 0, st, a);
+            if (drop) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, false, true, false, 0, false, false, SAVE>, grid, block, 0, st, a);
+            else      launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, false, false, false, 0, false, false, SAVE>, grid, block, 0, st, a);
         }
         NGACF_CHECK_LAUNCH();
     }
     if (nsplit > 0 && a.tickets == nullptr) {
-        launch_k(NGACF_TAG_PROP_FWD_SPLIT, prop_fwd_split_kernel<T, D, HEADS>, dim3((nsplit + 3) / 4), dim3(256), 0, st, a, split, nsplit);
+        launch_k(NGACF_TAG_PROP_FWD_SPLIT, prop_fwd_split_kernel<T, D, HEADS, SAVE>, dim3((nsplit + 3) / 4), dim3(256), 0, st, a, split, nsplit);
         NGACF_CHECK_LAUNCH();
     }
     return 0;
+}
+
+// agg and R given (a train-mode forward): the SAVE instantiations, which also keep the negative-side sums (second planes of agg / R)
+template <typename T, int D, int HEADS>
+static int launch_fwd(PropArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st, int next_dout = 0, bool next_one = false,
+                      bool next_staged = false) {
+    if (a.agg) return launch_fwd_s<T, D, HEADS, true>(a, split, nsplit, from_row, drop, st, next_dout, next_one, next_staged);
+    return launch_fwd_s<T, D, HEADS, false>(a, split, nsplit, from_row, drop, st, next_dout, next_one, next_staged);
 }
 
 }  // namespace ngacf
@@ -654,6 +760,7 @@ extern "C" int ngacf_prop_fwd_next(const int32_t* segs, int nseg, const int32_t*
     if (nseg + nshort + nhub == 0) return 0;
     if (!col || !H || !S_dst || !rowptr) return NGACF_E_ARG;
     if (!out && !next) return NGACF_E_ARG;                                      // (out may be NULL only when the next stage's operands are the result)
+    if ((agg == nullptr) != (R == nullptr)) return NGACF_E_ARG;                 // saved together (two planes each) or not at all
     if ((nseg > 0 && !segs) || (nshort > 0 && !srow) || (nhub > 0 && !hrow)) return NGACF_E_ARG;
     const bool from_row = (flags & NGACF_SCORE_ROW) != 0;
     if (from_row ? !avec : !S_src) return NGACF_E_ARG;

@@ -1,23 +1,30 @@
 // Attention propagation, backward (pull-only, no atomics): autograd of
-// graphattention/SPUIGACF.py:359-397; formulas SURVEY.md 8(a) row A4b.
+// graphattention/SPUIGACF.py:359-397; formulas SURVEY.md 8(a) row A4b, regrouped ("split-sign" form):
 //
-// Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  t[n,h] = (g . agg)_h / R
-// Step 2 (per directed edge, pulled by the destination row n, source c):
-//     e  = exp(-lrelu(S_dst[n] + S_src[c]))          m = edge dropout multiplier
-//     de = m * (Gn[n].H[c] + Gn[c].H[n])_h - t[n] - t[c]
-//     dS[n,h] += -e * lrelu'(s) * de                  acc[n] += m e Gn[c]
+//   e = exp(-lrelu(s)),  s = S[n] + S[c],  m = edge dropout multiplier,
+//   ds(n,c) = -lrelu'(s) e (m (Gn[n].H[c] + Gn[c].H[n])_h - t[n] - t[c]),        dS[n,h] = sum_c ds(n,c)
+//   splits into the terms that carry the row's OWN gradient and those that carry the neighbour's:
+//     own:    sum_c -lrelu'(s) e (m Gn[n].H[c] - t[n])  =  (1 - alpha) (R[n] (Gn[n].aggn[n])_h - Rn[n] t[n])        =: P1[n,h]
+//             (lrelu' is 1 where s > 0 and alpha elsewhere; sum_c m e H[c] = R agg and t R = Gn.(R agg) cancel; what is left is
+//              the sum over the edges with s <= 0, which the train-mode forward keeps: aggn = that sum / R, Rn = the sum of
+//              their e -- the second planes of agg / R, propagate.hip NegSums)
+//     other:  sum_c -lrelu'(s) e (m Gn[c].H[n] - t[c])                                                  (the edge step)
+//
+// Step 1 (per node):  g = gout * ELU'(out);  Gn = g / R;  t = (Gn . agg)_h;  ST[n,h] = (S[n,h], t[n,h]);  dS[n,h] = P1[n,h]
+// Step 2 (per directed edge, pulled by the destination row n, source c): gathers the row Gn[c] and the pair ST[c,h]
+//     dS[n,h] += -e lrelu'(s) (m (Gn[c].H[n])_h - t[c])                 acc[n] += m e Gn[c]
 //   epilogue: dH[n] = g[n] + acc[n] + dS[n,h] * avec[type(n)]
+// One row gather and 8 bytes per head per edge (the form with Gn[n].H[c] in the edge step gathered H[c] too: 292 against 196
+// bytes and three against two cache-line requests per edge at d = 64, bf16).
 //
-// Same two traversal modes and lane layout as the forward (propagate.hip): a lane owns a 16-byte
-// slice of the feature row H[c] AND of the normalised-gradient row Gn[c], which is stored in the
-// same type T as H (bf16 storage halves the dominant gather of the backward too).
+// Same two traversal modes and lane layout as the forward (propagate.hip): a lane owns a 16-byte slice of the normalised-
+// gradient row Gn[c], which is stored in the same type T as H (bf16 storage halves the gather).
 #include "ngacf_common.hpp"
 
 namespace ngacf {
 
-constexpr int UNROLL = 2;            // edges of gathers in flight per lane group (3 rows each).  4: 102-122 VGPRs, 4 waves/SIMD; 2: 92 VGPRs, 5 waves/SIMD --
-                                     // alone 66 -> 65 us with dropout (72 -> 73 without), inside the train step 0.668 -> 0.662 ms
-constexpr int UNROLL_Q = 2;          // edges in flight per lane group while a row outside the batch walks its queue (2-5 entries, typically)
+constexpr int UNROLL = 4;            // edges of gathers in flight per lane group (one row + one pair each)
+constexpr int UNROLL_Q = 2;          // edges in flight per lane group while a row walks its queue (row flags: 2-5 entries, typically)
 
 struct PropBwdArgs {
     const int4* segs;
@@ -29,17 +36,17 @@ struct PropBwdArgs {
     const int* col;
     const void* H;
     const float* S_dst;
-    const float* S_src;
+    const float* S_src;            // step 1 copies the node's score from here into ST
     const float* avec;
     const void* out;
-    const void* agg;               // [N][d] in the storage type (as ngacf_prop_fwd saved it)
-    const float* R;
+    const void* agg;               // [2][N][d] in the storage type (as ngacf_prop_fwd saved it: agg, then the negative-side aggn)
+    const float* R;                // [2][N][heads]: R, then Rn
     const void* gout;              // [rows][d] of the stage's storage type (the dtype autograd hands back)
     float* G;
     void* Gn;
-    float* Tn;                     // t[N][heads]
+    float2* ST;                    // [N][heads] pairs (S, t)
     void* dH;                      // [N][d] in H's storage type: its consumer (transform_bwd.hip) rounds a bf16 stage's dH to bf16 anyway
-    float* dS;
+    float* dS;                     // step 1 leaves P1 here, step 2 adds the edge sums
     float* part_acc;
     float* part_r;
     const int* split;              // {row, first slot, slots} of the hub rows
@@ -55,26 +62,27 @@ struct PropBwdArgs {
     uint64_t seed;
     const uint64_t* seed_dev;
     int flags;
-    const uint32_t* needed;         // optional, one bit per row: gout is zero outside these rows (the last stage of a scored batch), so Gn and t
-                                   // are zero there and an edge whose two ends are both outside contributes exactly nothing
-    const int* rows;               // with needed: the same rows as a list (duplicates allowed, -1 = skip)
+    const uint32_t* needed;         // optional, one bit per row: gout is zero outside these rows (the last stage of a scored batch), so Gn, t and
+                                   // P1 are zero there and only the edges whose SOURCE is flagged contribute anything, to any row
+    const int* rows;               // with needed: the same rows as a list (duplicates allowed, -1 = skip): step 1 runs over it
     int nrows;
-    int short_max;                 // with needed: degree bound of the plan's short rows
     // The fused tail (ngacf_prop_bwd_dx; fx_dX == nullptr: none): the stage's transform backward dX = mask * (dH @ W[type]^T) of the
     // rows a workgroup has just finished, and on that dX row step 1 of the PREVIOUS stage's backward (pv_*: that stage's saved
-    // out / agg / R; its Gn and t tables are the results).
+    // out / agg / R and its scores; its Gn, ST and dS (P1) tables are the results).
     const void* fx_panel;          // [2][d/16][din/32][64] x 16 B: bf16 A fragments of W[type]^T (ngacf_transform_fwd_pack, kind 1)
     void* fx_dX;                   // [N][din]: bf16 (with pv_*), or fp32 (the first stage: the embedding table's gradient)
     uint32_t fx_drop_thr;          // the stage's feature dropout (0 = none)
     float fx_drop_scale;
     uint64_t fx_seed;
     const void* pv_out;
-    const void* pv_agg;
-    const float* pv_R;
+    const void* pv_agg;            // [2][N][din]
+    const float* pv_R;             // [2][N][din/8]
+    const float* pv_S;             // [N][din/8]
     void* pv_Gn;
-    float* pv_T;
+    float2* pv_ST;
+    float* pv_dS;
+    float pv_alpha;
     int pv_flags;                  // NGACF_ELU of the previous stage
-    int sp_rows_u, sp_nseg_u, sp_nshort_u;   // with needed: leading user entries of rows / segs / srow (which panel a workgroup fetches first)
 };
 
 template <typename T, int D, int HEADS>
@@ -112,6 +120,12 @@ __device__ __forceinline__ int slot_bcast_b(int v) {
     return __builtin_amdgcn_ds_swizzle(v, (J << 5) | and_mask);
 }
 
+// P1 of the header comment from the two head sums p = (Gn . agg)_h (= t) and pn = (Gn . aggn)_h; one explicit operation order
+// (the fused tail of the next stage's launch computes the same bits)
+__device__ __forceinline__ float own_term(float alpha, float r, float rn, float p, float pn) {
+    return (1.f - alpha) * fmaf(r, pn, -(rn * p));
+}
+
 // Step 1, per node.  One lane per 16-byte slice of the row.
 template <typename T, int D, int HEADS>
 __global__ __launch_bounds__(256) void prop_bwd_node_kernel(const PropBwdArgs a) {
@@ -130,58 +144,49 @@ __global__ __launch_bounds__(256) void prop_bwd_node_kernel(const PropBwdArgs a)
     }
     const size_t nn = n;
     const int head = (q * VEC) / HW;
-    float g[VEC], o[VEC], ag[VEC];
+    float g[VEC], o[VEC], ag[VEC], an[VEC];
     if (a.flags & NGACF_GOUT_F32) load_f32<VEC>(static_cast<const float*>(a.gout) + nn * D + q * VEC, g);
     else Slice<T>::load(static_cast<const T*>(a.gout) + (a.gout_local ? lj : nn) * D + q * VEC, g);
     Slice<T>::load(static_cast<const T*>(a.agg) + nn * D + q * VEC, ag);
+    Slice<T>::load(static_cast<const T*>(a.agg) + ((size_t)a.N + nn) * D + q * VEC, an);
     if (a.flags & NGACF_ELU) {
         Slice<T>::load(static_cast<const T*>(a.out) + nn * D + q * VEC, o);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) g[j] *= o[j] > 0.f ? 1.f : o[j] + 1.f;   // ELU' = exp(pre) = out + 1 on the negative side
     }
-    const float r = a.R[nn * HEADS + head];
+    const float r = a.R[nn * HEADS + head], rn = a.R[((size_t)a.N + nn) * HEADS + head];
     const float inv = r > 0.f ? 1.f / r : 0.f;                // isolated node: the aggregate is a constant 0
-    float gn[VEC], p = 0.f;
+    float gn[VEC], p = 0.f, pn = 0.f;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         gn[j] = Slice<T>::round(g[j] * inv);                  // t from the stored (rounded) Gn: both directions agree
         p = fmaf(gn[j], ag[j], p);
+        pn = fmaf(gn[j], an[j], pn);
     }
     p = lanes_sum<SH::LPH>(p);
+    pn = lanes_sum<SH::LPH>(pn);
     if (!ok) return;
     if (a.G) store_f32<VEC>(a.G + n * D + q * VEC, g);      // G == NULL: step 2 recomputes g from gout and out (same arithmetic)
     Slice<T>::store(static_cast<T*>(a.Gn) + n * D + q * VEC, gn);
-    if ((q * VEC) % HW == 0) a.Tn[n * HEADS + head] = p;
+    if ((q * VEC) % HW == 0) {
+        a.ST[n * HEADS + head] = make_float2(a.S_src[n * HEADS + head], p);
+        a.dS[n * HEADS + head] = own_term(a.alpha, r, rn, p, pn);
+    }
 }
 
 template <int VEC>
 struct RowCtx {
-    float h_own[VEC], gn_own[VEC], av[VEC];
-    float s_dst, t_own;
+    float h_own[VEC];
+    float s_dst;
     uint32_t row_key, salt_h;
     bool dst_is_user;
-    bool in_batch;                 // a.needed == NULL, or this dst row is one of the batch's rows
 };
 
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE>
+template <typename T, int D, int HEADS, bool DROP>
 __device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, int head, RowCtx<Slice<T>::VEC>& x) {
-    constexpr int VEC = Slice<T>::VEC;
     x.dst_is_user = row < a.U;
-    x.in_batch = !SPARSE || flagged(a.needed, row);
     load_row<T, D, HEADS>(a.H, row, q, x.h_own);
-    load_row<T, D, HEADS>(a.Gn, row, q, x.gn_own);
     x.s_dst = a.S_dst[(size_t)row * HEADS + head];
-    x.t_own = a.Tn[(size_t)row * HEADS + head];
-    if (SPARSE && !x.in_batch) {                              // Gn / t exist for the batch's rows only: zero elsewhere
-#pragma unroll
-        for (int j = 0; j < Slice<T>::VEC; ++j) x.gn_own[j] = 0.f;
-        x.t_own = 0.f;
-    }
-    if (FROM_ROW) {
-        const float* ap = a.avec + (x.dst_is_user ? D : 0) + q * VEC;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) x.av[j] = ap[j];
-    }
     x.salt_h = x.row_key = 0;
     if (DROP) {
         x.salt_h = salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + head);
@@ -189,21 +194,15 @@ __device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, i
     }
 }
 
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
-__device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<Slice<T>::VEC>& x, const float (&hv)[Slice<T>::VEC],
-                                            const float (&gv)[Slice<T>::VEC], float s_src, float t_src, bool ok, int c,
-                                            float (&acc)[Slice<T>::VEC], float& dsum) {
+template <typename T, int D, int HEADS, bool DROP>
+__device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<Slice<T>::VEC>& x, const float (&gv)[Slice<T>::VEC],
+                                            float2 st, bool ok, int c, float (&acc)[Slice<T>::VEC], float& dsum) {
     constexpr int LPH = BShape<T, D, HEADS>::LPH, VEC = Slice<T>::VEC;
-    float dot = 0.f, s = 0.f;
+    float dot = 0.f;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        dot = fmaf(x.gn_own[j], hv[j], dot);
-        dot = fmaf(gv[j], x.h_own[j], dot);
-        if (FROM_ROW) s = fmaf(hv[j], x.av[j], s);
-    }
+    for (int j = 0; j < VEC; ++j) dot = fmaf(gv[j], x.h_own[j], dot);
     dot = lanes_sum<LPH>(dot);
-    s = FROM_ROW ? lanes_sum<LPH>(s) : s_src;
-    s += x.s_dst;
+    const float s = x.s_dst + st.x;
     const float lr = fmaxf(s, a.alpha * s);
     const float ev = ok ? __expf(-lr) : 0.f;
     float m = 1.f;
@@ -211,41 +210,38 @@ __device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<S
         const uint32_t other = x.dst_is_user ? (uint32_t)c * RNG_K2 + x.salt_h : (uint32_t)c * RNG_K1;
         m = lowbias32(x.row_key ^ other) >= a.drop_thr ? a.drop_scale : 0.f;
     }
-    const float de = m * dot - x.t_own - t_src;
+    const float de = m * dot - st.y;
     dsum -= ev * de * (s > 0.f ? 1.f : a.alpha);
     const float wgt = m * ev;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = fmaf(wgt, gv[j], acc[j]);
 }
 
-// The gathers of one edge: H row, Gn row, t entry (S entry without NGACF_SCORE_ROW).  SPARSE (a row walking ALL its edges):
-// Gn / t of a neighbour outside the batch were never written -- they are zero, and the two loads are pointed at the row's
-// own entries instead (one cached line for all such lanes; the value is discarded), so only H[c] is really gathered there.
-template <typename T, int D, int HEADS, bool FROM_ROW, bool SPARSE>
-__device__ __forceinline__ void load_edge_b(const PropBwdArgs& a, int c, int row, int q, int head, float (&hv)[Slice<T>::VEC],
-                                            float (&gv)[Slice<T>::VEC], float& ss, float& tc) {
-    load_row<T, D, HEADS>(a.H, c, q, hv);
+// The gathers of one edge: the Gn row and the (S, t) pair of the lane's head.  SPARSE (hub-row workgroups, which walk ALL their
+// edges): Gn / ST of a neighbour outside the batch were never written -- such an edge contributes nothing, and its two loads are
+// pointed at the row's own entries instead (one cached line for all such lanes; the values are discarded).
+template <typename T, int D, int HEADS, bool SPARSE>
+__device__ __forceinline__ void load_edge_b(const PropBwdArgs& a, int c, int row, int q, int head, float (&gv)[Slice<T>::VEC], float2& st) {
     const bool in = !SPARSE || flagged(a.needed, c);
     const int cg = in ? c : row;
     load_row<T, D, HEADS>(a.Gn, cg, q, gv);
-    tc = a.Tn[(size_t)cg * HEADS + head];
-    ss = FROM_ROW ? 0.f : a.S_src[(size_t)c * HEADS + head];
+    st = a.ST[(size_t)cg * HEADS + head];
     if (SPARSE) {
 #pragma unroll
         for (int j = 0; j < Slice<T>::VEC; ++j) gv[j] = in ? gv[j] : 0.f;
-        tc = in ? tc : 0.f;
+        st = in ? st : make_float2(0.f, 0.f);
     }
 }
 
 // SPARSE traversal of one lane group's edges (positions ebase + k * estride, k < count): per chunk of QCAP edges,
-// (1) every lane of the group tests ONE edge -- it takes part when the own row is in the batch or the other end is (one
-//     flag byte) -- and the columns that take part are appended, in order, to the group's queue in LDS;
-// (2) the queue is walked exactly like the dense loop (UNROLL edges of gathers in flight).
-// Outside the batch ~|batch| / N of a row's edges survive, so the three row gathers of the others are never issued, and
-// the surviving ones are still issued in full batches.  The order of the additions is the dense kernel's, minus terms that
-// are exactly zero there: same bits.
+// (1) every lane of the group tests ONE edge -- it takes part when its source is in the batch (one flag bit) -- and the columns
+//     that take part are appended, in order, to the group's queue in LDS;
+// (2) the queue is walked exactly like the dense loop (UNROLL_Q edges of gathers in flight).
+// ~|batch| / N of a row's edges survive, whether the row itself is in the batch or not (its own gradient's terms are P1, from
+// step 1): the gathers of the others are never issued.  The order of the additions is the dense kernel's, minus terms that are
+// exactly zero there: same bits.
 constexpr int QCAP = 64;
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP>
+template <typename T, int D, int HEADS, bool DROP>
 __device__ __forceinline__ void sparse_edges_b(const PropBwdArgs& a, const RowCtx<Slice<T>::VEC>& x, int* __restrict__ qbuf, int row,
                                                int ebase, int estride, int count, int slot, int q, int head,
                                                float (&acc)[Slice<T>::VEC], float& dsum) {
@@ -269,12 +265,10 @@ __device__ __forceinline__ void sparse_edges_b(const PropBwdArgs& a, const RowCt
             act[i] = k < count;
             c[i] = a.col[act[i] ? ebase + k * estride : 0];
         }
-        if (!x.in_batch) {
 #pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                if (i * LPR >= rem) continue;
-                act[i] = act[i] && flagged(a.needed, c[i]);
-            }
+        for (int i = 0; i < NS; ++i) {
+            if (i * LPR >= rem) continue;
+            act[i] = act[i] && flagged(a.needed, c[i]);
         }
         int n = 0;                                              // queued so far (the same in every lane of the group)
 #pragma unroll
@@ -298,32 +292,31 @@ __device__ __forceinline__ void sparse_edges_b(const PropBwdArgs& a, const RowCt
                 ok[u] = b + u < n;
                 c[u] = ok[u] ? qbuf[b + u] : row;               // (idle: the own row, a cached line)
             }
-            float hv[UNROLL_Q][VEC], gv[UNROLL_Q][VEC];
-            float ss[UNROLL_Q], tc[UNROLL_Q];
+            float gv[UNROLL_Q][VEC];
+            float2 st[UNROLL_Q];
 #pragma unroll
             for (int u = 0; u < UNROLL_Q; ++u) {
-                load_row<T, D, HEADS>(a.H, c[u], q, hv[u]);
                 load_row<T, D, HEADS>(a.Gn, c[u], q, gv[u]);
-                tc[u] = a.Tn[(size_t)c[u] * HEADS + head];
-                ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[u] * HEADS + head];
-                if (!ok[u]) {                                   // idle: Gn / t of the own row (outside the batch) were never written
+                st[u] = a.ST[(size_t)c[u] * HEADS + head];
+                if (!ok[u]) {                                   // idle: Gn / ST of the own row may never have been written
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) gv[u][j] = 0.f;
-                    tc[u] = 0.f;
+                    st[u] = make_float2(0.f, 0.f);
                 }
             }
 #pragma unroll
             for (int u = 0; u < UNROLL_Q; ++u)
-                edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], ok[u], c[u], acc, dsum);
+                edge_step_b<T, D, HEADS, DROP>(a, x, gv[u], st[u], ok[u], c[u], acc, dsum);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-// dH[n] = g[n] + acc[n] + dS[n, h] * avec[type(n)]: the row's value (calc) and the two stores (store).  The fused launch puts the
-// workgroup's barrier BETWEEN them: a wave that has stores in flight waits for their acknowledgement at the barrier (vmcnt counts
-// stores too), which held every wave for a write round trip -- 114 against 81 us per launch inside the train step.
+// dS[n, h] = P1 (step 1 left it in dS) + the edge sums; dH[n] = g[n] + acc[n] + dS[n, h] * avec[type(n)]: the row's value (calc) and
+// the two stores (store).  The fused launch puts the workgroup's barrier BETWEEN them: a wave that has stores in flight waits for
+// their acknowledgement at the barrier (vmcnt counts stores too), which held every wave for a write round trip -- 114 against 81 us
+// per launch inside the train step.
 template <typename T, int D, int HEADS, int VEC>
 __device__ __forceinline__ void finish_row_store(const PropBwdArgs& a, int row, int q, int head, const float (&o)[VEC], float dsum) {
     constexpr int HW = D / HEADS;
@@ -332,10 +325,12 @@ __device__ __forceinline__ void finish_row_store(const PropBwdArgs& a, int row, 
 }
 
 template <typename T, int D, int HEADS, int VEC>
-__device__ __forceinline__ void finish_row_calc(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum, float (&o)[VEC]) {
+__device__ __forceinline__ void finish_row_calc(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float& dsum, float (&o)[VEC]) {
     float g[VEC];
+    const bool outside = a.needed && !flagged(a.needed, row);     // outside the batch: g = 0, P1 = 0, out is not valid
+    if (!outside) dsum += a.dS[(size_t)row * HEADS + head];        // P1 (step 1)
     if ((a.flags & NGACF_RESIDUAL) && a.G) load_f32<VEC>(a.G + (size_t)row * D + q * VEC, g);
-    else if ((a.flags & NGACF_RESIDUAL) && a.needed && !flagged(a.needed, row)) {          // outside the batch: g = 0, out is not valid
+    else if ((a.flags & NGACF_RESIDUAL) && outside) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) g[j] = 0.f;
     } else if (a.flags & NGACF_RESIDUAL) {         // g = gout * ELU'(out), exactly as step 1 computed it (no 4-byte G table)
@@ -377,12 +372,13 @@ struct RowDone {
 // to every wave's life -- with row flags most rows' finish has no load at all, and that launch went from 38 to 64 us.)
 // Tile layout: [32 rows][8 pieces of 16 B], no padding (a wave instruction writes 1 KB = the 8 rows of a wave, contiguous);
 // lane (slot, q) fetches piece q ^ slot, so position (row r, p) holds piece p ^ (r & 7) and the tail's reads of ONE piece over
-// 16 rows spread over all banks.  R: [32 rows][8 heads] floats.
+// 16 rows spread over all banks.  R, Rn, S: [32 rows][8 heads] floats each.
 template <typename T, int D, int VEC>
 struct PrevTiles {
     uint4* otile;
     uint4* atile;
-    float* rtile;
+    uint4* ntile;
+    float* rtile;                  // [3][32 * 8]: R, Rn, S
 };
 
 template <typename T, int D, int VEC>
@@ -390,12 +386,19 @@ __device__ __forceinline__ void dma_prev(const PropBwdArgs& a, const PrevTiles<T
     static_assert(sizeof(T) == 2 && D == 64, "bf16 rows of 64 columns");
     const int wave = threadIdx.x >> 6;
     const size_t off = (size_t)row * D * sizeof(T) + (size_t)((q ^ slot) * 16);
+    const size_t plane = (size_t)a.N * D * sizeof(T);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.pv_out) + off),
                                      (__attribute__((address_space(3))) void*)(pt.otile + wave * 64), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.pv_agg) + off),
                                      (__attribute__((address_space(3))) void*)(pt.atile + wave * 64), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.pv_agg) + plane + off),
+                                     (__attribute__((address_space(3))) void*)(pt.ntile + wave * 64), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.pv_R + (size_t)row * 8 + q),
                                      (__attribute__((address_space(3))) void*)(pt.rtile + wave * 64), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.pv_R + ((size_t)a.N + row) * 8 + q),
+                                     (__attribute__((address_space(3))) void*)(pt.rtile + 256 + wave * 64), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.pv_S + (size_t)row * 8 + q),
+                                     (__attribute__((address_space(3))) void*)(pt.rtile + 512 + wave * 64), 4, 0, 0);
 }
 
 template <typename T, int D, int HEADS, int FUSE, int VEC>
@@ -412,7 +415,7 @@ __device__ __forceinline__ void finish_row_t(const PropBwdArgs& a, int row, int 
 
 // The traversal of one wave's work item(s).  FUSE != 0 (ngacf_prop_bwd_dx): the row this lane's group finished is also handed
 // back in `rd` for the workgroup's tail, and no path leaves the KERNEL before that tail (the returns below leave this function).
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int FUSE>
+template <typename T, int D, int HEADS, bool DROP, bool SPARSE, int FUSE>
 __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, int widx, int wend, int* qmem, RowDone<Slice<T>::VEC>& rd,
                                               const PrevTiles<T, D, Slice<T>::VEC>& pt) {
     using SH = BShape<T, D, HEADS>;
@@ -435,7 +438,7 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
         const int wv = threadIdx.x >> 6;
         const int row = uniform(a.hrow[widx]);
         const int beg = uniform(a.rowptr[row]), end = uniform(a.rowptr[row + 1]);
-        load_ctx<T, D, HEADS, FROM_ROW, DROP, SPARSE>(a, row, q, head, x);
+        load_ctx<T, D, HEADS, DROP>(a, row, q, head, x);
         for (int base = beg + wv * EPI * UNR; base < end; base += 4 * EPI * UNR) {
             int c[UNR];
             bool ok[UNR];
@@ -445,15 +448,14 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
                 ok[u] = e < end;
                 c[u] = a.col[ok[u] ? e : end - 1];
             }
-            float hv[UNR][VEC], gv[UNR][VEC];
-            float ss[UNR], tc[UNR];
+            float gv[UNR][VEC];
+            float2 st[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {              // (SPARSE: every edge is gathered; the ones outside the batch add exact zeros)
-                load_edge_b<T, D, HEADS, FROM_ROW, SPARSE>(a, c[u], row, q, head, hv[u], gv[u], ss[u], tc[u]);
-            }
+            for (int u = 0; u < UNR; ++u)                 // (SPARSE: every edge is visited; the ones from outside the batch add exact zeros)
+                load_edge_b<T, D, HEADS, SPARSE>(a, c[u], row, q, head, gv[u], st[u]);
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], ok[u], c[u], acc, dsum);
+                edge_step_b<T, D, HEADS, DROP>(a, x, gv[u], st[u], ok[u], c[u], acc, dsum);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
@@ -480,16 +482,15 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
         // ------------------------------------------------------------------ short rows: slot per row
         const int ridx = widx + slot;
         const int rraw = a.srow[ridx < wend ? ridx : wend - 1];
-        bool live = ridx < wend && rraw >= 0;                // -1 = padding between the user and item lists
+        const bool live = ridx < wend && rraw >= 0;          // -1 = padding between the user and item lists
         const int row = live ? rraw : 0;
         const int beg = a.rowptr[row];
-        int deg = live ? a.rowptr[row + 1] - beg : 0;
-        if (SPARSE && flagged(a.needed, row)) { live = false; deg = 0; }      // a row of the batch: the row list carries it (long path)
+        const int deg = live ? a.rowptr[row + 1] - beg : 0;
         const int maxdeg = uniform(deg);                     // rows are sorted: slot 0 holds the longest
-        load_ctx<T, D, HEADS, FROM_ROW, DROP, SPARSE>(a, row, q, head, x);
+        load_ctx<T, D, HEADS, DROP>(a, row, q, head, x);
         if constexpr (FUSE == 2) dma_prev<T, D, VEC>(a, pt, row, slot, q);
-        if (SPARSE) {                                        // outside the batch: only the edges into the batch take part (the queue)
-            sparse_edges_b<T, D, HEADS, FROM_ROW, DROP>(a, x, qbuf, row, beg, 1, deg, slot, q, head, acc, dsum);
+        if (SPARSE) {                                        // only the edges out of the batch take part (the queue)
+            sparse_edges_b<T, D, HEADS, DROP>(a, x, qbuf, row, beg, 1, deg, slot, q, head, acc, dsum);
             if (live) finish_row_t<T, D, HEADS, FUSE, VEC>(a, row, q, head, acc, dsum, rd);
             return;
         }
@@ -505,15 +506,14 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
 #pragma unroll
             for (int h0 = 0; h0 < 8; h0 += UNR) {
                 if (h0 > 0 && k0 + h0 >= maxdeg) break;
-                float hv[UNR][VEC], gv[UNR][VEC];
-                float ss[UNR], tc[UNR];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    load_edge_b<T, D, HEADS, FROM_ROW, SPARSE>(a, c[h0 + u], row, q, head, hv[u], gv[u], ss[u], tc[u]);
-                }
+                float gv[UNR][VEC];
+                float2 st[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u)
-                    edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], k0 + h0 + u < deg, c[h0 + u], acc, dsum);
+                    load_edge_b<T, D, HEADS, false>(a, c[h0 + u], row, q, head, gv[u], st[u]);
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    edge_step_b<T, D, HEADS, DROP>(a, x, gv[u], st[u], k0 + h0 + u < deg, c[h0 + u], acc, dsum);
             }
             colv = coln;
         }
@@ -523,22 +523,13 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
 
     // ---------------------------------------------------------------------- long rows: wave per segment
     const int w = uniform(widx);
-    int row, beg, end, part;
-    if (SPARSE && w < a.order.nseg_u) {
-        // SPARSE, first group: the batch's own row list, a WAVE per short row; all its edges take part (the dense loop below)
-        row = uniform(a.rows[w]);
-        if (row < 0) return;
-        beg = uniform(a.rowptr[row]); end = uniform(a.rowptr[row + 1]); part = -1;
-        if (end - beg > a.short_max) return;                 // a long row: its segments carry it
-    } else {
-        const int4 sg = a.segs[SPARSE ? w - a.order.nseg_u : w];
-        row = uniform(sg.x); beg = uniform(sg.y); end = uniform(sg.z); part = uniform(sg.w);
-    }
-    load_ctx<T, D, HEADS, FROM_ROW, DROP, SPARSE>(a, row, q, head, x);
+    const int4 sg = a.segs[w];
+    const int row = uniform(sg.x), beg = uniform(sg.y), end = uniform(sg.z), part = uniform(sg.w);
+    load_ctx<T, D, HEADS, DROP>(a, row, q, head, x);
     if constexpr (FUSE == 2) dma_prev<T, D, VEC>(a, pt, row, slot, q);     // (a hub row's slices fetch it too: any of them may finish the row)
-    if (SPARSE && !x.in_batch) {                    // the lane group's edges: beg + slot, + EPI, ... (the dense loop's assignment)
+    if (SPARSE) {                                   // the lane group's edges: beg + slot, + EPI, ... (the dense loop's assignment)
         const int mine = end - beg - slot;
-        sparse_edges_b<T, D, HEADS, FROM_ROW, DROP>(a, x, qbuf, row, beg + slot, EPI, mine > 0 ? (mine + EPI - 1) / EPI : 0, slot, q, head, acc, dsum);
+        sparse_edges_b<T, D, HEADS, DROP>(a, x, qbuf, row, beg + slot, EPI, mine > 0 ? (mine + EPI - 1) / EPI : 0, slot, q, head, acc, dsum);
     } else {
         for (int base = beg; base < end; base += EPI * UNR) {
             int c[UNR];
@@ -549,15 +540,14 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
                 ok[u] = e < end;
                 c[u] = a.col[ok[u] ? e : end - 1];
             }
-            float hv[UNR][VEC], gv[UNR][VEC];
-            float ss[UNR], tc[UNR];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                load_edge_b<T, D, HEADS, FROM_ROW, SPARSE>(a, c[u], row, q, head, hv[u], gv[u], ss[u], tc[u]);
-            }
+            float gv[UNR][VEC];
+            float2 st[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                edge_step_b<T, D, HEADS, FROM_ROW, DROP>(a, x, hv[u], gv[u], ss[u], tc[u], ok[u], c[u], acc, dsum);
+                load_edge_b<T, D, HEADS, false>(a, c[u], row, q, head, gv[u], st[u]);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                edge_step_b<T, D, HEADS, DROP>(a, x, gv[u], st[u], ok[u], c[u], acc, dsum);
         }
     }
 #pragma unroll
@@ -621,7 +611,8 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
 // WORKGROUP has just finished go through the stage's transform backward while they are on chip,
 //     dX[n, :] = mask * (dH[n, :] @ W[type(n)]^T)                    (transform_bwd.hip: the dX half of transform_dw_mfma_kernel)
 // and, when dX is the gradient of the previous stage's output (FUSE == 2), that stage's step 1 runs on the finished dX row:
-//     g = dX * ELU'(out_prev);  Gn_prev = g / R_prev;  t_prev = (Gn_prev . agg_prev)_h          (prop_bwd_node_kernel)
+//     g = dX * ELU'(out_prev);  Gn_prev = g / R_prev;  t_prev = (Gn_prev . agg_prev)_h;  ST_prev = (S_prev, t_prev);  dS_prev = P1
+//                                                                                                (prop_bwd_node_kernel)
 //   1. every wave writes its finished dH rows -- the bf16 values the dH table stores -- into the workgroup's 32-row LDS tile;
 //      the same rows of out_prev / agg_prev / R_prev (dma_prev, issued when the wave learnt its rows) and the weight panel
 //      (bf16 A fragments of W[type]^T, packed once per step: ngacf_transform_fwd_pack kind 1) have arrived by LDS-DMA meanwhile;
@@ -629,16 +620,15 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
 //   3. wave 0: DKS x DOT v_mfma_f32_32x32x16_bf16 with the node on the lane, k ascending -- the arithmetic, order and bits of
 //      transform_dw_mfma_kernel<WITH_DX> -- then mask, rounding, the half-waves' exchange (a lane then holds 8 consecutive
 //      columns = one head of the previous stage) and the node step in prop_bwd_node_kernel's own operation order.
-// A dense launch's workgroups hold rows of one node type (work order); a launch with row flags (SPARSE) can mix them at the
-// seams of its groups: wave 0 then makes a second pass with the other type's panel (fetched by itself: rare).
+// A launch's workgroups hold rows of one node type (work order), with row flags too: one panel per workgroup.
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bw_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float bw_f32x16;
 constexpr int GROW_U4 = 9;           // a staged row: 128 B of bf16 + 16 B pad (36-dword stride: 16 rows hit 64 distinct banks)
 
-template <typename T, int HEADS, int D, int DIN, int FUSE, bool SPARSE>
-__device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, int gwave, uint4* otile, uint4* atile, float* rtile, int* xmeta,
-                                            int primary, const RowDone<8>& rd, int slot, int q) {
+template <typename T, int HEADS, int D, int DIN, int FUSE>
+__device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, int gwave, uint4* otile, uint4* atile, uint4* ntile, float* rtile,
+                                            int* xmeta, int primary, const RowDone<8>& rd, int slot, int q) {
     static_assert(D == 64 && DIN == 64, "fused dX: 64 -> 64 stages");
     constexpr int DKS = D / 16, DOT = DIN / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -673,19 +663,8 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
 #pragma unroll
     for (int sk = 0; sk < DKS; ++sk) bf[sk] = __builtin_bit_cast(bw_bf16x8, gtile[(r >> 3) * gwave + (r & 7) * GROW_U4 + 2 * sk + hh]);
     const uint32_t salt = a.fx_drop_thr ? salt_of(a.fx_seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
-#pragma unroll 1
-    for (int pass = 0; pass < (SPARSE ? 2 : 1); ++pass) {
-        bool mine = ok;
-        if constexpr (SPARSE) {
-            const int ty = pass == 0 ? primary : 1 - primary;
-            mine = ok && (node >= a.U ? 1 : 0) == ty;
-            if (pass == 1) {
-                if (__ballot(mine) == 0ull) break;
-                const uint4* src = reinterpret_cast<const uint4*>(a.fx_panel) + (size_t)ty * DKS * DOT * 64;
-#pragma unroll
-                for (int i = 0; i < DKS * DOT; ++i) af[i] = __builtin_bit_cast(bw_bf16x8, src[i * 64 + lane]);
-            }
-        }
+    {
+        const bool mine = ok;
 #pragma unroll
         for (int t = 0; t < DOT; ++t) {
             bw_f32x16 dacc;
@@ -727,29 +706,33 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
                     if constexpr (FUSE == 3) continue;        // (bf16 dX only: the previous stage runs its own step 1)
                     // step 1 of the previous stage's backward on this piece = head pc of that stage (prop_bwd_node_kernel, bf16, 8 heads)
                     const uint4 ov = otile[r * 8 + (pc ^ (r & 7))], gv = atile[r * 8 + (pc ^ (r & 7))];   // (dma_prev's layout)
-                    const float rr = rtile[r * 8 + pc];
-                    const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w}, aw[4] = {gv.x, gv.y, gv.z, gv.w};
-                    float g[8], o[8], ag[8];
+                    const uint4 nv = ntile[r * 8 + (pc ^ (r & 7))];
+                    const float rr = rtile[r * 8 + pc], rn = rtile[256 + r * 8 + pc], sp = rtile[512 + r * 8 + pc];
+                    const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w}, aw[4] = {gv.x, gv.y, gv.z, gv.w}, nw[4] = {nv.x, nv.y, nv.z, nv.w};
+                    float g[8], o[8], ag[8], an[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         g[2 * j] = __uint_as_float(w[j] << 16);   g[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
                         o[2 * j] = __uint_as_float(ow[j] << 16);  o[2 * j + 1] = __uint_as_float(ow[j] & 0xffff0000u);
                         ag[2 * j] = __uint_as_float(aw[j] << 16); ag[2 * j + 1] = __uint_as_float(aw[j] & 0xffff0000u);
+                        an[2 * j] = __uint_as_float(nw[j] << 16); an[2 * j + 1] = __uint_as_float(nw[j] & 0xffff0000u);
                     }
                     if (a.pv_flags & NGACF_ELU) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) g[j] *= o[j] > 0.f ? 1.f : o[j] + 1.f;
                     }
                     const float inv = rr > 0.f ? 1.f / rr : 0.f;
-                    float gn[8], p = 0.f;
+                    float gn[8], p = 0.f, pn = 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         gn[j] = Slice<bf16_t>::round(g[j] * inv);
                         p = fmaf(gn[j], ag[j], p);
+                        pn = fmaf(gn[j], an[j], pn);
                     }
                     if (mine) {
                         Slice<bf16_t>::store(static_cast<bf16_t*>(a.pv_Gn) + (size_t)node * DIN + 8 * pc, gn);
-                        a.pv_T[(size_t)node * (DIN / 8) + pc] = p;
+                        a.pv_ST[(size_t)node * (DIN / 8) + pc] = make_float2(sp, p);
+                        a.pv_dS[(size_t)node * (DIN / 8) + pc] = own_term(a.pv_alpha, rr, rn, p, pn);
                     }
                 }
             }
@@ -757,7 +740,7 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
     }
 }
 
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int FUSE = 0>
+template <typename T, int D, int HEADS, bool DROP, bool SPARSE, int FUSE = 0>
 __global__ __launch_bounds__(256, FUSE != 0 ? (DROP || SPARSE ? 4 : 1) : (SPARSE ? (DROP ? 5 : 4) : 1)) void prop_bwd_kernel(const PropBwdArgs a) {
     // (FUSE: 4 waves per SIMD = 128 VGPRs.  Bounded to 5 = 96 VGPRs the 8-head dropout instantiations spill one or two registers to
     //  scratch, and the one with row flags then faulted on the GPU; 5 against 4 waves per SIMD is worth ~1 % in this kernel.)
@@ -770,7 +753,7 @@ __global__ __launch_bounds__(256, FUSE != 0 ? (DROP || SPARSE ? 4 : 1) : (SPARSE
     rd.valid = false;
     rd.row = 0;
     if constexpr (FUSE != 0) {
-        static_assert(sizeof(T) == 2 && D == 64 && FROM_ROW, "fused dX: bf16 rows of 64 columns");
+        static_assert(sizeof(T) == 2 && D == 64, "fused dX: bf16 rows of 64 columns");
         constexpr int DIN = 64;
         // the finished dH rows: 8 rows of 144 B per wave.  With row flags they take over the wave's OWN column queues (2 080 B per
         // wave, dead once the wave has finished its rows -- and only the wave itself ever touched them)
@@ -782,22 +765,16 @@ __global__ __launch_bounds__(256, FUSE != 0 ? (DROP || SPARSE ? 4 : 1) : (SPARSE
         constexpr int gwave = SPARSE ? QWAVE_U4 : 8 * GROW_U4;
         __shared__ __attribute__((aligned(16))) uint4 otile_lds[FUSE == 2 ? 32 * 8 : 1];
         __shared__ __attribute__((aligned(16))) uint4 atile_lds[FUSE == 2 ? 32 * 8 : 1];
-        __shared__ __attribute__((aligned(16))) float rtile_lds[FUSE == 2 ? 32 * 8 : 4];
-        const PrevTiles<T, D, VEC> pt{otile_lds, atile_lds, rtile_lds};
+        __shared__ __attribute__((aligned(16))) uint4 ntile_lds[FUSE == 2 ? 32 * 8 : 1];
+        __shared__ __attribute__((aligned(16))) float rtile_lds[FUSE == 2 ? 3 * 32 * 8 : 4];
+        const PrevTiles<T, D, VEC> pt{otile_lds, atile_lds, ntile_lds, rtile_lds};
         __shared__ int xmeta_lds[32];
         const int lane = threadIdx.x & 63;
-        int primary;
-        if constexpr (!SPARSE) {
-            primary = (int)blockIdx.x < a.order.b2 ? 0 : 1;
-        } else {                                              // the node type of wave 0's first work item, from the lists' user counts
-            int k0, w0, e0;
-            locate(a.order, blockIdx.x, 0, EPI, k0, w0, e0);
-            primary = k0 == WORK_SHORT ? w0 >= a.sp_nshort_u : w0 < a.order.nseg_u ? w0 >= a.sp_rows_u : w0 - a.order.nseg_u >= a.sp_nseg_u;
-        }
-        prop_bwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, FUSE>(a, kind, widx, wend, qmem, rd, pt);
-        bwd_dx_tail<T, HEADS, D, DIN, FUSE, SPARSE>(a, gtile_lds, gwave, otile_lds, atile_lds, rtile_lds, xmeta_lds, primary, rd, lane / SH::LPR, lane % SH::LPR);
+        const int primary = (int)blockIdx.x < a.order.b2 ? 0 : 1;       // (work order: user rows first)
+        prop_bwd_body<T, D, HEADS, DROP, SPARSE, FUSE>(a, kind, widx, wend, qmem, rd, pt);
+        bwd_dx_tail<T, HEADS, D, DIN, FUSE>(a, gtile_lds, gwave, otile_lds, atile_lds, ntile_lds, rtile_lds, xmeta_lds, primary, rd, lane / SH::LPR, lane % SH::LPR);
     } else {
-        prop_bwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, 0>(a, kind, widx, wend, qmem, rd, PrevTiles<T, D, VEC>{nullptr, nullptr, nullptr});
+        prop_bwd_body<T, D, HEADS, DROP, SPARSE, 0>(a, kind, widx, wend, qmem, rd, PrevTiles<T, D, VEC>{nullptr, nullptr, nullptr, nullptr});
     }
 }
 
@@ -830,8 +807,7 @@ __global__ __launch_bounds__(256) void prop_bwd_split_kernel(const PropBwdArgs a
 }
 
 template <typename T, int D, int HEADS>
-static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row, bool drop, hipStream_t st,
-                      bool do_node, bool do_edges, int fuse = 0) {
+static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool drop, hipStream_t st, bool do_node, bool do_edges, int fuse = 0) {
     constexpr int EPI = BShape<T, D, HEADS>::EPI;
     if (do_node && (a.needed ? a.nrows : a.nu_n + a.ni_n) > 0) {
         const size_t threads = (size_t)(a.needed ? a.nrows : a.nu_n + a.ni_n) * BShape<T, D, HEADS>::LPR;
@@ -847,10 +823,10 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
             const dim3 grid(nb), block(256);
 #define NGACF_FX(F)                                                                                                          \
             do {                                                                                                             \
-                if (a.needed && drop) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, true, true, F>, grid, block, 0, st, a);    \
-                else if (a.needed)    launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, false, true, F>, grid, block, 0, st, a);   \
-                else if (drop)        launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, true, false, F>, grid, block, 0, st, a);   \
-                else                  launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, false, false, F>, grid, block, 0, st, a);  \
+                if (a.needed && drop) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, true, F>, grid, block, 0, st, a);    \
+                else if (a.needed)    launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, false, true, F>, grid, block, 0, st, a);   \
+                else if (drop)        launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, false, F>, grid, block, 0, st, a);   \
+                else                  launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, false, false, F>, grid, block, 0, st, a);  \
             } while (0)
             if (fuse == 1) NGACF_FX(1);
             else if (fuse == 2) NGACF_FX(2);
@@ -864,15 +840,12 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool from_row
     }
     if (nb > 0) {
         const dim3 grid(nb), block(256);
-        if (a.needed) {                 // (only with NGACF_SCORE_ROW: checked by the caller)
-            if (drop) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, true, true>, grid, block, 0, st, a);
-            else      launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, false, true>, grid, block, 0, st, a);
-        } else if (from_row) {
-            if (drop) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, true, false>, grid, block, 0, st, a);
-            else      launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, false, false>, grid, block, 0, st, a);
+        if (a.needed) {
+            if (drop) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, true>, grid, block, 0, st, a);
+            else      launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, false, true>, grid, block, 0, st, a);
         } else {
-            if (drop) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, false, true, false>, grid, block, 0, st, a);
-            else      launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, false, false, false>, grid, block, 0, st, a);
+            if (drop) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, true, false>, grid, block, 0, st, a);
+            else      launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, false, false>, grid, block, 0, st, a);
         }
         NGACF_CHECK_LAUNCH();
     }
@@ -898,7 +871,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
                          int U, int N, int d, int heads, float alpha,
                          float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
                          int nu_lo, int nu_n, int ni_lo, int ni_n, int gout_local, bool do_node, bool do_edges,
-                         const uint32_t* needed, const int32_t* rows, int nrows, int short_max, void* stream,
+                         const uint32_t* needed, const int32_t* rows, int nrows, void* stream,
                          const ngacf_bwd_dx* dx = nullptr) {
     if (nseg < 0 || nsplit < 0 || nshort < 0 || U < 0 || N < U) return NGACF_E_ARG;
     if (nseg_user < 0 || nseg_user > nseg || nshort_user < 0 || nshort_user > nshort || (nshort_user % 16 != 0 && nshort_user != nshort))
@@ -906,57 +879,54 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     if (nhub < 0 || nhub_user < 0 || nhub_user > nhub) return NGACF_E_ARG;
     if (nu_lo < 0 || nu_n < 0 || ni_lo < 0 || ni_n < 0 || nu_lo + nu_n > U || ni_lo + ni_n > N - U) return NGACF_E_ARG;
     if (N == 0) return 0;
-    if (!S_src || !Gn || !ST) return NGACF_E_ARG;
+    if (!Gn || !ST || !dS) return NGACF_E_ARG;
     if (!G && !(do_edges && !gout_local && out && gout)) return NGACF_E_ARG;   // without G the edge step recomputes g from global-row gout and out
-    if (do_node && (!out || !agg || !R || !gout)) return NGACF_E_ARG;
+    if (do_node && (!out || !agg || !R || !gout || !S_src)) return NGACF_E_ARG;
     if (do_edges) {
-        if (!col || !rowptr || !H || !S_dst || !avec || !dH || !dS) return NGACF_E_ARG;
+        if (!col || !rowptr || !H || !S_dst || !avec || !dH) return NGACF_E_ARG;
         if ((nseg > 0 && !segs) || (nshort > 0 && !srow) || (nhub > 0 && !hrow)) return NGACF_E_ARG;
         if (nsplit > 0 && (!split || !part_acc || !part_r)) return NGACF_E_ARG;
     }
     if (!(drop_p >= 0.f && drop_p < 1.f) || !(alpha > 0.f && alpha < 1.f)) return NGACF_E_ARG;
     if ((uint64_t)N * (uint64_t)d * (dtype == NGACF_BF16 ? 2ull : 4ull) >= (1ull << 32)) return NGACF_E_SHAPE;   // 32-bit row offsets
-    const bool from_row = (flags & NGACF_SCORE_ROW) != 0;
     PropBwdArgs a;
     a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
     a.hrow = hrow; a.order.nhub = nhub; a.order.nhub_u = nhub_user;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R; a.gout = gout;
-    a.G = G; a.Gn = Gn; a.Tn = ST; a.dH = dH; a.dS = dS; a.part_acc = part_acc; a.part_r = part_r;
+    a.G = G; a.Gn = Gn; a.ST = reinterpret_cast<float2*>(ST); a.dH = dH; a.dS = dS; a.part_acc = part_acc; a.part_r = part_r;
     a.split = split; a.part_split = part_split; a.tickets = (part_split && nsplit > 0) ? tickets : nullptr;
     a.U = U; a.N = N; a.nu_lo = nu_lo; a.nu_n = nu_n; a.ni_lo = ni_lo; a.ni_n = ni_n; a.gout_local = gout_local;
     a.order.nseg_u = nseg_user; a.order.nshort_u = nshort_user; a.alpha = alpha;
     a.drop_thr = drop_threshold(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed; a.seed_dev = seed_dev; a.flags = flags;
-    if (needed && (!from_row || nrows < 0 || (nrows > 0 && !rows))) return NGACF_E_ARG;          // row flags: the SPUIGACF stages only
-    a.needed = needed; a.rows = rows; a.nrows = nrows; a.short_max = short_max;
+    if (needed && (nrows < 0 || (nrows > 0 && !rows))) return NGACF_E_ARG;
+    a.needed = needed; a.rows = rows; a.nrows = nrows;
     if (needed && G) return NGACF_E_ARG;                       // (the G table is a node-partitioned run's; not with row flags)
-    a.sp_rows_u = a.sp_nseg_u = a.sp_nshort_u = 0;
-    if (needed) {              // groups: [the batch's row list, a wave per short row][-][all segments][all short rows minus the batch's]
-        a.sp_nseg_u = nseg_user; a.sp_nshort_u = nshort_user; a.sp_rows_u = dx ? dx->rows_user : 0;
-        a.order.nshort_u = 0; a.nseg = nrows + nseg; a.order.nseg_u = nrows;
-    }
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
     a.fx_panel = nullptr; a.fx_dX = nullptr; a.fx_drop_thr = 0; a.fx_drop_scale = 1.f; a.fx_seed = 0;
-    a.pv_out = a.pv_agg = nullptr; a.pv_R = nullptr; a.pv_Gn = nullptr; a.pv_T = nullptr; a.pv_flags = 0;
+    a.pv_out = a.pv_agg = nullptr; a.pv_R = a.pv_S = nullptr; a.pv_Gn = nullptr; a.pv_ST = nullptr; a.pv_dS = nullptr; a.pv_flags = 0;
+    a.pv_alpha = alpha;
     int fuse = 0;
     if (dx) {
         if (!dx->panel || !dx->dX) return NGACF_E_ARG;
-        if (!do_edges || G || gout_local || nhub > 0 || !from_row) return NGACF_E_ARG;
+        if (!do_edges || G || gout_local || nhub > 0) return NGACF_E_ARG;
         if (nsplit > 0 && a.tickets == nullptr) return NGACF_E_ARG;             // hub rows must be finished inside the launch
         if (dtype != NGACF_BF16 || d != 64 || dx->din != 64) return NGACF_E_SHAPE;
         if (nu_lo != 0 || nu_n != U || ni_lo != 0 || ni_n != N - U) return NGACF_E_ARG;
         if (!(dx->feat_drop_p >= 0.f && dx->feat_drop_p < 1.f)) return NGACF_E_ARG;
-        const bool prev = dx->prev_out || dx->prev_agg || dx->prev_R || dx->prev_Gn || dx->prev_T;
-        if (prev && !(dx->prev_out && dx->prev_agg && dx->prev_R && dx->prev_Gn && dx->prev_T)) return NGACF_E_ARG;
+        const bool prev = dx->prev_out || dx->prev_agg || dx->prev_R || dx->prev_S || dx->prev_Gn || dx->prev_ST || dx->prev_dS;
+        if (prev && !(dx->prev_out && dx->prev_agg && dx->prev_R && dx->prev_S && dx->prev_Gn && dx->prev_ST && dx->prev_dS)) return NGACF_E_ARG;
+        if (prev && !(dx->prev_alpha > 0.f && dx->prev_alpha < 1.f)) return NGACF_E_ARG;
         if (dx->dx_dtype != NGACF_BF16 && (prev || dx->dx_dtype != NGACF_F32)) return NGACF_E_SHAPE;   // a previous stage's output is bf16
         a.fx_panel = dx->panel; a.fx_dX = dx->dX;
         a.fx_drop_thr = dx->feat_drop_p > 0.f ? drop_threshold(dx->feat_drop_p) : 0u;
         a.fx_drop_scale = 1.f / (1.f - dx->feat_drop_p); a.fx_seed = dx->seed;
-        a.pv_out = dx->prev_out; a.pv_agg = dx->prev_agg; a.pv_R = dx->prev_R; a.pv_Gn = dx->prev_Gn; a.pv_T = dx->prev_T;
+        a.pv_out = dx->prev_out; a.pv_agg = dx->prev_agg; a.pv_R = dx->prev_R; a.pv_S = dx->prev_S; a.pv_Gn = dx->prev_Gn;
+        a.pv_ST = reinterpret_cast<float2*>(dx->prev_ST); a.pv_dS = dx->prev_dS; a.pv_alpha = dx->prev_alpha;
         a.pv_flags = dx->prev_flags;
         fuse = prev ? 2 : dx->dx_dtype == NGACF_F32 ? 1 : 3;
     }
-#define NGACF_CASE(T, D, HD) return launch_bwd<T, D, HD>(a, split, nsplit, from_row, drop, st, do_node, do_edges, fuse)
+#define NGACF_CASE(T, D, HD) return launch_bwd<T, D, HD>(a, split, nsplit, drop, st, do_node, do_edges, fuse)
     if (dtype == NGACF_F32) {
         if (d == 64 && heads == 8) NGACF_CASE(float, 64, 8);
         if (d == 64 && heads == 1) NGACF_CASE(float, 64, 1);
@@ -980,13 +950,13 @@ extern "C" int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* spli
                               const void* out, const void* agg, const float* R, const void* gout,
                               float* G, void* Gn, float* ST, void* dH, float* dS,
                               float* part_acc, float* part_r, const int32_t* part_split, int32_t* tickets,
-                              const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
+                              const uint32_t* needed, const int32_t* rows, int nrows,
                               int U, int N, int d, int heads, float alpha,
                               float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream) {
     const bool skip_node = (flags & NGACF_SKIP_NODE) != 0;
     return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, nseg_user, nshort_user, hrow, nhub, nhub_user, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
                          G, Gn, ST, dH, dS, part_acc, part_r, part_split, tickets, U, N, d, heads, alpha, drop_p, seed, seed_dev, flags,
-                         0, U, 0, N - U, 0, !skip_node, true, needed, rows, nrows, short_max, stream);
+                         0, U, 0, N - U, 0, !skip_node, true, needed, rows, nrows, stream);
 }
 
 extern "C" int ngacf_prop_bwd_dx(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
@@ -997,21 +967,21 @@ extern "C" int ngacf_prop_bwd_dx(const int32_t* segs, int nseg, const int32_t* s
                                  const void* out, const void* agg, const float* R, const void* gout,
                                  float* G, void* Gn, float* ST, void* dH, float* dS,
                                  float* part_acc, float* part_r, const int32_t* part_split, int32_t* tickets,
-                                 const uint32_t* needed, const int32_t* rows, int nrows, int short_max,
+                                 const uint32_t* needed, const int32_t* rows, int nrows,
                                  int U, int N, int d, int heads, float alpha,
                                  float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags,
                                  const ngacf_bwd_dx* dx, void* stream) {
     const bool skip_node = (flags & NGACF_SKIP_NODE) != 0;
     return prop_bwd_impl(segs, nseg, split, nsplit, srow, nshort, nseg_user, nshort_user, hrow, nhub, nhub_user, rowptr, col, H, dtype, S_dst, S_src, avec, out, agg, R, gout,
                          G, Gn, ST, dH, dS, part_acc, part_r, part_split, tickets, U, N, d, heads, alpha, drop_p, seed, seed_dev, flags,
-                         0, U, 0, N - U, 0, !skip_node, true, needed, rows, nrows, short_max, stream, dx);
+                         0, U, 0, N - U, 0, !skip_node, true, needed, rows, nrows, stream, dx);
 }
 
 extern "C" int ngacf_prop_bwd_node(const void* out, int dtype, const void* agg, const float* R, const void* gout,
-                                   const float* S_src, float* G, void* Gn, float* ST,
-                                   int U, int N, int d, int heads, int flags,
+                                   const float* S_src, float* G, void* Gn, float* ST, float* dS,
+                                   int U, int N, int d, int heads, float alpha, int flags,
                                    int u_lo, int u_n, int i_lo, int i_n, int gout_local, void* stream) {
     return prop_bwd_impl(nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, dtype, nullptr, S_src, nullptr,
-                         out, agg, R, gout, G, Gn, ST, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, U, N, d, heads, 0.2f, 0.f, 0, nullptr, flags,
-                         u_lo, u_n, i_lo, i_n, gout_local, true, false, nullptr, nullptr, 0, 0, stream);
+                         out, agg, R, gout, G, Gn, ST, nullptr, dS, nullptr, nullptr, nullptr, nullptr, U, N, d, heads, alpha, 0.f, 0, nullptr, flags,
+                         u_lo, u_n, i_lo, i_n, gout_local, true, false, nullptr, nullptr, 0, stream);
 }

@@ -19,7 +19,7 @@ of H (and vice versa), so a stage is two half-launches with different needs:
   forward   T(0,B) T(0,A) | V(s,A) T(s+1,A) V(s,B) T(s+1,B) | ...   with A alternating user/item from stage to stage:
             the all-gather that V(s,B) waits for runs under V(s,A), the one V(s+1,B) needs (started by T(s+1,A)) runs
             under V(s,B) -- only the very first all-gather of a forward is exposed.
-  backward  the mirror image with the node step N(s,t) (-> Gn, t tables, all-gathered per half), the edge step
+  backward  the mirror image with the node step N(s,t) (-> Gn and (S, t) tables, all-gathered per half), the edge step
             E(s,A) and the transform backward per half; dX of a half is the next stage's incoming gradient, so
             N(s-1,A) and its all-gather start while E(s,B) still runs.
 
@@ -298,8 +298,8 @@ class _ShardedStack(torch.autograd.Function):
             fused_next = s + 1 < L and fuse[s + 1]
             keep_out = need or not fused_next                        # an evaluation forward never reads a fused stage's own table
             out = torch.empty(N, dout, dtype=H.dtype, device=dev) if keep_out else None
-            agg = torch.empty(N, dout, dtype=H.dtype, device=dev) if need else None
-            R = torch.empty(N, heads, dtype=torch.float32, device=dev) if need else None
+            agg = torch.empty(2, N, dout, dtype=H.dtype, device=dev) if need else None       # (two planes: ops.prop_fwd)
+            R = torch.empty(2, N, heads, dtype=torch.float32, device=dev) if need else None
             if fused_next and Hs[s + 1] is None:
                 new_H(s + 1)
             Xs = dict(X)
@@ -349,10 +349,11 @@ class _ShardedStack(torch.autograd.Function):
             if tabs[s] is None:
                 d, heads = H.shape[1], cfg["heads"][s]
                 tabs[s] = (torch.empty(N, d, dtype=torch.float32, device=dev), comm.table(("Gn", s), (N, d), H.dtype, dev, lease),
-                           comm.table(("t", s), (N, heads), torch.float32, dev, lease),
+                           comm.table(("t", s), (N, 2 * heads), torch.float32, dev, lease),     # pairs (S, t) per head
                            torch.zeros(N, d, dtype=H.dtype, device=dev), torch.zeros(N, heads, dtype=torch.float32, device=dev))
-            G, Gn, ST, _, _ = tabs[s]
-            be.prop_bwd_node(out, agg, R, g[t], S, G, Gn, ST, part.Up, cfg["heads"][s], part.half_win(t), True, True)
+            G, Gn, ST, _, dS = tabs[s]
+            # (step 1 leaves the rows' own half of dS -- P1 -- in dS; the edge step of the same half finishes it in place)
+            be.prop_bwd_node(out, agg, R, g[t], S, G, Gn, ST, dS, part.Up, cfg["heads"][s], part.half_win(t), True, True, cfg["alpha"])
             pending[(s, t)] = comm.start_gather(t, Gn, ST)          # one grouped launch
 
         first = "user"

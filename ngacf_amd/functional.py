@@ -21,8 +21,8 @@ class StageLink:
     def __init__(self):
         self.pack, self.panels, self.pre = None, {}, None
         # the backward's mirror image (ngacf_prop_bwd_dx): pack_t = {stage: W} whose dX fragments the first transform's launch
-        # packs too, panels_t = those panels; saved[s] = (out, agg, R, elu) of stage s's forward, read by stage s+1's backward,
-        # which runs stage s's step 1 on the dX it produces and parks (dX, Gn, t) in node_pre[s]
+        # packs too, panels_t = those panels; saved[s] = (out, agg, R, S, elu, alpha) of stage s's forward, read by stage s+1's
+        # backward, which runs stage s's step 1 on the dX it produces and parks (dX, Gn, ST, dS) in node_pre[s]
         self.pack_t, self.panels_t, self.saved, self.node_pre = None, {}, {}, {}
         # defer_dw (a gradient sink is active: nobody reads a weight gradient before the stack's backward has finished): the stages
         # whose dX came out of the edge backward leave their dW / davec to ONE batched launch behind the stack's last backward
@@ -48,13 +48,13 @@ def _transform_or_pre(X, W, avec, plan, heads, h_dtype, feat_drop_p, seed, seed_
     return ops.transform_fwd(X, W, avec, plan.U, plan.I, heads, h_dtype, feat_drop_p, seed, seed_dev)
 
 
-def _remember(link, sidx, out, agg, R, elu, needed):
+def _remember(link, sidx, out, agg, R, S, elu, alpha, needed):
     """forward: leave this stage's saved tables where the NEXT stage's backward finds them (StageLink.saved)"""
     if link is None or sidx is None:
         return None
     link.bwd_stages.add(sidx)
     if needed is None:                                   # (a stage computed for a batch's rows only is nobody's previous stage)
-        link.saved[sidx] = (out, agg, R, elu)
+        link.saved[sidx] = (out, agg, R, S, elu, alpha)
     return (link, sidx)
 
 
@@ -65,7 +65,7 @@ FUSE_SPARSE = __import__("os").environ.get("NGACF_FUSE_SPARSE", "0") != "0"
 
 
 def _bwd_links(bw, gout, X, H, plan, feat_drop_p, seed, want_dx, sparse=False):
-    """backward of stage s: node = (Gn, t) when the next stage's backward already ran this stage's step 1 on exactly this gout;
+    """backward of stage s: node = (Gn, ST, dS) when the next stage's backward already ran this stage's step 1 on exactly this gout;
     dx = ops.BwdDx when this stage's launch can produce dX (and the previous stage's step 1) itself."""
     if bw is None or X is None:
         return None, None
@@ -73,11 +73,11 @@ def _bwd_links(bw, gout, X, H, plan, feat_drop_p, seed, want_dx, sparse=False):
     node = dx = None
     pre = link.node_pre.pop(s, None)
     if pre is not None and pre[0] is not None and pre[0].data_ptr() == gout.data_ptr() and pre[0].dtype == gout.dtype and gout.is_contiguous():
-        node = (pre[1], pre[2])
+        node = (pre[1], pre[2], pre[3])
     if want_dx and s in link.panels_t and (FUSE_SPARSE or not sparse):
         prev = link.saved.get(s - 1) if X.dtype == torch.bfloat16 and ops.FUSE_BWD >= 2 else None
-        if prev is not None and prev[0].data_ptr() != X.data_ptr():
-            prev = None                                  # X is not the previous stage's output table
+        if prev is not None and (prev[0].data_ptr() != X.data_ptr() or prev[3].shape[1] != X.shape[1] // 8):
+            prev = None                                  # X is not the previous stage's output table (or not in 8-column heads)
         if ops.can_fuse_bwd(plan, H.dtype, H.shape[1], X.shape[1], X.dtype, prev is not None):
             dx = ops.BwdDx(link.panels_t[s], X.dtype, feat_drop_p, seed, prev)
     return node, dx
@@ -104,7 +104,7 @@ def _transform_bwd_after(bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed
         return r
     link, s = bw
     if dx.prev is not None:
-        link.node_pre[s - 1] = (dx.dX, dx.Gn, dx.T)
+        link.node_pre[s - 1] = (dx.dX, dx.Gn, dx.ST, dx.dS)
     if link.defer_dw and DEFER_DW and tuple(W.shape) == (2, 64, 64) and H.dtype == torch.bfloat16:
         dW, da = torch.empty(2, 64, 64, dtype=torch.float32, device=H.device), torch.empty(2, 64, dtype=torch.float32, device=H.device)
         link.dw_jobs.append((X, H, dH, dS, heads, feat_drop_p, seed, dW, da))
@@ -136,7 +136,7 @@ class _Stage(torch.autograd.Function):
                                        seed_dev=seed_dev, needed=needed, next=nxt)
             ctx.save_for_backward(X, W, avec, H, S, out, agg, R)
             ctx.cfg = (plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual, needed)
-            ctx.bw = _remember(link, sidx, out, agg, R, elu, needed)
+            ctx.bw = _remember(link, sidx, out, agg, R, S, elu, alpha, needed)
         else:
             out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, seed_dev=seed_dev, needed=needed, next=nxt)
         if nxt is not None:
@@ -175,7 +175,7 @@ class _StageScore(torch.autograd.Function):
                                        seed_dev=seed_dev, needed=rows)
             ctx.save_for_backward(X, W, avec, H, S, out, agg, R, u, *items)
             ctx.cfg = (plan, heads, alpha, elu, drop_p, feat_drop_p, seed, seed_dev, residual, rows)
-            ctx.bw = _remember(link, sidx, out, agg, R, elu, rows)
+            ctx.bw = _remember(link, sidx, out, agg, R, S, elu, alpha, rows)
         else:
             out = ops.prop_fwd(plan, H, S, S, avec, heads, alpha, elu, residual, None, drop_p, seed, seed_dev=seed_dev, needed=rows)
         return tuple(ops.score_fwd(out, u, it, U) for it in items)

@@ -207,11 +207,10 @@ def _hub(plan, dev, half=None):
 class BatchRows:
     """The rows of the propagated table a scored batch reads (SPUIGACF.py:49-52): one flag bit per row (int32 words) and the
     same rows as an int32 list (first `n` entries; duplicates allowed), both written by ngacf_mark_rows."""
-    __slots__ = ("needed", "rows", "n", "U", "I", "g32", "consumed", "n_user")
+    __slots__ = ("needed", "rows", "n", "U", "I", "g32", "consumed")
 
     def __init__(self, needed, rows, n, U, I, g32=None):
         self.needed, self.rows, self.n, self.U, self.I = needed, rows, n, U, I
-        self.n_user = 0         # leading user entries of the list (the first marking's B)
         self.g32 = g32          # float [U+I, d], ZERO at the batch's rows (the rest is never read): where the scores' gradient lands
         self.consumed = False   # one backward per marking: a second one would add to the first one's gradient rows
 
@@ -230,7 +229,6 @@ def mark_rows(u, i, U, I, into=None, grad_d=0):
         into = BatchRows(torch.empty(((U + I + 31) // 32 + 15) // 16 * 16, dtype=torch.int32, device=dev)[:(U + I + 31) // 32], torch.empty(max(3 * B, 1), dtype=torch.int32, device=dev), 0, U, I,
                          torch.empty(U + I, grad_d, dtype=torch.float32, device=dev) if grad_d else None)
         up, clear, add = (_idx(u, "userIdx", B, dev) if B else 0), 1, 2 * B
-        into.n_user = B
     else:
         if into.n + B > into.rows.numel() or (into.U, into.I) != (U, I):
             raise ValueError("mark_rows: the row list has no room for %d more rows" % B)
@@ -250,23 +248,26 @@ def _needed_args(needed, plan, N, dev):
     return _chk(needed.needed, "needed", torch.int32, (N + 31) // 32, dev, align=4), needed.rows.data_ptr(), needed.n, int(plan.short_max)
 
 
-def _scratch(scratch, plan, d, heads, dev):
+def _scratch(scratch, plan, d, heads, dev, planes=1):
+    """the hub rows' partial-sum slots; planes = 2 for a forward that saves (a slot then also holds the negative-side sums)"""
     if scratch is None:
-        return (torch.empty(max(plan.nparts, 1), d, dtype=torch.float32, device=dev),
-                torch.empty(max(plan.nparts, 1), heads, dtype=torch.float32, device=dev))
+        return (torch.empty(max(plan.nparts, 1), planes * d, dtype=torch.float32, device=dev),
+                torch.empty(max(plan.nparts, 1), planes * heads, dtype=torch.float32, device=dev))
     pa, pr = scratch
-    _chk(pa, "scratch[0]", torch.float32, max(plan.nparts, 1) * d, dev)
-    _chk(pr, "scratch[1]", torch.float32, max(plan.nparts, 1) * heads, dev, align=4)
+    _chk(pa, "scratch[0]", torch.float32, max(plan.nparts, 1) * planes * d, dev)
+    _chk(pr, "scratch[1]", torch.float32, max(plan.nparts, 1) * planes * heads, dev, align=4)
     return pa, pr
 
 
 def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
              drop_p=0.0, seed=0, save=False, out=None, seed_dev=None, half=None, agg=None, R=None, needed=None, scratch=None,
              next=None, want_out=True):
-    """One propagation stage over plan's dst rows.  Returns out (and agg, R when save=True).
+    """One propagation stage over plan's dst rows.  Returns out (and agg [2, N, d], R [2, N, heads] when save=True: plane 0 = the
+    normalised aggregate and the denominators, plane 1 = the same sums over the edges with a non-positive score, which the
+    backward's row-local half of dS needs -- include/ngacf.h).
     half = "user" / "item": only the user / item dst rows (two calls with the same out / agg / R cover the stage).
-    scratch = (float [nparts, d], float [nparts, heads]): the hub rows' partial-sum slots (default: fresh buffers; the soak
-    test hands in buffers it has poisoned).
+    scratch = (float [nparts, d], float [nparts, heads]) ([nparts, 2 d], [nparts, 2 heads] with save): the hub rows' partial-sum
+    slots (default: fresh buffers; the soak test hands in buffers it has poisoned).
     next = NextStage: the launch also produces the next stage's H' [N, dout'] (bf16) and S' [N, heads'] in next.H / next.S; with
     want_out=False (an evaluation forward) `out` is not written at all and None is returned in its place."""
     dev, N, d = H.device, plan.N, H.shape[1]
@@ -290,13 +291,13 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     else:
         out, op = None, 0
     if save:
-        agg = torch.empty(N, d, dtype=H.dtype, device=dev) if agg is None else agg       # (storage type: bf16 tables halve it)
-        R = torch.empty(N, heads, dtype=torch.float32, device=dev) if R is None else R
-        _chk(agg, "agg", H.dtype, N * d, dev)
-        _chk(R, "R", torch.float32, N * heads, dev)
+        agg = torch.empty(2, N, d, dtype=H.dtype, device=dev) if agg is None else agg    # (storage type: bf16 tables halve it)
+        R = torch.empty(2, N, heads, dtype=torch.float32, device=dev) if R is None else R
+        _chk(agg, "agg", H.dtype, 2 * N * d, dev)
+        _chk(R, "R", torch.float32, 2 * N * heads, dev)
     else:
         agg = R = None
-    pa, pr = _scratch(scratch, plan, d, heads, dev)
+    pa, pr = _scratch(scratch, plan, d, heads, dev, 2 if save else 1)
     flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
     if next is not None:
         # (a half launch of the node-partitioned path hands in the global-row tables of the next stage: both halves fill them)
@@ -326,13 +327,14 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
 class BwdDx:
     """The stage's transform backward riding in its edge backward (ngacf_prop_bwd_dx): `panel` = the kind-1 fragments of the
     stage's W [2, 64, 64] (transform_fwd(pack=..., pack_kind=1) / pack_panels), x_dtype = the type of the stage's input X (dX's),
-    the stage's feature dropout and seed; prev = (out, agg, R, elu) of the PREVIOUS stage's forward when X is that stage's
-    output -- the launch then also runs that stage's step 1 on dX.  prop_bwd(dx=...) fills .dX (and .Gn / .T with prev)."""
-    __slots__ = ("panel", "x_dtype", "feat_drop_p", "seed", "prev", "dX", "Gn", "T")
+    the stage's feature dropout and seed; prev = (out, agg, R, S, elu, alpha) of the PREVIOUS stage's forward when X is that
+    stage's output -- the launch then also runs that stage's step 1 on dX.  prop_bwd(dx=...) fills .dX (and, with prev, .Gn /
+    .ST / .dS = that stage's Gn, (S, t) pairs and P1: its prop_bwd takes them as node=(Gn, ST, dS))."""
+    __slots__ = ("panel", "x_dtype", "feat_drop_p", "seed", "prev", "dX", "Gn", "ST", "dS")
 
     def __init__(self, panel, x_dtype, feat_drop_p=0.0, seed=0, prev=None):
         self.panel, self.x_dtype, self.feat_drop_p, self.seed, self.prev = panel, x_dtype, float(feat_drop_p), int(seed), prev
-        self.dX = self.Gn = self.T = None
+        self.dX = self.Gn = self.ST = self.dS = None
 
 
 # A/B switch of the backward's launch plan: 0 = dX and the node steps as their own launches; 1 = dX in the edge backward's tail;
@@ -353,59 +355,61 @@ def can_fuse_bwd(plan, H_dtype, d, din, x_dtype, has_prev):
 
 def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, elu=True, residual=True,
              score_from_row=None, drop_p=0.0, seed=0, seed_dev=None, needed=None, gout_f32=False, scratch=None, dx=None, node=None):
-    """Returns dH [N,d] in H's dtype (with the dS*avec term) and dS [N,heads] fp32.  scratch: as in prop_fwd.
-    node = (Gn [N,d] in H's dtype, t float [N,heads]): step 1 has been run elsewhere (a later stage's prop_bwd(dx=...)) on this gout.
+    """Returns dH [N,d] in H's dtype (with the dS*avec term) and dS [N,heads] fp32.  agg [2, N, d], R [2, N, heads]: as
+    prop_fwd(save=True) returned them.  scratch: as in prop_fwd (one plane).
+    node = (Gn [N,d] in H's dtype, ST float [N,heads,2], dS float [N,heads] holding P1): step 1 has been run elsewhere (a later
+    stage's prop_bwd(dx=...)) on this gout; that dS is finished in place and returned.
     dx = BwdDx: the launch also writes the gradient of the stage's input (dx.dX) and, with dx.prev, the previous stage's step 1."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
-    if score_from_row is None:
-        score_from_row = True      # recomputing a.h from the gathered row beats a second gather (profiles/)
     hp = _chk(H, "H", None, N * d, dev)
     sd = _chk(S_dst, "S_dst", torch.float32, N * heads, dev)
     ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
     ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
     op = _chk(out, "out", H.dtype, N * d, dev)
-    gp = _chk(agg, "agg", H.dtype, N * d, dev)
-    rp = _chk(R, "R", torch.float32, N * heads, dev)
+    gp = _chk(agg, "agg", H.dtype, 2 * N * d, dev)
+    rp = _chk(R, "R", torch.float32, 2 * N * heads, dev)
     go = _chk(gout, "gout", torch.float32 if gout_f32 else H.dtype, N * d, dev)
     pp = _plan_ptrs(plan, dev)
     f32 = dict(dtype=torch.float32, device=dev)
     dH = torch.empty(N, d, dtype=H.dtype, device=dev)      # (no G table: step 2 recomputes g = gout * ELU'(out))
     if node is None:
-        Gn, t = torch.empty(N, d, dtype=H.dtype, device=dev), torch.empty(N, heads, **f32)
+        Gn, st, dS = torch.empty(N, d, dtype=H.dtype, device=dev), torch.empty(N, heads, 2, **f32), torch.empty(N, heads, **f32)
     else:
-        Gn, t = node
+        Gn, st, dS = node
         _chk(Gn, "node Gn", H.dtype, N * d, dev)
-        _chk(t, "node t", torch.float32, N * heads, dev)
-    dS = torch.empty(N, heads, **f32)
+        _chk(st, "node ST", torch.float32, N * heads * 2, dev)
+        _chk(dS, "node dS", torch.float32, N * heads, dev)
     pa, pr = _scratch(scratch, plan, d, heads, dev)
     if plan.n_rows != N:
         dH.zero_()
-        dS.zero_()
-    flags = ((FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) |
+        if node is None:
+            dS.zero_()
+    flags = ((FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | FLAG_SCORE_ROW |
              (_lib.FLAG_GOUT_F32 if gout_f32 else 0) | (_lib.FLAG_SKIP_NODE if node is not None else 0))
     if dx is not None:
         din = 64
-        if not can_fuse_bwd(plan, H.dtype, d, din, dx.x_dtype, dx.prev is not None) or not score_from_row:
+        if not can_fuse_bwd(plan, H.dtype, d, din, dx.x_dtype, dx.prev is not None):
             raise ValueError("prop_bwd(dx=...): not available for this launch (ops.can_fuse_bwd)")
         dx.dX = torch.empty(N, din, dtype=dx.x_dtype, device=dev)
         panel = dx.panel.get() if hasattr(dx.panel, "get") else dx.panel
-        pv = [0, 0, 0, 0, 0, 0]
+        pv = [0, 0, 0, 0, 0, 0, 0, 0.2, 0]
         if dx.prev is not None:
-            p_out, p_agg, p_R, p_elu = dx.prev
-            dx.Gn, dx.T = torch.empty(N, din, dtype=H.dtype, device=dev), torch.empty(N, din // 8, **f32)
-            pv = [_chk(p_out, "prev out", H.dtype, N * din, dev), _chk(p_agg, "prev agg", H.dtype, N * din, dev),
-                  _chk(p_R, "prev R", torch.float32, N * (din // 8), dev), dx.Gn.data_ptr(), dx.T.data_ptr(), FLAG_ELU if p_elu else 0]
-        st = _lib.BwdDx(_chk(panel, "dx.panel", torch.uint8, 2 * din * d * 2, dev), dx.dX.data_ptr(), din, _DT[dx.x_dtype],
-                        dx.feat_drop_p, dx.seed & 0xFFFFFFFFFFFFFFFF, *pv, needed.n_user if needed is not None else 0)
+            p_out, p_agg, p_R, p_S, p_elu, p_alpha = dx.prev
+            dx.Gn, dx.ST, dx.dS = torch.empty(N, din, dtype=H.dtype, device=dev), torch.empty(N, din // 8, 2, **f32), torch.empty(N, din // 8, **f32)
+            pv = [_chk(p_out, "prev out", H.dtype, N * din, dev), _chk(p_agg, "prev agg", H.dtype, 2 * N * din, dev),
+                  _chk(p_R, "prev R", torch.float32, 2 * N * (din // 8), dev), _chk(p_S, "prev S", torch.float32, N * (din // 8), dev),
+                  dx.Gn.data_ptr(), dx.ST.data_ptr(), dx.dS.data_ptr(), float(p_alpha), FLAG_ELU if p_elu else 0]
+        st_ = _lib.BwdDx(_chk(panel, "dx.panel", torch.uint8, 2 * din * d * 2, dev), dx.dX.data_ptr(), din, _DT[dx.x_dtype],
+                         dx.feat_drop_p, dx.seed & 0xFFFFFFFFFFFFFFFF, *pv)
         _lib.check(lib.ngacf_prop_bwd_dx(*pp, hp, _DT[H.dtype], sd, ss, ap,
-                                         op, gp, rp, go, 0, Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
-                                         dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev), *_needed_args(needed, plan, N, dev), plan.U, N, d, heads, float(alpha),
-                                         float(drop_p), int(seed), _sd(seed_dev, dev), flags, ctypes.byref(st), _stream()), "ngacf_prop_bwd_dx")
+                                         op, gp, rp, go, 0, Gn.data_ptr(), st.data_ptr(), dH.data_ptr(),
+                                         dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev), *_needed_args(needed, plan, N, dev)[:3], plan.U, N, d, heads, float(alpha),
+                                         float(drop_p), int(seed), _sd(seed_dev, dev), flags, ctypes.byref(st_), _stream()), "ngacf_prop_bwd_dx")
         return dH, dS
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, ss, ap,
-                                  op, gp, rp, go, 0, Gn.data_ptr(), t.data_ptr(), dH.data_ptr(),
-                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev), *_needed_args(needed, plan, N, dev), plan.U, N, d, heads, float(alpha),
+                                  op, gp, rp, go, 0, Gn.data_ptr(), st.data_ptr(), dH.data_ptr(),
+                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev), *_needed_args(needed, plan, N, dev)[:3], plan.U, N, d, heads, float(alpha),
                                   float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_bwd")
     return dH, dS
 
@@ -723,48 +727,52 @@ def transform_bwd_rows(X, W, H, dH, dS, U, I, heads, win, x_local, feat_drop_p=0
     return dX, dW, da
 
 
-def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local, elu=True):
-    """Step 1 of the propagation backward over the rows of `win`; writes G, Gn, ST at global rows."""
+def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, dS, U, heads, win, gout_local, elu=True, alpha=0.2):
+    """Step 1 of the propagation backward over the rows of `win`; writes G, Gn, ST [N, heads, 2] (pairs (S, t)) and P1 into dS,
+    at global rows.  agg [2, N, d], R [2, N, heads]: the forward's saved planes."""
     dev, N, d = out.device, out.shape[0], out.shape[1]
     _heads_ok(d, heads)
     u_lo, u_n, i_lo, i_n = win
     op = _chk(out, "out", None, N * d, dev)
-    ap = _chk(agg, "agg", out.dtype, N * d, dev)
-    rp = _chk(R, "R", torch.float32, N * heads, dev)
+    ap = _chk(agg, "agg", out.dtype, 2 * N * d, dev)
+    rp = _chk(R, "R", torch.float32, 2 * N * heads, dev)
     go = _chk(gout, "gout", out.dtype, ((u_n + i_n) if gout_local else N) * d, dev)
     ss = _chk(S_src, "S_src", torch.float32, N * heads, dev)
     gp = _chk(G, "G", torch.float32, N * d, dev)
     gn = _chk(Gn, "Gn", out.dtype, N * d, dev)
-    st = _chk(ST, "ST", torch.float32, N * heads, dev)
-    _lib.check(lib.ngacf_prop_bwd_node(op, _DT[out.dtype], ap, rp, go, ss, gp, gn, st, U, N, d, heads,
+    st = _chk(ST, "ST", torch.float32, N * heads * 2, dev)
+    ds = _chk(dS, "dS", torch.float32, N * heads, dev)
+    _lib.check(lib.ngacf_prop_bwd_node(op, _DT[out.dtype], ap, rp, go, ss, gp, gn, st, ds, U, N, d, heads, float(alpha),
                                        FLAG_ELU if elu else 0, u_lo, u_n, i_lo, i_n, int(bool(gout_local)), _stream()),
                "ngacf_prop_bwd_node")
 
 
 def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=True, score_from_row=True,
                    drop_p=0.0, seed=0, seed_dev=None, half=None, dH=None, dS=None):
-    """Step 2 alone (G, Gn, ST ready for every source row).  Returns dH, dS (rows of the plan valid).
-    half = "user" / "item": only those dst rows, written into the dH / dS given (or fresh zeroed tables)."""
+    """Step 2 alone (G for the plan's rows, Gn and ST for every source row, and dS holding step 1's P1 for the plan's rows).
+    Returns dH, dS (rows of the plan valid; dS finished in place).
+    half = "user" / "item": only those dst rows, written into the dH given (or a fresh zeroed table)."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
+    if dS is None:
+        raise ValueError("prop_bwd_edges: dS must hold step 1's P1 (prop_bwd_node) for the rows of the plan")
     hp = _chk(H, "H", None, N * d, dev)
     sd = _chk(S_dst, "S_dst", torch.float32, N * heads, dev)
     ap = _chk(avec, "avec", torch.float32, 2 * d, dev)
     gp = _chk(G, "G", torch.float32, N * d, dev)
     gn = _chk(Gn, "Gn", H.dtype, N * d, dev)
-    st = _chk(ST, "ST", torch.float32, N * heads, dev)
+    st = _chk(ST, "ST", torch.float32, N * heads * 2, dev)
     hub = _hub(plan, dev, half)
     pp = _plan_ptrs(plan, dev, half, inkernel=hub[1] != 0)
     f32 = dict(dtype=torch.float32, device=dev)
     dH = torch.zeros(N, d, dtype=H.dtype, device=dev) if dH is None else dH
-    dS = torch.zeros(N, heads, **f32) if dS is None else dS
     _chk(dH, "dH", H.dtype, N * d, dev)
     _chk(dS, "dS", torch.float32, N * heads, dev)
     pa = torch.empty(max(plan.nparts, 1), d, **f32)
     pr = torch.empty(max(plan.nparts, 1), heads, **f32)
-    flags = (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) | _lib.FLAG_SKIP_NODE
+    flags = (FLAG_RESIDUAL if residual else 0) | FLAG_SCORE_ROW | _lib.FLAG_SKIP_NODE
     _lib.check(lib.ngacf_prop_bwd(*pp, hp, _DT[H.dtype], sd, sd, ap, hp, gp, sd, gp, gp, gn, st, dH.data_ptr(),
-                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *hub, 0, 0, 0, 0, plan.U, N, d, heads, float(alpha),
+                                  dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *hub, 0, 0, 0, plan.U, N, d, heads, float(alpha),
                                   float(drop_p), int(seed), _sd(seed_dev, dev), flags, _stream()), "ngacf_prop_bwd")
     return dH, dS
 

@@ -52,24 +52,31 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     assert score_from_row, "dist.py never gathers S: source scores come from the gathered rows"
     t = _types(plan.U, N, H.device)
     s_src = (H[src].float() * avec[t[src]]).view(-1, heads, hw).sum(2)
-    e = torch.exp(-F.leaky_relu(S_dst[dst] + s_src, alpha))                            # [E', heads]
+    s = S_dst[dst] + s_src
+    e = torch.exp(-F.leaky_relu(s, alpha))                                             # [E', heads]
+    en = torch.where(s > 0, torch.zeros_like(e), e)                                    # the edges with a non-positive score
     R = torch.zeros(N, heads).index_add_(0, dst, e)
+    Rn = torch.zeros(N, heads).index_add_(0, dst, en)
     num = torch.zeros(N, d).index_add_(0, dst, e.repeat_interleave(hw, 1) * H[src].float())
+    numn = torch.zeros(N, d).index_add_(0, dst, en.repeat_interleave(hw, 1) * H[src].float())
     Rw = R.repeat_interleave(hw, 1)
     agg = torch.where(Rw > 0, num / Rw.clamp_min(1e-38), torch.zeros_like(num))
+    aggn = torch.where(Rw > 0, numn / Rw.clamp_min(1e-38), torch.zeros_like(numn))
     pre = (H.float() + agg) if residual else agg
     o = F.elu(pre) if elu else pre
     res = torch.zeros(N, d, dtype=H.dtype) if out is None else out
     rows = torch.cat([torch.arange(lo, hi) for lo, hi in _half_ranges(plan, half)])
     res[rows] = o[rows].to(H.dtype)
-    if save and agg_out is not None:                      # half launches fill the caller's tables
-        agg_out[rows] = agg[rows]
-        R_out[rows] = R[rows]
-        agg, R = agg_out, R_out
-    return (res, agg, R) if save else res
+    if save:                                              # two planes each (ops.prop_fwd); half launches fill the caller's tables
+        if agg_out is None:
+            agg_out, R_out = torch.zeros(2, N, d, dtype=H.dtype), torch.zeros(2, N, heads)
+        agg_out[0, rows], agg_out[1, rows] = agg[rows].to(H.dtype), aggn[rows].to(H.dtype)
+        R_out[0, rows], R_out[1, rows] = R[rows], Rn[rows]
+        return res, agg_out, R_out
+    return res
 
 
-def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local, elu=True):
+def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, dS, U, heads, win, gout_local, elu=True, alpha=0.2):
     rows = _win_rows(U, win, out.device)
     d = out.shape[1]
     hw = d // heads
@@ -77,41 +84,42 @@ def prop_bwd_node(out, agg, R, gout, S_src, G, Gn, ST, U, heads, win, gout_local
     if elu:
         o = out[rows].float()
         g = g * torch.where(o > 0, torch.ones_like(o), o + 1.0)
-    r = R[rows]
+    r, rn = R[0, rows], R[1, rows]
     inv = torch.where(r > 0, 1.0 / r.clamp_min(1e-38), torch.zeros_like(r)).repeat_interleave(hw, 1)
     gn = (g * inv).to(Gn.dtype)
     G[rows] = g
     Gn[rows] = gn
-    ST[rows] = (gn.float() * agg[rows]).view(-1, heads, hw).sum(2)
+    t = (gn.float() * agg[0, rows].float()).view(-1, heads, hw).sum(2)
+    tn = (gn.float() * agg[1, rows].float()).view(-1, heads, hw).sum(2)
+    ST.view(-1, heads, 2)[rows] = torch.stack([S_src[rows], t], dim=2)           # pairs (S, t)
+    dS[rows] = (1.0 - alpha) * (r * tn - rn * t)                                 # P1: the rows' own half of dS (include/ngacf.h)
 
 
 def prop_bwd_edges(plan, H, S_dst, avec, G, Gn, ST, heads, alpha=0.2, residual=True, score_from_row=True,
                    drop_p=0.0, seed=0, half=None, dH=None, dS=None):
-    assert drop_p == 0.0
+    assert drop_p == 0.0 and dS is not None
     N, d = H.shape
     hw = d // heads
     dst, src = _edges(plan, half)
-    dH_out, dS_out = dH, dS
     Hf, Gf = H.float(), Gn.float()
-    assert score_from_row
-    tt = _types(plan.U, N, H.device)
-    s = S_dst[dst] + (Hf[src] * avec[tt[src]]).view(-1, heads, hw).sum(2)
+    st = ST.view(-1, heads, 2)
+    s = S_dst[dst] + st[src, :, 0]
     e = torch.exp(-F.leaky_relu(s, alpha))
-    dot = (Gf[dst] * Hf[src] + Gf[src] * Hf[dst]).view(-1, heads, hw).sum(2)
-    de = dot - ST[dst] - ST[src]
+    dot = (Gf[src] * Hf[dst]).view(-1, heads, hw).sum(2)
+    de = dot - st[src, :, 1]
     ds = -e * de * torch.where(s > 0, torch.ones_like(s), torch.full_like(s, alpha))
-    dS = torch.zeros(N, heads).index_add_(0, dst, ds)
+    dS_full = dS + torch.zeros(N, heads).index_add_(0, dst, ds)
     acc = torch.zeros(N, d).index_add_(0, dst, e.repeat_interleave(hw, 1) * Gf[src])
     t = _types(plan.U, N, H.device)
-    dH = (G if residual else torch.zeros_like(G)) + acc + dS.repeat_interleave(hw, 1) * avec[t]
+    dHf = (G if residual else torch.zeros_like(G)) + acc + dS_full.repeat_interleave(hw, 1) * avec[t]
     keep = torch.zeros(N, dtype=torch.bool)
     for lo, hi in _half_ranges(plan, half):
         keep[lo:hi] = True
-    if dH_out is not None:
-        dH_out[keep] = dH[keep]
-        dS_out[keep] = dS[keep]
-        return dH_out, dS_out
-    return dH * keep[:, None], dS * keep[:, None]
+    if dH is None:
+        dH = torch.zeros(N, d, dtype=H.dtype)
+    dH[keep] = dHf[keep].to(dH.dtype)
+    dS[keep] = dS_full[keep]
+    return dH, dS
 
 
 def transform_bwd_rows(X, W, H, dH, dS, U, I, heads, win, x_local, feat_drop_p=0.0, seed=0):

@@ -56,24 +56,32 @@ def test_partitioned_stage_equals_single_gpu(P, dt):
             o = torch.zeros_like(out0); a_ = torch.zeros_like(agg0); r_ = torch.zeros_like(R0)
             for half in ("item", "user"):
                 ops.prop_fwd(pl, H, S, S, avec, heads, drop_p=0.1, seed=5, save=True, out=o, agg=a_, R=r_, half=half)
-        for lo, hi in p.row_ranges:
-            out[lo:hi], agg[lo:hi], R[lo:hi] = o[lo:hi], a_[lo:hi], r_[lo:hi]
+        for lo, hi in p.row_ranges:                       # (agg / R: two planes each, ops.prop_fwd)
+            out[lo:hi], agg[:, lo:hi], R[:, lo:hi] = o[lo:hi], a_[:, lo:hi], r_[:, lo:hi]
     tol = 1e-6 if dt == torch.float32 else 1e-2
     assert float((out.float() - out0.float()).abs().max()) <= tol and float((R - R0).abs().max() / R0.abs().max()) < 1e-5
-    G = torch.empty(N, 64, device=dev); Gn = torch.empty(N, 64, device=dev, dtype=dt); ST = torch.empty(N, heads, device=dev)
+    assert float((agg.float() - agg0.float()).abs().max()) <= tol
+    G = torch.empty(N, 64, device=dev); Gn = torch.empty(N, 64, device=dev, dtype=dt); ST = torch.empty(N, heads, 2, device=dev)
+    P1 = torch.zeros(N, heads, device=dev)                # step 1's half of dS, per row
     for p in parts:
-        ops.prop_bwd_node(out0, agg0, R0, p.local_rows(gout).contiguous(), S, G, Gn, ST, Up, heads, p.win, True)
+        ops.prop_bwd_node(out0, agg0, R0, p.local_rows(gout).contiguous(), S, G, Gn, ST, P1, Up, heads, p.win, True)
+
+    def own_p1(p):                                        # a rank's dS table: P1 at its own rows, zero elsewhere
+        t = torch.zeros_like(P1)
+        for lo, hi in p.row_ranges:
+            t[lo:hi] = P1[lo:hi]
+        return t
     dH = torch.zeros_like(dH0); dS = torch.zeros_like(dS0)
     dX = torch.zeros_like(dX0).float(); dW = torch.zeros_like(dW0); da = torch.zeros_like(da0)
     for k, (p, pl) in enumerate(zip(parts, plans)):
         if k % 2 == 0:
-            h_, s_ = ops.prop_bwd_edges(pl, H, S, avec, G, Gn, ST, heads, drop_p=0.1, seed=5)
+            h_, s_ = ops.prop_bwd_edges(pl, H, S, avec, G, Gn, ST, heads, drop_p=0.1, seed=5, dS=own_p1(p))
             x_, w_, a_ = ops.transform_bwd_rows(p.local_rows(Xt).contiguous(), W, H, h_, s_, Up, Ip, heads, p.win, True, 0.1, 5)
             dW += w_; da += a_
             dX[p.u_lo:p.u_lo + p.cu] = x_[:p.cu].float()
             dX[Up + p.i_lo:Up + p.i_lo + p.ci] = x_[p.cu:].float()
         else:                                             # per half: edge step, then the half's transform backward
-            h_ = torch.zeros_like(dH0); s_ = torch.zeros_like(dS0)
+            h_ = torch.zeros_like(dH0); s_ = own_p1(p)
             for half in ("user", "item"):
                 ops.prop_bwd_edges(pl, H, S, avec, G, Gn, ST, heads, drop_p=0.1, seed=5, half=half, dH=h_, dS=s_)
                 x_, w_, a_ = ops.transform_bwd_rows(p.block(Xt, half).contiguous(), W, H, h_, s_, Up, Ip, heads, p.half_win(half), True, 0.1, 5)

@@ -97,6 +97,7 @@ def test_g1_layer_k64_noconcat_and_rowsums(dev):
     for from_row in (False, True):
         out, agg, R = ops.prop_fwd(plan, H, S, S, avec, 1, 0.2, elu=False, score_from_row=from_row, save=True)
         assert _maxabs(out, g["out"]) < 1e-5
+        R = R[0]                                                           # (plane 0: the denominators; plane 1: the s <= 0 part)
         assert _maxabs(R[:U, 0], g["e_rowsum"]) < 1e-4 and _maxabs(R[U:, 0], g["e_colsum"]) < 1e-4
         assert float(R[U + 37:].abs().max()) == 0.0                       # isolated items
         assert torch.equal(out[U + 37:], H[U + 37:])                       # NaN->0 path: out = h
@@ -494,7 +495,18 @@ def test_gowalla_scale_properties(dev):
         s = S[dst] + S[src]
         e = torch.exp(-torch.nn.functional.leaky_relu(s, 0.2))                      # [2E, heads]
         Rref = torch.zeros(N, heads, device=dev).index_add_(0, dst, e)
-        assert float(((R - Rref).abs() / Rref.clamp_min(1e-6)).max()) < 1e-4        # checksum of all 2E coefficients
+        assert float(((R[0] - Rref).abs() / Rref.clamp_min(1e-6)).max()) < 1e-4     # checksum of all 2E coefficients
+        # the second planes: the same sums over the edges with a non-positive score (what the backward's row-local half reads)
+        en = torch.where(s > 0, torch.zeros_like(e), e)
+        Rn = torch.zeros(N, heads, device=dev).index_add_(0, dst, en)
+        far = (s.abs() > 1e-4).float()                                              # (a score within rounding of 0 may fall on either side)
+        Rn_sure = torch.zeros(N, heads, device=dev).index_add_(0, dst, en * far)
+        slack = torch.zeros(N, heads, device=dev).index_add_(0, dst, e * (1 - far))
+        assert bool(((R[1] - Rn_sure) >= -1e-4 * Rref.clamp_min(1e-6)).all()) and bool(((R[1] - Rn_sure) <= slack + 1e-4 * Rref.clamp_min(1e-6)).all())
+        if float(slack.max()) == 0.0:
+            numn = torch.zeros(N, 64, device=dev).index_add_(0, dst, en.repeat_interleave(hw, 1) * H[src])
+            aggn = torch.where(Rref.repeat_interleave(hw, 1) > 0, numn / Rref.repeat_interleave(hw, 1), torch.zeros_like(numn))
+            assert float((agg[1] - aggn).abs().max()) < TOL and float((R[1] - Rn).abs().max()) < 1e-4 * float(Rref.max())
         num = torch.zeros(N, 64, device=dev).index_add_(0, dst, e.repeat_interleave(hw, 1) * H[src])
         pre = H + torch.where(Rref.repeat_interleave(hw, 1) > 0, num / Rref.repeat_interleave(hw, 1), torch.zeros_like(num))
         ref = torch.nn.functional.elu(pre)
@@ -503,7 +515,7 @@ def test_gowalla_scale_properties(dev):
         z = torch.zeros_like(avec)
         H0, S0 = ops.transform_fwd(X, W, z, U, I, heads)
         out0, _, R0 = ops.prop_fwd(plan, H0, S0, S0, z, heads, elu=False, save=True)
-        assert torch.equal(R0[:, 0], plan.degrees.float())
+        assert torch.equal(R0[0, :, 0], plan.degrees.float())
     # linearity of the aggregate in H at fixed scores: prop(2H) - 2 prop(H) == 0 without ELU
     o1 = ops.prop_fwd(plan, H, S, S, avec, 1, elu=False, score_from_row=False)
     o2 = ops.prop_fwd(plan, 2 * H, S, S, avec, 1, elu=False, score_from_row=False)

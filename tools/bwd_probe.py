@@ -32,8 +32,8 @@ def main():
     res = {"workload": a.workload, "drop": p, "N": N, "E": int(edge.shape[1])}
     W = rnd(2, d, d) * 0.2
     panel = ops.pack_panels([W], kinds=[1])[0]
-    p_out, p_agg = (rnd(N, d) * 0.5).to(bf), (rnd(N, d) * 0.5).to(bf)
-    p_R = rnd(N, 8).abs() + 0.1
+    p_out, p_agg = (rnd(N, d) * 0.5).to(bf), (rnd(2, N, d) * 0.5).to(bf)
+    p_R, p_S = rnd(2, N, 8).abs() + 0.1, rnd(N, 8) * 0.3
     for heads in (8, 1):
         X = (rnd(N, d) * 0.5).to(bf)
         avec = rnd(2, d) * 0.2
@@ -54,21 +54,21 @@ def main():
             r["node+edges"] = timed(lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, **kw))
             dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, **kw)
             if not sparse:
-                Gn, T = torch.empty(N, d, dtype=bf, device=dev), torch.empty(N, heads, device=dev)
-                r["edges (node=)"] = timed(lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T), **kw))
+                Gn, T, P1 = torch.zeros(N, d, dtype=bf, device=dev), torch.zeros(N, heads, 2, device=dev), torch.zeros(N, heads, device=dev)
+                r["edges (node=)"] = timed(lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T, P1), **kw))
             r["dW+dX (bf16 X)"] = timed(lambda: ops.transform_bwd(X, W, H, dH, dS, U, I, heads, p, 3))
             r["dW only"] = timed(lambda: ops.transform_bwd(X, W, H, dH, dS, U, I, heads, p, 3, part="dw"))
             r["dW+dX (fp32 X)"] = timed(lambda: ops.transform_bwd(X.float(), W, H, dH, dS, U, I, heads, p, 3))
             dx1 = ops.BwdDx(panel, torch.float32, p, 3)
             r["edges+dX fp32 (fuse 1)"] = timed(lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, dx=dx1, **kw))
-            dx2 = ops.BwdDx(panel, bf, p, 3, prev=(p_out, p_agg, p_R, True))
+            dx2 = ops.BwdDx(panel, bf, p, 3, prev=(p_out, p_agg, p_R, p_S, True, 0.2))
             r["edges+dX+prev node (fuse 2)"] = timed(lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, dx=dx2, **kw))
             res[tag] = {k: round(v, 1) for k, v in r.items()}
             print(tag, json.dumps(res[tag]), flush=True)
     G = torch.empty(N, d, device=dev)
-    Gn, T = torch.empty(N, d, dtype=bf, device=dev), torch.empty(N, 8, device=dev)
+    Gn, T, P1 = torch.empty(N, d, dtype=bf, device=dev), torch.empty(N, 8, 2, device=dev), torch.empty(N, 8, device=dev)
     dXb = rnd(N, d).to(bf)
-    res["prev node step alone"] = round(timed(lambda: ops.prop_bwd_node(p_out, p_agg, p_R, dXb, T, G, Gn, T, U, 8, (0, U, 0, I), False)), 1)
+    res["prev node step alone"] = round(timed(lambda: ops.prop_bwd_node(p_out, p_agg, p_R, dXb, p_S, G, Gn, T, P1, U, 8, (0, U, 0, I), False)), 1)
     print("prev node step alone", res["prev node step alone"], flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bwd_probe_%s.json" % a.workload), "w") as f:

@@ -63,7 +63,9 @@ def main(argv=None):
         torch.cuda.synchronize()
         bad = torch.zeros(2, dtype=torch.int64, device=dev)          # [forward launches that differ, backward launches that differ]
         nan = float("nan")
-        scr = {s_: (torch.empty(max(plan.nparts, 1), 64, device=dev), torch.empty(max(plan.nparts, 1), heads, device=dev)) for s_ in ("f", "b")}
+        # (a forward that saves keeps two planes of partial sums per slot: ops.prop_fwd)
+        scr = {s_: (torch.empty(max(plan.nparts, 1), k_ * 64, device=dev), torch.empty(max(plan.nparts, 1), k_ * heads, device=dev))
+               for s_, k_ in (("f", 2), ("b", 1))}
         noise = torch.randn(16_000_000, device=dev)
         per_dt = a.launches // 2
         it = 0

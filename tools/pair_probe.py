@@ -66,22 +66,22 @@ def main():
         H, S = ops.transform_fwd(X, W, avec, U, I, heads, h_dtype=bf, feat_drop_p=p, seed=3)
         gout = rnd(N, d).to(bf)
         out, agg, R = ops.prop_fwd(plan, H, S, S, avec, heads, save=True, drop_p=p, seed=5)
-        p_out, p_agg, p_R = (rnd(N, d) * 0.5).to(bf), (rnd(N, d) * 0.5).to(bf), rnd(N, 8).abs() + 0.1
-        Gn, T = torch.empty(N, d, dtype=bf, device=dev), torch.empty(N, heads, device=dev)
+        p_out, p_agg, p_R, p_S = (rnd(N, d) * 0.5).to(bf), (rnd(2, N, d) * 0.5).to(bf), rnd(2, N, 8).abs() + 0.1, rnd(N, 8) * 0.3
+        Gn, T, P1 = torch.zeros(N, d, dtype=bf, device=dev), torch.zeros(N, heads, 2, device=dev), torch.zeros(N, heads, device=dev)
         G = torch.empty(N, d, device=dev)
         kw = dict(drop_p=p, seed=5)
         dH, dS = ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, **kw)
         c = {}
         c["fwd (train)"] = lambda: ops.prop_fwd(plan, H, S, S, avec, heads, save=True, drop_p=p, seed=5, out=out, agg=agg, R=R)
-        c["edges"] = lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T), **kw)
-        c["node"] = lambda: ops.prop_bwd_node(p_out, p_agg, p_R, gout, T, G, Gn, T, U, 8, (0, U, 0, I), False)
+        c["edges"] = lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T, P1), **kw)
+        c["node"] = lambda: ops.prop_bwd_node(p_out, p_agg, p_R, gout, p_S, G, Gn, T, P1, U, 8, (0, U, 0, I), False)
         c["dW+dX"] = lambda: ops.transform_bwd(X, W, H, dH, dS, U, I, heads, p, 3)
         c["dW"] = lambda: ops.transform_bwd(X, W, H, dH, dS, U, I, heads, p, 3, part="dw")
         dx1, dx3 = ops.BwdDx(panel, torch.float32, p, 3), ops.BwdDx(panel, bf, p, 3)
-        dx2 = ops.BwdDx(panel, bf, p, 3, prev=(p_out, p_agg, p_R, True))
-        c["edges+dX f32"] = lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T), dx=dx1, **kw)
-        c["edges+dX bf16"] = lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T), dx=dx3, **kw)
-        c["edges+dX+node"] = lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T), dx=dx2, **kw)
+        dx2 = ops.BwdDx(panel, bf, p, 3, prev=(p_out, p_agg, p_R, p_S, True, 0.2))
+        c["edges+dX f32"] = lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T, P1), dx=dx1, **kw)
+        c["edges+dX bf16"] = lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T, P1), dx=dx3, **kw)
+        c["edges+dX+node"] = lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T, P1), dx=dx2, **kw)
         c["separate: node, edges, dW+dX"] = lambda: (c["node"](), c["edges"](), c["dW+dX"]())
         c["fused 3: node, edges+dX, dW"] = lambda: (c["node"](), c["edges+dX bf16"](), c["dW"]())
         c["fused 2: edges+dX+node, dW"] = lambda: (c["edges+dX+node"](), c["dW"]())

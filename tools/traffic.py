@@ -68,8 +68,8 @@ def train_pass(counters, dtype):
         if not m:
             return None
         k, targs = m.group(1), (m.group(3) or "").replace(" ", "").split(",")
-        if k == "prop_bwd_kernel":                         # <T, D, HEADS, FROM_ROW, DROP, SPARSE, FUSE>
-            return "prop_bwd_kernel " + ("scored batch" if targs[5] == "true" else "dense")
+        if k == "prop_bwd_kernel":                         # <T, D, HEADS, DROP, SPARSE, FUSE>
+            return "prop_bwd_kernel " + ("scored batch" if targs[4] == "true" else "dense")
         if k == "prop_fwd_kernel":
             return "prop_fwd_kernel " + ("scored batch" if targs[5] == "true" else "dense (train: out / agg / R written)")
         if k in ("prop_bwd_node_kernel", "transform_dw_mfma_kernel", "transform_dw_batch_kernel", "transform_bwd_reduce_kernel",
