@@ -112,9 +112,12 @@ struct NegSums {
     float rneg;
 };
 
+// A finished row: the values (calc) and the stores (store).  The fused launch (NEXT) puts the workgroup's barrier BETWEEN them: a
+// wave with stores in flight waits for their acknowledgement at the barrier (vmcnt counts stores too), and a train-mode forward has
+// five of them per row (out, agg, aggn, R, Rn) -- 45 against 37 us per launch.
 template <typename T, int D, int HEADS, bool SAVE>
-__device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum,
-                                           NegSums<Slice<T>::VEC>& ng, float (&o)[Slice<T>::VEC]) {
+__device__ __forceinline__ void finish_row_calc(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum,
+                                                NegSums<Slice<T>::VEC>& ng, float (&o)[Slice<T>::VEC]) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC;
     float own[VEC];
@@ -126,14 +129,25 @@ __device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, in
         const float pre = (a.flags & NGACF_RESIDUAL) ? own[j] + acc[j] : acc[j];
         o[j] = (a.flags & NGACF_ELU) ? elu_fast(pre) : pre;
     }
-    if (a.out) Slice<T>::store(static_cast<T*>(a.out) + (size_t)row * D + q * VEC, o);     // (NULL: only the next stage's operands are wanted)
-    if (a.agg) Slice<T>::store(static_cast<T*>(a.agg) + (size_t)row * D + q * VEC, acc);    // (bf16 storage: 128 B per row instead of 256)
-    if (a.R && (q * VEC) % SH::HW == 0) a.R[(size_t)row * HEADS + head] = rsum;
-    if constexpr (SAVE) {                                 // second planes of agg / R: the negative-side aggregate and denominator
+    if constexpr (SAVE) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) ng.accn[j] *= inv;
+    }
+}
+
+template <typename T, int D, int HEADS, bool SAVE>
+__device__ __forceinline__ void finish_row_store(const PropArgs& a, int row, int q, int head, const float (&acc)[Slice<T>::VEC], float rsum,
+                                                 const NegSums<Slice<T>::VEC>& ng, const float (&o)[Slice<T>::VEC]) {
+    using SH = Shape<T, D, HEADS>;
+    constexpr int VEC = SH::VEC;
+    if (a.out) Slice<T>::store(static_cast<T*>(a.out) + (size_t)row * D + q * VEC, o);     // (NULL: only the next stage's operands are wanted)
+    if constexpr (SAVE) {                                 // agg / R (both given: the launcher picks SAVE by them), two planes each
+        Slice<T>::store(static_cast<T*>(a.agg) + (size_t)row * D + q * VEC, acc);            // (bf16 storage: 128 B per row instead of 256)
         Slice<T>::store(static_cast<T*>(a.agg) + ((size_t)a.N + row) * D + q * VEC, ng.accn);
-        if ((q * VEC) % SH::HW == 0) a.R[((size_t)a.N + row) * HEADS + head] = ng.rneg;
+        if ((q * VEC) % SH::HW == 0) {
+            a.R[(size_t)row * HEADS + head] = rsum;
+            a.R[((size_t)a.N + row) * HEADS + head] = ng.rneg;
+        }
     }
 }
 
@@ -141,7 +155,32 @@ template <typename T, int D, int HEADS, bool SAVE>
 __device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum,
                                            NegSums<Slice<T>::VEC>& ng) {
     float o[Slice<T>::VEC];
-    finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, o);
+    finish_row_calc<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, o);
+    finish_row_store<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, o);
+}
+
+// What a lane group hands to the fused tail (NEXT): the row it finished; the tail stores it, behind its barrier.
+template <int VEC>
+struct RowOut {
+    float o[VEC], agg[VEC];
+    NegSums<VEC> ng;
+    float rsum;
+    int row;
+    bool valid;
+};
+
+template <typename T, int D, int HEADS, bool SAVE>
+__device__ __forceinline__ void finish_row_defer(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum,
+                                                 NegSums<Slice<T>::VEC>& ng, RowOut<Slice<T>::VEC>& r) {
+    finish_row_calc<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, r.o);
+    if constexpr (SAVE) {
+#pragma unroll
+        for (int j = 0; j < Slice<T>::VEC; ++j) { r.agg[j] = acc[j]; r.ng.accn[j] = ng.accn[j]; }
+        r.ng.rneg = ng.rneg;
+        r.rsum = rsum;
+    }
+    r.row = row;
+    r.valid = true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -156,9 +195,9 @@ __device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, in
 //      v_mfma_f32_32x32x16_bf16, mfma_fwd_epilogue (H' rows as 16-byte stores, S' from the rounded H').  Same arithmetic, same
 //      order, same bits as the stand-alone launch on the stored table.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int D, int NEXT, bool NONE, bool STAGE_OUT>
+template <int D, int NEXT, bool NONE, bool STAGE_OUT, typename STORES>
 __device__ __forceinline__ void next_transform_tail(const PropArgs& a, uint4* xtile, int* xmeta, const uint4* panel, const float* av,
-                                                    bool valid, int row, int slot, int q, const float (&o)[8]) {
+                                                    bool valid, int row, int slot, int q, const float (&o)[8], STORES&& stores) {
     constexpr int KS = D / 16, OT = NEXT / 32, NH = NONE ? 1 : NEXT / 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tr = 8 * wave + slot;
@@ -182,6 +221,7 @@ __device__ __forceinline__ void next_transform_tail(const PropArgs& a, uint4* xt
     }
     if (q == 0) xmeta[tr] = valid ? row : -1;
     __syncthreads();                                          // (the compiler drains the LDS-DMA of the panel in front of it)
+    stores();                                                 // the row's own stores (out / agg / R), behind the barrier
     if (wave != 0) return;
     const int r = lane & 31, h = lane >> 5;
     const int nrow = xmeta[r];
@@ -208,9 +248,9 @@ __device__ __forceinline__ void next_transform_tail(const PropArgs& a, uint4* xt
 // wave finishes 4 rows and the workgroup 16: exactly the 16 node columns of v_mfma_f32_16x16x4_f32, the exact-fp32 matrix-core
 // instruction (its accumulation is an fmaf chain, k ascending: the bits of the stand-alone launch, which runs the same step).
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int D, int NEXT, bool NONE>
+template <int D, int NEXT, bool NONE, typename STORES>
 __device__ __forceinline__ void next_transform_tail_f32(const PropArgs& a, float* xtile, int* xmeta, const float* panel, const float* av,
-                                                        float* sx, bool valid, int row, int slot, int q, const float (&o)[4]) {
+                                                        float* sx, bool valid, int row, int slot, int q, const float (&o)[4], STORES&& stores) {
     static_assert(D == 64, "fp32 fused transform: 64 input columns");
     const int wave = threadIdx.x >> 6;
     const int tr = 4 * wave + slot;
@@ -227,6 +267,7 @@ __device__ __forceinline__ void next_transform_tail_f32(const PropArgs& a, float
     }
     if (q == 0) xmeta[tr] = valid ? row : -1;
     __syncthreads();                                          // tile + panel (LDS-DMA drained in front of it) are in LDS
+    stores();
     f32_tile_step<NEXT, NONE>(xtile, xmeta, panel, av, sx, a.next_H, a.next_S);
 }
 
@@ -256,20 +297,28 @@ __device__ __forceinline__ void edge_step(const PropArgs& a, const float (&hv)[S
         const uint32_t other = dst_is_user ? (uint32_t)c * RNG_K2 + salt_h : (uint32_t)c * RNG_K1;
         ev = lowbias32(row_key ^ other) >= a.drop_thr ? ev * a.drop_scale : 0.f;
     }
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(ev, hv[j], acc[j]);
     if constexpr (SAVE) {
-        const float evn = s > 0.f ? 0.f : ev;
+        // both sums of a column in ONE packed FMA: (acc[j], accn[j]) += (ev, evn) * (h[j], h[j]) -- v_pk_fma_f32 with the column
+        // broadcast by op_sel; as two independent loops the compiler paired neighbouring columns and spent 7 moves per edge on it
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 w = {ev, s > 0.f ? 0.f : ev};
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) ng.accn[j] = fmaf(evn, hv[j], ng.accn[j]);
+        for (int j = 0; j < VEC; ++j) {
+            f32x2 p = {acc[j], ng.accn[j]};
+            const f32x2 h2 = {hv[j], hv[j]};
+            p = __builtin_elementwise_fma(w, h2, p);
+            acc[j] = p.x; ng.accn[j] = p.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(ev, hv[j], acc[j]);
     }
 }
 
 // The traversal of one wave's work item(s).  NEXT (the fused form, ngacf_prop_fwd_next): the finished row of this lane's group
-// is also handed back (rvalid, rrow, ro) for the workgroup's transform tail, and no path leaves before it.
+// is handed back in `ro` for the workgroup's transform tail (which also stores it), and no path leaves before it.
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, bool NEXT, bool SAVE>
-__device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int widx, int wend, bool& rvalid, int& rrow,
-                                              float (&ro)[Slice<T>::VEC]) {
+__device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int widx, int wend, RowOut<Slice<T>::VEC>& ro) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC, LPR = SH::LPR, EPI = SH::EPI, SHIFT = SH::ROW_SHIFT;
     const int lane = threadIdx.x & 63;
@@ -410,7 +459,7 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
             colv = coln;
         }
         if (live) {
-            if constexpr (NEXT) { finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro); rvalid = true; rrow = row; }
+            if constexpr (NEXT) finish_row_defer<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro);
             else finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
         }
         return;
@@ -472,7 +521,7 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
     }
     if (part < 0) {
         if (slot == 0) {                                      // one finished row per wave, in lane group 0
-            if constexpr (NEXT) { finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro); rvalid = true; rrow = row; }
+            if constexpr (NEXT) finish_row_defer<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro);
             else finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
         }
         return;
@@ -561,7 +610,7 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
         ng.rneg = group_sum<LPR, WAVE>(ng.rneg);
     }
     if (slot == 0) {
-        if constexpr (NEXT) { finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro); rvalid = true; rrow = row; }
+        if constexpr (NEXT) finish_row_defer<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro);
         else finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
     }
 }
@@ -575,9 +624,13 @@ __global__ __launch_bounds__(256, NEXT == 64 ? (SAVE ? 4 : 5) : NEXT == 128 ? 4 
     static_assert(NEXT == 0 || (D == 64 && !SPARSE), "fused next-stage transform: rows of 64 columns");
     int kind, widx, wend;
     locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, kind, widx, wend);
-    bool rvalid = false;
-    int rrow = 0;
-    float ro[VEC];
+    RowOut<VEC> ro;
+    ro.valid = false;
+    ro.row = 0;
+    const int lane_q = (threadIdx.x & 63) % SH::LPR;
+    auto stores = [&]() {
+        if (ro.valid) finish_row_store<T, D, HEADS, SAVE>(a, ro.row, lane_q, (lane_q * VEC) / SH::HW, ro.agg, ro.rsum, ro.ng, ro.o);
+    };
     if constexpr (NEXT > 0 && sizeof(T) == 2) {
         // the workgroup's weight panel (its rows are all users or all items) goes global -> LDS by LDS-DMA right here and lands
         // while the waves traverse; the barrier of the tail publishes it together with the finished rows
@@ -597,10 +650,10 @@ __global__ __launch_bounds__(256, NEXT == 64 ? (SAVE ? 4 : 5) : NEXT == 128 ? 4 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.next_avec + (users ? 0 : NEXT) + 4 * lane),
                                              (__attribute__((address_space(3))) void*)avec_lds, 16, 0, 0);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) ro[j] = 0.f;
-        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true, SAVE>(a, kind, widx, wend, rvalid, rrow, ro);
-        next_transform_tail<D, NEXT, NONE, STAGE_OUT>(a, xtile_lds, xmeta_lds, panel_lds, reinterpret_cast<const float*>(avec_lds), rvalid, rrow,
-                                           lane / SH::LPR, lane % SH::LPR, ro);
+        for (int j = 0; j < VEC; ++j) ro.o[j] = 0.f;
+        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true, SAVE>(a, kind, widx, wend, ro);
+        next_transform_tail<D, NEXT, NONE, STAGE_OUT>(a, xtile_lds, xmeta_lds, panel_lds, reinterpret_cast<const float*>(avec_lds), ro.valid, ro.row,
+                                           lane / SH::LPR, lane % SH::LPR, ro.o, stores);
     } else if constexpr (NEXT > 0) {
         // fp32 storage: the panel is the next stage's fp32 W'[type] itself ([64][NEXT], no packing); a 1 KB LDS-DMA piece = 256
         // consecutive floats of the LDS image; the lane's 16 bytes come from the column block the source-side swizzle names
@@ -617,12 +670,12 @@ __global__ __launch_bounds__(256, NEXT == 64 ? (SAVE ? 4 : 5) : NEXT == 128 ? 4 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.next_avec + (users ? 0 : NEXT) + 4 * lane),
                                              (__attribute__((address_space(3))) void*)avec_f32, 16, 0, 0);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) ro[j] = 0.f;
-        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true, SAVE>(a, kind, widx, wend, rvalid, rrow, ro);
-        next_transform_tail_f32<D, NEXT, NONE>(a, xtile_f32, xmeta_f32, panel_f32, avec_f32, sx_f32, rvalid, rrow, lane / SH::LPR,
-                                               lane % SH::LPR, ro);
+        for (int j = 0; j < VEC; ++j) ro.o[j] = 0.f;
+        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, true, SAVE>(a, kind, widx, wend, ro);
+        next_transform_tail_f32<D, NEXT, NONE>(a, xtile_f32, xmeta_f32, panel_f32, avec_f32, sx_f32, ro.valid, ro.row, lane / SH::LPR,
+                                               lane % SH::LPR, ro.o, stores);
     } else {
-        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, false, SAVE>(a, kind, widx, wend, rvalid, rrow, ro);
+        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, false, SAVE>(a, kind, widx, wend, ro);
     }
 }
 
