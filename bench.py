@@ -287,8 +287,17 @@ def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dim
     dense = [x for s_ in range(L) for x in per_stage[s_] if not (sparse_last and s_ == L - 1)]
     avg_ms = sum(dense) / len(dense)
     heads_dense = int(dims[0][2]) if len(dims[0]) > 2 else d // 8
-    bytes_launch = 2 * E * (4 + d * elem + 8 * heads_dense) + N * (2 * d * elem + 8)
+    bytes_edges = 2 * E * (4 + d * elem + 8 * heads_dense) + N * (2 * d * elem + 8)
     bytes_survey = 2 * E * (4 + 2 * d * elem) + N * (2 * d * elem + 8)
+    # the fused tail's own rows (bf16 plans): stage 0 writes the fp32 dX; a later dense stage writes dX and, at level 2, reads the
+    # previous stage's out / agg / aggn / R / Rn / S and writes its Gn / ST / P1
+    fused = bool(ops.FUSE_BWD) and dtype == "bf16"
+    n_dense = L - 1 if sparse_last else L
+    tail = 0
+    if fused and n_dense > 0:
+        later = N * d * elem + (N * (4 * d * elem + 24 * heads_dense) if ops.FUSE_BWD >= 2 else 0)
+        tail = (N * d * 4 + (n_dense - 1) * later) / n_dense
+    bytes_launch = bytes_edges + tail
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
     hit, hit_src = BK.bwd_hit_from_profile(ROOT, wl, dtype)
     regime = BK.gather_regime(N * (d * elem + 8 * heads_dense), max(U, I) * (d * elem + 8 * heads_dense))   # gathered: Gn rows and (S, t) pairs
@@ -302,7 +311,9 @@ def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dim
         peak = blend if elem == 2 else l2blend
         note = "as `roofline` (ceiling fixed by dtype), at the edge backward's own L2 hit rate %.3f (%s)" % (hit, hit_src)
     else:
-        bound, peak, note = "l2+mall gather", regime["roof_GBps"], "no request-counter profile: the regime's row-gather rate"
+        # no counter profile of this workload / dtype: the L2's own peak is the only ceiling that holds whatever the hit rate is
+        bound, peak, note = "l2 peak (upper bound)", BK.L2_PEAK_GBS, ("no request-counter profile of the edge backward for this workload and dtype "
+                                                                       "(tools/traffic.py trainstep): measured against the L2 peak, an upper bound of any blend")
     from ngacf_amd import functional as NF
     return {"bound": bound, "kernel": "prop_bwd_kernel, dense stages (NGACF_FUSE_BWD=%d: %s); l2_hit_rate: from_profile"
                                       % (ops.FUSE_BWD, "with the stage's dX%s in its tail" % (" and the previous stage's node step" if ops.FUSE_BWD >= 2 else "")
@@ -312,7 +323,10 @@ def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dim
             "frac_of_guide_gather_blend": round(achieved / blend, 4) if blend else None,
             "frac_of_l2_peak_blend": round(achieved / l2blend, 4) if l2blend else None,
             "l2_hit_rate": hit, "bytes_per_launch": int(bytes_launch),
-            "bytes_note": "2E (4 + d T + 8 heads) + N (2 d T + 8): one gathered row and a (S, t) pair per head per edge (split-sign backward); the fused tail's rows are not counted",
+            "bytes_note": "2E (4 + d T + 8 heads) + N (2 d T + 8): one gathered row and a (S, t) pair per head per edge (split-sign backward)"
+                          + (", + the fused tail's own rows, averaged over the dense stages: %d bytes per launch (dX; at level 2 the previous stage's out / agg / aggn "
+                             "in, Gn / ST / P1 out)" % int(tail) if tail else ""),
+            "bytes_edge_step_only": int(bytes_edges),
             "GBps_if_counted_in_the_two_row_form_of_SURVEY_8d": round(bytes_survey / (avg_ms * 1e-3) / 1e9, 1),
             "avg_launch_us": round(avg_ms * 1e3, 2),
             "per_stage_us": [round(1e3 * sum(x) / len(x), 2) for x in per_stage],

@@ -230,21 +230,13 @@ def l2_hit_from_profile(root, workload, dtype):
 
 
 def bwd_hit_from_profile(root, workload, dtype):
-    """(L2 hit rate of the dense edge backward, source): tools/traffic.py trainstep (r04: the kernels of the replayed train step
-    under rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum), or round 2's tools/reqcount.py passes over tools/kbench.py."""
-    for rnd in _ROUNDS:
-        rel = os.path.join("profiles", "%s_traffic_trainstep.json" % rnd)
-        p = os.path.join(root, rel)
-        if os.path.exists(p) and workload == "gowalla":
-            k = (json.load(open(p)).get("by_dtype", {}).get(dtype) or {}).get("kernels", {}).get("prop_bwd_kernel dense")
-            if k and k.get("l2_hit_rate") is not None:
-                return k["l2_hit_rate"], "from_profile: %s" % rel
-        rel = os.path.join("profiles", "%s_reqcount_%s_%s.json" % (rnd, workload, dtype))
-        p = os.path.join(root, rel)
-        if os.path.exists(p):
-            ks = json.load(open(p)).get("kernels", {})
-            rates = [v["per_directed_edge"]["L2_hit_rate"] for k, v in sorted(ks.items())
-                     if k.startswith("prop_bwd_kernel") and "L2_hit_rate" in v.get("per_directed_edge", {})]
-            if rates:
-                return round(sum(rates) / len(rates), 4), "from_profile: %s (tools/reqcount.py over tools/kbench.py, round 2's numbering)" % rel
+    """(L2 hit rate of the dense edge backward, source): tools/traffic.py trainstep -- the kernels of the replayed train step under
+    rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum, per workload and dtype.  (Only files of the round that wrote the current edge
+    backward count: the split-sign kernel gathers other tables than rounds 1-3's.)"""
+    rel = os.path.join("profiles", "%s_traffic_trainstep%s.json" % (_ROUNDS[0], "" if workload == "gowalla" else "_" + workload))
+    p = os.path.join(root, rel)
+    if os.path.exists(p):
+        k = (json.load(open(p)).get("by_dtype", {}).get(dtype) or {}).get("kernels", {}).get("prop_bwd_kernel dense")
+        if k and k.get("l2_hit_rate") is not None:
+            return k["l2_hit_rate"], "from_profile: %s" % rel
     return None, None

@@ -4,7 +4,7 @@ doubled on gfx950; a third pass collects TCC_HIT_sum / TCC_MISS_sum (the L2 hit 
 from).  Writes gpurun_out/r04_traffic_<workload>.json -- copy it to profiles/ (bench.py reads roofline.traffic and
 roofline.l2_hit_rate from there and labels them from_profile).
 Run on the GPU box:  python tools/traffic.py gowalla   (this process never touches the GPU itself).
-    python tools/traffic.py trainstep [bf16,fp32]   -> gpurun_out/r04_traffic_trainstep.json: the same three passes over the
+    python tools/traffic.py trainstep [bf16,fp32] [yelp]   -> gpurun_out/r04_traffic_trainstep[_yelp].json: the same three passes over the
     replayed reference-semantics TRAIN step (tools/train_profile.py), per kernel family of the backward (bench.py's train_roofline
     reads the dense edge backward's L2 hit rate from there).  Under --pmc every dispatch runs alone: these are the kernels' own
     figures, not those of two chains sharing the GPU."""
@@ -51,13 +51,13 @@ KERNELS = ("prop_fwd_kernel", "prop_fwd_split_kernel", "transform_mfma_kernel", 
 ROUND = "r04"
 
 
-def train_pass(counters, dtype):
-    """{counter: {kernel label: (mean per launch, launches)}} over the kernels of the replayed train step (Gowalla scale)."""
+def train_pass(counters, dtype, workload="gowalla"):
+    """{counter: {kernel label: (mean per launch, launches)}} over the kernels of the replayed train step."""
     counters = [counters] if isinstance(counters, str) else list(counters)
     out = os.path.join(ROOT, "gpurun_out", "pmc_train_%s_%s" % (dtype, counters[0]))
     subprocess.run(["rm", "-rf", out])
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "tools", "train_profile.py"), "--steps", "6", "--dtype", dtype]
+           sys.executable, os.path.join(ROOT, "tools", "train_profile.py"), "--steps", "6", "--dtype", dtype, "--workload", workload]
     subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     tot = {c: collections.defaultdict(float) for c in counters}
     n = {c: collections.defaultdict(int) for c in counters}
@@ -89,15 +89,15 @@ def train_pass(counters, dtype):
     return {c: {k: (tot[c][k] / n[c][k], n[c][k]) for k in tot[c]} for c in counters}
 
 
-def main_train(dtypes):
-    res = {"workload": "gowalla", "what": "the kernels of one replayed reference-semantics train step (B = 2048, dropout 0.1, SPUIMultiGACF)",
+def main_train(dtypes, workload="gowalla"):
+    res = {"workload": workload, "what": "the kernels of one replayed reference-semantics train step (B = 2048, dropout 0.1, SPUIMultiGACF)",
            "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum} -- python tools/train_profile.py --steps 6 "
-                      "[--dtype fp32]  (tools/traffic.py trainstep; three separate passes; FETCH_SIZE x2 = gfx950 correction; under --pmc every "
+                      "[--dtype fp32] [--workload yelp]  (tools/traffic.py trainstep; three separate passes; FETCH_SIZE x2 = gfx950 correction; under --pmc every "
                       "dispatch runs alone)", "by_dtype": {}}
     for dt in dtypes:
-        fetch = train_pass("FETCH_SIZE", dt)["FETCH_SIZE"]
-        write = train_pass("WRITE_SIZE", dt)["WRITE_SIZE"]
-        hm = train_pass(["TCC_HIT_sum", "TCC_MISS_sum"], dt)
+        fetch = train_pass("FETCH_SIZE", dt, workload)["FETCH_SIZE"]
+        write = train_pass("WRITE_SIZE", dt, workload)["WRITE_SIZE"]
+        hm = train_pass(["TCC_HIT_sum", "TCC_MISS_sum"], dt, workload)
         ks = {}
         for k in sorted(fetch):
             hit, miss = hm["TCC_HIT_sum"].get(k, (0.0, 0))[0], hm["TCC_MISS_sum"].get(k, (0.0, 0))[0]
@@ -107,7 +107,7 @@ def main_train(dtypes):
                      "tcc_hit_per_launch": round(hit, 1), "tcc_miss_per_launch": round(miss, 1)}
             print(dt, k, ks[k], flush=True)
         res["by_dtype"][dt] = {"kernels": ks}
-    with open(os.path.join(ROOT, "gpurun_out", "%s_traffic_trainstep.json" % ROUND), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "%s_traffic_trainstep%s.json" % (ROUND, "" if workload == "gowalla" else "_" + workload)), "w") as f:
         json.dump(res, f, indent=1)
 
 
@@ -115,7 +115,7 @@ def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "gowalla"
     dtypes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["bf16", "fp32"]
     if wl == "trainstep":
-        return main_train(dtypes)
+        return main_train(dtypes, sys.argv[3] if len(sys.argv) > 3 else "gowalla")
     res = {"workload": wl, "stages": 3,
            "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum} -- python bench.py --steps 3 --warmup 1 "
                       "--passes-per-step 4 --no-cpu-baseline --no-train --no-probe --workload %s [--dtype fp32]  (tools/traffic.py; "
