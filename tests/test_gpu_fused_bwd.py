@@ -242,3 +242,112 @@ def test_graphed_step_with_deferred_weight_gradients(dev, level, sparse_fused):
     for n in res[0][1]:
         a_, b_ = res[level][1][n].double(), res[0][1][n].double()
         assert float((a_ - b_).norm() / b_.norm().clamp_min(1e-30)) < 1e-4, n
+
+
+@pytest.mark.parametrize("heads", [8, 1])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_split_sign_backward_of_one_stage_vs_float64_autograd(dev, heads, dt):
+    """The regrouped backward (include/ngacf.h, ngacf_prop_bwd): the forward's second planes (the sums over the edges with a
+    non-positive score), step 1's (S, t) pairs and P1, and the stage's dH / dS, each against a float64 statement of
+    SPUIGACF.py:359-397 and its autograd (fixed dropout mask = the kernels' own bits), on a graph with short rows, long rows, a hub
+    row cut into slices and isolated items."""
+    import torch.nn.functional as F
+    from ngacf_amd import ops
+    from ngacf_amd.plan import build_plan
+    U, I = 700, 503
+    N, d, hw, alpha, p = U + I, 64, 64 // heads, 0.2, 0.25
+    edge_np = _graph(U, I, 21000, 7, hub=450)
+    edge = torch.from_numpy(edge_np).to(dev)
+    plan = build_plan(edge, U, I, seg_len=128)
+    assert plan.nsplit > 0
+    rs = np.random.RandomState(3 + heads)
+    X = torch.from_numpy(rs.randn(N, 64).astype(np.float32) * 0.7).to(dev).to(dt)
+    W = torch.from_numpy((rs.randn(2, 64, 64) * 0.25).astype(np.float32)).to(dev)
+    a = torch.from_numpy((rs.randn(2, 64) * 0.4).astype(np.float32)).to(dev)
+    H, S = ops.transform_fwd(X, W, a, U, I, heads, dt)
+    gout = torch.from_numpy(rs.randn(N, 64).astype(np.float32) * 0.2).to(dev).to(dt)
+    out, agg, R = ops.prop_fwd(plan, H, S, S, a, heads, alpha, drop_p=p, seed=11, save=True)
+    dH, dS = ops.prop_bwd(plan, H, S, S, a, out, agg, R, gout, heads, alpha, drop_p=p, seed=11)
+    G = torch.empty(N, d, device=dev); Gn = torch.empty(N, d, dtype=dt, device=dev)
+    ST = torch.empty(N, heads, 2, device=dev); P1 = torch.empty(N, heads, device=dev)
+    ops.prop_bwd_node(out, agg, R, gout, S, G, Gn, ST, P1, U, heads, (0, U, 0, I), False, alpha=alpha)
+    # ---- float64 statement: both directions of every (user, item) pair, the kernels' own mask bits
+    eu, ei = edge[0], edge[1] + U
+    dst, src = torch.cat([eu, ei]), torch.cat([ei, eu])
+    from ngacf_amd import rng
+    a32, b32 = edge[0].int().contiguous(), (edge[1] + U).int().contiguous()
+    thr = int(rng.threshold(p))
+    keep = torch.stack([(ops.dropout_bits(1, 11, a32, b32, torch.full_like(a32, h)).long() & 0xFFFFFFFF) >= thr for h in range(heads)], 1).double() / (1 - p)
+    m = torch.cat([keep, keep])                                       # one mask per pair, both directions (SPUIGACF.py:375)
+    Hd = H.double().requires_grad_(True)
+    Sd = S.double().requires_grad_(True)
+    s = Sd[dst] + Sd[src]
+    e = torch.exp(-F.leaky_relu(s, alpha))
+    Rr = torch.zeros(N, heads, dtype=torch.double, device=dev).index_add(0, dst, e)
+    A = torch.zeros(N, d, dtype=torch.double, device=dev).index_add(0, dst, (m * e).repeat_interleave(hw, 1) * Hd[src])
+    Rw = Rr.repeat_interleave(hw, 1)
+    aggr = torch.where(Rw > 0, A / Rw.clamp_min(1e-300), torch.zeros_like(A))
+    o = F.elu(Hd + aggr)
+    gH, gS = torch.autograd.grad(o, [Hd, Sd], gout.double())
+    with torch.no_grad():
+        neg = (s <= 0).double()
+        Rn = torch.zeros_like(Rr).index_add(0, dst, neg * e)
+        An = torch.zeros_like(A).index_add(0, dst, (neg * m * e).repeat_interleave(hw, 1) * Hd[src])
+        aggn = torch.where(Rw > 0, An / Rw.clamp_min(1e-300), torch.zeros_like(An))
+        g = gout.double() * torch.where(o > 0, torch.ones_like(o), o + 1.0)
+        gn = torch.where(Rw > 0, g / Rw.clamp_min(1e-300), torch.zeros_like(g))
+        t = (gn * aggr).view(N, heads, hw).sum(2)
+        p1 = (1 - alpha) * (Rr * (gn * aggn).view(N, heads, hw).sum(2) - Rn * t)
+        a_own = torch.cat([a[0].expand(U, d), a[1].expand(I, d)]).double()
+        dH_ref = gH + gS.repeat_interleave(hw, 1) * a_own                # S = H . a: the transform's share of dH, as the kernel folds it in
+    tol = 2e-5 if dt == torch.float32 else 4e-2
+    rel = lambda x, y: float((x.double() - y).abs().max() / y.abs().max().clamp_min(1e-30))
+    # a score within rounding of zero may fall on either side of the split: exclude rows that have one (none with these seeds in fp32)
+    near = torch.zeros(N, dtype=torch.bool, device=dev).index_put_((dst,), (s.detach().abs() < 1e-5).any(1), accumulate=True)
+    ok = ~near
+    assert int(ok.sum()) > 0.98 * N
+    assert rel(R[0], Rr.detach()) < 1e-5 and rel(R[1][ok], Rn[ok]) < (1e-5 if dt == torch.float32 else 2e-2)
+    assert rel(agg[0], aggr.detach()) < tol and rel(agg[1][ok], aggn[ok]) < tol
+    assert rel(Gn, gn) < tol and rel(ST[:, :, 1], t) < tol and torch.equal(ST[:, :, 0], S)
+    assert rel(P1[ok], p1[ok]) < (2e-4 if dt == torch.float32 else 6e-2)
+    assert rel(dS, gS) < (2e-4 if dt == torch.float32 else 6e-2) and rel(dH, dH_ref) < tol
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_flagged_backward_equals_the_unflagged_one_on_a_gradient_that_is_zero_outside(dev, drop):
+    """ngacf_prop_bwd with a scored batch's row flags (only edges whose source is flagged are walked, step 1 over the batch's list)
+    against the plain call on the same gradient, which is zero outside the batch: dH and dS bit for bit.  The forward's saved rows
+    exist for the batch's rows only in the flagged case: the plain call gets a full forward."""
+    from ngacf_amd import ops
+    from ngacf_amd.plan import build_plan
+    U, I = 900, 640
+    N = U + I
+    edge = torch.from_numpy(_graph(U, I, 30000, 2, hub=600)).to(dev)
+    plan = build_plan(edge, U, I, seg_len=128)
+    rs = np.random.RandomState(5)
+    bf = torch.bfloat16
+    X = torch.from_numpy(rs.randn(N, 64).astype(np.float32) * 0.5).to(dev).to(bf)
+    W = torch.from_numpy((rs.randn(2, 64, 64) * 0.2).astype(np.float32)).to(dev)
+    a = torch.from_numpy((rs.randn(2, 64) * 0.3).astype(np.float32)).to(dev)
+    H, S = ops.transform_fwd(X, W, a, U, I, 1, bf)
+    g = torch.Generator(device=dev); g.manual_seed(8)
+    B = 150
+    bu, bi = torch.randint(0, U, (B,), device=dev, generator=g), torch.randint(0, I - 3, (B,), device=dev, generator=g)
+    rows = ops.mark_rows(bu, bi, U, I, grad_d=64)
+    rows.g32.zero_()
+    rows.g32[torch.cat([bu, U + bi])] = torch.from_numpy(rs.randn(2 * B, 64).astype(np.float32) * 0.1).to(dev)
+    gfull = torch.zeros(N, 64, device=dev)
+    sel = rows.mask()
+    gfull[sel] = rows.g32[sel]
+    kw = dict(drop_p=drop, seed=4)
+    out_s, agg_s, R_s = ops.prop_fwd(plan, H, S, S, a, 1, save=True, needed=rows, **kw)
+    out_f, agg_f, R_f = ops.prop_fwd(plan, H, S, S, a, 1, save=True, **kw)
+    dH_s, dS_s = ops.prop_bwd(plan, H, S, S, a, out_s, agg_s, R_s, rows.g32, 1, needed=rows, gout_f32=True, **kw)
+    dH_f, dS_f = ops.prop_bwd(plan, H, S, S, a, out_f, agg_f, R_f, gfull, 1, gout_f32=True, **kw)
+    torch.cuda.synchronize()
+    # (the flagged forward adds a batch row's short-row terms in another order than the plain one: its saved rows agree to rounding,
+    #  so the comparison of the backward runs on the plain forward's rows for both)
+    dH_s2, dS_s2 = ops.prop_bwd(plan, H, S, S, a, out_f, agg_f, R_f, rows.g32, 1, needed=rows, gout_f32=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(dH_s2), _bits(dH_f)) and torch.equal(_bits(dS_s2), _bits(dS_f))
+    assert float((dH_s.float() - dH_f.float()).abs().max()) <= 2e-2 * float(dH_f.float().abs().max())
