@@ -617,8 +617,10 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
 
 // NEXT > 0 (= the next stage's output width; NONE: that stage has ONE head): the fused form of ngacf_prop_fwd_next.
 // SAVE: a train-mode forward (agg / R given): also the negative-side sums the backward wants (NegSums above).
+// (fp32 SAVE instantiations are bounded to 6 waves per SIMD: left alone the compiler takes 90 VGPRs (5 waves) where 66-78 do without a
+//  spill; bf16 ones spill at 6 and stay at 5.)
 template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int NEXT = 0, bool NONE = false, bool STAGE_OUT = false, bool SAVE = false>
-__global__ __launch_bounds__(256, NEXT == 64 ? (SAVE ? 4 : 5) : NEXT == 128 ? 4 : (sizeof(T) == 2 && D == 64 && !SPARSE ? (SAVE ? 5 : 6) : 1)) void prop_fwd_kernel(const PropArgs a) {
+__global__ __launch_bounds__(256, NEXT == 64 ? (SAVE ? (sizeof(T) == 4 ? 6 : 4) : 5) : NEXT == 128 ? 4 : (sizeof(T) == 2 && D == 64 && !SPARSE ? (SAVE ? 5 : 6) : (SAVE && sizeof(T) == 4 && D == 64 ? 6 : 1))) void prop_fwd_kernel(const PropArgs a) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC, EPI = SH::EPI;
     static_assert(NEXT == 0 || (D == 64 && !SPARSE), "fused next-stage transform: rows of 64 columns");
