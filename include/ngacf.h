@@ -290,7 +290,7 @@ int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* 
                         float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* The weight halves (dW, davec) of ngacf_transform_bwd for up to NGACF_DW_BATCH_MAX stages in ONE launch plus one reduction --
- * 64 -> 64 stages with bf16 H / dH (the stages whose dX came out of ngacf_prop_bwd_dx).  A train step needs these sums only
+ * 64 -> 64 stages, bf16 storage (bf16 MFMA) or fp32 storage (exact, on v_mfma_f32_16x16x4_f32).  A train step needs these sums only
  * at the optimizer, so the per-stage launches between the edge backwards (each latency-bound at 18 MB) collapse into one behind
  * the chain's last edge backward.  jobs: HOST array (copied into the kernel's arguments).
  *   work float[njobs][work_blocks][64*64 + 64]: per-workgroup partial sums, reduced in workgroup order (bitwise reproducible;
@@ -298,12 +298,12 @@ int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, const void* 
 #define NGACF_DW_BATCH_MAX 6
 typedef struct ngacf_dw_job {
     const void* X;        /* [N][64] x_dtype: the stage's input */
-    const void* H;        /* [N][64] bf16 */
-    const void* dH;       /* [N][64] bf16 */
+    const void* H;        /* [N][64] h_dtype */
+    const void* dH;       /* [N][64] h_dtype */
     const float* dS;      /* [N][heads] */
     float* dW;            /* [2][64][64] */
     float* davec;         /* [2][64] */
-    int32_t x_dtype, din, dout, heads;
+    int32_t x_dtype, h_dtype, din, dout, heads;    /* h_dtype: the type of H and dH (one per launch); fp32 storage: x_dtype is fp32 too */
     float feat_drop_p;
     uint64_t seed;
 } ngacf_dw_job;

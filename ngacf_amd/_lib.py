@@ -76,7 +76,7 @@ DW_BATCH_MAX = 6                   # NGACF_DW_BATCH_MAX
 
 class DwJob(ctypes.Structure):
     """ngacf_dw_job of include/ngacf.h"""
-    _fields_ = [("X", _p), ("H", _p), ("dH", _p), ("dS", _p), ("dW", _p), ("davec", _p), ("x_dtype", ctypes.c_int32),
+    _fields_ = [("X", _p), ("H", _p), ("dH", _p), ("dS", _p), ("dW", _p), ("davec", _p), ("x_dtype", ctypes.c_int32), ("h_dtype", ctypes.c_int32),
                 ("din", ctypes.c_int32), ("dout", ctypes.c_int32), ("heads", ctypes.c_int32), ("feat_drop_p", _f), ("seed", _u64)]
 
 

@@ -646,6 +646,107 @@ __global__ __launch_bounds__(256) void transform_dw_batch_kernel(const DwBatchAr
     }
 }
 
+// The same for fp32 storage (H, dH, X in fp32), exact on v_mfma_f32_16x16x4_f32: the contraction runs over nodes, 4 per MFMA;
+// a 64-node tile of X (masked) and of dH sits row-major in LDS (68-float stride: the four node rows of a step start on banks
+// 0, 4, 8, 12), wave w owns the 16 feature rows 16 w .. of the [64][64] result and all four 16-column blocks: per step one A read,
+// four B reads, four MFMAs.  The per-stage fp32 launches it replaces: an FMA kernel with 1024 partial sums + an 18 us reduction.
+typedef float dwf_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void transform_dw_batch_f32_kernel(const DwBatchArgs a) {
+    constexpr int DIN = 64, DOUT = 64, TN = 64, ST = 68;
+    __shared__ __attribute__((aligned(16))) float Xs[TN * ST];
+    __shared__ __attribute__((aligned(16))) float Gs[TN * ST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jb = blockIdx.x / a.nb, bj = blockIdx.x % a.nb;
+    const ngacf_dw_job& J = a.job[jb];
+    const int HW = DOUT / J.heads;
+    const uint32_t drop_thr = J.feat_drop_p > 0.f ? drop_threshold(J.feat_drop_p) : 0u;
+    const float drop_scale = 1.f / (1.f - J.feat_drop_p);
+    const bool drop = J.feat_drop_p > 0.f;
+    const uint32_t salt = drop ? salt_of(J.seed + (a.seed_dev ? *a.seed_dev : 0ull), 0u) : 0u;
+    const bool users = bj < a.nbu;
+    const int nb = users ? a.nbu : a.nbi;
+    const int bl = users ? bj : bj - a.nbu;
+    const int rbeg = users ? 0 : a.U, rend = users ? a.U : a.U + a.I;
+    const int ntiles = (rend - rbeg + TN - 1) / TN;
+    const float* Xg = static_cast<const float*>(J.X);
+    const float* Hg = static_cast<const float*>(J.H);
+    const float* Dg = static_cast<const float*>(J.dH);
+
+    dwf_f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = dwf_f32x4{0.f, 0.f, 0.f, 0.f};
+    float da[4] = {0.f, 0.f, 0.f, 0.f};
+    // a thread stages 4 float4 of X and 4 of dH per tile: item i = tid + 256 j -> node i / 16, columns 4 (i % 16) .. +3
+    float4 xr[4], gr[4];
+    auto fetch = [&](int tile) {
+        const int row0 = rbeg + tile * TN;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j, r = i >> 4, q = i & 15;
+            const int row = row0 + r;
+            if (row < rend) {
+                float4 v = *reinterpret_cast<const float4*>(Xg + (size_t)row * DIN + 4 * q);
+                if (drop) {
+                    v.x = feat_bits(salt, row, 4 * q + 0) >= drop_thr ? v.x * drop_scale : 0.f;
+                    v.y = feat_bits(salt, row, 4 * q + 1) >= drop_thr ? v.y * drop_scale : 0.f;
+                    v.z = feat_bits(salt, row, 4 * q + 2) >= drop_thr ? v.z * drop_scale : 0.f;
+                    v.w = feat_bits(salt, row, 4 * q + 3) >= drop_thr ? v.w * drop_scale : 0.f;
+                }
+                xr[j] = v;
+                gr[j] = *reinterpret_cast<const float4*>(Dg + (size_t)row * DOUT + 4 * q);
+                const float4 hv = *reinterpret_cast<const float4*>(Hg + (size_t)row * DOUT + 4 * q);
+                const float sc = J.dS[(size_t)row * J.heads + (4 * q) / HW];
+                da[0] = fmaf(sc, hv.x, da[0]); da[1] = fmaf(sc, hv.y, da[1]); da[2] = fmaf(sc, hv.z, da[2]); da[3] = fmaf(sc, hv.w, da[3]);
+            } else {
+                xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                gr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    const int n16 = lane & 15, g4 = lane >> 4;
+    int tile = bl;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += nb) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j, r = i >> 4, q = i & 15;
+            *reinterpret_cast<float4*>(Xs + r * ST + 4 * q) = xr[j];
+            *reinterpret_cast<float4*>(Gs + r * ST + 4 * q) = gr[j];
+        }
+        __syncthreads();
+        if (tile + nb < ntiles) fetch(tile + nb);
+#pragma unroll 4
+        for (int st = 0; st < TN / 4; ++st) {
+            const int node = 4 * st + g4;
+            const float av = Xs[node * ST + 16 * wave + n16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Gs[node * ST + 16 * t + n16], acc[t], 0, 0, 0);
+        }
+    }
+    // lane (n16, g4): acc[t][j] = dW[16 wave + 4 g4 + j][16 t + n16]
+    float* wkp = a.work + ((size_t)jb * a.nb + bj) * (DIN * DOUT + DOUT);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wkp[(size_t)(16 * wave + 4 * g4 + j) * DOUT + 16 * t + n16] = acc[t][j];
+    {   // davec: the 16 threads that share a column group (tid & 15) fold through LDS
+        __syncthreads();
+        float* red = Xs;                                     // [256][4]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[tid * 4 + e] = da[e];
+        __syncthreads();
+        if (tid < DOUT) {
+            const int q = tid >> 2, e = tid & 3;
+            float sm = 0.f;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) sm += red[(q + 16 * m) * 4 + e];
+            wkp[DIN * DOUT + tid] = sm;
+        }
+    }
+}
+
 // dW[type], davec[type] of every job = the sums of that job's and type's workgroup partials, in workgroup order
 __global__ __launch_bounds__(256) void transform_dw_batch_reduce_kernel(const DwBatchArgs a) {
     constexpr int wsz = 64 * 64 + 64, dwsz = 64 * 64, PER_JOB = (2 * wsz + 63) / 64;
@@ -810,6 +911,9 @@ extern "C" int ngacf_transform_dw_batch(const ngacf_dw_job* jobs, int njobs, flo
         if (!j.X || !j.H || !j.dH || !j.dS || !j.dW || !j.davec) return NGACF_E_ARG;
         if (j.din != 64 || j.dout != 64 || (j.heads != 8 && j.heads != 1)) return NGACF_E_SHAPE;
         if (j.x_dtype != NGACF_F32 && j.x_dtype != NGACF_BF16) return NGACF_E_SHAPE;
+        if (j.h_dtype != NGACF_F32 && j.h_dtype != NGACF_BF16) return NGACF_E_SHAPE;
+        if (j.h_dtype != jobs[0].h_dtype) return NGACF_E_SHAPE;                   // one storage type per launch
+        if (j.h_dtype == NGACF_F32 && j.x_dtype != NGACF_F32) return NGACF_E_SHAPE;    // fp32 storage: every table is fp32
         if (!(j.feat_drop_p >= 0.f && j.feat_drop_p < 1.f)) return NGACF_E_ARG;
         a.job[k] = j;
     }
@@ -833,7 +937,8 @@ extern "C" int ngacf_transform_dw_batch(const ngacf_dw_job* jobs, int njobs, flo
         if (tu == 0) a.nbu = 0;
     }
     a.nb = a.nbu + a.nbi; a.njobs = njobs; a.work = work; a.U = U; a.I = I; a.seed_dev = seed_dev;
-    hipLaunchKernelGGL(transform_dw_batch_kernel, dim3(njobs * a.nb), dim3(256), 0, st, a);
+    if (jobs[0].h_dtype == NGACF_F32) hipLaunchKernelGGL(transform_dw_batch_f32_kernel, dim3(njobs * a.nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(transform_dw_batch_kernel, dim3(njobs * a.nb), dim3(256), 0, st, a);
     NGACF_CHECK_LAUNCH();
     constexpr int wsz = 64 * 64 + 64;
     hipLaunchKernelGGL(transform_dw_batch_reduce_kernel, dim3(njobs * ((2 * wsz + 63) / 64)), dim3(256), 0, st, a);

@@ -99,14 +99,16 @@ def _flush_dw(bw, plan, seed_dev):
 
 def _transform_bwd_after(bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed, seed_dev):
     if dx is None:
-        if (bw is not None and bw[0].defer_dw and DEFER_DW and X is not None and H.dtype == torch.bfloat16 and tuple(W.shape) == (2, 64, 64)
-                and plan.n_rows == plan.N and bw[1] != min(bw[0].bwd_stages)):
-            # (the stage of a scored batch, which keeps its edge backward unfused:) dX now -- the next backward stage waits for it --
-            # and the weights' gradient with the chain's other stages in the batched launch: 9 us in front of the next stage
-            # instead of 15 + 9 (dW + dX, then the reduction of its 1024 partial sums)
+        f32_stage = H.dtype == torch.float32 and X is not None and X.dtype == torch.float32
+        if (bw is not None and bw[0].defer_dw and DEFER_DW and X is not None and (H.dtype == torch.bfloat16 or f32_stage)
+                and tuple(W.shape) == (2, 64, 64) and plan.n_rows == plan.N):
+            # (bf16: the stage of a scored batch, which keeps its edge backward unfused; fp32 storage: every stage:) dX now -- the next
+            # backward stage waits for it -- and the weights' gradient with the chain's other stages in the batched launch: 9 us in
+            # front of the next stage instead of 15 + 9 (dW + dX, then the reduction of its 1024 partial sums); fp32: 24 instead of 39 + 18
             dX, _, _ = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev, part="dx")
             dW, da = torch.empty(2, 64, 64, dtype=torch.float32, device=H.device), torch.empty(2, 64, dtype=torch.float32, device=H.device)
             bw[0].dw_jobs.append((X, H, dH, dS, heads, feat_drop_p, seed, dW, da))
+            _flush_dw(bw, plan, seed_dev)                    # (fp32 storage: every stage comes through here, the chain's first one too)
             return dX, dW, da
         r = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
         _flush_dw(bw, plan, seed_dev)

@@ -445,7 +445,7 @@ DW_BATCH_BLOCKS = int(__import__("os").environ.get("NGACF_DW_BATCH_BLOCKS", "192
 
 
 def transform_dw_batch(jobs, U, I, seed_dev=None):
-    """The weight halves of transform_bwd for several 64 -> 64 bf16 stages in one launch + one reduction
+    """The weight halves of transform_bwd for several 64 -> 64 stages (bf16 or fp32 storage) in one launch + one reduction
     (ngacf_transform_dw_batch).  jobs: [(X, H, dH, dS, heads, feat_drop_p, seed, dW, da)] with dW float [2, 64, 64] and
     da float [2, 64] given (they may have been handed out before this call fills them)."""
     n = len(jobs)
@@ -456,11 +456,12 @@ def transform_dw_batch(jobs, U, I, seed_dev=None):
     dev, N = jobs[0][0].device, U + I
     arr = (_lib.DwJob * n)()
     for k, (X, H, dH, dS, heads, p, seed, dW, da) in enumerate(jobs):
-        if X.dtype not in _DT or H.dtype != torch.bfloat16:
-            raise ValueError("transform_dw_batch: bf16 stages (X fp32 or bf16)")
-        arr[k] = _lib.DwJob(_chk(X, "X", None, N * 64, dev), _chk(H, "H", torch.bfloat16, N * 64, dev), _chk(dH, "dH", torch.bfloat16, N * 64, dev),
+        if X.dtype not in _DT or H.dtype not in _DT or H.dtype != jobs[0][1].dtype or (H.dtype == torch.float32 and X.dtype != torch.float32):
+            raise ValueError("transform_dw_batch: one storage type per call; fp32 storage takes fp32 X")
+        arr[k] = _lib.DwJob(_chk(X, "X", None, N * 64, dev), _chk(H, "H", None, N * 64, dev), _chk(dH, "dH", H.dtype, N * 64, dev),
                             _chk(dS, "dS", torch.float32, N * heads, dev), _chk(dW, "dW", torch.float32, 2 * 64 * 64, dev),
-                            _chk(da, "davec", torch.float32, 2 * 64, dev), _DT[X.dtype], 64, 64, int(heads), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF)
+                            _chk(da, "davec", torch.float32, 2 * 64, dev), _DT[X.dtype], _DT[H.dtype], 64, 64, int(heads), float(p),
+                            int(seed) & 0xFFFFFFFFFFFFFFFF)
     work = torch.empty(n, DW_BATCH_BLOCKS, 64 * 64 + 64, dtype=torch.float32, device=dev)
     _lib.check(lib.ngacf_transform_dw_batch(arr, n, work.data_ptr(), DW_BATCH_BLOCKS, U, I, _sd(seed_dev, dev), _stream()),
                "ngacf_transform_dw_batch")

@@ -201,6 +201,42 @@ def test_batched_weight_gradients_equal_the_per_stage_launches(dev):
             assert float((a_.double() - b_.double()).norm() / a_.double().norm()) < 2e-6
 
 
+def test_batched_weight_gradients_fp32_storage(dev):
+    """The fp32-storage form of ngacf_transform_dw_batch (exact fp32 matrix cores, v_mfma_f32_16x16x4_f32) against ngacf_transform_bwd's
+    weight half and against float64: 8 heads and 1, with and without feature dropout, row counts that are no multiple of the tile;
+    a launch that mixes storage types is refused."""
+    from ngacf_amd import ops, rng
+    U, I = 3100, 2501
+    N = U + I
+    g = torch.Generator(device=dev); g.manual_seed(6)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    jobs, want = [], []
+    for heads, p in ((8, 0.2), (1, 0.0), (8, 0.0)):
+        X, W = rnd(N, 64) * 0.5, rnd(2, 64, 64) * 0.2
+        H, dH, dS = rnd(N, 64) * 0.5, rnd(N, 64) * 0.1, rnd(N, heads) * 0.1
+        _, dW, da = ops.transform_bwd(X, W, H, dH, dS, U, I, heads, p, 23, part="dw")
+        Xm = X.double()
+        if p > 0:
+            n_idx = torch.arange(N, device=dev, dtype=torch.int32).repeat_interleave(64)
+            c_idx = torch.arange(64, device=dev, dtype=torch.int32).repeat(N)
+            keep = ((ops.dropout_bits(0, 23, n_idx, c_idx).long() & 0xFFFFFFFF) >= int(rng.threshold(p))).view(N, 64)
+            Xm = Xm * keep / (1 - p)
+        ref_dW = torch.stack([Xm[:U].t() @ dH[:U].double(), Xm[U:].t() @ dH[U:].double()])
+        ref_da = torch.stack([(dS[:U].double().repeat_interleave(64 // heads, 1) * H[:U].double()).sum(0),
+                              (dS[U:].double().repeat_interleave(64 // heads, 1) * H[U:].double()).sum(0)])
+        want.append((dW, da, ref_dW, ref_da))
+        jobs.append((X, H, dH, dS, heads, p, 23, torch.empty(2, 64, 64, device=dev), torch.empty(2, 64, device=dev)))
+    ops.transform_dw_batch(jobs, U, I)
+    torch.cuda.synchronize()
+    rel = lambda a_, b_: float((a_.double() - b_.double()).norm() / b_.double().norm())
+    for (dW, da, ref_dW, ref_da), j in zip(want, jobs):
+        assert rel(j[7], dW) < 2e-6 and rel(j[8], da) < 2e-6
+        assert rel(j[7], ref_dW) < 2e-6 and rel(j[8], ref_da) < 2e-6
+    bad = list(jobs[:1]) + [(jobs[1][0], jobs[1][1].bfloat16(), jobs[1][2].bfloat16()) + tuple(jobs[1][3:])]
+    with pytest.raises(ValueError):
+        ops.transform_dw_batch(bad, U, I)
+
+
 @pytest.mark.parametrize("level,sparse_fused", [(1, False), (2, False), (2, True)])
 def test_graphed_step_with_deferred_weight_gradients(dev, level, sparse_fused):
     """GraphedBPRStep (two chains, gradient sinks: the weight gradients of the fused stages are left to one batched launch per
@@ -242,6 +278,50 @@ def test_graphed_step_with_deferred_weight_gradients(dev, level, sparse_fused):
     for n in res[0][1]:
         a_, b_ = res[level][1][n].double(), res[0][1][n].double()
         assert float((a_ - b_).norm() / b_.norm().clamp_min(1e-30)) < 1e-4, n
+
+
+def test_graphed_fp32_step_with_deferred_weight_gradients(dev):
+    """fp32 storage: the graphed two-chain step with every stage's dW / davec left to the chain's batched launch (exact fp32 matrix
+    cores) against the same steps with NGACF_DEFER_DW = 0 (a dW launch + a reduction per stage): same losses and the same parameters
+    after four Adam steps, to the noise of fp32 sums (dropout off: both captures see the same masks)."""
+    import copy
+    import ngacf_amd
+    from ngacf_amd import functional as NF
+    from ngacf_amd.graphs import GraphedBPRStep
+    from ngacf_amd.optim import Adam
+    U, I, B = 900, 700, 64
+    edge = torch.from_numpy(_graph(U, I, 30000, 2, hub=400)).to(dev)
+    torch.manual_seed(2)
+    m0 = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev)
+    with torch.no_grad():
+        m0.uEmbd.weight.mul_(30.0); m0.iEmbd.weight.mul_(30.0)
+    g = torch.Generator(device=dev); g.manual_seed(4)
+    upn = torch.stack([torch.randint(0, U, (B,), device=dev, generator=g), torch.randint(0, I, (B,), device=dev, generator=g),
+                       torch.randint(0, I, (B,), device=dev, generator=g)])
+    res, calls = {}, {}
+    was, real = NF.DEFER_DW, NF.ops.transform_dw_batch
+    try:
+        for defer in (True, False):
+            NF.DEFER_DW = defer
+            n = [0]
+
+            def spy(*a, _n=n, **k):
+                _n[0] += 1
+                return real(*a, **k)
+            NF.ops.transform_dw_batch = spy
+            m = copy.deepcopy(m0)
+            opt = Adam(m.parameters(), lr=1e-2, weight_decay=1e-5)
+            step = GraphedBPRStep(m, ngacf_amd.BPRLoss(), opt, edge, B, preserve_state=True)
+            losses = [float(step(upn)) for _ in range(4)]
+            torch.cuda.synchronize()
+            res[defer], calls[defer] = (losses, {k: p.detach().clone() for k, p in m.named_parameters()}), n[0]
+    finally:
+        NF.DEFER_DW, NF.ops.transform_dw_batch = was, real
+    assert calls[True] > 0 and calls[False] == 0
+    assert np.allclose(res[True][0], res[False][0], rtol=1e-5, atol=1e-7), (res[True][0], res[False][0])
+    for k in res[False][1]:
+        a_, b_ = res[True][1][k].double(), res[False][1][k].double()
+        assert float((a_ - b_).norm() / b_.norm().clamp_min(1e-30)) < 1e-5, k
 
 
 @pytest.mark.parametrize("heads", [8, 1])
