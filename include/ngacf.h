@@ -310,6 +310,28 @@ typedef struct ngacf_dw_job {
 int ngacf_transform_dw_batch(const ngacf_dw_job* jobs, int njobs, float* work, int work_blocks,
                              int U, int I, const uint64_t* seed_dev, void* stream);
 
+/* fp32 storage, a 64 -> 64 stage whose input is the previous stage's output: the dX half of ngacf_transform_bwd,
+ *   dX[n, :] = mask * (dH[n, :] @ W[type(n)]^T),
+ * with step 1 of the PREVIOUS stage's backward (ngacf_prop_bwd_node: Gn, the (S, t) pairs, P1) on every dX row in the same
+ * launch -- the fp32 counterpart of ngacf_prop_bwd_dx's prev_* (autograd of SPUIGACF.py:356-357 chained through :207-215, :382-397);
+ * bit for bit what ngacf_transform_bwd + ngacf_prop_bwd_node compute through the stored dX.
+ *   prev->out [N][64], agg [2][N][64], R float[2][N][8], S float[N][8]: as the previous stage's forward left them (fp32, 8-column heads)
+ *   prev->Gn [N][64], ST float[N][8][2], dS float[N][8]: results;  alpha: that stage's leaky-relu slope;  flags: its NGACF_ELU */
+typedef struct ngacf_dx_prev {
+    const void* out;
+    const void* agg;
+    const float* R;
+    const float* S;
+    void* Gn;
+    float* ST;
+    float* dS;
+    float alpha;
+    int32_t flags;
+} ngacf_dx_prev;
+int ngacf_transform_dx_node(const float* dH, const float* W, float* dX, int U, int I,
+                            float feat_drop_p, uint64_t seed, const uint64_t* seed_dev,
+                            const ngacf_dx_prev* prev, void* stream);
+
 /* Row-window form (see ngacf_transform_fwd_rows): X and dX local when x_local != 0; dW and davec are the
  * sums over the window rows only (all-reduce them across ranks). */
 int ngacf_transform_bwd_rows(const void* X, int x_dtype, const float* W, const void* H, int h_dtype,

@@ -39,6 +39,7 @@ SIGNATURES = {
     "ngacf_prop_bwd_dx": [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
                           _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i, _p, _p],
     "ngacf_transform_dw_batch": [_p, _i, _p, _i, _i, _i, _p, _p],
+    "ngacf_transform_dx_node": [_p, _p, _p, _i, _i, _f, _u64, _p, _p, _p],
     "ngacf_adam_step": [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p],
     "ngacf_bpr_fwd_bwd": [_p, _p, _p, _p, _p, _i, _p],
     "ngacf_tick": [_p, _p, _i, _p, _i, _p],
@@ -78,6 +79,11 @@ class DwJob(ctypes.Structure):
     """ngacf_dw_job of include/ngacf.h"""
     _fields_ = [("X", _p), ("H", _p), ("dH", _p), ("dS", _p), ("dW", _p), ("davec", _p), ("x_dtype", ctypes.c_int32), ("h_dtype", ctypes.c_int32),
                 ("din", ctypes.c_int32), ("dout", ctypes.c_int32), ("heads", ctypes.c_int32), ("feat_drop_p", _f), ("seed", _u64)]
+
+
+class DxPrev(ctypes.Structure):
+    """ngacf_dx_prev of include/ngacf.h"""
+    _fields_ = [("out", _p), ("agg", _p), ("R", _p), ("S", _p), ("Gn", _p), ("ST", _p), ("dS", _p), ("alpha", _f), ("flags", ctypes.c_int32)]
 
 
 class BwdDx(ctypes.Structure):

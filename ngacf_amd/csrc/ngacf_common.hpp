@@ -156,6 +156,13 @@ __device__ __forceinline__ void locate(const WorkOrder& o, int block, int wave, 
 // row flags of a scored batch: one bit per row (N / 8 bytes: the table of a 10^5-row graph sits in a CU's vector L1)
 __device__ __forceinline__ bool flagged(const uint32_t* __restrict__ bits, int row) { return (bits[row >> 5] >> (row & 31)) & 1u; }
 
+// The row-local half of the backward's dS (propagate_bwd.hip, header comment): P1 = (1 - alpha) (R (Gn . aggn)_h - Rn t) from the two
+// head sums p = (Gn . agg)_h (= t) and pn = (Gn . aggn)_h; ONE explicit operation order (step 1 has three homes: prop_bwd_node_kernel,
+// the edge backward's fused tail, the fp32 dX kernel's epilogue -- the same bits in all of them)
+__device__ __forceinline__ float own_term(float alpha, float r, float rn, float p, float pn) {
+    return (1.f - alpha) * fmaf(r, pn, -(rn * p));
+}
+
 // Kernel launch with optional dispatch-timestamp timing (timing.hip; tags: NGACF_TAG_* of include/ngacf.h).
 bool timing_on();
 int timing_events(int tag, hipEvent_t* a, hipEvent_t* b);

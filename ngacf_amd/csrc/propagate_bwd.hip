@@ -120,12 +120,6 @@ __device__ __forceinline__ int slot_bcast_b(int v) {
     return __builtin_amdgcn_ds_swizzle(v, (J << 5) | and_mask);
 }
 
-// P1 of the header comment from the two head sums p = (Gn . agg)_h (= t) and pn = (Gn . aggn)_h; one explicit operation order
-// (the fused tail of the next stage's launch computes the same bits)
-__device__ __forceinline__ float own_term(float alpha, float r, float rn, float p, float pn) {
-    return (1.f - alpha) * fmaf(r, pn, -(rn * p));
-}
-
 // Step 1, per node.  One lane per 16-byte slice of the row.
 template <typename T, int D, int HEADS>
 __global__ __launch_bounds__(256) void prop_bwd_node_kernel(const PropBwdArgs a) {

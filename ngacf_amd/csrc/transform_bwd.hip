@@ -26,10 +26,23 @@ struct TransBwdArgs {
     uint64_t seed;
     const uint64_t* seed_dev;
     int nbu, nbi;          // workgroups of the dW kernel given to user rows / item rows
+    // ngacf_transform_dx_node (fp32 storage): step 1 of the PREVIOUS stage's backward on the dX rows, in the dX kernel's epilogue
+    const float* pv_out;   // [N][din]
+    const float* pv_agg;   // [2][N][din]
+    const float* pv_R;     // [2][N][din/8]
+    const float* pv_S;     // [N][din/8]
+    float* pv_Gn;          // [N][din]
+    float2* pv_ST;         // [N][din/8]
+    float* pv_dS;          // [N][din/8]
+    float pv_alpha;
+    int pv_flags;
 };
 
 // dX = mask * (dH @ W[type]^T): the forward tile kernel with the panel transposed on its way into LDS.
-template <typename TX, int DIN, int DOUT, bool DROP>
+// NODE (ngacf_transform_dx_node; fp32 rows, the previous stage in 8-column heads): the thread that holds four columns of a dX row
+// also runs that row's share of step 1 of the previous stage's backward -- prop_bwd_node_kernel<float, 64, 8>'s arithmetic in its
+// own order (a head = two neighbouring lanes, folded by the same DPP add): the same bits, without dX's trip through memory.
+template <typename TX, int DIN, int DOUT, bool DROP, bool NODE = false>
 __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArgs a) {
     constexpr int GS = DOUT + 4;                   // LDS row stride of the dH tile
     constexpr int WS = DIN + 4;                    // LDS row stride of W^T  [DOUT][DIN]
@@ -102,6 +115,33 @@ __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArg
             for (int j = 0; j < 4; ++j) {
                 o[j] = acc[i][4 * g + j];
                 if (DROP) o[j] = feat_bits(salt, row, 64 * g + 4 * tx + j) >= a.drop_thr ? o[j] * a.drop_scale : 0.f;
+            }
+            if constexpr (NODE) {
+                static_assert(!NODE || (sizeof(TX) == 4 && DIN == 64), "dX + node step: fp32 rows of 64 columns");
+                const size_t n = (size_t)row, Nn = (size_t)a.U + a.I;
+                const int head = tx >> 1;
+                const float4 ov = *reinterpret_cast<const float4*>(a.pv_out + n * DIN + 4 * tx);
+                const float4 av = *reinterpret_cast<const float4*>(a.pv_agg + n * DIN + 4 * tx);
+                const float4 nv = *reinterpret_cast<const float4*>(a.pv_agg + (Nn + n) * DIN + 4 * tx);
+                const float r = a.pv_R[n * 8 + head], rn = a.pv_R[(Nn + n) * 8 + head];
+                const float outv[4] = {ov.x, ov.y, ov.z, ov.w}, ag[4] = {av.x, av.y, av.z, av.w}, an[4] = {nv.x, nv.y, nv.z, nv.w};
+                float gg[4], gn[4], p = 0.f, pn = 0.f;
+                const float inv = r > 0.f ? 1.f / r : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    gg[j] = o[j];
+                    if (a.pv_flags & NGACF_ELU) gg[j] *= outv[j] > 0.f ? 1.f : outv[j] + 1.f;
+                    gn[j] = gg[j] * inv;
+                    p = fmaf(gn[j], ag[j], p);
+                    pn = fmaf(gn[j], an[j], pn);
+                }
+                p = lanes_sum<2>(p);
+                pn = lanes_sum<2>(pn);
+                *reinterpret_cast<float4*>(a.pv_Gn + n * DIN + 4 * tx) = make_float4(gn[0], gn[1], gn[2], gn[3]);
+                if ((tx & 1) == 0) {
+                    a.pv_ST[n * 8 + head] = make_float2(a.pv_S[n * 8 + head], p);
+                    a.pv_dS[n * 8 + head] = own_term(a.pv_alpha, r, rn, p, pn);
+                }
             }
             if constexpr (sizeof(TX) == 4) {
                 *reinterpret_cast<float4*>(static_cast<float*>(a.dX) + (size_t)(row - xoff) * DIN + 64 * g + 4 * tx) = make_float4(o[0], o[1], o[2], o[3]);
@@ -898,6 +938,29 @@ extern "C" int ngacf_transform_bwd(const void* X, int x_dtype, const float* W, c
                                    float feat_drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     return ngacf_transform_bwd_rows(X, x_dtype, W, H, h_dtype, dH, dS, dX, dW, davec, work, U, I, din, dout, heads,
                                     0, U, 0, I, 0, feat_drop_p, seed, seed_dev, stream);
+}
+
+extern "C" int ngacf_transform_dx_node(const float* dH, const float* W, float* dX, int U, int I,
+                                       float feat_drop_p, uint64_t seed, const uint64_t* seed_dev,
+                                       const ngacf_dx_prev* prev, void* stream) {
+    if (U < 0 || I < 0 || !dH || !W || !dX || !prev) return NGACF_E_ARG;
+    if (!prev->out || !prev->agg || !prev->R || !prev->S || !prev->Gn || !prev->ST || !prev->dS) return NGACF_E_ARG;
+    if (!(feat_drop_p >= 0.f && feat_drop_p < 1.f) || !(prev->alpha > 0.f && prev->alpha < 1.f)) return NGACF_E_ARG;
+    if (U + I == 0) return 0;
+    TransBwdArgs a{};
+    a.W = W; a.dH = dH; a.dX = dX; a.U = U; a.I = I; a.u_lo = 0; a.u_n = U; a.i_lo = 0; a.i_n = I; a.x_local = 0;
+    a.drop_p = feat_drop_p; a.drop_thr = feat_drop_p > 0.f ? drop_threshold(feat_drop_p) : 0u; a.drop_scale = 1.f / (1.f - feat_drop_p);
+    a.seed = seed; a.seed_dev = seed_dev;
+    a.pv_out = static_cast<const float*>(prev->out); a.pv_agg = static_cast<const float*>(prev->agg); a.pv_R = prev->R; a.pv_S = prev->S;
+    a.pv_Gn = static_cast<float*>(prev->Gn); a.pv_ST = reinterpret_cast<float2*>(prev->ST); a.pv_dS = prev->dS;
+    a.pv_alpha = prev->alpha; a.pv_flags = prev->flags;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tu = (U + TM - 1) / TM, ti = (I + TM - 1) / TM;
+    constexpr size_t lds = (size_t)(TM * (64 + 4) + 64 * (64 + 4)) * sizeof(float);
+    if (feat_drop_p > 0.f) hipLaunchKernelGGL((transform_bwd_dx_kernel<float, 64, 64, true, true>), dim3(tu + ti), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((transform_bwd_dx_kernel<float, 64, 64, false, true>), dim3(tu + ti), dim3(256), lds, st, a);
+    NGACF_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int ngacf_transform_dw_batch(const ngacf_dw_job* jobs, int njobs, float* work, int work_blocks,

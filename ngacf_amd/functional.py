@@ -84,6 +84,7 @@ def _bwd_links(bw, gout, X, H, plan, feat_drop_p, seed, want_dx, sparse=False):
 
 
 DEFER_DW = __import__("os").environ.get("NGACF_DEFER_DW", "1") != "0"      # A/B switch of the batched, deferred weight gradients
+FUSE_DX_NODE = __import__("os").environ.get("NGACF_FUSE_DX_NODE", "1") != "0"   # A/B switch (fp32 storage): the previous stage's step 1 in the dX kernel
 
 
 def _flush_dw(bw, plan, seed_dev):
@@ -105,7 +106,14 @@ def _transform_bwd_after(bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed
             # (bf16: the stage of a scored batch, which keeps its edge backward unfused; fp32 storage: every stage:) dX now -- the next
             # backward stage waits for it -- and the weights' gradient with the chain's other stages in the batched launch: 9 us in
             # front of the next stage instead of 15 + 9 (dW + dX, then the reduction of its 1024 partial sums); fp32: 24 instead of 39 + 18
-            dX, _, _ = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev, part="dx")
+            prev = bw[0].saved.get(bw[1] - 1) if f32_stage and FUSE_DX_NODE else None
+            if prev is not None and (prev[0].data_ptr() != X.data_ptr() or prev[0].dtype != torch.float32 or tuple(prev[3].shape) != (plan.N, 8)):
+                prev = None                                  # X is not the previous stage's fp32 output table in 8-column heads
+            if prev is not None:                             # fp32 storage: the previous stage's step 1 in the dX kernel's epilogue
+                dX, Gn, ST, P1 = ops.transform_dx_node(dH, W, plan.U, plan.I, feat_drop_p, seed, seed_dev, prev)
+                bw[0].node_pre[bw[1] - 1] = (dX, Gn, ST, P1)
+            else:
+                dX, _, _ = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev, part="dx")
             dW, da = torch.empty(2, 64, 64, dtype=torch.float32, device=H.device), torch.empty(2, 64, dtype=torch.float32, device=H.device)
             bw[0].dw_jobs.append((X, H, dH, dS, heads, feat_drop_p, seed, dW, da))
             _flush_dw(bw, plan, seed_dev)                    # (fp32 storage: every stage comes through here, the chain's first one too)

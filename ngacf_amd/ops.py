@@ -441,6 +441,24 @@ def transform_bwd(X, W, H, dH, dS, U, I, heads, feat_drop_p=0.0, seed=0, seed_de
     return dX, dW, da
 
 
+def transform_dx_node(dH, W, U, I, feat_drop_p, seed, seed_dev, prev):
+    """fp32 storage, a 64 -> 64 stage: dX = mask * (dH @ W^T) and, in the same launch, step 1 of the previous stage's backward on it
+    (ngacf_transform_dx_node).  prev = (out, agg, R, S, elu, alpha) of that stage's forward (8-column heads).  Returns
+    dX, Gn, ST [N, 8, 2], dS [N, 8] (P1): the previous stage's prop_bwd takes node=(Gn, ST, dS)."""
+    dev, N = dH.device, U + I
+    p_out, p_agg, p_R, p_S, p_elu, p_alpha = prev
+    f32 = dict(dtype=torch.float32, device=dev)
+    dX, Gn = torch.empty(N, 64, **f32), torch.empty(N, 64, **f32)
+    ST, dS = torch.empty(N, 8, 2, **f32), torch.empty(N, 8, **f32)
+    pv = _lib.DxPrev(_chk(p_out, "prev out", torch.float32, N * 64, dev), _chk(p_agg, "prev agg", torch.float32, 2 * N * 64, dev),
+                     _chk(p_R, "prev R", torch.float32, 2 * N * 8, dev), _chk(p_S, "prev S", torch.float32, N * 8, dev),
+                     Gn.data_ptr(), ST.data_ptr(), dS.data_ptr(), float(p_alpha), FLAG_ELU if p_elu else 0)
+    _lib.check(lib.ngacf_transform_dx_node(_chk(dH, "dH", torch.float32, N * 64, dev), _chk(W, "W", torch.float32, 2 * 64 * 64, dev),
+                                           dX.data_ptr(), U, I, float(feat_drop_p), int(seed), _sd(seed_dev, dev), ctypes.byref(pv), _stream()),
+               "ngacf_transform_dx_node")
+    return dX, Gn, ST, dS
+
+
 DW_BATCH_BLOCKS = int(__import__("os").environ.get("NGACF_DW_BATCH_BLOCKS", "192"))     # workgroups per job of the batched dW launch
 
 

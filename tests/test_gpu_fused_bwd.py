@@ -280,6 +280,32 @@ def test_graphed_step_with_deferred_weight_gradients(dev, level, sparse_fused):
         assert float((a_ - b_).norm() / b_.norm().clamp_min(1e-30)) < 1e-4, n
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.3])
+def test_fp32_dx_with_the_previous_node_step_bitwise(dev, drop):
+    """ngacf_transform_dx_node (fp32 storage: dX and the previous stage's step 1 in one launch) against ngacf_transform_bwd's dX half
+    followed by ngacf_prop_bwd_node on the stored dX: dX, Gn, the (S, t) pairs and P1 bit for bit; row counts that are no multiple
+    of the 64-row tile, an isolated row of the previous stage (R = 0)."""
+    from ngacf_amd import ops
+    U, I = 1033, 771
+    N = U + I
+    g = torch.Generator(device=dev); g.manual_seed(12)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    W, dH = rnd(2, 64, 64) * 0.2, rnd(N, 64) * 0.1
+    X, H, dS = rnd(N, 64) * 0.5, rnd(N, 64) * 0.5, rnd(N, 8) * 0.1
+    p_out, p_agg, p_R, p_S = rnd(N, 64) * 0.5, rnd(2, N, 64) * 0.5, rnd(2, N, 8).abs() + 0.1, rnd(N, 8) * 0.3
+    p_R[0, 7, 2] = 0.0
+    p_R[0, U + 5] = 0.0
+    dX, _, _ = ops.transform_bwd(X, W, H, dH, dS, U, I, 8, drop, 31, part="dx")
+    G = torch.empty(N, 64, device=dev); Gn = torch.empty(N, 64, device=dev)
+    ST = torch.empty(N, 8, 2, device=dev); P1 = torch.empty(N, 8, device=dev)
+    ops.prop_bwd_node(p_out, p_agg, p_R, dX, p_S, G, Gn, ST, P1, U, 8, (0, U, 0, I), False, elu=True, alpha=0.2)
+    dX2, Gn2, ST2, P12 = ops.transform_dx_node(dH, W, U, I, drop, 31, None, (p_out, p_agg, p_R, p_S, True, 0.2))
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(dX), _bits(dX2)) and torch.equal(_bits(Gn), _bits(Gn2))
+    assert torch.equal(_bits(ST), _bits(ST2)) and torch.equal(_bits(P1), _bits(P12))
+    assert float(Gn2[U + 5].abs().max()) == 0.0 and float(ST2[7, 2, 1]) == 0.0
+
+
 def test_graphed_fp32_step_with_deferred_weight_gradients(dev):
     """fp32 storage: the graphed two-chain step with every stage's dW / davec left to the chain's batched launch (exact fp32 matrix
     cores) against the same steps with NGACF_DEFER_DW = 0 (a dW launch + a reduction per stage): same losses and the same parameters
