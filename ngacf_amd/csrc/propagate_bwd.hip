@@ -23,7 +23,7 @@
 
 namespace ngacf {
 
-constexpr int UNROLL = 4;            // edges of gathers in flight per lane group (one row + one pair each); 2: 86 against 81.5 us per pair of launches
+constexpr int UNROLL = 4;            // edges of gathers in flight per lane group (one row + one pair each); per pair of launches: 2 -> 86.0, 4 -> 81.5, 8 -> 88.4 us (4 waves / SIMD)
 constexpr int UNROLL_Q = 2;          // edges in flight per lane group while a row walks its queue (row flags: 2-5 entries, typically)
 
 struct PropBwdArgs {
