@@ -78,6 +78,25 @@ __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArg
     }
     __syncthreads();
     const int ty = tid >> 4, tx = tid & 15;
+    // NODE: the previous stage's rows of this thread's four dX rows are requested HERE, in front of the contraction, which hides
+    // their trip (loaded in the epilogue they cost the launch as much as the node step's own kernel: 54 against 24 + 28 us)
+    float4 pv_o[NODE ? 4 : 1], pv_a[NODE ? 4 : 1], pv_n[NODE ? 4 : 1];
+    float pv_r[NODE ? 4 : 1], pv_rn[NODE ? 4 : 1], pv_s[NODE ? 4 : 1];
+    if constexpr (NODE) {
+        const size_t Nn = (size_t)a.U + a.I;
+        const int head = tx >> 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 4 * ty + i;
+            const size_t n = row < row_end ? (size_t)row : (size_t)(row_end - 1);
+            pv_o[i] = *reinterpret_cast<const float4*>(a.pv_out + n * DIN + 4 * tx);
+            pv_a[i] = *reinterpret_cast<const float4*>(a.pv_agg + n * DIN + 4 * tx);
+            pv_n[i] = *reinterpret_cast<const float4*>(a.pv_agg + (Nn + n) * DIN + 4 * tx);
+            pv_r[i] = a.pv_R[n * 8 + head];
+            pv_rn[i] = a.pv_R[(Nn + n) * 8 + head];
+            pv_s[i] = a.pv_S[n * 8 + head];
+        }
+    }
     float acc[4][4 * CG];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -118,12 +137,10 @@ __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArg
             }
             if constexpr (NODE) {
                 static_assert(!NODE || (sizeof(TX) == 4 && DIN == 64), "dX + node step: fp32 rows of 64 columns");
-                const size_t n = (size_t)row, Nn = (size_t)a.U + a.I;
+                const size_t n = (size_t)row;
                 const int head = tx >> 1;
-                const float4 ov = *reinterpret_cast<const float4*>(a.pv_out + n * DIN + 4 * tx);
-                const float4 av = *reinterpret_cast<const float4*>(a.pv_agg + n * DIN + 4 * tx);
-                const float4 nv = *reinterpret_cast<const float4*>(a.pv_agg + (Nn + n) * DIN + 4 * tx);
-                const float r = a.pv_R[n * 8 + head], rn = a.pv_R[(Nn + n) * 8 + head];
+                const float4 ov = pv_o[i], av = pv_a[i], nv = pv_n[i];
+                const float r = pv_r[i], rn = pv_rn[i];
                 const float outv[4] = {ov.x, ov.y, ov.z, ov.w}, ag[4] = {av.x, av.y, av.z, av.w}, an[4] = {nv.x, nv.y, nv.z, nv.w};
                 float gg[4], gn[4], p = 0.f, pn = 0.f;
                 const float inv = r > 0.f ? 1.f / r : 0.f;
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(256) void transform_bwd_dx_kernel(const TransBwdArg
                 pn = lanes_sum<2>(pn);
                 *reinterpret_cast<float4*>(a.pv_Gn + n * DIN + 4 * tx) = make_float4(gn[0], gn[1], gn[2], gn[3]);
                 if ((tx & 1) == 0) {
-                    a.pv_ST[n * 8 + head] = make_float2(a.pv_S[n * 8 + head], p);
+                    a.pv_ST[n * 8 + head] = make_float2(pv_s[i], p);
                     a.pv_dS[n * 8 + head] = own_term(a.pv_alpha, r, rn, p, pn);
                 }
             }
