@@ -26,6 +26,8 @@ for cfg in "yelp bf16" "yelp fp32" "gowalla fp32" "gowalla128 bf16" "gowalla128 
 done
 say "synthetic200m";                     timeout -k 10 500 python bench.py --workload synthetic200m --steps 10 --warmup 2 > $out/${tag}_bench_synthetic200m_bf16.json 2>> $out/err.log || exit 1
 say "synthetic200m under rocprof";       prof synthetic200m_bf16 --workload synthetic200m --steps 5 --warmup 1 --no-cpu-baseline || exit 1
+for w in gowalla_real yelp_real; do say "bench $w"; timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > $out/${tag}_bench_${w}_bf16.json 2>> $out/err.log || exit 1; done
+say "hub-finish soak";                   timeout -k 10 600 python tools/hub_soak.py --launches 120000 > $out/${tag}_hub_soak.json 2>> $out/err.log || exit 1
 say "rehearsal (1 RCCL rank)";           NGACF_BENCH_FORCE_DIST=1 timeout -k 10 400 python bench.py --gpus 1 > $out/${tag}_bench_rehearsal_1rank_rccl.json 2>> $out/err.log || exit 1
 fi
 if [ "$part" = all ] || [ "$part" = pmc ]; then
@@ -33,7 +35,9 @@ say "PMC traffic + L2 hit rate: gowalla"; timeout -k 10 600 python tools/traffic
 say "PMC traffic + L2 hit rate: yelp";    timeout -k 10 600 python tools/traffic.py yelp bf16,fp32 > $out/traffic_yelp.log 2>&1 && cp gpurun_out/${tag}_traffic_yelp.json $out/
 say "PMC traffic: synthetic1b";           timeout -k 10 900 python tools/traffic.py synthetic1b bf16 > $out/traffic_1b.log 2>&1 && cp gpurun_out/${tag}_traffic_synthetic1b.json $out/
 say "PMC traffic: synthetic200m";         timeout -k 10 600 python tools/traffic.py synthetic200m bf16 > $out/traffic_200m.log 2>&1 && cp gpurun_out/${tag}_traffic_synthetic200m.json $out/
-say "PMC traffic + L2 hit rate: the kernels of the train step"; timeout -k 10 600 python tools/traffic.py trainstep bf16 > $out/traffic_trainstep.log 2>&1 && cp gpurun_out/${tag}_traffic_trainstep.json $out/
+say "PMC traffic + L2 hit rate: the kernels of the train step (Gowalla, Yelp; bf16, fp32)"
+timeout -k 10 600 python tools/traffic.py trainstep bf16,fp32 > $out/traffic_trainstep.log 2>&1 && cp gpurun_out/${tag}_traffic_trainstep.json $out/
+timeout -k 10 600 python tools/traffic.py trainstep bf16,fp32 yelp > $out/traffic_trainstep_yelp.log 2>&1 && cp gpurun_out/${tag}_traffic_trainstep_yelp.json $out/
 fi
 if [ "$part" = all ] || [ "$part" = train ]; then
 say "train step breakdown";              timeout -k 10 300 python tools/train_profile.py --profile > $out/tp_refsem.log 2>&1 && cp gpurun_out/trainprof_refsem.txt $out/${tag}_trainstep_kernels_refsem.txt
