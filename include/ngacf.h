@@ -53,8 +53,9 @@ extern "C" {
 #define NGACF_RESIDUAL   2   /* out = h_dst + agg (SPUIGACF.py:383,390); clear for SPGA.py:405-409 */
 #define NGACF_SKIP_NODE  8   /* ngacf_prop_bwd: step 1 was already run by ngacf_prop_bwd_node */
 #define NGACF_GOUT_F32  16  /* ngacf_prop_bwd: gout is float[N][d] whatever the storage dtype (the scored batch's gradient rows, ngacf_score_bwd) */
-#define NGACF_SCORE_ROW  4   /* recompute the source score a_src . h_src from the gathered row
-                                instead of reading S_src (saves 4*heads bytes per edge) */
+#define NGACF_SCORE_ROW  4   /* ngacf_prop_fwd: recompute the source score a_src . h_src from the gathered row
+                                instead of reading S_src (saves 4*heads bytes per edge); ngacf_prop_bwd ignores it: it gathers
+                                the source's score with t as one (S, t) pair */
 
 #define NGACF_TBWD_BLOCKS 1024 /* workgroups of the dW reduction in ngacf_transform_bwd */
 

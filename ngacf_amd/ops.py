@@ -359,6 +359,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     prop_fwd(save=True) returned them.  scratch: as in prop_fwd (one plane).
     node = (Gn [N,d] in H's dtype, ST float [N,heads,2], dS float [N,heads] holding P1): step 1 has been run elsewhere (a later
     stage's prop_bwd(dx=...)) on this gout; that dS is finished in place and returned.
+    score_from_row: accepted for symmetry with prop_fwd and ignored -- the backward reads a neighbour's score from its (S, t) pair.
     dx = BwdDx: the launch also writes the gradient of the stage's input (dx.dX) and, with dx.prev, the previous stage's step 1."""
     dev, N, d = H.device, plan.N, H.shape[1]
     _heads_ok(d, heads)
