@@ -56,6 +56,13 @@ extern "C" {
 #define NGACF_SCORE_ROW  4   /* ngacf_prop_fwd: recompute the source score a_src . h_src from the gathered row
                                 instead of reading S_src (saves 4*heads bytes per edge); ngacf_prop_bwd ignores it: it gathers
                                 the source's score with t as one (S, t) pair */
+/* MEASUREMENT ONLY (tools/gather_roof.py; d == 64, eval / dense launches without dropout, row flags or fused tails): the traversal
+   kernel stripped to its memory operations -- same work order, lane layout, index loads, row (and (S, t) pair) gathers, loop
+   structure and stores; per gathered element one add (ROOF_ADD) or per gathered dword one xor (ROOF_XOR); no score, exp, mask,
+   division, ELU.  The outputs are meaningless; the launch's DURATION is the measured gather roof bench.py grades the kernels
+   against (roofline.measured_gather_roof_GBps). */
+#define NGACF_ROOF_ADD  32
+#define NGACF_ROOF_XOR  64
 
 #define NGACF_TBWD_BLOCKS 1024 /* workgroups of the dW reduction in ngacf_transform_bwd */
 

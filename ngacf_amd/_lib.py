@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("NGACF_LIB_PATH") or os.path.join(_HERE, "lib", "libng
 
 F32, BF16 = 0, 1
 FLAG_ELU, FLAG_RESIDUAL, FLAG_SCORE_ROW, FLAG_SKIP_NODE, FLAG_GOUT_F32 = 1, 2, 4, 8, 16
+FLAG_ROOF = (0, 32, 64)      # NGACF_ROOF_ADD / NGACF_ROOF_XOR: the measurement-only instantiations of the traversal kernels
 ADAM_MAX_TENSORS = 24            # NGACF_ADAM_MAX_TENSORS
 TICK_MAX = 48                      # NGACF_TICK_MAX
 TBWD_BLOCKS = 1024

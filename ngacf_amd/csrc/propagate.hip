@@ -86,6 +86,24 @@ __device__ __forceinline__ void load_slice(const void* base, int c, int q, float
     Slice<T>::load(reinterpret_cast<const T*>(static_cast<const char*>(base) + off), f);
 }
 
+// Measurement-only instantiations (ROOF != 0; NGACF_ROOF_ADD / NGACF_ROOF_XOR in `flags`, tools/gather_roof.py): the SAME work order, lane
+// layout, index loads, row gathers, loop structure and stores as the kernel they are stripped from, with the per-edge arithmetic
+// reduced to what keeps the loads live -- ROOF 1: one add per gathered element (bf16 rows are still unpacked); ROOF 2: one xor per
+// gathered DWORD (no unpack: the memory system's own ceiling for this access pattern).  No score, exp, mask, division or ELU.  Their
+// results mean nothing; their duration is the measured roof bench.py grades the traversal against.
+template <typename T, int SHIFT, int ROOF>
+__device__ __forceinline__ void gather_slice(const void* base, int c, int q, float (&f)[Slice<T>::VEC]) {
+    if constexpr (ROOF == 2) {
+        const uint32_t off = (static_cast<uint32_t>(c) << SHIFT) | (static_cast<uint32_t>(q) << 4);
+        const float4 v = *reinterpret_cast<const float4*>(static_cast<const char*>(base) + off);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+#pragma unroll
+        for (int j = 4; j < Slice<T>::VEC; ++j) f[j] = 0.f;
+    } else {
+        load_slice<T, SHIFT>(base, c, q, f);
+    }
+}
+
 // ELU with a short series near 0 (expm1f costs ~25 VALU per value; this is ~9)
 __device__ __forceinline__ float elu_fast(float x) {
     const float series = x * (1.f + x * (0.5f + x * (1.f / 6.f + x * (1.f / 24.f + x * (1.f / 120.f)))));
@@ -115,13 +133,18 @@ struct NegSums {
 // A finished row: the values (calc) and the stores (store).  The fused launch (NEXT) puts the workgroup's barrier BETWEEN them: a
 // wave with stores in flight waits for their acknowledgement at the barrier (vmcnt counts stores too), and a train-mode forward has
 // five of them per row (out, agg, aggn, R, Rn) -- 45 against 37 us per launch.
-template <typename T, int D, int HEADS, bool SAVE>
+template <typename T, int D, int HEADS, bool SAVE, int ROOF = 0>
 __device__ __forceinline__ void finish_row_calc(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum,
                                                 NegSums<Slice<T>::VEC>& ng, float (&o)[Slice<T>::VEC]) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC;
     float own[VEC];
     load_slice<T, SH::ROW_SHIFT>(a.H, row, q, own);
+    if constexpr (ROOF != 0) {                            // (measurement only: the row's own load and one add per element)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = own[j] + acc[j];
+        return;
+    }
     const float inv = rsum > 0.f ? 1.f / rsum : 0.f;   // isolated node: aggregate is 0 (SPUIGACF.py:389)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -151,11 +174,11 @@ __device__ __forceinline__ void finish_row_store(const PropArgs& a, int row, int
     }
 }
 
-template <typename T, int D, int HEADS, bool SAVE>
+template <typename T, int D, int HEADS, bool SAVE, int ROOF = 0>
 __device__ __forceinline__ void finish_row(const PropArgs& a, int row, int q, int head, float (&acc)[Slice<T>::VEC], float rsum,
                                            NegSums<Slice<T>::VEC>& ng) {
     float o[Slice<T>::VEC];
-    finish_row_calc<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, o);
+    finish_row_calc<T, D, HEADS, SAVE, ROOF>(a, row, q, head, acc, rsum, ng, o);
     finish_row_store<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, o);
 }
 
@@ -271,53 +294,161 @@ __device__ __forceinline__ void next_transform_tail_f32(const PropArgs& a, float
     f32_tile_step<NEXT, NONE>(xtile, xmeta, panel, av, sx, a.next_H, a.next_S);
 }
 
-// one edge: score, exp(-leakyrelu), optional dropout, accumulate
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SAVE>
-__device__ __forceinline__ void edge_step(const PropArgs& a, const float (&hv)[Slice<T>::VEC], float s_src, bool ok, int c,
-                                          float s_dst, const float (&av)[Slice<T>::VEC], bool dst_is_user,
-                                          uint32_t row_key, uint32_t salt_h, float (&acc)[Slice<T>::VEC], float& rsum,
-                                          NegSums<Slice<T>::VEC>& ng) {
+// The raw 16 bytes of slice `q` of row `c` (the gather itself: nothing but the address and the load) and their unpacking.  The
+// traversal loops keep TWO batches of UNROLL raw slices per lane: the next batch's gathers are issued before the current batch
+// is unpacked and used, so a wave always has UNROLL..2 UNROLL row requests in flight (the r1-r4 loops issued UNROLL, waited,
+// computed with none in flight, and relied on the other waves of the SIMD alone to cover the round trip).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // one 128-bit register tuple: pinned whole, it stays one
+template <int SHIFT>
+__device__ __forceinline__ u32x4 gather_raw(const void* base, int c, int q) {
+    const uint32_t off = (static_cast<uint32_t>(c) << SHIFT) | (static_cast<uint32_t>(q) << 4);
+    return *reinterpret_cast<const u32x4*>(static_cast<const char*>(base) + off);
+}
+template <typename T, int ROOF>
+__device__ __forceinline__ void unpack_raw(const u32x4& v, float (&f)[Slice<T>::VEC]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (sizeof(T) == 4 || ROOF == 2) {           // fp32 rows; ROOF 2: the raw dwords (no unpack)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = __uint_as_float(w[j]);
+#pragma unroll
+        for (int j = 4; j < Slice<T>::VEC; ++j) f[j] = 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j]     = __uint_as_float(w[j] << 16);
+            f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+    }
+}
+
+constexpr float NEG_LOG2E = -1.4426950408889634f;
+
+// Ordering pins.  The compiler is free to unpack all four edges of a batch first and accumulate them last (32 VGPRs of unpacked
+// columns live at once) and to hoist the next batch's gathers above the current batch's arithmetic; either pushes the raw slices
+// of the batch in flight out to scratch, with an s_waitcnt vmcnt(0) in front of the spill.  A scheduling fence
+// (__builtin_amdgcn_sched_barrier) does not bind pure arithmetic at instruction selection, so the order is pinned by DATA: an
+// empty volatile asm that takes the running sums (and the next edge's raw slice) in and out -- volatile asms keep their order,
+// an edge's arithmetic must be complete in front of its pin, the next edge's unpack can only start behind it -- and an empty
+// volatile asm with a memory clobber at the phase boundaries, which no load crosses.
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(int& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(u32x4& v) { asm volatile("" : "+v"(v)); }
+template <int N>
+__device__ __forceinline__ void pin(float (&x)[N]) {
+    if constexpr (N == 4) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    else if constexpr (N == 8) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) pin(x[j]);
+    }
+}
+#define NGACF_PHASE_FENCE() asm volatile("" ::: "memory")
+
+// The running sums of a lane while it walks its edges, as the register PAIRS v_pk_fma_f32 works on (pinned as pairs, they stay
+// pairs): eval (acc[2j], acc[2j + 1]); SAVE (acc[j], accn[j]) -- both sums of a column advance in one packed FMA.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pin(f32x2& x) { asm volatile("" : "+v"(x)); }
+template <int VEC, bool SAVE>
+struct Sums {
+    static constexpr int NP2 = SAVE ? VEC : VEC / 2;
+    f32x2 a2[NP2];
+    float rsum, rneg;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int j = 0; j < NP2; ++j) a2[j] = f32x2{0.f, 0.f};
+        rsum = rneg = 0.f;
+    }
+    template <int ROOF>
+    __device__ __forceinline__ void pin_all() {
+#pragma unroll
+        for (int j = 0; j < NP2; ++j) pin(a2[j]);
+        if constexpr (ROOF == 0) pin(rsum);
+        if constexpr (SAVE) pin(rneg);
+    }
+    __device__ __forceinline__ void get(float (&acc)[VEC], float& r, NegSums<VEC>& ng) const {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if constexpr (SAVE) { acc[j] = a2[j].x; ng.accn[j] = a2[j].y; }
+            else acc[j] = (j & 1) ? a2[j / 2].y : a2[j / 2].x;
+        }
+        r = rsum;
+        if constexpr (SAVE) ng.rneg = rneg;
+    }
+};
+
+// one edge: score, exp(-leakyrelu), optional dropout, accumulate.
+// The scores arrive PRE-SCALED by -log2(e) (sd = -log2e S[dst], av = -log2e a[src type], ss = -log2e S[src]), so that
+//     e = exp(-max(s, alpha s)) = exp2(min(s', alpha s')),   s' = -log2e s
+// is one multiply, one min and the v_exp_f32 itself (exp() of an unscaled score spends a third multiply on the conversion), and the
+// recomputed source score a . h runs as VEC / 2 packed FMAs (v_pk_fma_f32) that start from (sd, 0) where a lane holds a whole head.
+// s > 0 (the backward's lrelu' = 1 side) is s' < 0.
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SAVE, int ROOF = 0>
+__device__ __forceinline__ void edge_step(const PropArgs& a, const float (&hv)[Slice<T>::VEC], float ss, bool ok, int c,
+                                          float sd, const float (&av)[Slice<T>::VEC], bool dst_is_user,
+                                          uint32_t row_key, uint32_t salt_h, Sums<Slice<T>::VEC, SAVE>& sm) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC;
+    if constexpr (ROOF == 1) {                            // one add per gathered element
+#pragma unroll
+        for (int j = 0; j < VEC / 2; ++j) sm.a2[j] += f32x2{hv[2 * j], hv[2 * j + 1]};
+        return;
+    } else if constexpr (ROOF == 2) {                     // one xor per gathered dword
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            sm.a2[j].x = __uint_as_float(__float_as_uint(sm.a2[j].x) ^ __float_as_uint(hv[2 * j]));
+            sm.a2[j].y = __uint_as_float(__float_as_uint(sm.a2[j].y) ^ __float_as_uint(hv[2 * j + 1]));
+        }
+        return;
+    }
     float s;
     if (FROM_ROW) {
-        float p = 0.f;
+        f32x2 p = {SH::LPH == 1 ? sd : 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) p = fmaf(hv[j], av[j], p);
-        s = lanes_sum<SH::LPH>(p);
+        for (int j = 0; j < VEC; j += 2) {
+            const f32x2 h2 = {hv[j], hv[j + 1]}, a2 = {av[j], av[j + 1]};
+            p = __builtin_elementwise_fma(h2, a2, p);
+        }
+        s = p.x + p.y;
+        if constexpr (SH::LPH > 1) s = lanes_sum<SH::LPH>(s) + sd;
     } else {
-        s = s_src;
+        s = ss + sd;
     }
-    s += s_dst;
-    const float lr = fmaxf(s, a.alpha * s);               // leaky relu, 0 < alpha < 1
-    float ev = ok ? __expf(-lr) : 0.f;
-    rsum += ev;
-    if constexpr (SAVE) ng.rneg += s > 0.f ? 0.f : ev;    // (the backward's lrelu' takes alpha exactly where s > 0 is false)
+    const float lr = fminf(s, a.alpha * s);               // -log2e * leaky relu, 0 < alpha < 1
+    float ev = ok ? __builtin_amdgcn_exp2f(lr) : 0.f;
+    sm.rsum += ev;
+    const bool neg = !(s < 0.f);                          // the unscaled score is not positive (the backward's lrelu' takes alpha there)
+    if constexpr (SAVE) sm.rneg += neg ? ev : 0.f;
     if (DROP) {
         const uint32_t other = dst_is_user ? (uint32_t)c * RNG_K2 + salt_h : (uint32_t)c * RNG_K1;
         ev = lowbias32(row_key ^ other) >= a.drop_thr ? ev * a.drop_scale : 0.f;
     }
     if constexpr (SAVE) {
-        // both sums of a column in ONE packed FMA: (acc[j], accn[j]) += (ev, evn) * (h[j], h[j]) -- v_pk_fma_f32 with the column
-        // broadcast by op_sel; as two independent loops the compiler paired neighbouring columns and spent 7 moves per edge on it
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 w = {ev, s > 0.f ? 0.f : ev};
+        // both sums of a column in ONE packed FMA: (acc[j], accn[j]) += (ev, evn) * (h[j], h[j]) -- the column broadcast by op_sel
+        const f32x2 w = {ev, neg ? ev : 0.f};
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            f32x2 p = {acc[j], ng.accn[j]};
-            const f32x2 h2 = {hv[j], hv[j]};
-            p = __builtin_elementwise_fma(w, h2, p);
-            acc[j] = p.x; ng.accn[j] = p.y;
-        }
+        for (int j = 0; j < VEC; ++j) sm.a2[j] = __builtin_elementwise_fma(w, f32x2{hv[j], hv[j]}, sm.a2[j]);
     } else {
+        const f32x2 w = {ev, ev};
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(ev, hv[j], acc[j]);
+        for (int j = 0; j < VEC / 2; ++j) sm.a2[j] = __builtin_elementwise_fma(w, f32x2{hv[2 * j], hv[2 * j + 1]}, sm.a2[j]);
+    }
+}
+
+// The per-row constants of edge_step, pre-scaled (see there)
+template <typename T, int D, int HEADS, bool FROM_ROW>
+__device__ __forceinline__ void row_consts(const PropArgs& a, int row, int q, int head, bool dst_is_user, float& sd, float (&av)[Slice<T>::VEC]) {
+    constexpr int VEC = Slice<T>::VEC;
+    sd = NEG_LOG2E * a.S_dst[(size_t)row * HEADS + head];
+    if (FROM_ROW) {
+        const float* ap = a.avec + (dst_is_user ? D : 0) + q * VEC;   // sources are of the other type
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) av[j] = NEG_LOG2E * ap[j];
     }
 }
 
 // The traversal of one wave's work item(s).  NEXT (the fused form, ngacf_prop_fwd_next): the finished row of this lane's group
 // is handed back in `ro` for the workgroup's transform tail (which also stores it), and no path leaves before it.
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, bool NEXT, bool SAVE>
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, bool NEXT, bool SAVE, int ROOF = 0>
 __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int widx, int wend, RowOut<Slice<T>::VEC>& ro) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC, LPR = SH::LPR, EPI = SH::EPI, SHIFT = SH::ROW_SHIFT;
@@ -334,6 +465,8 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
     ng.rneg = 0.f;
     constexpr int NP = SAVE ? 2 : 1;                      // planes of a hub row's partial sums: (acc, rsum) and, SAVE, (accn, rneg)
     float av[VEC];
+    Sums<VEC, SAVE> sm;                                   // the running sums inside the edge loops (pairs); acc / rsum / ng take them over behind
+    sm.zero();
     if (kind == WORK_HUB) {
         // ------------------------------------------------------------------ hub rows: workgroup per row
         // The four waves stride over the row's edges (EPI * UNROLL per wave and step); slots fold inside each wave,
@@ -345,12 +478,8 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
         if (SPARSE && !flagged(a.needed, row)) return;                // (block-uniform: no wave reaches the barrier below)
         const int beg = uniform(a.rowptr[row]), end = uniform(a.rowptr[row + 1]);
         const bool dst_is_user = row < a.U;
-        const float s_dst = a.S_dst[(size_t)row * HEADS + head];
-        if (FROM_ROW) {
-            const float* ap = a.avec + (dst_is_user ? D : 0) + q * VEC;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) av[j] = ap[j];
-        }
+        float s_dst;
+        row_consts<T, D, HEADS, FROM_ROW>(a, row, q, head, dst_is_user, s_dst, av);
         uint32_t salt_h = 0, row_key = 0;
         if (DROP) {
             salt_h = salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + head);
@@ -368,13 +497,14 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
             float hv[UNROLL][VEC], ss[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                load_slice<T, SHIFT>(a.H, c[u], q, hv[u]);
-                ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[u] * HEADS + head];
+                gather_slice<T, SHIFT, ROOF>(a.H, c[u], q, hv[u]);
+                ss[u] = FROM_ROW ? 0.f : NEG_LOG2E * a.S_src[(size_t)c[u] * HEADS + head];
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE>(a, hv[u], ss[u], ok[u], c[u], s_dst, av, dst_is_user, row_key, salt_h, acc, rsum, ng);
+                edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE, ROOF>(a, hv[u], ss[u], ok[u], c[u], s_dst, av, dst_is_user, row_key, salt_h, sm);
         }
+        sm.get(acc, rsum, ng);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
         rsum = group_sum<LPR, WAVE>(rsum);
@@ -406,11 +536,24 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
                     ng.rneg += hub_r[x][HEADS + head];
                 }
             }
-            finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
+            finish_row<T, D, HEADS, SAVE, ROOF>(a, row, q, head, acc, rsum, ng);
         }
         return;
     }
     if (widx >= wend) return;
+    // A batch of UNROLL gathers in flight: the raw slices, the sources' scores (only without NGACF_SCORE_ROW) and their ids.
+    struct Batch {
+        u32x4 r[UNROLL];
+        float ss[UNROLL];
+        int c[UNROLL];
+    };
+    auto issue = [&](Batch& b) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            b.r[u] = gather_raw<SHIFT>(a.H, b.c[u], q);
+            b.ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)b.c[u] * HEADS + head];
+        }
+    };
     if (kind == WORK_SHORT) {
         // ------------------------------------------------------------------ short rows: slot per row
         const int ridx = widx + slot;
@@ -421,46 +564,73 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
         const int deg = live ? a.rowptr[row + 1] - beg : 0;
         const int maxdeg = uniform(deg);                  // rows are sorted: slot 0 holds the longest
         const bool dst_is_user = row < a.U;
-        const float s_dst = a.S_dst[(size_t)row * HEADS + head];
-        if (FROM_ROW) {
-            const float* ap = a.avec + (dst_is_user ? D : 0) + q * VEC;   // sources are of the other type
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) av[j] = ap[j];
-        }
+        float s_dst;
+        row_consts<T, D, HEADS, FROM_ROW>(a, row, q, head, dst_is_user, s_dst, av);
         uint32_t salt_h = 0, row_key = 0;
         if (DROP) {
             salt_h = salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + head);
             row_key = dst_is_user ? (uint32_t)row * RNG_K1 : (uint32_t)row * RNG_K2 + salt_h;
         }
         const int last = deg > 0 ? beg + deg - 1 : 0;     // any valid index for the masked tail
-        // lanes 0..7 of a slot hold the next 8 column indices of the slot's row
-        int colv = a.col[min(beg + (q & 7), last)];
-        for (int k0 = 0; k0 < maxdeg; k0 += 8) {
-            const int coln = a.col[min(beg + k0 + 8 + (q & 7), last)];     // prefetch the next 8
-            int c[8];
-            c[0] = slot_bcast<LPR, 0>(colv); c[1] = slot_bcast<LPR, 1>(colv);
-            c[2] = slot_bcast<LPR, 2>(colv); c[3] = slot_bcast<LPR, 3>(colv);
-            c[4] = slot_bcast<LPR, 4>(colv); c[5] = slot_bcast<LPR, 5>(colv);
-            c[6] = slot_bcast<LPR, 6>(colv); c[7] = slot_bcast<LPR, 7>(colv);
+        auto compute = [&](Batch& b, int k) {             // edges k .. k + UNROLL - 1 of every slot's row
 #pragma unroll
-            for (int h0 = 0; h0 < 8; h0 += UNROLL) {
-                if (h0 > 0 && k0 + h0 >= maxdeg) break;
-                float hv[UNROLL][VEC], ss[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    load_slice<T, SHIFT>(a.H, c[h0 + u], q, hv[u]);
-                    ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[h0 + u] * HEADS + head];
-                }
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u)
-                    edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE>(a, hv[u], ss[u], k0 + h0 + u < deg, c[h0 + u], s_dst, av,
-                                                                 dst_is_user, row_key, salt_h, acc, rsum, ng);
+            for (int u = 0; u < UNROLL; ++u) {
+                float hv[VEC];
+                if (u == 0) pin(b.r[0]);                  // (the batch's first unpack stays behind the phase fence in front of it)
+                unpack_raw<T, ROOF>(b.r[u], hv);
+                edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE, ROOF>(a, hv, NEG_LOG2E * b.ss[u], k + u < deg, b.c[u], s_dst, av, dst_is_user,
+                                                                   row_key, salt_h, sm);
+                sm.template pin_all<ROOF>();
+                if (u + 1 < UNROLL) pin(b.r[u + 1]);
             }
-            colv = coln;
+        };
+        // Lanes 0..7 of a slot hold the next 8 column indices of the slot's row: batch 2i = the first four, batch 2i + 1 = the last
+        // four.  Batches alternate between A and B; inside the steady-state loop every issue is UNCONDITIONAL (a load behind a
+        // branch makes the compiler wait for vmcnt(0) at the next use of anything older) and the phases are fenced for the
+        // scheduler, which otherwise hoists the next issue above the compute and copies the batch: issue B | compute A | issue A' |
+        // compute B.
+        static_assert(UNROLL == 4, "two batches of four per 8 broadcast indices");
+        const int nb = (maxdeg + UNROLL - 1) / UNROLL;    // batches of the longest row (uniform)
+        int colv = a.col[min(beg + (q & 7), last)];
+        Batch A, B;
+        auto pick_lo = [&](Batch& b, int cv) {
+            b.c[0] = slot_bcast<LPR, 0>(cv); b.c[1] = slot_bcast<LPR, 1>(cv); b.c[2] = slot_bcast<LPR, 2>(cv); b.c[3] = slot_bcast<LPR, 3>(cv);
+        };
+        auto pick_hi = [&](Batch& b, int cv) {
+            b.c[0] = slot_bcast<LPR, 4>(cv); b.c[1] = slot_bcast<LPR, 5>(cv); b.c[2] = slot_bcast<LPR, 6>(cv); b.c[3] = slot_bcast<LPR, 7>(cv);
+        };
+        if (nb > 0) {
+            pick_lo(A, colv);
+            issue(A);
+            int j = 0;
+            for (; j + 2 < nb; j += 2) {                  // batches j (A, in flight), j + 1 and j + 2 exist
+                const int coln = a.col[min(beg + 4 * j + 8 + (q & 7), last)];     // the next 8 indices
+                pick_hi(B, colv);
+                issue(B);
+                NGACF_PHASE_FENCE();
+                compute(A, 4 * j);
+                NGACF_PHASE_FENCE();
+                colv = coln;
+                pick_lo(A, colv);
+                issue(A);
+                NGACF_PHASE_FENCE();
+                compute(B, 4 * j + 4);
+                NGACF_PHASE_FENCE();
+            }
+            if (j + 1 < nb) {                             // two batches left: A in flight, B the last
+                pick_hi(B, colv);
+                issue(B);
+                NGACF_PHASE_FENCE();
+                compute(A, 4 * j);
+                compute(B, 4 * j + 4);
+            } else {
+                compute(A, 4 * j);
+            }
         }
+        sm.get(acc, rsum, ng);
         if (live) {
             if constexpr (NEXT) finish_row_defer<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro);
-            else finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
+            else finish_row<T, D, HEADS, SAVE, ROOF>(a, row, q, head, acc, rsum, ng);
         }
         return;
     }
@@ -481,36 +651,69 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
         if (SPARSE && !flagged(a.needed, row)) return;       // (its partial-sum slot stays unwritten: the second kernel skips the row too)
     }
     const bool dst_is_user = row < a.U;
-    const float s_dst = a.S_dst[(size_t)row * HEADS + head];
-    if (FROM_ROW) {
-        const float* ap = a.avec + (dst_is_user ? D : 0) + q * VEC;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) av[j] = ap[j];
-    }
+    float s_dst;
+    row_consts<T, D, HEADS, FROM_ROW>(a, row, q, head, dst_is_user, s_dst, av);
     uint32_t salt_h = 0, row_key = 0;
     if (DROP) {
         salt_h = salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + head);
         row_key = dst_is_user ? (uint32_t)row * RNG_K1 : (uint32_t)row * RNG_K2 + salt_h;
     }
-    for (int base = beg; base < end; base += EPI * UNROLL) {
-        int c[UNROLL];
-        bool ok[UNROLL];
+    {
+        // A step covers STEP = EPI * UNROLL edges: slot `sl`, gather `u` takes edge base + u * EPI + sl (the order of r1-r4).  The
+        // column indices of EIGHT steps are fetched at once -- lane q & 7 of a slot keeps the slot's four indices of step q & 7 --
+        // and handed out with ds_bpermute, so a step no longer starts with a dependent index load in front of its row gathers; the
+        // row gathers of step t + 1 are issued before step t is computed (two batches in flight, as in the short rows).
+        constexpr int STEP = EPI * UNROLL, CHUNK = 8 * STEP;
+        const int bp_base = (lane & ~(LPR - 1)) << 2;        // byte address of lane 0 of this slot, for ds_bpermute
+        for (int cb = beg; cb < end; cb += CHUNK) {           // (one chunk per segment at the default seg_len with 128-byte rows)
+            int colr[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int e = base + u * EPI + slot;
-            ok[u] = e < end;
-            c[u] = a.col[ok[u] ? e : end - 1];
+            for (int u = 0; u < UNROLL; ++u) colr[u] = a.col[min(cb + (q & 7) * STEP + u * EPI + slot, end - 1)];
+            const int nstep = min(8, (end - cb + STEP - 1) / STEP);       // (uniform)
+            auto pick = [&](Batch& b, int t) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) b.c[u] = __builtin_amdgcn_ds_bpermute(bp_base + (t << 2), colr[u]);
+            };
+            auto compute = [&](Batch& b, int t) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    float hv[VEC];
+                    if (u == 0) pin(b.r[0]);
+                    unpack_raw<T, ROOF>(b.r[u], hv);
+                    edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE, ROOF>(a, hv, NEG_LOG2E * b.ss[u], cb + t * STEP + u * EPI + slot < end, b.c[u], s_dst, av,
+                                                                       dst_is_user, row_key, salt_h, sm);
+                    sm.template pin_all<ROOF>();
+                    if (u + 1 < UNROLL) pin(b.r[u + 1]);
+                }
+            };
+            Batch A, B;
+            pick(A, 0);
+            issue(A);
+            int t = 0;
+            for (; t + 2 < nstep; t += 2) {                   // unconditional issues, fenced phases (see the short rows)
+                pick(B, t + 1);
+                issue(B);
+                NGACF_PHASE_FENCE();
+                compute(A, t);
+                NGACF_PHASE_FENCE();
+                pick(A, t + 2);
+                issue(A);
+                NGACF_PHASE_FENCE();
+                compute(B, t + 1);
+                NGACF_PHASE_FENCE();
+            }
+            if (t + 1 < nstep) {
+                pick(B, t + 1);
+                issue(B);
+                NGACF_PHASE_FENCE();
+                compute(A, t);
+                compute(B, t + 1);
+            } else {
+                compute(A, t);
+            }
         }
-        float hv[UNROLL][VEC], ss[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            load_slice<T, SHIFT>(a.H, c[u], q, hv[u]);
-            ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[u] * HEADS + head];
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE>(a, hv[u], ss[u], ok[u], c[u], s_dst, av, dst_is_user, row_key, salt_h, acc, rsum, ng);
     }
+    sm.get(acc, rsum, ng);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     rsum = group_sum<LPR, WAVE>(rsum);
@@ -522,7 +725,7 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
     if (part < 0) {
         if (slot == 0) {                                      // one finished row per wave, in lane group 0
             if constexpr (NEXT) finish_row_defer<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro);
-            else finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
+            else finish_row<T, D, HEADS, SAVE, ROOF>(a, row, q, head, acc, rsum, ng);
         }
         return;
     }
@@ -611,19 +814,50 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
     }
     if (slot == 0) {
         if constexpr (NEXT) finish_row_defer<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng, ro);
-        else finish_row<T, D, HEADS, SAVE>(a, row, q, head, acc, rsum, ng);
+        else finish_row<T, D, HEADS, SAVE, ROOF>(a, row, q, head, acc, rsum, ng);
     }
+}
+
+// Waves per SIMD the instantiations are bounded to (= their VGPR budget: 512 / waves, in steps of 8).  With two batches of gathers
+// in flight a lane holds 32 VGPRs of raw slices; the budgets below are the largest occupancy each family reaches without spilling
+// (tools/kres.py over -Rpass-analysis=kernel-resource-usage), A/B'd on the GPU through the -D overrides (tools/build_variant.sh).
+#ifndef NGACF_W_EVAL_BF16
+#define NGACF_W_EVAL_BF16 5
+#endif
+#ifndef NGACF_W_NEXT_BF16
+#define NGACF_W_NEXT_BF16 4
+#endif
+#ifndef NGACF_W_SAVE_BF16
+#define NGACF_W_SAVE_BF16 4
+#endif
+#ifndef NGACF_W_NEXT_SAVE_BF16
+#define NGACF_W_NEXT_SAVE_BF16 4
+#endif
+#ifndef NGACF_W_SAVE_F32
+#define NGACF_W_SAVE_F32 5
+#endif
+#ifndef NGACF_W_NEXT_SAVE_F32
+#define NGACF_W_NEXT_SAVE_F32 5
+#endif
+template <typename T, int D, bool SPARSE, int NEXT, bool SAVE>
+constexpr int fwd_waves() {
+    constexpr bool B16 = sizeof(T) == 2;
+    if (NEXT == 128) return 4;
+    if (NEXT == 64) return SAVE ? (B16 ? NGACF_W_NEXT_SAVE_BF16 : NGACF_W_NEXT_SAVE_F32) : (B16 ? NGACF_W_NEXT_BF16 : 1);
+    if (D != 64) return 1;
+    if (B16 && !SPARSE) return SAVE ? NGACF_W_SAVE_BF16 : NGACF_W_EVAL_BF16;
+    if (!B16 && SAVE) return NGACF_W_SAVE_F32;
+    return 1;
 }
 
 // NEXT > 0 (= the next stage's output width; NONE: that stage has ONE head): the fused form of ngacf_prop_fwd_next.
 // SAVE: a train-mode forward (agg / R given): also the negative-side sums the backward wants (NegSums above).
-// (fp32 SAVE instantiations are bounded to 6 waves per SIMD: left alone the compiler takes 90 VGPRs (5 waves) where 66-78 do without a
-//  spill; bf16 ones spill at 6 and stay at 5.)
-template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int NEXT = 0, bool NONE = false, bool STAGE_OUT = false, bool SAVE = false>
-__global__ __launch_bounds__(256, NEXT == 64 ? (SAVE ? (sizeof(T) == 4 ? 6 : 4) : 5) : NEXT == 128 ? 4 : (sizeof(T) == 2 && D == 64 && !SPARSE ? (SAVE ? 5 : 6) : (SAVE && sizeof(T) == 4 && D == 64 ? 6 : 1))) void prop_fwd_kernel(const PropArgs a) {
+template <typename T, int D, int HEADS, bool FROM_ROW, bool DROP, bool SPARSE, int NEXT = 0, bool NONE = false, bool STAGE_OUT = false, bool SAVE = false, int ROOF = 0>
+__global__ __launch_bounds__(256, (fwd_waves<T, D, SPARSE, NEXT, SAVE>())) void prop_fwd_kernel(const PropArgs a) {
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC, EPI = SH::EPI;
     static_assert(NEXT == 0 || (D == 64 && !SPARSE), "fused next-stage transform: rows of 64 columns");
+    static_assert(ROOF == 0 || (NEXT == 0 && FROM_ROW && !DROP && !SPARSE && !SAVE), "measurement-only instantiations: the plain eval traversal");
     int kind, widx, wend;
     locate(a.order, blockIdx.x, threadIdx.x >> 6, EPI, kind, widx, wend);
     RowOut<VEC> ro;
@@ -677,7 +911,7 @@ __global__ __launch_bounds__(256, NEXT == 64 ? (SAVE ? (sizeof(T) == 4 ? 6 : 4) 
         next_transform_tail_f32<D, NEXT, NONE>(a, xtile_f32, xmeta_f32, panel_f32, avec_f32, sx_f32, ro.valid, ro.row, lane / SH::LPR,
                                                lane % SH::LPR, ro.o, stores);
     } else {
-        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, false, SAVE>(a, kind, widx, wend, ro);
+        prop_fwd_body<T, D, HEADS, FROM_ROW, DROP, SPARSE, false, SAVE, ROOF>(a, kind, widx, wend, ro);
     }
 }
 
@@ -756,6 +990,19 @@ static int launch_fwd_s(PropArgs a, const int* split, int nsplit, bool from_row,
             else if (next_dout == 128) NGACF_NEXT(128, true, false);
             else return NGACF_E_SHAPE;
 #undef NGACF_NEXT
+            NGACF_CHECK_LAUNCH();
+            return 0;
+        } else {
+            return NGACF_E_SHAPE;
+        }
+    }
+    if (a.flags & (NGACF_ROOF_ADD | NGACF_ROOF_XOR)) {          // measurement only (tools/gather_roof.py): see gather_slice
+        if constexpr (!SAVE && D == 64) {
+            if (a.needed || !from_row || drop || (nsplit > 0 && a.tickets == nullptr)) return NGACF_E_ARG;
+            if (nb == 0) return 0;
+            const dim3 grid(nb), block(256);
+            if (a.flags & NGACF_ROOF_XOR) launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, false, 0, false, false, false, 2>, grid, block, 0, st, a);
+            else                          launch_k(NGACF_TAG_PROP_FWD, prop_fwd_kernel<T, D, HEADS, true, false, false, 0, false, false, false, 1>, grid, block, 0, st, a);
             NGACF_CHECK_LAUNCH();
             return 0;
         } else {

@@ -188,10 +188,23 @@ __device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, i
     }
 }
 
-template <typename T, int D, int HEADS, bool DROP>
+// ROOF != 0: the measurement-only instantiations (NGACF_ROOF_ADD / NGACF_ROOF_XOR, include/ngacf.h; propagate.hip gather_slice): the
+// same gathers (Gn row + (S, t) pair per head), loop structure and stores, one add per gathered element / one xor per gathered dword.
+template <typename T, int D, int HEADS, bool DROP, int ROOF = 0>
 __device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<Slice<T>::VEC>& x, const float (&gv)[Slice<T>::VEC],
                                             float2 st, bool ok, int c, float (&acc)[Slice<T>::VEC], float& dsum) {
     constexpr int LPH = BShape<T, D, HEADS>::LPH, VEC = Slice<T>::VEC;
+    if constexpr (ROOF == 1) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += gv[j];
+        dsum += st.x + st.y;
+        return;
+    } else if constexpr (ROOF == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __uint_as_float(__float_as_uint(acc[j]) ^ __float_as_uint(gv[j]));
+        dsum = __uint_as_float(__float_as_uint(dsum) ^ __float_as_uint(st.x) ^ __float_as_uint(st.y));
+        return;
+    }
     float dot = 0.f;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) dot = fmaf(gv[j], x.h_own[j], dot);
@@ -214,11 +227,17 @@ __device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<S
 // The gathers of one edge: the Gn row and the (S, t) pair of the lane's head.  SPARSE (hub-row workgroups, which walk ALL their
 // edges): Gn / ST of a neighbour outside the batch were never written -- such an edge contributes nothing, and its two loads are
 // pointed at the row's own entries instead (one cached line for all such lanes; the values are discarded).
-template <typename T, int D, int HEADS, bool SPARSE>
+template <typename T, int D, int HEADS, bool SPARSE, int ROOF = 0>
 __device__ __forceinline__ void load_edge_b(const PropBwdArgs& a, int c, int row, int q, int head, float (&gv)[Slice<T>::VEC], float2& st) {
     const bool in = !SPARSE || flagged(a.needed, c);
     const int cg = in ? c : row;
-    load_row<T, D, HEADS>(a.Gn, cg, q, gv);
+    if constexpr (ROOF == 2) {                               // raw dwords, no unpack
+        const uint32_t off = (static_cast<uint32_t>(cg) << BShape<T, D, HEADS>::SHIFT) | (static_cast<uint32_t>(q) << 4);
+        const float4 v = *reinterpret_cast<const float4*>(static_cast<const char*>(a.Gn) + off);
+        gv[0] = v.x; gv[1] = v.y; gv[2] = v.z; gv[3] = v.w;
+#pragma unroll
+        for (int j = 4; j < Slice<T>::VEC; ++j) gv[j] = 0.f;
+    } else load_row<T, D, HEADS>(a.Gn, cg, q, gv);
     st = a.ST[(size_t)cg * HEADS + head];
     if (SPARSE) {
 #pragma unroll
@@ -409,7 +428,7 @@ __device__ __forceinline__ void finish_row_t(const PropBwdArgs& a, int row, int 
 
 // The traversal of one wave's work item(s).  FUSE != 0 (ngacf_prop_bwd_dx): the row this lane's group finished is also handed
 // back in `rd` for the workgroup's tail, and no path leaves the KERNEL before that tail (the returns below leave this function).
-template <typename T, int D, int HEADS, bool DROP, bool SPARSE, int FUSE>
+template <typename T, int D, int HEADS, bool DROP, bool SPARSE, int FUSE, int ROOF = 0>
 __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, int widx, int wend, int* qmem, RowDone<Slice<T>::VEC>& rd,
                                               const PrevTiles<T, D, Slice<T>::VEC>& pt) {
     using SH = BShape<T, D, HEADS>;
@@ -446,10 +465,10 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
             float2 st[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u)                 // (SPARSE: every edge is visited; the ones from outside the batch add exact zeros)
-                load_edge_b<T, D, HEADS, SPARSE>(a, c[u], row, q, head, gv[u], st[u]);
+                load_edge_b<T, D, HEADS, SPARSE, ROOF>(a, c[u], row, q, head, gv[u], st[u]);
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                edge_step_b<T, D, HEADS, DROP>(a, x, gv[u], st[u], ok[u], c[u], acc, dsum);
+                edge_step_b<T, D, HEADS, DROP, ROOF>(a, x, gv[u], st[u], ok[u], c[u], acc, dsum);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
@@ -504,10 +523,10 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
                 float2 st[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u)
-                    load_edge_b<T, D, HEADS, false>(a, c[h0 + u], row, q, head, gv[u], st[u]);
+                    load_edge_b<T, D, HEADS, false, ROOF>(a, c[h0 + u], row, q, head, gv[u], st[u]);
 #pragma unroll
                 for (int u = 0; u < UNR; ++u)
-                    edge_step_b<T, D, HEADS, DROP>(a, x, gv[u], st[u], k0 + h0 + u < deg, c[h0 + u], acc, dsum);
+                    edge_step_b<T, D, HEADS, DROP, ROOF>(a, x, gv[u], st[u], k0 + h0 + u < deg, c[h0 + u], acc, dsum);
             }
             colv = coln;
         }
@@ -538,10 +557,10 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
             float2 st[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                load_edge_b<T, D, HEADS, false>(a, c[u], row, q, head, gv[u], st[u]);
+                load_edge_b<T, D, HEADS, false, ROOF>(a, c[u], row, q, head, gv[u], st[u]);
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                edge_step_b<T, D, HEADS, DROP>(a, x, gv[u], st[u], ok[u], c[u], acc, dsum);
+                edge_step_b<T, D, HEADS, DROP, ROOF>(a, x, gv[u], st[u], ok[u], c[u], acc, dsum);
         }
     }
 #pragma unroll
@@ -734,8 +753,9 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
     }
 }
 
-template <typename T, int D, int HEADS, bool DROP, bool SPARSE, int FUSE = 0>
+template <typename T, int D, int HEADS, bool DROP, bool SPARSE, int FUSE = 0, int ROOF = 0>
 __global__ __launch_bounds__(256, FUSE != 0 ? (DROP || SPARSE ? 4 : 1) : (SPARSE ? (DROP ? 5 : 4) : 1)) void prop_bwd_kernel(const PropBwdArgs a) {
+    static_assert(ROOF == 0 || (FUSE == 0 && !DROP && !SPARSE), "measurement-only instantiations: the dense edge backward alone");
     // (FUSE: 4 waves per SIMD = 128 VGPRs.  Bounded to 5 = 96 VGPRs the 8-head dropout instantiations spill one or two registers to
     //  scratch, and the one with row flags then faulted on the GPU; 5 against 4 waves per SIMD is worth ~1 % in this kernel.)
     using SH = BShape<T, D, HEADS>;
@@ -768,7 +788,7 @@ __global__ __launch_bounds__(256, FUSE != 0 ? (DROP || SPARSE ? 4 : 1) : (SPARSE
         prop_bwd_body<T, D, HEADS, DROP, SPARSE, FUSE>(a, kind, widx, wend, qmem, rd, pt);
         bwd_dx_tail<T, HEADS, D, DIN, FUSE>(a, gtile_lds, gwave, otile_lds, atile_lds, ntile_lds, rtile_lds, xmeta_lds, primary, rd, lane / SH::LPR, lane % SH::LPR);
     } else {
-        prop_bwd_body<T, D, HEADS, DROP, SPARSE, 0>(a, kind, widx, wend, qmem, rd, PrevTiles<T, D, VEC>{nullptr, nullptr, nullptr, nullptr});
+        prop_bwd_body<T, D, HEADS, DROP, SPARSE, 0, ROOF>(a, kind, widx, wend, qmem, rd, PrevTiles<T, D, VEC>{nullptr, nullptr, nullptr, nullptr});
     }
 }
 
@@ -826,6 +846,18 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool drop, hi
             else if (fuse == 2) NGACF_FX(2);
             else NGACF_FX(3);
 #undef NGACF_FX
+            NGACF_CHECK_LAUNCH();
+            return 0;
+        } else {
+            return NGACF_E_SHAPE;
+        }
+    }
+    if (a.flags & (NGACF_ROOF_ADD | NGACF_ROOF_XOR)) {          // measurement only (tools/gather_roof.py)
+        if constexpr (D == 64) {
+            if (a.needed || drop || (nsplit > 0 && a.tickets == nullptr)) return NGACF_E_ARG;
+            if (nb == 0) return 0;
+            if (a.flags & NGACF_ROOF_XOR) launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, false, false, 0, 2>, dim3(nb), dim3(256), 0, st, a);
+            else                          launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, false, false, 0, 1>, dim3(nb), dim3(256), 0, st, a);
             NGACF_CHECK_LAUNCH();
             return 0;
         } else {

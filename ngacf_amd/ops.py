@@ -261,7 +261,7 @@ def _scratch(scratch, plan, d, heads, dev, planes=1):
 
 def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=True, score_from_row=None,
              drop_p=0.0, seed=0, save=False, out=None, seed_dev=None, half=None, agg=None, R=None, needed=None, scratch=None,
-             next=None, want_out=True):
+             next=None, want_out=True, roof=0):
     """One propagation stage over plan's dst rows.  Returns out (and agg [2, N, d], R [2, N, heads] when save=True: plane 0 = the
     normalised aggregate and the denominators, plane 1 = the same sums over the edges with a non-positive score, which the
     backward's row-local half of dS needs -- include/ngacf.h).
@@ -269,8 +269,12 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     scratch = (float [nparts, d], float [nparts, heads]) ([nparts, 2 d], [nparts, 2 heads] with save): the hub rows' partial-sum
     slots (default: fresh buffers; the soak test hands in buffers it has poisoned).
     next = NextStage: the launch also produces the next stage's H' [N, dout'] (bf16) and S' [N, heads'] in next.H / next.S; with
-    want_out=False (an evaluation forward) `out` is not written at all and None is returned in its place."""
+    want_out=False (an evaluation forward) `out` is not written at all and None is returned in its place.
+    roof = 1 / 2: MEASUREMENT ONLY (tools/gather_roof.py) -- the stripped instantiation (NGACF_ROOF_ADD / NGACF_ROOF_XOR): the same
+    gathers and stores, no attention arithmetic; `out` is meaningless."""
     dev, N, d = H.device, plan.N, H.shape[1]
+    if roof and (save or next is not None or needed is not None or drop_p or d != 64 or roof not in (1, 2)):
+        raise ValueError("prop_fwd(roof=...): the plain eval launch of a 64-column stage only")
     _heads_ok(d, heads)
     if score_from_row is None:
         score_from_row = True      # recomputing a.h from the gathered row beats a second gather (profiles/)
@@ -298,7 +302,7 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
     else:
         agg = R = None
     pa, pr = _scratch(scratch, plan, d, heads, dev, 2 if save else 1)
-    flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0)
+    flags = (FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | (FLAG_SCORE_ROW if score_from_row else 0) | _lib.FLAG_ROOF[roof]
     if next is not None:
         # (a half launch of the node-partitioned path hands in the global-row tables of the next stage: both halves fill them)
         if next.H is None:
@@ -354,14 +358,17 @@ def can_fuse_bwd(plan, H_dtype, d, din, x_dtype, has_prev):
 
 
 def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, elu=True, residual=True,
-             score_from_row=None, drop_p=0.0, seed=0, seed_dev=None, needed=None, gout_f32=False, scratch=None, dx=None, node=None):
+             score_from_row=None, drop_p=0.0, seed=0, seed_dev=None, needed=None, gout_f32=False, scratch=None, dx=None, node=None, roof=0):
     """Returns dH [N,d] in H's dtype (with the dS*avec term) and dS [N,heads] fp32.  agg [2, N, d], R [2, N, heads]: as
     prop_fwd(save=True) returned them.  scratch: as in prop_fwd (one plane).
     node = (Gn [N,d] in H's dtype, ST float [N,heads,2], dS float [N,heads] holding P1): step 1 has been run elsewhere (a later
     stage's prop_bwd(dx=...)) on this gout; that dS is finished in place and returned.
     score_from_row: accepted for symmetry with prop_fwd and ignored -- the backward reads a neighbour's score from its (S, t) pair.
-    dx = BwdDx: the launch also writes the gradient of the stage's input (dx.dX) and, with dx.prev, the previous stage's step 1."""
+    dx = BwdDx: the launch also writes the gradient of the stage's input (dx.dX) and, with dx.prev, the previous stage's step 1.
+    roof = 1 / 2: MEASUREMENT ONLY (tools/gather_roof.py): the edge step stripped to its gathers and stores (results meaningless)."""
     dev, N, d = H.device, plan.N, H.shape[1]
+    if roof and (dx is not None or needed is not None or drop_p or d != 64 or roof not in (1, 2)):
+        raise ValueError("prop_bwd(roof=...): the dense edge backward of a 64-column stage, alone")
     _heads_ok(d, heads)
     hp = _chk(H, "H", None, N * d, dev)
     sd = _chk(S_dst, "S_dst", torch.float32, N * heads, dev)
@@ -387,7 +394,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
         if node is None:
             dS.zero_()
     flags = ((FLAG_ELU if elu else 0) | (FLAG_RESIDUAL if residual else 0) | FLAG_SCORE_ROW |
-             (_lib.FLAG_GOUT_F32 if gout_f32 else 0) | (_lib.FLAG_SKIP_NODE if node is not None else 0))
+             (_lib.FLAG_GOUT_F32 if gout_f32 else 0) | (_lib.FLAG_SKIP_NODE if node is not None else 0) | _lib.FLAG_ROOF[roof])
     if dx is not None:
         din = 64
         if not can_fuse_bwd(plan, H.dtype, d, din, dx.x_dtype, dx.prev is not None):
