@@ -23,9 +23,10 @@
  *   col   int32[2E]      source node (global id) of every directed edge; the 2E entries
  *                        are the CSR of the user rows followed by the CSC of the item rows
  *   rowptr int32[N+1]    edge range of every dst row in `col`
- *   srow  int32[nshort]  the short dst rows (degree <= plan.short_max): traversed one lane group per row.
- *                        First the user rows (sorted by degree, descending, padded with -1 to a multiple of
- *                        16 = nshort_user entries), then the item rows (sorted likewise)
+ *   srow  int32[nshort][4] the short dst rows (degree <= plan.short_max), one record {row, first edge, degree, 0} each (the
+ *                        row's slice of rowptr, copied: a wave learns row and edge range with one 16-byte load): traversed one
+ *                        lane group per row.  First the user rows (sorted by degree, descending, padded with records of row -1
+ *                        and degree 0 to a multiple of 16 = nshort_user entries), then the item rows (sorted likewise)
  *   hrow  int32[nhub]    the hub rows (plan.seg_len < degree <= plan.hub_cap): ONE WORKGROUP per row, its four waves
  *                        stride over the row's edges and fold through LDS; the first nhub_user entries are user rows
  *   nseg_user            number of leading entries of `segs` that are user rows; a launch works through

@@ -25,7 +25,7 @@ namespace ngacf {
 struct PropArgs {
     const int4* segs;      // long mode work items
     int nseg;
-    const int* srow;       // short mode: dst rows sorted by degree, descending
+    const int4* srec;      // short mode: {row, first edge, degree, 0} of the dst rows, sorted by degree, descending
     int nshort;
     const int* hrow;       // hub mode: one workgroup per row (users first, by degree descending)
     const int* rowptr;     // int32 [N+1]
@@ -77,6 +77,15 @@ struct Shape {
     static_assert(LPR >= 8, "column-index broadcast uses lanes 0..7 of a slot");
 };
 
+#ifndef NGACF_PIPE_TRAIN
+#define NGACF_PIPE_TRAIN 1
+#endif
+#ifndef NGACF_FWD_PIN
+#define NGACF_FWD_PIN 1
+#endif
+#ifndef NGACF_FWD_PIN_TRAIN
+#define NGACF_FWD_PIN_TRAIN 2
+#endif
 constexpr int UNROLL = 4;
 
 // 16-byte slice `q` of row `c`: uniform base + 32-bit byte offset (table < 4 GiB, checked by the host entry)
@@ -110,6 +119,14 @@ __device__ __forceinline__ float elu_fast(float x) {
     const float em1 = x > -0.125f ? series : __expf(x) - 1.f;
     return x > 0.f ? x : em1;
 }
+// The value a bf16 table stores keeps 8 bits: exp(x) - 1 straight from v_exp_f32 is exact to ~1e-7 ABSOLUTE, three orders below
+// the rounding of the store (the series above is there for fp32 storage's 1e-4 bar near 0).  4 VALU per value instead of 14: an
+// 8-column lane saves what three edges cost.
+template <typename T>
+__device__ __forceinline__ float elu_store(float x) {
+    if constexpr (sizeof(T) == 2) return x > 0.f ? x : __builtin_amdgcn_exp2f(x * 1.4426950408889634f) - 1.f;
+    else return elu_fast(x);
+}
 
 // value of lane (slot*LPR + J) broadcast to every lane of the slot: ds_swizzle bit-mode, no LDS memory
 template <int LPR, int J>
@@ -130,6 +147,33 @@ struct NegSums {
     float rneg;
 };
 
+// The raw 16 bytes of slice `q` of row `c` (the gather itself: nothing but the address and the load) and their unpacking.  The
+// traversal loops keep TWO batches of UNROLL raw slices per lane: the next batch's gathers are issued before the current batch
+// is unpacked and used, so a wave always has UNROLL..2 UNROLL row requests in flight (the r1-r4 loops issued UNROLL, waited,
+// computed with none in flight, and relied on the other waves of the SIMD alone to cover the round trip).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // one 128-bit register tuple: pinned whole, it stays one
+template <int SHIFT>
+__device__ __forceinline__ u32x4 gather_raw(const void* base, int c, int q) {
+    const uint32_t off = (static_cast<uint32_t>(c) << SHIFT) | (static_cast<uint32_t>(q) << 4);
+    return *reinterpret_cast<const u32x4*>(static_cast<const char*>(base) + off);
+}
+template <typename T, int ROOF>
+__device__ __forceinline__ void unpack_raw(const u32x4& v, float (&f)[Slice<T>::VEC]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (sizeof(T) == 4 || ROOF == 2) {           // fp32 rows; ROOF 2: the raw dwords (no unpack)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = __uint_as_float(w[j]);
+#pragma unroll
+        for (int j = 4; j < Slice<T>::VEC; ++j) f[j] = 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j]     = __uint_as_float(w[j] << 16);
+            f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+    }
+}
+
 // A finished row: the values (calc) and the stores (store).  The fused launch (NEXT) puts the workgroup's barrier BETWEEN them: a
 // wave with stores in flight waits for their acknowledgement at the barrier (vmcnt counts stores too), and a train-mode forward has
 // five of them per row (out, agg, aggn, R, Rn) -- 45 against 37 us per launch.
@@ -139,6 +183,8 @@ __device__ __forceinline__ void finish_row_calc(const PropArgs& a, int row, int 
     using SH = Shape<T, D, HEADS>;
     constexpr int VEC = SH::VEC;
     float own[VEC];
+    // (requesting the row's own slice when the wave learns its row instead of here was measured: no difference -- the other waves
+    //  of the SIMD cover this round trip -- and it holds four more VGPRs through the loop)
     load_slice<T, SH::ROW_SHIFT>(a.H, row, q, own);
     if constexpr (ROOF != 0) {                            // (measurement only: the row's own load and one add per element)
 #pragma unroll
@@ -150,7 +196,7 @@ __device__ __forceinline__ void finish_row_calc(const PropArgs& a, int row, int 
     for (int j = 0; j < VEC; ++j) {
         acc[j] *= inv;
         const float pre = (a.flags & NGACF_RESIDUAL) ? own[j] + acc[j] : acc[j];
-        o[j] = (a.flags & NGACF_ELU) ? elu_fast(pre) : pre;
+        o[j] = (a.flags & NGACF_ELU) ? elu_store<T>(pre) : pre;
     }
     if constexpr (SAVE) {
 #pragma unroll
@@ -294,33 +340,6 @@ __device__ __forceinline__ void next_transform_tail_f32(const PropArgs& a, float
     f32_tile_step<NEXT, NONE>(xtile, xmeta, panel, av, sx, a.next_H, a.next_S);
 }
 
-// The raw 16 bytes of slice `q` of row `c` (the gather itself: nothing but the address and the load) and their unpacking.  The
-// traversal loops keep TWO batches of UNROLL raw slices per lane: the next batch's gathers are issued before the current batch
-// is unpacked and used, so a wave always has UNROLL..2 UNROLL row requests in flight (the r1-r4 loops issued UNROLL, waited,
-// computed with none in flight, and relied on the other waves of the SIMD alone to cover the round trip).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // one 128-bit register tuple: pinned whole, it stays one
-template <int SHIFT>
-__device__ __forceinline__ u32x4 gather_raw(const void* base, int c, int q) {
-    const uint32_t off = (static_cast<uint32_t>(c) << SHIFT) | (static_cast<uint32_t>(q) << 4);
-    return *reinterpret_cast<const u32x4*>(static_cast<const char*>(base) + off);
-}
-template <typename T, int ROOF>
-__device__ __forceinline__ void unpack_raw(const u32x4& v, float (&f)[Slice<T>::VEC]) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    if constexpr (sizeof(T) == 4 || ROOF == 2) {           // fp32 rows; ROOF 2: the raw dwords (no unpack)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) f[j] = __uint_as_float(w[j]);
-#pragma unroll
-        for (int j = 4; j < Slice<T>::VEC; ++j) f[j] = 0.f;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f[2 * j]     = __uint_as_float(w[j] << 16);
-            f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
-        }
-    }
-}
-
 constexpr float NEG_LOG2E = -1.4426950408889634f;
 
 // Ordering pins.  The compiler is free to unpack all four edges of a batch first and accumulate them last (32 VGPRs of unpacked
@@ -343,6 +362,7 @@ __device__ __forceinline__ void pin(float (&x)[N]) {
     }
 }
 #define NGACF_PHASE_FENCE() asm volatile("" ::: "memory")
+template <bool B> struct BoolC { static constexpr bool value = B; };
 
 // The running sums of a lane while it walks its edges, as the register PAIRS v_pk_fma_f32 works on (pinned as pairs, they stay
 // pairs): eval (acc[2j], acc[2j + 1]); SAVE (acc[j], accn[j]) -- both sums of a column advance in one packed FMA.
@@ -377,7 +397,7 @@ struct Sums {
 };
 
 // one edge: score, exp(-leakyrelu), optional dropout, accumulate.
-// The scores arrive PRE-SCALED by -log2(e) (sd = -log2e S[dst], av = -log2e a[src type], ss = -log2e S[src]), so that
+// The scores arrive PRE-SCALED by -log2(e) (sd = -log2e S[dst], av = -log2e a[src type]; a gathered S[src] is scaled here), so that
 //     e = exp(-max(s, alpha s)) = exp2(min(s', alpha s')),   s' = -log2e s
 // is one multiply, one min and the v_exp_f32 itself (exp() of an unscaled score spends a third multiply on the conversion), and the
 // recomputed source score a . h runs as VEC / 2 packed FMAs (v_pk_fma_f32) that start from (sd, 0) where a lane holds a whole head.
@@ -411,7 +431,7 @@ __device__ __forceinline__ void edge_step(const PropArgs& a, const float (&hv)[S
         s = p.x + p.y;
         if constexpr (SH::LPH > 1) s = lanes_sum<SH::LPH>(s) + sd;
     } else {
-        s = ss + sd;
+        s = fmaf(NEG_LOG2E, ss, sd);                      // (ss: the source's score as stored)
     }
     const float lr = fminf(s, a.alpha * s);               // -log2e * leaky relu, 0 < alpha < 1
     float ev = ok ? __builtin_amdgcn_exp2f(lr) : 0.f;
@@ -465,6 +485,14 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
     ng.rneg = 0.f;
     constexpr int NP = SAVE ? 2 : 1;                      // planes of a hub row's partial sums: (acc, rsum) and, SAVE, (accn, rneg)
     float av[VEC];
+    // edges of a batch whose arithmetic the compiler may interleave (the order pins sit behind every PIN_EVERY-th edge): 1 keeps the
+    // fewest registers live (eval: 5 waves per SIMD); a train-mode forward (dropout hash, two planes of sums: 4 waves anyway) can
+    // afford a second edge in flight for its slow integer multiplies to hide behind
+    constexpr int PIN_EVERY = (SAVE || DROP) ? NGACF_FWD_PIN_TRAIN : NGACF_FWD_PIN;
+    // Two batches of gathers in flight per wave.  NGACF_PIPE_TRAIN=0 keeps ONE for a train-mode forward (which carries the second
+    // plane of sums and the dropout hash: the second batch costs it a wave per SIMD) -- measured: alone 45.6 / 43.8 us against 42.7 /
+    // 39.5 with two (8 heads / 1), the two-chain bf16 train step the same (0.620 / 0.621 ms), the fp32 one 0.945 against 0.931.
+    constexpr bool PIPE = SAVE ? (NGACF_PIPE_TRAIN != 0) : true;
     Sums<VEC, SAVE> sm;                                   // the running sums inside the edge loops (pairs); acc / rsum / ng take them over behind
     sm.zero();
     if (kind == WORK_HUB) {
@@ -498,7 +526,7 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 gather_slice<T, SHIFT, ROOF>(a.H, c[u], q, hv[u]);
-                ss[u] = FROM_ROW ? 0.f : NEG_LOG2E * a.S_src[(size_t)c[u] * HEADS + head];
+                ss[u] = FROM_ROW ? 0.f : a.S_src[(size_t)c[u] * HEADS + head];
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
@@ -557,11 +585,11 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
     if (kind == WORK_SHORT) {
         // ------------------------------------------------------------------ short rows: slot per row
         const int ridx = widx + slot;
-        const int rraw = a.srow[ridx < wend ? ridx : wend - 1];
-        const bool live = ridx < wend && rraw >= 0;          // -1 = padding between the user and item lists
-        const int row = live ? rraw : 0;
-        const int beg = a.rowptr[row];
-        const int deg = live ? a.rowptr[row + 1] - beg : 0;
+        const int4 rec = a.srec[ridx < wend ? ridx : wend - 1];
+        const bool live = ridx < wend && rec.x >= 0;         // row -1 = padding between the user and item lists
+        const int row = live ? rec.x : 0;
+        const int beg = live ? rec.y : 0;
+        const int deg = live ? rec.z : 0;
         const int maxdeg = uniform(deg);                  // rows are sorted: slot 0 holds the longest
         const bool dst_is_user = row < a.U;
         float s_dst;
@@ -572,17 +600,27 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
             row_key = dst_is_user ? (uint32_t)row * RNG_K1 : (uint32_t)row * RNG_K2 + salt_h;
         }
         const int last = deg > 0 ? beg + deg - 1 : 0;     // any valid index for the masked tail
-        auto compute = [&](Batch& b, int k) {             // edges k .. k + UNROLL - 1 of every slot's row
+        // edges k .. k + UNROLL - 1 of every slot's row.  Rows are sorted by degree, so the wave's shortest row sits in its last
+        // slot: while k + UNROLL <= that degree no slot has a masked edge and the compare + select per edge are left out.
+        const int mindeg = __builtin_amdgcn_readlane(deg, 63);
+        auto compute_t = [&](Batch& b, int k, auto masked) {
+            constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 float hv[VEC];
                 if (u == 0) pin(b.r[0]);                  // (the batch's first unpack stays behind the phase fence in front of it)
                 unpack_raw<T, ROOF>(b.r[u], hv);
-                edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE, ROOF>(a, hv, NEG_LOG2E * b.ss[u], k + u < deg, b.c[u], s_dst, av, dst_is_user,
+                edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE, ROOF>(a, hv, b.ss[u], MASKED ? k + u < deg : true, b.c[u], s_dst, av, dst_is_user,
                                                                    row_key, salt_h, sm);
-                sm.template pin_all<ROOF>();
-                if (u + 1 < UNROLL) pin(b.r[u + 1]);
+                if ((u + 1) % PIN_EVERY == 0 || u + 1 == UNROLL) {
+                    sm.template pin_all<ROOF>();
+                    if (u + 1 < UNROLL) pin(b.r[u + 1]);
+                }
             }
+        };
+        auto compute = [&](Batch& b, int k) {
+            if (k + UNROLL <= mindeg) compute_t(b, k, BoolC<false>{});
+            else compute_t(b, k, BoolC<true>{});
         };
         // Lanes 0..7 of a slot hold the next 8 column indices of the slot's row: batch 2i = the first four, batch 2i + 1 = the last
         // four.  Batches alternate between A and B; inside the steady-state loop every issue is UNCONDITIONAL (a load behind a
@@ -599,7 +637,20 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
         auto pick_hi = [&](Batch& b, int cv) {
             b.c[0] = slot_bcast<LPR, 4>(cv); b.c[1] = slot_bcast<LPR, 5>(cv); b.c[2] = slot_bcast<LPR, 6>(cv); b.c[3] = slot_bcast<LPR, 7>(cv);
         };
-        if (nb > 0) {
+        if constexpr (!PIPE) {                            // one batch at a time (train mode: see PIPE)
+            for (int j = 0; j < nb; j += 2) {
+                const int coln = a.col[min(beg + 4 * j + 8 + (q & 7), last)];
+                pick_lo(A, colv);
+                issue(A);
+                compute(A, 4 * j);
+                if (j + 1 < nb) {
+                    pick_hi(A, colv);
+                    issue(A);
+                    compute(A, 4 * j + 4);
+                }
+                colv = coln;
+            }
+        } else if (nb > 0) {
             pick_lo(A, colv);
             issue(A);
             int j = 0;
@@ -680,13 +731,23 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
                     float hv[VEC];
                     if (u == 0) pin(b.r[0]);
                     unpack_raw<T, ROOF>(b.r[u], hv);
-                    edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE, ROOF>(a, hv, NEG_LOG2E * b.ss[u], cb + t * STEP + u * EPI + slot < end, b.c[u], s_dst, av,
+                    edge_step<T, D, HEADS, FROM_ROW, DROP, SAVE, ROOF>(a, hv, b.ss[u], cb + t * STEP + u * EPI + slot < end, b.c[u], s_dst, av,
                                                                        dst_is_user, row_key, salt_h, sm);
-                    sm.template pin_all<ROOF>();
-                    if (u + 1 < UNROLL) pin(b.r[u + 1]);
+                    if ((u + 1) % PIN_EVERY == 0 || u + 1 == UNROLL) {
+                        sm.template pin_all<ROOF>();
+                        if (u + 1 < UNROLL) pin(b.r[u + 1]);
+                    }
                 }
             };
             Batch A, B;
+            if constexpr (!PIPE) {
+                for (int t = 0; t < nstep; ++t) {
+                    pick(A, t);
+                    issue(A);
+                    compute(A, t);
+                }
+                continue;
+            }
             pick(A, 0);
             issue(A);
             int t = 0;
@@ -828,10 +889,10 @@ __device__ __forceinline__ void prop_fwd_body(const PropArgs& a, int kind, int w
 #define NGACF_W_NEXT_BF16 4
 #endif
 #ifndef NGACF_W_SAVE_BF16
-#define NGACF_W_SAVE_BF16 4
+#define NGACF_W_SAVE_BF16 (NGACF_PIPE_TRAIN ? 4 : 5)
 #endif
 #ifndef NGACF_W_NEXT_SAVE_BF16
-#define NGACF_W_NEXT_SAVE_BF16 4
+#define NGACF_W_NEXT_SAVE_BF16 (NGACF_PIPE_TRAIN ? 4 : 5)
 #endif
 #ifndef NGACF_W_SAVE_F32
 #define NGACF_W_SAVE_F32 5
@@ -1071,7 +1132,7 @@ extern "C" int ngacf_prop_fwd_next(const int32_t* segs, int nseg, const int32_t*
     const uint64_t elem = dtype == NGACF_BF16 ? 2 : 4;
     if ((uint64_t)N * (uint64_t)d * elem >= (1ull << 32)) return NGACF_E_SHAPE;   // 32-bit row offsets
     PropArgs a;
-    a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
+    a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srec = reinterpret_cast<const int4*>(srow); a.nshort = nshort; a.rowptr = rowptr;
     a.hrow = hrow; a.order.nhub = nhub; a.order.nhub_u = nhub_user;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R;
     a.part_acc = part_acc; a.part_r = part_r; a.split = split; a.part_split = part_split; a.needed = needed; a.rows = rows; a.short_max = short_max;

@@ -29,7 +29,7 @@ constexpr int UNROLL_Q = 2;          // edges in flight per lane group while a r
 struct PropBwdArgs {
     const int4* segs;
     int nseg;
-    const int* srow;
+    const int4* srec;              // short rows: {row, first edge, degree, 0}, sorted by degree, descending
     int nshort;
     const int* hrow;               // hub rows: one workgroup per row (see propagate.hip)
     const int* rowptr;
@@ -168,6 +168,26 @@ __global__ __launch_bounds__(256) void prop_bwd_node_kernel(const PropBwdArgs a)
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float NEG_LOG2E = -1.4426950408889634f;
+
+// The running sums of a lane while it walks its edges: acc as the register pairs v_pk_fma_f32 works on, and the head's dS sum.
+template <int VEC>
+struct BSums {
+    f32x2 a2[VEC / 2];
+    float dsum;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int j = 0; j < VEC / 2; ++j) a2[j] = f32x2{0.f, 0.f};
+        dsum = 0.f;
+    }
+    __device__ __forceinline__ void get(float (&acc)[VEC], float& d) const {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = (j & 1) ? a2[j / 2].y : a2[j / 2].x;
+        d = dsum;
+    }
+};
+
 template <int VEC>
 struct RowCtx {
     float h_own[VEC];
@@ -180,7 +200,7 @@ template <typename T, int D, int HEADS, bool DROP>
 __device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, int head, RowCtx<Slice<T>::VEC>& x) {
     x.dst_is_user = row < a.U;
     load_row<T, D, HEADS>(a.H, row, q, x.h_own);
-    x.s_dst = a.S_dst[(size_t)row * HEADS + head];
+    x.s_dst = NEG_LOG2E * a.S_dst[(size_t)row * HEADS + head];        // pre-scaled: e = exp2(min(s', alpha s')), s' = -log2e (S[dst] + S[src])
     x.salt_h = x.row_key = 0;
     if (DROP) {
         x.salt_h = salt_of(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), 1u + head);
@@ -192,36 +212,42 @@ __device__ __forceinline__ void load_ctx(const PropBwdArgs& a, int row, int q, i
 // same gathers (Gn row + (S, t) pair per head), loop structure and stores, one add per gathered element / one xor per gathered dword.
 template <typename T, int D, int HEADS, bool DROP, int ROOF = 0>
 __device__ __forceinline__ void edge_step_b(const PropBwdArgs& a, const RowCtx<Slice<T>::VEC>& x, const float (&gv)[Slice<T>::VEC],
-                                            float2 st, bool ok, int c, float (&acc)[Slice<T>::VEC], float& dsum) {
+                                            float2 st, bool ok, int c, BSums<Slice<T>::VEC>& sm) {
     constexpr int LPH = BShape<T, D, HEADS>::LPH, VEC = Slice<T>::VEC;
     if constexpr (ROOF == 1) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] += gv[j];
-        dsum += st.x + st.y;
+        for (int j = 0; j < VEC / 2; ++j) sm.a2[j] += f32x2{gv[2 * j], gv[2 * j + 1]};
+        sm.dsum += st.x + st.y;
         return;
     } else if constexpr (ROOF == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __uint_as_float(__float_as_uint(acc[j]) ^ __float_as_uint(gv[j]));
-        dsum = __uint_as_float(__float_as_uint(dsum) ^ __float_as_uint(st.x) ^ __float_as_uint(st.y));
+        for (int j = 0; j < 2; ++j) {
+            sm.a2[j].x = __uint_as_float(__float_as_uint(sm.a2[j].x) ^ __float_as_uint(gv[2 * j]));
+            sm.a2[j].y = __uint_as_float(__float_as_uint(sm.a2[j].y) ^ __float_as_uint(gv[2 * j + 1]));
+        }
+        sm.dsum = __uint_as_float(__float_as_uint(sm.dsum) ^ __float_as_uint(st.x) ^ __float_as_uint(st.y));
         return;
     }
-    float dot = 0.f;
+    f32x2 p = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) dot = fmaf(gv[j], x.h_own[j], dot);
-    dot = lanes_sum<LPH>(dot);
-    const float s = x.s_dst + st.x;
-    const float lr = fmaxf(s, a.alpha * s);
-    const float ev = ok ? __expf(-lr) : 0.f;
+    for (int j = 0; j < VEC; j += 2) p = __builtin_elementwise_fma(f32x2{gv[j], gv[j + 1]}, f32x2{x.h_own[j], x.h_own[j + 1]}, p);
+    const float dot = lanes_sum<LPH>(p.x + p.y);
+    const float s = fmaf(st.x, NEG_LOG2E, x.s_dst);             // -log2e (S[dst] + S[src])
+    const float lr = fminf(s, a.alpha * s);
+    const float ev = ok ? __builtin_amdgcn_exp2f(lr) : 0.f;
     float m = 1.f;
     if (DROP) {
         const uint32_t other = x.dst_is_user ? (uint32_t)c * RNG_K2 + x.salt_h : (uint32_t)c * RNG_K1;
         m = lowbias32(x.row_key ^ other) >= a.drop_thr ? a.drop_scale : 0.f;
     }
-    const float de = m * dot - st.y;
-    dsum -= ev * de * (s > 0.f ? 1.f : a.alpha);
+    // (explicit fused operations: left to -ffp-contract the dense loop and the row-flag queue walk were contracted differently,
+    //  and the two must agree bit for bit)
+    const float de = fmaf(m, dot, -st.y);
+    sm.dsum = fmaf(-(ev * de), s < 0.f ? 1.f : a.alpha, sm.dsum);   // (s' < 0: the unscaled score is positive, lrelu' = 1)
     const float wgt = m * ev;
+    const f32x2 w = {wgt, wgt};
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(wgt, gv[j], acc[j]);
+    for (int j = 0; j < VEC / 2; ++j) sm.a2[j] = __builtin_elementwise_fma(w, f32x2{gv[2 * j], gv[2 * j + 1]}, sm.a2[j]);
 }
 
 // The gathers of one edge: the Gn row and the (S, t) pair of the lane's head.  SPARSE (hub-row workgroups, which walk ALL their
@@ -257,7 +283,7 @@ constexpr int QCAP = 64;
 template <typename T, int D, int HEADS, bool DROP>
 __device__ __forceinline__ void sparse_edges_b(const PropBwdArgs& a, const RowCtx<Slice<T>::VEC>& x, int* __restrict__ qbuf, int row,
                                                int ebase, int estride, int count, int slot, int q, int head,
-                                               float (&acc)[Slice<T>::VEC], float& dsum) {
+                                               BSums<Slice<T>::VEC>& sm) {
     constexpr int LPR = BShape<T, D, HEADS>::LPR, VEC = Slice<T>::VEC;
     int mc = count;
 #pragma unroll
@@ -319,7 +345,7 @@ __device__ __forceinline__ void sparse_edges_b(const PropBwdArgs& a, const RowCt
             }
 #pragma unroll
             for (int u = 0; u < UNROLL_Q; ++u)
-                edge_step_b<T, D, HEADS, DROP>(a, x, gv[u], st[u], ok[u], c[u], acc, dsum);
+                edge_step_b<T, D, HEADS, DROP>(a, x, gv[u], st[u], ok[u], c[u], sm);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -441,8 +467,9 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     float dsum = 0.f;
+    BSums<VEC> sm;                                          // the running sums inside the edge loops; acc / dsum take them over behind
+    sm.zero();
     RowCtx<VEC> x;
-
     int* qbuf = qmem + (SPARSE ? ((threadIdx.x >> 6) * EPI + slot) * (QCAP + 1) : 0);
     if (kind == WORK_HUB) {
         // ------------------------------------------------------------------ hub rows: workgroup per row (as in the forward)
@@ -468,8 +495,9 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
                 load_edge_b<T, D, HEADS, SPARSE, ROOF>(a, c[u], row, q, head, gv[u], st[u]);
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                edge_step_b<T, D, HEADS, DROP, ROOF>(a, x, gv[u], st[u], ok[u], c[u], acc, dsum);
+                edge_step_b<T, D, HEADS, DROP, ROOF>(a, x, gv[u], st[u], ok[u], c[u], sm);
         }
+        sm.get(acc, dsum);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
         dsum = group_sum<LPR, WAVE>(dsum);
@@ -494,19 +522,23 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
     if (kind == WORK_SHORT) {
         // ------------------------------------------------------------------ short rows: slot per row
         const int ridx = widx + slot;
-        const int rraw = a.srow[ridx < wend ? ridx : wend - 1];
-        const bool live = ridx < wend && rraw >= 0;          // -1 = padding between the user and item lists
-        const int row = live ? rraw : 0;
-        const int beg = a.rowptr[row];
-        const int deg = live ? a.rowptr[row + 1] - beg : 0;
+        const int4 rec = a.srec[ridx < wend ? ridx : wend - 1];
+        const bool live = ridx < wend && rec.x >= 0;         // row -1 = padding between the user and item lists
+        const int row = live ? rec.x : 0;
+        const int beg = live ? rec.y : 0;
+        const int deg = live ? rec.z : 0;
         const int maxdeg = uniform(deg);                     // rows are sorted: slot 0 holds the longest
         load_ctx<T, D, HEADS, DROP>(a, row, q, head, x);
         if constexpr (FUSE == 2) dma_prev<T, D, VEC>(a, pt, row, slot, q);
         if (SPARSE) {                                        // only the edges out of the batch take part (the queue)
-            sparse_edges_b<T, D, HEADS, DROP>(a, x, qbuf, row, beg, 1, deg, slot, q, head, acc, dsum);
+            sparse_edges_b<T, D, HEADS, DROP>(a, x, qbuf, row, beg, 1, deg, slot, q, head, sm);
+            sm.get(acc, dsum);
             if (live) finish_row_t<T, D, HEADS, FUSE, VEC>(a, row, q, head, acc, dsum, rd);
             return;
         }
+        // (The forward's two-batches-in-flight loop was tried here too, propagate.hip: the stripped instantiations gain 2-5 %, the
+        //  kernel with dropout -- the one a train step runs -- LOSES 1.5 us alone and the two-chain step 2 %: it holds a second batch
+        //  of rows and (S, t) pairs on top of the row's own H slice, at the same four waves per SIMD.  The r4 loop stays.)
         const int last = deg > 0 ? beg + deg - 1 : 0;
         int colv = a.col[min(beg + (q & 7), last)];
         for (int k0 = 0; k0 < maxdeg; k0 += 8) {
@@ -526,10 +558,11 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
                     load_edge_b<T, D, HEADS, false, ROOF>(a, c[h0 + u], row, q, head, gv[u], st[u]);
 #pragma unroll
                 for (int u = 0; u < UNR; ++u)
-                    edge_step_b<T, D, HEADS, DROP, ROOF>(a, x, gv[u], st[u], k0 + h0 + u < deg, c[h0 + u], acc, dsum);
+                    edge_step_b<T, D, HEADS, DROP, ROOF>(a, x, gv[u], st[u], k0 + h0 + u < deg, c[h0 + u], sm);
             }
             colv = coln;
         }
+        sm.get(acc, dsum);
         if (live) finish_row_t<T, D, HEADS, FUSE, VEC>(a, row, q, head, acc, dsum, rd);
         return;
     }
@@ -542,7 +575,7 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
     if constexpr (FUSE == 2) dma_prev<T, D, VEC>(a, pt, row, slot, q);     // (a hub row's slices fetch it too: any of them may finish the row)
     if (SPARSE) {                                   // the lane group's edges: beg + slot, + EPI, ... (the dense loop's assignment)
         const int mine = end - beg - slot;
-        sparse_edges_b<T, D, HEADS, DROP>(a, x, qbuf, row, beg + slot, EPI, mine > 0 ? (mine + EPI - 1) / EPI : 0, slot, q, head, acc, dsum);
+        sparse_edges_b<T, D, HEADS, DROP>(a, x, qbuf, row, beg + slot, EPI, mine > 0 ? (mine + EPI - 1) / EPI : 0, slot, q, head, sm);
     } else {
         for (int base = beg; base < end; base += EPI * UNR) {
             int c[UNR];
@@ -560,9 +593,10 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
                 load_edge_b<T, D, HEADS, false, ROOF>(a, c[u], row, q, head, gv[u], st[u]);
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                edge_step_b<T, D, HEADS, DROP, ROOF>(a, x, gv[u], st[u], ok[u], c[u], acc, dsum);
+                edge_step_b<T, D, HEADS, DROP, ROOF>(a, x, gv[u], st[u], ok[u], c[u], sm);
         }
     }
+    sm.get(acc, dsum);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = group_sum<LPR, WAVE>(acc[j]);
     dsum = group_sum<LPR, WAVE>(dsum);
@@ -754,7 +788,7 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
 }
 
 template <typename T, int D, int HEADS, bool DROP, bool SPARSE, int FUSE = 0, int ROOF = 0>
-__global__ __launch_bounds__(256, FUSE != 0 ? (DROP || SPARSE ? 4 : 1) : (SPARSE ? (DROP ? 5 : 4) : 1)) void prop_bwd_kernel(const PropBwdArgs a) {
+__global__ __launch_bounds__(256, FUSE != 0 ? 4 : (SPARSE ? (DROP ? 5 : 4) : 1)) void prop_bwd_kernel(const PropBwdArgs a) {
     static_assert(ROOF == 0 || (FUSE == 0 && !DROP && !SPARSE), "measurement-only instantiations: the dense edge backward alone");
     // (FUSE: 4 waves per SIMD = 128 VGPRs.  Bounded to 5 = 96 VGPRs the 8-head dropout instantiations spill one or two registers to
     //  scratch, and the one with row flags then faulted on the GPU; 5 against 4 waves per SIMD is worth ~1 % in this kernel.)
@@ -916,7 +950,7 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     if (!(drop_p >= 0.f && drop_p < 1.f) || !(alpha > 0.f && alpha < 1.f)) return NGACF_E_ARG;
     if ((uint64_t)N * (uint64_t)d * (dtype == NGACF_BF16 ? 2ull : 4ull) >= (1ull << 32)) return NGACF_E_SHAPE;   // 32-bit row offsets
     PropBwdArgs a;
-    a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srow = srow; a.nshort = nshort; a.rowptr = rowptr;
+    a.segs = reinterpret_cast<const int4*>(segs); a.nseg = nseg; a.srec = reinterpret_cast<const int4*>(srow); a.nshort = nshort; a.rowptr = rowptr;
     a.hrow = hrow; a.order.nhub = nhub; a.order.nhub_u = nhub_user;
     a.col = col; a.H = H; a.S_dst = S_dst; a.S_src = S_src; a.avec = avec; a.out = out; a.agg = agg; a.R = R; a.gout = gout;
     a.G = G; a.Gn = Gn; a.ST = reinterpret_cast<float2*>(ST); a.dH = dH; a.dS = dS; a.part_acc = part_acc; a.part_r = part_r;

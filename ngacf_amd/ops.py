@@ -161,7 +161,7 @@ def _plan_ptrs(plan, dev, half=None, inkernel=False):
     segs = _chk(plan.segs, "plan.segs", torch.int32, plan.nseg * 4, dev) if plan.nseg else 0
     split = _chk(plan.split, "plan.split", torch.int32, plan.nsplit * 3, dev) if plan.nsplit else 0
     col = _chk(plan.col, "plan.col", torch.int32, plan.n_edges_directed, dev) if plan.n_edges_directed else 0
-    srow = _chk(plan.srow, "plan.srow", torch.int32, plan.nshort, dev) if plan.nshort else 0
+    srow = _chk(plan.srec, "plan.srec", torch.int32, plan.nshort * 4, dev) if plan.nshort else 0
     rowptr = _chk(plan.rowptr32, "plan.rowptr32", torch.int32, plan.N + 1, dev)
     hrow = _chk(plan.hrow, "plan.hrow", torch.int32, plan.nhub, dev, align=4) if plan.nhub else 0
     if half is None:
@@ -180,7 +180,7 @@ def _plan_ptrs(plan, dev, half=None, inkernel=False):
         ns, nsh = plan.nseg - plan.nseg_user, plan.nshort - plan.nshort_user
         nh = plan.nhub - plan.nhub_user
         return (segs + 16 * plan.nseg_user if ns else 0, ns, si[0], si[1],
-                srow + 4 * plan.nshort_user if nsh else 0, nsh, 0, 0, hrow + 4 * plan.nhub_user if nh else 0, nh, 0, rowptr, col)
+                srow + 16 * plan.nshort_user if nsh else 0, nsh, 0, 0, hrow + 4 * plan.nhub_user if nh else 0, nh, 0, rowptr, col)
     raise ValueError("half must be None, 'user' or 'item'")
 
 

@@ -37,6 +37,13 @@ class GraphPlan:
         # short rows (degree <= short_max), sorted by degree descending: one lane group per row
         self.srow = srow if srow is not None else torch.empty(0, dtype=torch.int32, device=col.device)
         self.nshort, self.short_max = int(self.srow.shape[0]), short_max
+        # what the kernels read: one 16-byte record {row, first edge, degree, 0} per short row (padding: row -1, no edges) -- a
+        # wave learns its rows' edge ranges with ONE load instead of the chain srow -> rowptr[row], rowptr[row + 1]
+        rr = self.srow.long().clamp(min=0)
+        live = (self.srow >= 0)
+        beg = torch.where(live, rowptr[rr], torch.zeros_like(rr))
+        deg = torch.where(live, rowptr[rr + 1] - rowptr[rr], torch.zeros_like(rr))
+        self.srec = torch.stack([self.srow.long(), beg, deg, torch.zeros_like(rr)], 1).to(torch.int32).contiguous()
         self.nseg_user, self.nshort_user, self.nsplit_user = self.nseg, self.nshort, self.nsplit   # build_plan sets the user/item split
         # hub rows (degree > seg_len, up to hub_cap): one WORKGROUP per row, its four waves stride over the row's edges and
         # fold through LDS -- no partial sums in memory, no second kernel.  Users first, each half by degree descending.
