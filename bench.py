@@ -53,6 +53,7 @@ def parse(argv=None):
     ap.add_argument("--seg-len", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-cpu-train", action="store_true", help="skip the CPU baseline's two train steps (~20-40 s)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--target-seconds", type=float, default=0.6, help="length of the timed region the pass count R is sized for")
@@ -134,8 +135,7 @@ def cpu_baseline_leg(torch, p_cpu, names, edge_c, Us, Is, L, budget_s, sample):
     sec, iters = run(share, budget_s * 0.6 if usable > share else budget_s)
     out = {"value": round(trav / sec, 1), "unit": "edges/s", "cores": share, "kind": "port",
            "cpu_model": bk.cpu_model_name(), "host_cpus": host, "usable_cpus": usable,
-           "sample": "%d eval forward(s) over %s, same weights (L=%d, fp32), %.2f s each, torch CPU ops in the reference's "
-                     "operator order (oracle/cpu_baseline.py)" % (iters, sample, L, sec)}
+           "sample": "%d eval forward(s), %s, %.2f s each (oracle/cpu_baseline.py)" % (iters, sample, sec)}
     # every core (torch.set_num_threads(os.cpu_count())).  Only where the process really HAS more cores
     # than the 16-thread share: on the MI355X pool a one-GPU job gets 16 of the host's 256 CPUs (cgroup quota), and 256 torch
     # threads on them take 65 s for ONE forward over 10^5 edges (9 k edges/s, measured once: profiles/r03_cpu_all_cores.json)
@@ -145,10 +145,30 @@ def cpu_baseline_leg(torch, p_cpu, names, edge_c, Us, Is, L, budget_s, sample):
         out["all_cores"] = {"value": round(trav / sec_a, 1), "unit": "edges/s", "cores": usable,
                             "sample": "%d forward(s), %.2f s each, torch.set_num_threads(%d)" % (it_a, sec_a, usable)}
     else:
-        out["all_cores"] = {"value": None, "cores": host, "skipped": "the job may use %d of the host's %d CPUs (affinity / cgroup quota): "
-                            "the 16-thread figure IS the all-usable-cores figure; %d threads on them were measured once at 9.1 k edges/s "
-                            "(profiles/r03_cpu_all_cores.json)" % (usable, host, host)}
+        out["all_cores"] = {"value": None, "cores": host, "skipped": "job may use %d of %d CPUs" % (usable, host)}
     return out
+
+
+def cpu_train_leg(torch, model, edge, U, I, wl, names, B, droprate, target_edges=100_000):
+    """`cpu_baseline.train_*` ("... and 2 timed train steps"): two reference-semantics BPR train steps of
+    oracle/cpu_baseline.py (the reference's operator order, torch autograd, torch.optim.Adam) on the induced subgraph of the first
+    users holding ~10^5 edges (a full Gowalla-scale step is 145 s on 8 threads); same batch size as the GPU leg."""
+    from oracle import cpu_baseline as CB
+    bk = _benchkit()
+    p_cpu = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    E = int(edge.shape[1])
+    k = min(target_edges, E - 1)
+    u_hi = int(edge[0][k]) + 1
+    n_e = int((edge[0] < u_hi).sum())
+    sub = edge[:, :n_e]
+    items, inv = torch.unique(sub[1], return_inverse=True)
+    p_cpu["uEmbd.weight"] = p_cpu["uEmbd.weight"][:u_hi]
+    p_cpu["iEmbd.weight"] = p_cpu["iEmbd.weight"][items.cpu()]
+    share = min(bk.usable_cpus(), 16)
+    torch.set_num_threads(share)
+    sec, n = CB.time_train_steps(p_cpu, torch.stack([sub[0], inv]).cpu(), u_hi, int(items.numel()), names, B=B, droprate=droprate, steps=2)
+    return {"train_pairs_per_s": round(B / sec, 2), "train_s_per_step": round(sec, 2), "train_cores": share,
+            "train_sample": "%d steps, B=%d, subgraph of the first %d users (%d edges, %d items)" % (n, B, u_hi, n_e, int(items.numel()))}
 
 
 def cpu_sample(torch, model, edge, U, I, wl):
@@ -158,7 +178,7 @@ def cpu_sample(torch, model, edge, U, I, wl):
     p_cpu = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     E = int(edge.shape[1])
     if E <= 4_000_000:
-        return p_cpu, edge.cpu(), U, I, "the whole %s graph" % wl
+        return p_cpu, edge.cpu(), U, I, "whole %s graph" % wl
     u_hi = int(edge[0][1_000_000]) + 1
     n_e = int((edge[0] < u_hi).sum())
     sub = edge[:, :n_e]
@@ -166,7 +186,7 @@ def cpu_sample(torch, model, edge, U, I, wl):
     p_cpu["uEmbd.weight"] = p_cpu["uEmbd.weight"][:u_hi]
     p_cpu["iEmbd.weight"] = p_cpu["iEmbd.weight"][items.cpu()]
     return (p_cpu, torch.stack([sub[0], inv]).cpu(), u_hi, int(items.numel()),
-            "the subgraph of the first %d users of the %s graph (%d edges, %d items touched)" % (u_hi, wl, n_e, int(items.numel())))
+            "subgraph of the first %d users of %s (%d edges, %d items)" % (u_hi, wl, n_e, int(items.numel())))
 
 
 def measure_forward(torch, BK, ops, model, edge, steps, warmup, target_s, passes_per_step, eager, n_timed):
@@ -203,14 +223,25 @@ def measure_forward(torch, BK, ops, model, edge, steps, warmup, target_s, passes
             "n_timed": n_timed}
 
 
-def roofline_of(BK, D, wl, dtype, U, I, E, dims, elem, prop_ms, n_timed, fused):
-    """`roofline` of the dominant kernel (attention propagation) from its algorithmic bytes per launch (SURVEY.md 8(d):
-    2E (4 + d T) + N (2 d T + 8)) and its average duration.  The roof depends on where the gathered rows come from:
-      * table far beyond the 256 MiB Infinity Cache: HBM, peak 8 TB/s -- `frac` is the fraction of the HBM roofline;
-      * table inside L2 + Infinity Cache (Gowalla / Yelp): the gather never reaches HBM; the roof is the blend of the measured
-        L2-hit and Infinity-Cache row-gather rates (MI355X_MICROARCH.md, "Indexed rows") at the kernel's measured L2 hit
-        rate, 1 / (hit / 17.8 + miss / 8.6) TB/s; the algorithmic rate over the HBM peak is reported separately as
-        `frac_hbm_algorithmic` (it may exceed 1 there and is NOT an HBM statement)."""
+def measure_roofs(torch, BK, ops, model, edge, U, I, seg_len, dims, dtype, n, bwd=False):
+    """The measured gather roof (benchkit.gather_roof_*_us: the traversal kernels' stripped instantiations over the BENCHED plan) per
+    distinct head count of the model's 64-column stages; None when a stage is not 64 columns wide (no stripped instantiation)."""
+    if any(dout != 64 for _, dout, _ in dims):
+        return None
+    plan = model.gat._plans.get(edge, U, I, seg_len)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    fn = BK.gather_roof_bwd_us if bwd else BK.gather_roof_fwd_us
+    return {h: fn(torch, ops, plan, U, I, tdt, h, n) for h in sorted({int(hd) for _, _, hd in dims})}
+
+
+def roofline_of(BK, D, wl, dtype, U, I, E, dims, elem, prop_ms, n_timed, fused, roofs=None):
+    """`roofline` of the dominant kernel (attention propagation): algorithmic bytes per launch (2E (4 + d T) + N (2 d T
+    + 8)) over its average duration, against
+      * table far beyond the 256 MiB Infinity Cache: the HBM peak (8 TB/s) -- `frac` is the fraction of the HBM roofline;
+      * table inside L2 + Infinity Cache (Gowalla / Yelp): the MEASURED gather roof -- the same bytes over the duration of the
+        kernel's stripped instantiation on the same plan (`roofs`, measure_roofs: one xor per gathered dword), ONE yardstick for
+        both storage types.  The guide-rate blends at the profiled L2 hit rate stay in the line as secondary figures
+        (profiles/README.md explains every field)."""
     L = len(dims)
     N, d = U + I, dims[0][1]
     per_launch_bytes = [D.algorithmic_bytes_stage(U, I, E, din, dout, elem)[0] for din, dout, _ in dims]
@@ -220,55 +251,43 @@ def roofline_of(BK, D, wl, dtype, U, I, E, dims, elem, prop_ms, n_timed, fused):
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
     per_stage_ms = [sum(prop_ms[s::L]) / n_timed for s in range(L)]
     regime = BK.gather_regime(N * d * elem, max(U, I) * d * elem)
-    traffic, traffic_src = BK.traffic_from_profile(ROOT, wl, dtype, L, d)
-    hit, hit_src = BK.l2_hit_from_profile(ROOT, wl, dtype)
+    traffic, _ = BK.traffic_from_profile(ROOT, wl, dtype, L, d)
+    hit, _ = BK.l2_hit_from_profile(ROOT, wl, dtype)
+    roof_us = roof_add_us = roof_GBps = None
+    if roofs:
+        roof_us = sum(roofs[int(hd)]["xor"] for _, _, hd in dims) / L
+        roof_add_us = sum(roofs[int(hd)]["add"] for _, _, hd in dims) / L
+        roof_GBps = avg_bytes / (roof_us * 1e-6) / 1e9
     blend = l2blend = None
+    if hit is not None:
+        blend = 1.0 / (hit / BK.ROOF_L2_GATHER_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
+        l2blend = 1.0 / (hit / BK.L2_PEAK_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
     if regime["regime"] == "HBM":
-        bound, peak, peak_note = "hbm", BK.HBM_PEAK_GBS, "HBM3E spec peak"
+        bound, peak = "hbm", BK.HBM_PEAK_GBS
+    elif roof_GBps:
+        bound, peak = "l2+mall gather (measured roof)", roof_GBps
     else:
-        # The ceiling is fixed by regime and dtype BEFORE anything is measured.  The guide's two row-gather rates (L2-resident
-        # 17.8 TB/s, Infinity-Cache 8.6 TB/s) are measured LOWER bounds of one loop over 1152-byte rows; blended by the kernel's L2
-        # hit rate they are the roof of the bf16 kernel (128-byte rows: one line per gathered row).  fp32's 256-byte rows (two
-        # lines per request burst) are known to exceed that blend, so their roof takes the L2's own peak (34.5 TB/s) for the hits.
-        # Both fractions are in the line whatever the dtype.
-        bound = "l2+mall gather"
-        if hit is not None:
-            blend = 1.0 / (hit / BK.ROOF_L2_GATHER_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
-            l2blend = 1.0 / (hit / BK.L2_PEAK_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
-            if elem == 2:
-                peak = blend
-                peak_note = ("bf16 rows: 1 / (hit / %.0f + miss / %.0f) GB/s (the guide's L2-resident and Infinity-Cache row-gather rates) at "
-                             "the kernel's L2 hit rate %.3f (%s)" % (BK.ROOF_L2_GATHER_GBS, BK.ROOF_MALL_GATHER_GBS, hit, hit_src))
-            else:
-                peak = l2blend
-                peak_note = ("fp32 rows: 1 / (hit / %.0f [the L2's own peak] + miss / %.0f) GB/s at the kernel's L2 hit rate %.3f (%s); "
-                             "chosen by dtype before measuring -- 256-byte rows exceed the guide's gather blend, a measured lower bound"
-                             % (BK.L2_PEAK_GBS, BK.ROOF_MALL_GATHER_GBS, hit, hit_src))
-        else:
-            peak, peak_note = regime["roof_GBps"], "no request-counter profile for this workload: the regime's row-gather rate"
-    out = {"bound": bound, "kernel": "prop_fwd_kernel (ngacf_prop_fwd%s); traffic / l2_hit_rate: from_profile, not collected in this run"
-                                     % (": with the next stage's transform in its epilogue on all but the last stage" if fused else ""),
-           "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s", "frac": round(achieved / peak, 4),
-           "peak_note": peak_note, "traffic": traffic, "traffic_source": traffic_src,
-           "frac_hbm_algorithmic": round(achieved / BK.HBM_PEAK_GBS, 4),
-           "frac_of_guide_gather_blend": round(achieved / blend, 4) if blend else None,
-           "frac_of_l2_peak_blend": round(achieved / l2blend, 4) if l2blend else None,
-           "counter_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
-           "regime": regime["regime"], "regime_note": regime["note"], "l2_hit_rate": hit,
-           "bytes_per_launch": int(avg_bytes), "avg_launch_us": round(avg_ms * 1e3, 2),
-           "per_stage_us": [round(x * 1e3, 2) for x in per_stage_ms], "launches_timed": len(prop_ms),
-           "timing": "dispatch-packet timestamps (hipExtLaunchKernel start/stop events) of eager launches of the replayed graph's kernels",
-           "edges_per_s_in_kernel": round(2 * E / (avg_ms * 1e-3), 1)}
-    return out
+        bound, peak = "l2+mall gather (guide blend)", (blend if blend else regime["roof_GBps"])
+    return {"bound": bound, "kernel": "prop_fwd_kernel" + (" (+ next stage's transform in its tail on all but the last stage)" if fused else ""),
+            "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s", "frac": round(achieved / peak, 4),
+            "traffic": traffic, "avg_launch_us": round(avg_ms * 1e3, 2), "bytes_per_launch": int(avg_bytes),
+            "measured_gather_roof_GBps": round(roof_GBps, 1) if roof_GBps else None,
+            "measured_gather_roof_us": round(roof_us, 2) if roof_us else None,
+            "gather_roof_one_add_per_element_us": round(roof_add_us, 2) if roof_add_us else None,
+            "frac_of_measured_gather_roof": round(achieved / roof_GBps, 4) if roof_GBps else None,
+            "frac_hbm_algorithmic": round(achieved / BK.HBM_PEAK_GBS, 4),
+            "frac_of_guide_gather_blend": round(achieved / blend, 4) if blend else None,
+            "frac_of_l2_peak_blend": round(achieved / l2blend, 4) if l2blend else None,
+            "l2_hit_rate": hit, "regime": regime["regime"],
+            "per_stage_us": [round(x * 1e3, 2) for x in per_stage_ms], "launches_timed": len(prop_ms),
+            "edges_per_s_in_kernel": round(2 * E / (avg_ms * 1e-3), 1)}
 
 
-def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dims, elem, n_steps=10):
-    """`train_roofline`: the train step's dominant kernel -- the dense stages' edge backward (ngacf_prop_bwd / ngacf_prop_bwd_dx,
-    four launches per step, the bulk of the backward) -- from its algorithmic bytes, 2E (4 + d T + 8 heads) + N (2 d T + 8) (the
-    split-sign form gathers ONE row and a (S, t) pair per head per edge: include/ngacf.h; SURVEY.md 8(d)'s form had 2 d T), and its own
-    duration: dispatch-packet timestamps of eager train steps (launches one after the other; inside the replayed two-chain step
-    a launch shares the GPU with the other chain's and lasts 1.3-1.7 x as long: profiles/r04_trainstep_timeline.txt).  Roof as in
-    `roofline`: the cache-gather blend at the kernel's own L2 hit rate (profiles/r04_traffic_trainstep.json)."""
+def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dims, elem, n_steps=10, roofs=None):
+    """`train_roofline`: the train step's dominant kernel -- the dense stages' edge backward (ngacf_prop_bwd / ngacf_prop_bwd_dx) --
+    from its algorithmic bytes, 2E (4 + d T + 8 heads) + N (2 d T + 8) (+ the fused tail's own rows), and its own duration:
+    dispatch-packet timestamps of EAGER train steps (one launch at a time; inside the replayed two-chain step a launch shares the
+    GPU with the other chain's).  Roof: the stripped edge backward over the same plan (`roofs`), as in `roofline`."""
     L = len(dims)
     N, d = U + I, dims[0][1]
     for _ in range(2):
@@ -288,9 +307,6 @@ def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dim
     avg_ms = sum(dense) / len(dense)
     heads_dense = int(dims[0][2]) if len(dims[0]) > 2 else d // 8
     bytes_edges = 2 * E * (4 + d * elem + 8 * heads_dense) + N * (2 * d * elem + 8)
-    bytes_survey = 2 * E * (4 + 2 * d * elem) + N * (2 * d * elem + 8)
-    # the fused tail's own rows (bf16 plans): stage 0 writes the fp32 dX; a later dense stage writes dX and, at level 2, reads the
-    # previous stage's out / agg / aggn / R / Rn / S and writes its Gn / ST / P1
     fused = bool(ops.FUSE_BWD) and dtype == "bf16"
     n_dense = L - 1 if sparse_last else L
     tail = 0
@@ -299,40 +315,26 @@ def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dim
         tail = (N * d * 4 + (n_dense - 1) * later) / n_dense
     bytes_launch = bytes_edges + tail
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
-    hit, hit_src = BK.bwd_hit_from_profile(ROOT, wl, dtype)
-    regime = BK.gather_regime(N * (d * elem + 8 * heads_dense), max(U, I) * (d * elem + 8 * heads_dense))   # gathered: Gn rows and (S, t) pairs
-    blend = l2blend = None
+    hit, _ = BK.bwd_hit_from_profile(ROOT, wl, dtype)
+    regime = BK.gather_regime(N * (d * elem + 8 * heads_dense), max(U, I) * (d * elem + 8 * heads_dense))
+    roof_us = roofs[heads_dense]["xor"] if roofs and heads_dense in roofs else None
+    if roof_us is not None and roofs[heads_dense]["add"] < roof_us:      # (the xor form is not always the faster of the two stripped forms)
+        roof_us = roofs[heads_dense]["add"]
+    roof_GBps = bytes_edges / (roof_us * 1e-6) / 1e9 if roof_us else None
+    blend = 1.0 / (hit / BK.ROOF_L2_GATHER_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS) if hit is not None else None
     if regime["regime"] == "HBM":
-        bound, peak, note = "hbm", BK.HBM_PEAK_GBS, "HBM3E spec peak"
-    elif hit is not None:
-        bound = "l2+mall gather"
-        blend = 1.0 / (hit / BK.ROOF_L2_GATHER_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
-        l2blend = 1.0 / (hit / BK.L2_PEAK_GBS + (1.0 - hit) / BK.ROOF_MALL_GATHER_GBS)
-        peak = blend if elem == 2 else l2blend
-        note = "as `roofline` (ceiling fixed by dtype), at the edge backward's own L2 hit rate %.3f (%s)" % (hit, hit_src)
+        bound, peak = "hbm", BK.HBM_PEAK_GBS
+    elif roof_GBps:
+        bound, peak = "l2+mall gather (measured roof)", roof_GBps
     else:
-        # no counter profile of this workload / dtype: the L2's own peak is the only ceiling that holds whatever the hit rate is
-        bound, peak, note = "l2 peak (upper bound)", BK.L2_PEAK_GBS, ("no request-counter profile of the edge backward for this workload and dtype "
-                                                                       "(tools/traffic.py trainstep): measured against the L2 peak, an upper bound of any blend")
-    from ngacf_amd import functional as NF
-    return {"bound": bound, "kernel": "prop_bwd_kernel, dense stages (NGACF_FUSE_BWD=%d: %s); l2_hit_rate: from_profile"
-                                      % (ops.FUSE_BWD, "with the stage's dX%s in its tail" % (" and the previous stage's node step" if ops.FUSE_BWD >= 2 else "")
-                                         if ops.FUSE_BWD and dtype == "bf16" else "edge backward alone"),
-            "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s", "frac": round(achieved / peak, 4), "peak_note": note,
+        bound, peak = "l2 peak (upper bound)", (blend if blend else BK.L2_PEAK_GBS)
+    return {"bound": bound, "kernel": "prop_bwd_kernel, dense stages, NGACF_FUSE_BWD=%d" % ops.FUSE_BWD,
+            "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s", "frac": round(achieved / peak, 4),
+            "avg_launch_us": round(avg_ms * 1e3, 2), "bytes_per_launch": int(bytes_launch), "bytes_edge_step_only": int(bytes_edges),
+            "measured_gather_roof_us": round(roof_us, 2) if roof_us else None,
             "frac_hbm_algorithmic": round(achieved / BK.HBM_PEAK_GBS, 4),
-            "frac_of_guide_gather_blend": round(achieved / blend, 4) if blend else None,
-            "frac_of_l2_peak_blend": round(achieved / l2blend, 4) if l2blend else None,
-            "l2_hit_rate": hit, "bytes_per_launch": int(bytes_launch),
-            "bytes_note": "2E (4 + d T + 8 heads) + N (2 d T + 8): one gathered row and a (S, t) pair per head per edge (split-sign backward)"
-                          + (", + the fused tail's own rows, averaged over the dense stages: %d bytes per launch (dX; at level 2 the previous stage's out / agg / aggn "
-                             "in, Gn / ST / P1 out)" % int(tail) if tail else ""),
-            "bytes_edge_step_only": int(bytes_edges),
-            "GBps_if_counted_in_the_two_row_form_of_SURVEY_8d": round(bytes_survey / (avg_ms * 1e-3) / 1e9, 1),
-            "avg_launch_us": round(avg_ms * 1e3, 2),
-            "per_stage_us": [round(1e3 * sum(x) / len(x), 2) for x in per_stage],
-            "last_stage_is_the_scored_batch_only": sparse_last and NF is not None,
-            "launches_timed": len(dense), "edges_per_s_in_kernel": round(2 * E / (avg_ms * 1e-3), 1),
-            "timing": "dispatch-packet timestamps of EAGER train steps (one launch at a time)"}
+            "frac_of_guide_gather_blend": round(achieved / blend, 4) if blend else None, "l2_hit_rate": hit,
+            "per_stage_us": [round(1e3 * sum(x) / len(x), 2) for x in per_stage], "launches_timed": len(dense)}
 
 
 def performed_train_traversals(torch, model, plan, ub, pb, nb_, L, E):
@@ -412,11 +414,15 @@ def worker(args):
     value = trav_per_step * args.steps / t_fwd
     ms_per_step = 1e3 * t_fwd / args.steps
     med_ms = BK.median(windows)
-    roofline = roofline_of(BK, D, wl, args.dtype, U, I, E, dims, elem, fm["prop_ms"], fm["n_timed"], fused)
+    roofs = None
+    try:
+        roofs = measure_roofs(torch, BK, ops, model, edge, U, I, args.seg_len, dims, args.dtype, 10 if big else 100)
+    except Exception as e:                        # (a secondary figure must not cost the line)
+        print("[bench] gather roof failed: %r" % (e,), file=sys.stderr, flush=True)
+    roofline = roofline_of(BK, D, wl, args.dtype, U, I, E, dims, elem, fm["prop_ms"], fm["n_timed"], fused, roofs)
     roofline["measured_copy_GBps"] = BK.copy_rate_GBps(torch, dev)
     if fm["transform_ms"]:
         roofline["transform_launch_us"] = round(1e3 * sum(fm["transform_ms"]) / len(fm["transform_ms"]), 2)
-        roofline["transform_launches_per_pass"] = len(fm["transform_ms"]) // fm["n_timed"]
     fwd_bytes = sum(sum(D.algorithmic_bytes_stage(U, I, E, din, dout, elem)) for din, dout, _ in dims)
 
     tif = None
@@ -473,17 +479,16 @@ def worker(args):
         t_tr, ksteps, loss = time_train(step)
         train_rl = None
         try:
-            train_rl = train_roofline_of(torch, BK, ops, eager_step, model, wl, args.dtype, U, I, E, dims, elem)
+            broofs = None if big else measure_roofs(torch, BK, ops, model, edge, U, I, args.seg_len, dims, args.dtype, 100, bwd=True)
+            train_rl = train_roofline_of(torch, BK, ops, eager_step, model, wl, args.dtype, U, I, E, dims, elem, roofs=broofs)
         except Exception as e:                        # (a secondary figure must not cost the line)
             print("[bench] train_roofline failed: %r" % (e,), file=sys.stderr, flush=True)
         plan = model.gat._plans.get(edge, U, I, args.seg_len)
         performed = performed_train_traversals(torch, model, plan, ub, pb, nb, L, E)
         train = {"bpr_pairs_per_s": round(B * ksteps / t_tr, 1), "train_ms_per_step": round(1e3 * t_tr / ksteps, 3),
                  "train_steps": ksteps, "batch": B, "droprate": args.droprate, "final_loss": round(float(loss.detach()), 6),
-                 "train_traversals_per_step": {"performed": performed, "if_every_stage_ran_in_full": 4 * trav_per_pass,
-                                               "note": "directed-edge gathers of one step (2 propagations, forward + backward); the last "
-                                                       "stage of a scored batch walks the batch's rows only"},
-                 "train_traversals_per_s": round(performed * ksteps / t_tr, 1), "train_roofline": train_rl}
+                 "train_traversals_per_step": performed, "train_traversals_per_s": round(performed * ksteps / t_tr, 1),
+                 "train_roofline": train_rl}
         if not args.eager and not big:
             # reported SEPARATELY: the opt-in mode that shares one propagation between the
             # positive and the negative scoring of a step -- not reference semantics, never the headline number
@@ -498,23 +503,33 @@ def worker(args):
     if not args.no_cpu_baseline:
         p_cpu, e_c, Us, Is, desc = cpu_sample(torch, model, edge, U, I, wl)
         cpu = cpu_baseline_leg(torch, p_cpu, stage_layer_names(model), e_c, Us, Is, L, args.cpu_budget, desc)
+        if train and not args.no_cpu_train:
+            try:
+                cpu.update(cpu_train_leg(torch, model, edge, U, I, wl, stage_layer_names(model), args.batch, args.droprate))
+            except Exception as e:
+                print("[bench] cpu train leg failed: %r" % (e,), file=sys.stderr, flush=True)
 
-    out = {"metric": "propagation edges/sec (directed edge traversals, forward, all stages)", "value": round(value, 1),
+    # The driver's record keeps the SCALARS of `config`, `roofline` and `cpu_baseline`: the second half of the metric (BPR pairs/s)
+    # and the train leg's roofline therefore also sit there, flat.  profiles/README.md explains every field of the line.
+    config = {"workload": "%s U=%d I=%d E=%d, d=%d, L=%d (%s)"
+                          % ("real %s test-half list" % wl if wl in D.REAL_WORKLOADS else "%s-scale synthetic bipartite graph" % wl,
+                             U, I, E, d, L, type(model).__name__),
+              "passes_per_step": R, "edges_directed_per_pass": trav_per_pass, "seg_len": args.seg_len, "parallelism": "1 GPU",
+              "launch": "eager" if args.eager else "hipGraph replay", "launches_per_pass": (L + 1 if fused else 2 * L),
+              "fused_next_stage_transform": bool(fused), "node_numbering": args.renumber,
+              "graph": graph_law(torch, model, edge, U, I, args.seg_len)}
+    if train:
+        config.update({"bpr_pairs_per_s": train["bpr_pairs_per_s"], "train_ms_per_step": train["train_ms_per_step"], "batch": train["batch"],
+                       "droprate": train["droprate"]})
+        trl = train.get("train_roofline")
+        if trl:
+            roofline.update({"train_kernel": trl["kernel"], "train_avg_launch_us": trl["avg_launch_us"], "train_frac": trl["frac"],
+                             "train_achieved_GBps": trl["achieved"], "train_peak_GBps": trl["peak"],
+                             "train_measured_gather_roof_us": trl["measured_gather_roof_us"]})
+    out = {"metric": "propagation edges/sec (directed edge traversals, forward, all stages) + BPR pairs/sec", "value": round(value, 1),
            "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": "%s U=%d I=%d E=%d, d=%d, L=%d stages (%s), 8 heads x 8 + 1 x %d"
-                                  % (("the reference's data/%s_test.csv interaction list (real topology; the train half is a missing blob)"
-                                      % {"gowalla_real": "Gowalla/g", "yelp_real": "Yelp/y"}[wl]) if wl in D.REAL_WORKLOADS
-                                     else "%s-scale bipartite graph" % wl, U, I, E, d, L, type(model).__name__, d),
-                      "graph": graph_law(torch, model, edge, U, I, args.seg_len),
-                      "passes_per_step": R, "edges_directed_per_pass": trav_per_pass, "edges_directed_per_step": trav_per_step,
-                      "seg_len": args.seg_len, "parallelism": "1 GPU",
-                      "launch": "eager" if args.eager else "hipGraph replay",
-                      "launches_per_pass": (L + 1 if fused else 2 * L),
-                      "fused_next_stage_transform": bool(fused),
-                      "node_numbering": "by degree, descending, at ingest (ngacf_amd.data.degree_order: run_Gowalla.py's default)"
-                                        if args.renumber == "degree" else "the generator's ids"},
-           "ms_per_pass": round(ms_per_step / R, 5), "timed_region_s": round(t_fwd, 4),
+           "config": config, "ms_per_pass": round(ms_per_step / R, 5), "timed_region_s": round(t_fwd, 4),
            "value_median_window": round(trav_per_step / (med_ms * 1e-3), 1) if med_ms > 0 else None,
            "window_ms": {"median": round(med_ms, 4), "min": round(min(windows), 4), "max": round(max(windows), 4)},
            "fwd_algorithmic_GBps": round(fwd_bytes * R / (ms_per_step * 1e-3) / 1e9, 1),
@@ -586,9 +601,7 @@ def two_in_flight(torch, model, edge, E, L, seconds=0.3):
         d = [float((r.out.float() - want.float()).abs().max()) for r in runs] + [float((runs[0].out.float() - runs[1].out.float()).abs().max())]
         raise RuntimeError("two passes in flight: a pass differs from the sequential forward (max |diff| pass 0 / pass 1 / between: %r)" % (d,))
     return {"value": round(L * 2 * E * n / dt, 1), "unit": "edges/s", "passes": n, "ms_per_pass_throughput": round(1e3 * dt / n, 5),
-            "outputs_equal_the_sequential_forward": same,
-            "note": "two complete, independent passes in flight on two streams (two captured graphs with their own tables); "
-                    "NOT the headline: `value` above times passes one after the other"}
+            "outputs_equal_the_sequential_forward": same}
 
 
 def ingest_graph(D, wl, dev, args):
@@ -615,10 +628,17 @@ def forward_probe(args, torch, ng, BK, D, NF, ops, dev, wl, dtype):
     K = max(5, min(args.steps, 10))
     fm = measure_forward(torch, BK, ops, model, edge, K, 2, 0.3, 0, args.eager, 50)
     trav = len(dims) * 2 * E
-    rl = roofline_of(BK, D, wl, dtype, U, I, E, dims, elem, fm["prop_ms"], fm["n_timed"], stack_fuses_next(NF, ops, model, edge, U, I, 256))
-    return {"workload": "%s-scale bipartite graph U=%d I=%d E=%d, d=64, L=3, eval forward" % (wl, U, I, E),
+    roofs = None
+    try:
+        roofs = measure_roofs(torch, BK, ops, model, edge, U, I, 256, dims, dtype, 50)
+    except Exception as e:
+        print("[bench] gather roof (%s %s) failed: %r" % (wl, dtype, e), file=sys.stderr, flush=True)
+    rl = roofline_of(BK, D, wl, dtype, U, I, E, dims, elem, fm["prop_ms"], fm["n_timed"], stack_fuses_next(NF, ops, model, edge, U, I, 256), roofs)
+    keep = ("bound", "achieved", "peak", "frac", "avg_launch_us", "measured_gather_roof_us", "frac_hbm_algorithmic", "frac_of_guide_gather_blend",
+            "frac_of_l2_peak_blend", "l2_hit_rate", "per_stage_us", "bytes_per_launch")
+    return {"workload": "%s-scale U=%d I=%d E=%d d=64 L=3 eval forward" % (wl, U, I, E),
             "value": round(trav * fm["R"] * K / fm["t"], 1), "unit": "edges/s", "ms_per_pass": round(1e3 * fm["t"] / K / fm["R"], 5),
-            "steps": K, "passes_per_step": fm["R"], "dtype": dtype, "roofline": rl}
+            "dtype": dtype, "roofline": {k: rl[k] for k in keep}}
 
 
 def main(argv=None):

@@ -240,3 +240,55 @@ def bwd_hit_from_profile(root, workload, dtype):
         if k and k.get("l2_hit_rate") is not None:
             return k["l2_hit_rate"], "from_profile: %s" % rel
     return None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The MEASURED roof of the traversal's access pattern (tools/gather_roof.py; include/ngacf.h NGACF_ROOF_ADD / NGACF_ROOF_XOR): the
+# traversal kernel's own stripped instantiation over the SAME plan -- same work order, lane layout, index loads, row gathers, loop
+# structure and stores, the arithmetic reduced to one xor per gathered dword ("xor": the memory system's ceiling for this pattern)
+# or one add per gathered element ("add").  bench.py grades both storage types against it (one yardstick).
+# ---------------------------------------------------------------------------------------------------------------------------
+def _timed_us(torch, ops, fn, tag, n, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    with ops.KernelTimer() as kt:
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+    ms = kt.durations_ms(tag)
+    if len(ms) != n:
+        raise RuntimeError("gather roof: timed %d launches, expected %d" % (len(ms), n))
+    return 1e3 * sum(ms) / n
+
+
+def gather_roof_fwd_us(torch, ops, plan, U, I, dtype, heads, n=100):
+    """{"xor": us, "add": us}: mean duration of the stripped forward traversal (d = 64) over `plan`."""
+    dev, N = plan.device, U + I
+    g = torch.Generator(device=dev).manual_seed(11)
+    H = (torch.randn(N, 64, device=dev, generator=g) * 0.1).to(dtype)
+    S = torch.randn(N, heads, device=dev, generator=g) * 0.1
+    avec = torch.randn(2, 64, device=dev, generator=g) * 0.2
+    out = torch.empty(N, 64, dtype=dtype, device=dev)
+    T = ops.KernelTimer
+    return {k: round(_timed_us(torch, ops, lambda: ops.prop_fwd(plan, H, S, S, avec, heads, out=out, roof=r), T.TAG_PROP_FWD, n), 2)
+            for k, r in (("xor", 2), ("add", 1))}
+
+
+def gather_roof_bwd_us(torch, ops, plan, U, I, dtype, heads, n=100):
+    """The same for the dense edge backward (one Gn row + one (S, t) pair per head per edge)."""
+    dev, N = plan.device, U + I
+    g = torch.Generator(device=dev).manual_seed(12)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.1
+    H, out, gout, Gn = (rnd(N, 64).to(dtype) for _ in range(4))
+    agg = rnd(2, N, 64).to(dtype)
+    S, R = rnd(N, heads), rnd(2, N, heads).abs() + 0.1
+    avec = rnd(2, 64)
+    ST, P1 = rnd(N, heads, 2), [rnd(N, heads) for _ in range(2)]
+    k = [0]
+
+    def run(r):
+        k[0] += 1
+        return ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, ST, P1[k[0] & 1]), roof=r)
+    T = ops.KernelTimer
+    return {key: round(_timed_us(torch, ops, lambda: run(r), T.TAG_PROP_BWD, n), 2) for key, r in (("xor", 2), ("add", 1))}

@@ -723,11 +723,9 @@ def scaling_probe(args, world, rank, dev, d=64):
     traffic, traffic_src = BK.traffic_from_profile(root, wl, args.dtype, 3, d) if world == 1 else (None, None)
     roofline = {"bound": "hbm", "kernel": "prop_fwd_kernel + the hub rows' second kernel (11 M slices: beyond the in-kernel finish)",
                 "achieved": round(achieved, 1), "peak": BK.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / BK.HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic": traffic,
                 "counter_GBps": round(traffic / (stage_ms * 1e-3) / 1e9, 1) if traffic else None,
-                "bytes_per_launch": int(bytes_stage), "avg_launch_us": round(stage_ms * 1e3, 1),
-                "timing": "dispatch-packet timestamps of %d eager launches (slowest rank)" % len(durs),
-                "regime": "HBM", "regime_note": "%.2f GB table, far beyond the 256 MiB Infinity Cache" % (n_local * d * elem / 1e9)}
+                "bytes_per_launch": int(bytes_stage), "avg_launch_us": round(stage_ms * 1e3, 1), "regime": "HBM"}
     return {"workload": "%s bipartite graph U=%d I=%d E=%d, d=%d, L=3, eval forward" % (wl, U, I, E, d), "n_gpus": world,
             "roofline": roofline,
             "value": round(L * 2 * E * K / best, 1), "unit": "edges/s", "ms_per_pass": round(1e3 * best / K, 3), "passes": K,
@@ -763,8 +761,7 @@ def allgather_summary(ag, transport):
     nb = sum(b for _, b in ag) / len(ag)
     rate = nb / max(ms * 1e-3, 1e-12) / 1e9
     return {"avg_us_serial": round(ms * 1e3, 2), "avg_bytes_received_per_rank": int(nb), "GBps_received_per_rank": round(rate, 1),
-            "needed_GBps_for_6x_at_8_gpus_on_1e9_edges": NEEDED_RECEIVE_GBPS_FOR_6X, "transport": transport,
-            "note": "one async all-gather per half-table per stage; serial-pass duration start -> wait on this rank"}
+            "needed_GBps_for_6x_at_8_gpus_on_1e9_edges": NEEDED_RECEIVE_GBPS_FOR_6X, "transport": transport}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -856,7 +853,7 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
     ag_bytes = sum(nb for _, nb in ag) / max(len(ag), 1)
     roofline = {"bound": "hbm", "kernel": "prop_fwd_kernel (ngacf_prop_fwd: 2 half-launches per stage), slowest rank",
                 "achieved": round(achieved, 1), "peak": BK.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / BK.HBM_PEAK_GBS, 4),
-                "traffic": None, "regime": regime["regime"], "regime_note": regime["note"],
+                "traffic": None, "regime": regime["regime"],
                 "applicable_roof_GBps": regime["roof_GBps"], "frac_of_applicable_roof": round(achieved / regime["roof_GBps"], 4),
                 "bytes_per_stage_per_rank": int(bytes_stage), "avg_stage_kernel_us": round(stage_ms * 1e3, 2),
                 "launches_per_forward": n_launch, "local_directed_edges": int(local_edges),
