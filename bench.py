@@ -2,7 +2,7 @@
 """bench.py -- propagation edges/s (+ BPR pairs/s) of the HIP path on N MI355X.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gowalla|yelp|gowalla128|synthetic200m|synthetic1b|gowalla_real|yelp_real]
-  (gowalla_real / yelp_real: the REAL interaction lists the reference ships -- its test halves, tests/golden/*_test_pairs.npz;
+  (gowalla_real / yelp_real: the REAL interaction lists the reference ships -- its test halves, data/real/*_test_pairs.npz;
   one GPU; the degree law of every workload's graph is printed in config.graph)
 
 N = 1 runs in this process.  N > 1 (or NGACF_BENCH_FORCE_DIST=1: the N > 1 code path rehearsed on one rank) without a

@@ -364,7 +364,9 @@ int ngacf_prop_bwd_node(const void* out, int dtype, const void* agg, const float
  * and each such pair adds 1 to *bad_index (int32 device counter, may be NULL) for the host to raise on. */
 int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
                     float* score, int32_t* bad_index, int B, int U, int I, int d, void* stream);
-/* gF[u[b]] += g[b] * F[U+i[b]],  gF[U+i[b]] += g[b] * F[u[b]]   (float atomics; gF float[N][d]) */
+/* gF[u[b]] += g[b] * F[U+i[b]],  gF[U+i[b]] += g[b] * F[u[b]]   (gF float[N][d]).  B <= 8192: NO atomics -- the first pair that
+ * names a row adds the contributions of all the pairs naming it, in ascending pair order, and does the row's one read-modify-write
+ * (bit-reproducible; the rows named by a batch must not be written by anything else in flight).  Larger batches: float atomics. */
 int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
                     const float* gscore, float* gF, int32_t* bad_index, int B, int U, int I, int d, void* stream);
 
@@ -452,7 +454,8 @@ int ngacf_mha_bwd(const float* Q, const float* K, const float* V, const uint32_t
  * host thread of the process: autograd launches a backward from its own), the launches of the traversal and transform kernels carry start / stop events of their dispatch packets
  * (hipExtLaunchKernel): the kernel's own duration, without the host's launch gaps -- the number a kernel trace reports.
  * ngacf_timing_end synchronises, writes up to cap (duration in ms, NGACF_TAG_*) pairs in launch order and returns their count
- * (negative on error).  Not for use inside a stream capture.  Per-thread state; nothing happens unless a thread asks. */
+ * (negative on error).  Not for use inside a stream capture.  Per-PROCESS state behind a mutex (the launches of any host thread
+ * between begin and end are recorded: autograd runs a backward's launches on its own thread); nothing happens unless somebody asks. */
 #define NGACF_TAG_PROP_FWD        1   /* prop_fwd_kernel (also with the fused next-stage transform) */
 #define NGACF_TAG_PROP_FWD_SPLIT  2   /* prop_fwd_split_kernel (hub rows' partial sums, second kernel) */
 #define NGACF_TAG_TRANSFORM_FWD   3   /* transform_mfma_kernel / transform_fwd_kernel, forward */

@@ -339,7 +339,7 @@ class _GATBase(nn.Module):
                 fuse_b[s] = NF.ops.can_fuse_bwd(plan, self.compute_dtype, shapes[s][1], shapes[s][0], x_dtype, has_prev)
         link = NF.StageLink() if any(fuse) or any(fuse_b) else None
         if link is not None:
-            link.defer_dw = NF.sink_active()
+            link.defer_dw = NF.sink_defers()
         if link is not None and self.compute_dtype == torch.bfloat16:
             link.pack = {s: ops_[s][0].detach() for s in range(1, L) if fuse[s]}       # bf16 fragments, packed by the first transform's launch
             link.pack_t = {s: ops_[s][0].detach() for s in range(L) if fuse_b[s]}

@@ -165,14 +165,17 @@ __device__ __forceinline__ float own_term(float alpha, float r, float rn, float 
 
 // Kernel launch with optional dispatch-timestamp timing (timing.hip; tags: NGACF_TAG_* of include/ngacf.h).
 bool timing_on();
-int timing_events(int tag, hipEvent_t* a, hipEvent_t* b);
+int timing_events(hipEvent_t* a, hipEvent_t* b);
+void timing_record(int tag, hipEvent_t a, hipEvent_t b);
 template <typename K, typename... Args>
 inline void launch_k(int tag, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
     hipEvent_t ea, eb;
-    if (timing_on() && timing_events(tag, &ea, &eb) == 0)
+    if (timing_on() && timing_events(&ea, &eb) == 0) {
         hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, ea, eb, 0, args...);
-    else
+        timing_record(tag, ea, eb);                     // (behind the launch: see timing.hip)
+    } else {
         hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+    }
 }
 
 #define NGACF_CHECK_LAUNCH()                                   \

@@ -687,7 +687,11 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
         gtile[wave * gwave + slot * GROW_U4 + q] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     if (q == 0) xmeta[tr] = rd.valid ? rd.row : -1;
-    __syncthreads();        // (all this wave's loads, the LDS-DMA of the previous stage's rows included, were consumed before `rd` existed)
+    // The previous stage's rows (FUSE 2) came global -> LDS by LDS-DMA (dma_prev): they are vector-memory operations of THIS wave,
+    // and a workgroup barrier does not drain them (no vmcnt in a workgroup-scope release) -- drain them explicitly before the
+    // barrier publishes the tiles (every wave has finished its traversal by now: nothing is waited for that was not needed).
+    if constexpr (FUSE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     // The weight panel (8 KB of bf16 A fragments, L2-resident) goes straight into wave 0's registers, requested in front of the
     // wave's own stores: the MFMAs then wait for these loads only.  (As an LDS-DMA image it cost every workgroup 8 KB of LDS for
     // its whole life: two of these launches share the CUs in a train step, and with row flags that halved the workgroups in flight.)

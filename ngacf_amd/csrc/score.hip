@@ -31,13 +31,108 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const T* __restrict__ F,
     }
 }
 
-// gF[u] += g * F[i], gF[i] += g * F[u].  A lane owns one column, so every atomic wave-instruction adds 256
-// contiguous bytes of one row (the shape float atomics run at full rate with; 4-byte atomics scattered over
-// 8 rows per instruction measured 56 us for 2048 pairs).  One wave per PAIRS_PER_WAVE pairs.
+// gF[u] += g * F[i], gF[i] += g * F[u], WITHOUT atomics: bit-reproducible under a seed.
+// A row of gF collects the contributions of every pair of the batch that names it (a user drawn twice, an item that is one pair's
+// positive and another's negative).  Every (pair, side) is looked at by one wave: it scans the batch's row ids of that side (in LDS)
+// in ascending pair order; the FIRST pair that names a row owns it -- its wave adds the contributions of all the pairs naming the
+// row, in ascending pair order, in registers, and performs the single read-modify-write of the row; the later pairs' waves find an
+// earlier match and leave.  O(B^2 / 64) compares per launch (B = 2048: 131 k wave-steps, ~2 us), no sort, no order that depends on
+// timing.  (Rounds 1-4 added the products with float atomics: two runs of a train step differed in the last bit.)
+constexpr int SCORE_BWD_DET_MAX_B = 8192;        // 2 B ids in 64 KB of LDS; beyond it score_bwd_atomic_kernel (order not fixed)
+constexpr int SIDES_PER_WAVE = 4;                // (pair, side) items per wave, all of ONE side: they share the scan of that side's ids
 template <typename T, int D>
 __global__ __launch_bounds__(256) void score_bwd_kernel(const T* __restrict__ F, const int64_t* __restrict__ u,
                                                         const int64_t* __restrict__ it, const float* __restrict__ g,
                                                         float* __restrict__ gF, int* __restrict__ bad, int B, int U, int I) {
+    extern __shared__ int ids[];                 // [2][B]: global row of the user side / of the item side; -1: pair out of range
+    for (int k = threadIdx.x; k < B; k += 256) {
+        const int64_t ub = u[k], ib = it[k];
+        const bool ok = ub >= 0 && ub < U && ib >= 0 && ib < I;
+        ids[k] = ok ? (int)ub : -1;
+        ids[B + k] = ok ? U + (int)ib : -1;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wpl = (B + SIDES_PER_WAVE - 1) / SIDES_PER_WAVE;        // waves per list
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= 2 * wpl) return;
+    const int side = w >= wpl;
+    const int b0 = (side ? w - wpl : w) * SIDES_PER_WAVE;
+    const int* mine = ids + side * B;
+    const int* other = ids + (1 - side) * B;
+    constexpr int CPL = D / 64;                  // columns per lane
+    // One scan of the list for the wave's four rows: per row the number of pairs naming it and the first of them.  (Almost always
+    // one pair, itself; the ordered walk below runs only for a row named more than once.)
+    int row[SIDES_PER_WAVE], cnt[SIDES_PER_WAVE], first[SIDES_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < SIDES_PER_WAVE; ++j) {
+        row[j] = b0 + j < B ? mine[b0 + j] : -1;
+        cnt[j] = 0;
+        first[j] = 0x7fffffff;
+    }
+    for (int k = lane; k < B; k += 64) {
+        const int v = mine[k];
+#pragma unroll
+        for (int j = 0; j < SIDES_PER_WAVE; ++j) {
+            const bool m = v == row[j];
+            cnt[j] += m ? 1 : 0;
+            first[j] = m ? min(first[j], k) : first[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SIDES_PER_WAVE; ++j) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            cnt[j] += __shfl_xor(cnt[j], m, 64);
+            first[j] = min(first[j], __shfl_xor(first[j], m, 64));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SIDES_PER_WAVE; ++j) {
+        const int b = b0 + j;
+        if (b >= B) break;
+        if (row[j] < 0) {                        // out-of-range pair: no write anywhere, counted once
+            if (side == 0 && lane == 0 && bad) atomicAdd(bad, 1);
+            continue;
+        }
+        if (first[j] != b) continue;             // an earlier pair names this row: its wave does the sum
+        float acc[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+        auto add = [&](int kk) {
+            const float gk = g[kk];
+            const size_t orow = (size_t)other[kk];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int col = lane + 64 * c;
+                float y;
+                if constexpr (sizeof(T) == 4) y = reinterpret_cast<const float*>(F)[orow * D + col];
+                else y = bf16_to_f32(reinterpret_cast<const uint16_t*>(F)[orow * D + col]);
+                acc[c] = fmaf(gk, y, acc[c]);
+            }
+        };
+        if (cnt[j] == 1) {
+            add(b);
+        } else {                                 // the pairs naming the row, in ascending order
+            for (int k0 = b & ~63; k0 < B; k0 += 64) {
+                const int k = k0 + lane;
+                unsigned long long m = __ballot(k < B && k >= b && mine[k] == row[j]);
+                while (m) {
+                    add(k0 + __builtin_ctzll(m));
+                    m &= m - 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) gF[(size_t)row[j] * D + lane + 64 * c] += acc[c];
+    }
+}
+
+// The same with float atomics (the order of the additions is not fixed): batches beyond SCORE_BWD_DET_MAX_B pairs only.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void score_bwd_atomic_kernel(const T* __restrict__ F, const int64_t* __restrict__ u,
+                                                               const int64_t* __restrict__ it, const float* __restrict__ g,
+                                                               float* __restrict__ gF, int* __restrict__ bad, int B, int U, int I) {
     constexpr int PPW = 4;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -195,9 +290,15 @@ extern "C" int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define NGACF_CASE(T, D)                                                                                   \
     {                                                                                                      \
-        constexpr int PPB = 16;                                                                            \
-        hipLaunchKernelGGL((score_bwd_kernel<T, D>), dim3((B + PPB - 1) / PPB), dim3(256), 0, st,          \
-                           static_cast<const T*>(F), u, i, gscore, gF, bad_index, B, U, I);                              \
+        if (B <= SCORE_BWD_DET_MAX_B) {                                                                    \
+            const int waves = 2 * ((B + SIDES_PER_WAVE - 1) / SIDES_PER_WAVE);                             \
+            hipLaunchKernelGGL((score_bwd_kernel<T, D>), dim3((waves + 3) / 4), dim3(256), 2 * (size_t)B * sizeof(int), st, \
+                               static_cast<const T*>(F), u, i, gscore, gF, bad_index, B, U, I);            \
+        } else {                                                                                           \
+            constexpr int PPB = 16;                                                                        \
+            hipLaunchKernelGGL((score_bwd_atomic_kernel<T, D>), dim3((B + PPB - 1) / PPB), dim3(256), 0, st, \
+                               static_cast<const T*>(F), u, i, gscore, gF, bad_index, B, U, I);            \
+        }                                                                                                  \
         NGACF_CHECK_LAUNCH();                                                                              \
         return 0;                                                                                          \
     }

@@ -25,14 +25,19 @@ static Timing& timing() {
 
 bool timing_on() { return timing().on.load(std::memory_order_relaxed); }
 
-int timing_events(int tag, hipEvent_t* a, hipEvent_t* b) {
+int timing_events(hipEvent_t* a, hipEvent_t* b) {
     hipError_t e = hipEventCreate(a);
     if (e != hipSuccess) return static_cast<int>(e);
     e = hipEventCreate(b);
     if (e != hipSuccess) { (void)hipEventDestroy(*a); return static_cast<int>(e); }
-    std::lock_guard<std::mutex> lk(timing().mu);
-    timing().v.push_back({*a, *b, tag});
     return 0;
+}
+
+// AFTER the launch that records the pair has been issued: a concurrent ngacf_timing_end (another host thread) must never meet
+// an event that no launch has been attached to yet.  (A pair recorded after that end stays in the list until the next begin.)
+void timing_record(int tag, hipEvent_t a, hipEvent_t b) {
+    std::lock_guard<std::mutex> lk(timing().mu);
+    timing().v.push_back({a, b, tag});
 }
 
 }  // namespace ngacf

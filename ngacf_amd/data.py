@@ -136,8 +136,9 @@ REAL_WORKLOADS = ("gowalla_real", "yelp_real")
 def real_pairs(name):
     """(user int64[n], item int64[n], U, I): the interaction pairs of the reference's data/Gowalla/g_test.csv or data/Yelp/y_test.csv
     (loader layout data/loadGowalla.py:35-45), from the data fixture oracle/gen_real_pairs.py wrote
-    (tests/golden/<name>_test_pairs.npz: two id columns, sorted row-major, unique = the coalesced ui_mat of :244-253)."""
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "%s_test_pairs.npz" % name)
+    (data/real/<name>_test_pairs.npz: two id columns, sorted row-major, unique = the coalesced ui_mat of :244-253).  A DATA file
+    beside the package, not a test fixture (the product does not reach into tests/)."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "real", "%s_test_pairs.npz" % name)
     z = np.load(path)
     return z["user"].astype(np.int64), z["item"].astype(np.int64), int(z["U"]), int(z["I"])
 

@@ -16,7 +16,7 @@ class StageLink:
     """What travels from one stage of a stack to the next when the next stage's transform rides in this stage's traversal
     (ngacf_prop_fwd_next): `pack` (stage 0 only) = the later stages' weights to pack in the first transform's launch, `panels` =
     the packed panels by stage index, `pre` = (H, S) of the coming stage, produced by the previous traversal."""
-    __slots__ = ("pack", "panels", "pre", "pack_t", "panels_t", "saved", "node_pre", "defer_dw", "dw_jobs", "bwd_stages")
+    __slots__ = ("pack", "panels", "pre", "pack_t", "panels_t", "saved", "node_pre", "defer_dw", "dw_jobs", "bwd_stages", "dw_ctx")
 
     def __init__(self):
         self.pack, self.panels, self.pre = None, {}, None
@@ -28,6 +28,7 @@ class StageLink:
         # whose dX came out of the edge backward leave their dW / davec to ONE batched launch behind the stack's last backward
         # (ngacf_transform_dw_batch); dw_jobs = the pending jobs, bwd_stages = the stages that have a backward
         self.defer_dw, self.dw_jobs, self.bwd_stages = False, [], set()
+        self.dw_ctx = None           # (plan, seed_dev, stream) of the pending jobs, for the end-of-backward flush (_defer_dw)
 
 
 def _transform_or_pre(X, W, avec, plan, heads, h_dtype, feat_drop_p, seed, seed_dev, link):
@@ -87,15 +88,42 @@ DEFER_DW = __import__("os").environ.get("NGACF_DEFER_DW", "1") != "0"      # A/B
 FUSE_DX_NODE = __import__("os").environ.get("NGACF_FUSE_DX_NODE", "1") != "0"   # A/B switch (fp32 storage): the previous stage's step 1 in the dX kernel
 
 
+def _launch_dw(link):
+    jobs, link.dw_jobs = link.dw_jobs, []
+    plan, seed_dev, _ = link.dw_ctx
+    for k in range(0, len(jobs), ops._lib.DW_BATCH_MAX):
+        ops.transform_dw_batch(jobs[k:k + ops._lib.DW_BATCH_MAX], plan.U, plan.I, seed_dev)
+
+
 def _flush_dw(bw, plan, seed_dev):
     """the stack's last backward stage: every deferred weight gradient in one launch"""
     if bw is None:
         return
     link, s = bw
     if link.dw_jobs and s == min(link.bwd_stages):
-        jobs, link.dw_jobs = link.dw_jobs, []
-        for k in range(0, len(jobs), ops._lib.DW_BATCH_MAX):
-            ops.transform_dw_batch(jobs[k:k + ops._lib.DW_BATCH_MAX], plan.U, plan.I, seed_dev)
+        _launch_dw(link)
+
+
+def _defer_dw(link, job, plan, seed_dev):
+    """Park a stage's weight-gradient job for the chain's batched launch.  The launch normally rides behind the backward of the
+    stack's LOWEST stage (_flush_dw) -- but that backward need not run at all (torch.autograd.grad on later stages' parameters, a
+    frozen first stage whose inputs need no gradient): the first job of a backward pass therefore also queues an end-of-pass
+    callback that launches whatever is still pending, on the stream the jobs were recorded on, so that no handed-out dW / davec
+    tensor ever stays unwritten."""
+    first = not link.dw_jobs
+    link.dw_jobs.append(job)
+    link.dw_ctx = (plan, seed_dev, torch.cuda.current_stream() if job[0].is_cuda else None)
+
+    def _at_end():
+        if link.dw_jobs:
+            st = link.dw_ctx[2]
+            if st is not None:
+                with torch.cuda.stream(st):
+                    _launch_dw(link)
+            else:
+                _launch_dw(link)
+    if first:
+        torch.autograd.Variable._execution_engine.queue_callback(_at_end)
 
 
 def _transform_bwd_after(bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed, seed_dev):
@@ -115,7 +143,7 @@ def _transform_bwd_after(bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed
             else:
                 dX, _, _ = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev, part="dx")
             dW, da = torch.empty(2, 64, 64, dtype=torch.float32, device=H.device), torch.empty(2, 64, dtype=torch.float32, device=H.device)
-            bw[0].dw_jobs.append((X, H, dH, dS, heads, feat_drop_p, seed, dW, da))
+            _defer_dw(bw[0], (X, H, dH, dS, heads, feat_drop_p, seed, dW, da), plan, seed_dev)
             _flush_dw(bw, plan, seed_dev)                    # (fp32 storage: every stage comes through here, the chain's first one too)
             return dX, dW, da
         r = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev)
@@ -126,7 +154,7 @@ def _transform_bwd_after(bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed
         link.node_pre[s - 1] = (dx.dX, dx.Gn, dx.ST, dx.dS)
     if link.defer_dw and DEFER_DW and tuple(W.shape) == (2, 64, 64) and H.dtype == torch.bfloat16:
         dW, da = torch.empty(2, 64, 64, dtype=torch.float32, device=H.device), torch.empty(2, 64, dtype=torch.float32, device=H.device)
-        link.dw_jobs.append((X, H, dH, dS, heads, feat_drop_p, seed, dW, da))
+        _defer_dw(link, (X, H, dH, dS, heads, feat_drop_p, seed, dW, da), plan, seed_dev)
     else:
         _, dW, da = ops.transform_bwd(X, W, H, dH, dS, plan.U, plan.I, heads, feat_drop_p, seed, seed_dev, part="dw")
     _flush_dw(bw, plan, seed_dev)
@@ -254,15 +282,20 @@ class _Sink(torch.autograd.Function):
     accumulates into .grad, and the owner of the sink decides how the pieces are summed (ngacf_adam_step takes two)."""
 
     @staticmethod
-    def forward(ctx, p, sink, key):
-        ctx.sink, ctx.key = sink, key
+    def forward(ctx, p, sink, key, deferred=False):
+        ctx.sink, ctx.key, ctx.deferred = sink, key, deferred
         return p.view_as(p)
 
     @staticmethod
     def backward(ctx, g):
         prev = ctx.sink.get(ctx.key)
+        if prev is not None and ctx.deferred:
+            # a deferred sink's pieces may still be unwritten (the chain's batched dW launch fills them at the end of the backward):
+            # adding two of them here would read uninitialised memory, silently
+            raise RuntimeError("grad_sink(deferred_ok=True) takes ONE gradient piece per parameter: a parameter was read twice inside "
+                               "the block (or two chains share the sink); give each chain its own sink, or drop deferred_ok")
         ctx.sink[ctx.key] = g if prev is None else prev + g
-        return None, None, None
+        return None, None, None, None
 
 
 _SINKS = threading.local()
@@ -270,14 +303,18 @@ _SINKS = threading.local()
 
 class grad_sink:
     """with grad_sink(d): parameters read by the modules of this package inside the block (stage weights, embedding tables)
-    deliver their gradient to d[parameter] in the backward, not to parameter.grad."""
+    deliver their gradient to d[parameter] in the backward, not to parameter.grad.
+    deferred_ok=True: the OWNER of the sink promises to read it only after the whole backward pass has finished (and its streams
+    have been joined).  Only then may a stage hand the sink a weight gradient that is FILLED LATER -- by the chain's one batched
+    ngacf_transform_dw_batch launch (StageLink.defer_dw); such a sink takes one piece per parameter (a second piece would be
+    added to memory that may not have been written yet: it raises).  Without the flag every piece is complete when it arrives."""
 
-    def __init__(self, sink):
-        self.sink = sink
+    def __init__(self, sink, deferred_ok=False):
+        self.sink, self.deferred_ok = sink, bool(deferred_ok)
 
     def __enter__(self):                     # (sink None: an explicit "no sink here" -- parameters get .grad as usual)
         stack = _SINKS.__dict__.setdefault("stack", [])
-        stack.append(self.sink)
+        stack.append((self.sink, self.deferred_ok))
         return self.sink
 
     def __exit__(self, *exc):
@@ -286,15 +323,21 @@ class grad_sink:
 
 def sink_active():
     stack = _SINKS.__dict__.get("stack")
-    return bool(stack) and stack[-1] is not None
+    return bool(stack) and stack[-1][0] is not None
+
+
+def sink_defers():
+    """Is the innermost sink one whose owner accepts gradients that are filled after they were handed over (grad_sink(deferred_ok=True))?"""
+    stack = _SINKS.__dict__.get("stack")
+    return bool(stack) and stack[-1][0] is not None and stack[-1][1]
 
 
 def through_sink(p):
     """p itself, or (inside a grad_sink block, for a parameter that wants a gradient) p behind the sink"""
     stack = _SINKS.__dict__.get("stack")
-    if not stack or stack[-1] is None or not p.requires_grad or not torch.is_grad_enabled():
+    if not stack or stack[-1][0] is None or not p.requires_grad or not torch.is_grad_enabled():
         return p
-    return _Sink.apply(p, stack[-1], p)
+    return _Sink.apply(p, stack[-1][0], p, stack[-1][1])
 
 
 class _Score(torch.autograd.Function):

@@ -130,9 +130,10 @@ class GraphedBPRStep:
                     # split_grads: every branch parks its parameter gradients in its own sink and the optimizer's kernel adds
                     # the two (ngacf_adam_step's grads2) -- autograd would run one accumulation kernel per parameter, eight
                     # launch-bound kernels at the very end of the slower branch
-                    with torch.cuda.stream(sa), NF.grad_sink(sinks[0] if split_grads else None):
+                    # (deferred_ok: this step reads its sinks after the whole backward and after both branch streams were joined)
+                    with torch.cuda.stream(sa), NF.grad_sink(sinks[0] if split_grads else None, deferred_ok=True):
                         ps = model(self.u, self.p, adj)
-                    with torch.cuda.stream(sb), NF.grad_sink(sinks[1] if split_grads else None):
+                    with torch.cuda.stream(sb), NF.grad_sink(sinks[1] if split_grads else None, deferred_ok=True):
                         ns = model(self.u, self.n, adj)
                     cur.wait_stream(sa)
                     cur.wait_stream(sb)

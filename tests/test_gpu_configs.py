@@ -207,6 +207,8 @@ def _full_size_check(dev, workload, dt, d=64, stages=3, renumber=False):
     else:
         edge = D.synthetic_bipartite(U, I, E, seed=2019, device=dev)
         assert abs(edge.shape[1] - E) < 0.01 * E
+        if renumber:                                   # bench.py's ingest (ingest_graph): the plan the headline is timed on
+            edge = D.renumber(edge, *D.degree_order(edge, U, I))
     torch.manual_seed(5)
     if stages == 3 and d == 64:
         m = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev).train()
@@ -241,6 +243,7 @@ def _full_size_check(dev, workload, dt, d=64, stages=3, renumber=False):
     assert err_F < out_tol * max(fmax, 1.0), (err_F, fmax)
     smax = float(max(ps64.detach().abs().max(), ns64.detach().abs().max()))
     assert float((ps.double() - ps64.detach()).abs().max()) < out_tol * max(smax, 1.0) * (4 if dt == "fp32" else 1)
+    assert float((ns.double() - ns64.detach()).abs().max()) < out_tol * max(smax, 1.0) * (4 if dt == "fp32" else 1)
     assert abs(float(loss.detach()) - float(loss64.detach())) < loss_tol
     gX = torch.cat([m.uEmbd.weight.grad, m.iEmbd.weight.grad])
     errs = {"embeddings": _rel_l2(gX, X64.grad)}
@@ -260,19 +263,56 @@ def _full_size_check(dev, workload, dt, d=64, stages=3, renumber=False):
     assert torch.equal(a1, a2) and not torch.equal(a1, a3) and bool(torch.isfinite(a1.float()).all())
 
 
+@pytest.mark.parametrize("workload,renumber", [("gowalla", False), ("yelp", False), ("gowalla", True), ("yelp", True)])
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_full_size_three_stage_stack_forward_and_gradients(dev, workload, renumber, dt):
+    """BASELINE configs 1 and 2 at their full shapes: SPUIMultiGACF (L=3) propagation, B=2048 pair scores (positive AND negative),
+    BPR loss and the gradient of every parameter (both embedding tables, 3 x {W, a}) against the float64 statement + torch
+    autograd -- under the generator's ids and under the degree numbering of bench.py's ingest (the benched plan)."""
+    _full_size_check(dev, workload, dt, renumber=renumber)
+
+
 @pytest.mark.parametrize("workload", ["gowalla", "yelp"])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-def test_full_size_three_stage_stack_forward_and_gradients(dev, workload, dt):
-    """BASELINE configs 1 and 2 at their full shapes: SPUIMultiGACF (L=3) propagation, B=2048 pair scores, BPR loss and
-    the gradient of every parameter (both embedding tables, 3 x {W, a}) against the float64 statement + torch autograd."""
-    _full_size_check(dev, workload, dt)
+def test_the_benched_path_itself_against_float64(dev, workload, dt):
+    """What bench.py TIMES, tested directly: the eval-mode forward of the degree-renumbered synthetic graph
+    as GraphedPropagate replays it -- one captured hipGraph, every later stage's transform in the previous traversal's tail --
+    against the float64 statement at full size; the replay is run twice (a replayed graph must not depend on its first run)."""
+    import ngacf_amd
+    from ngacf_amd import data as D
+    from ngacf_amd.graphs import GraphedPropagate
+    U, I, _ = D.SHAPES[workload]
+    edge = D.workload_graph(workload, dev)
+    edge = D.renumber(edge, *D.degree_order(edge, U, I))              # bench.ingest_graph
+    torch.manual_seed(2019)
+    m = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.1).to(dev)
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30.0); m.iEmbd.weight.mul_(30.0)
+    if dt == "bf16":
+        ngacf_amd.set_compute_dtype(m, torch.bfloat16)
+    m.eval()
+    with torch.no_grad():
+        run = GraphedPropagate(m, edge)
+        run()
+        first = run.out.clone()
+        run()
+        torch.cuda.synchronize()
+        assert torch.equal(first, run.out)
+        eager = m.propagate(edge)
+        assert torch.equal(eager, run.out)                             # the replayed graph == the eager launches, bit for bit
+        X64 = torch.cat([m.uEmbd.weight, m.iEmbd.weight]).double()
+        F64 = stack_f64(X64, [(W.detach(), a.detach(), h) for W, a, h in _stages_of(m)], edge, U, I)
+    tol = FP32_OUT if dt == "fp32" else BF16_OUT
+    err, fmax = float((run.out.double() - F64).abs().max()), float(F64.abs().max())
+    print("%s %s benched path: |F| max %.3f, err %.2e" % (workload, dt, fmax, err))
+    assert err < tol * max(fmax, 1.0), (err, fmax)
 
 
 @pytest.mark.parametrize("workload,renumber", [("gowalla_real", False), ("gowalla_real", True), ("yelp_real", True)])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_real_topology_three_stage_stack_forward_and_gradients(dev, workload, renumber, dt):
     """The same full-stack check on REAL topology: the interaction lists the reference ships (data/Gowalla/g_test.csv: 217 242
-    pairs, a 895-edge item, 2 435 isolated items; data/Yelp/y_test.csv: 253 578 pairs), fixtures tests/golden/*_test_pairs.npz --
+    pairs, a 895-edge item, 2 435 isolated items; data/Yelp/y_test.csv: 253 578 pairs), data files data/real/*_test_pairs.npz --
     real hubs, real isolated items, under the data set's ids and under the ingest's degree numbering."""
     _full_size_check(dev, workload, dt, renumber=renumber)
 

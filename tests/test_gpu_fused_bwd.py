@@ -457,3 +457,37 @@ def test_flagged_backward_equals_the_unflagged_one_on_a_gradient_that_is_zero_ou
     torch.cuda.synchronize()
     assert torch.equal(_bits(dH_s2), _bits(dH_f)) and torch.equal(_bits(dS_s2), _bits(dS_f))
     assert float((dH_s.float() - dH_f.float()).abs().max()) <= 2e-2 * float(dH_f.float().abs().max())
+
+
+def test_deferred_weight_gradients_are_written_even_when_the_lowest_stage_has_no_backward(dev):
+    """inside a deferred gradient sink a stage hands out dW / davec tensors that the chain's ONE batched launch fills
+    behind the backward of the stack's lowest stage.  When that backward never runs (torch.autograd.grad on the LATER stages'
+    parameters only) the end-of-pass callback must launch the batch: the gradients equal the ones of a plain backward."""
+    import ngacf_amd
+    from ngacf_amd import functional as NF
+    U, I = 700, 500
+    edge = torch.from_numpy(_graph(U, I, 20000, 3, hub=300)).to(dev)
+    torch.manual_seed(3)
+    m = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev).train()
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30.0); m.iEmbd.weight.mul_(30.0)
+    ngacf_amd.set_compute_dtype(m, torch.bfloat16)
+    later = [p for n, p in m.named_parameters() if "stage1" in n or "stage2" in n]
+    assert later
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    u, it = torch.randint(0, U, (128,), device=dev, generator=g), torch.randint(0, I, (128,), device=dev, generator=g)
+    type(m).sparse_last_stage, was = False, type(m).sparse_last_stage      # (every stage dense: the jobs of stages 1 and 2 are deferred)
+    try:
+        want = torch.autograd.grad(m(u, it, edge).sum(), later)
+        sink = {}
+        with NF.grad_sink(sink, deferred_ok=True):
+            y = m(u, it, edge).sum()
+        torch.autograd.grad(y, [p for p in later], allow_unused=True)       # the sunk parameters deliver to `sink`; stage 0's backward does not run
+        torch.cuda.synchronize()
+    finally:
+        type(m).sparse_last_stage = was
+    assert len(sink) >= len(later)
+    for p_, w in zip(later, want):
+        # (the batched launch and the per-stage one reduce their partial sums in different orders: equal to fp32 rounding)
+        err = float((sink[p_].double() - w.double()).norm() / w.double().norm().clamp_min(1e-30))
+        assert bool(torch.isfinite(sink[p_]).all()) and err < 1e-5, (tuple(p_.shape), err)

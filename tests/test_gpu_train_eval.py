@@ -409,6 +409,7 @@ def test_bench_prints_one_contract_line():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
+    assert len(lines[0]) < 6144, len(lines[0])                            # the driver's record keeps an 8 KB tail
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -416,35 +417,43 @@ def test_bench_prints_one_contract_line():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "edges/s" and d["vs_baseline"] is None
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
-    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
-    ac = d["cpu_baseline"]["all_cores"]                                   # every usable core, or why that is the 16-thread figure already
-    assert d["cpu_baseline"]["cores"] <= 16 and (ac["value"] is not None or "skipped" in ac)
+    cb = d["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] == "port"
+    ac = cb["all_cores"]                                                  # every usable core, or why that is the 16-thread figure already
+    assert cb["cores"] <= 16 and (ac["value"] is not None or "skipped" in ac)
+    # "... and 2 timed train steps" -- the CPU leg's pairs/s on a bounded subgraph, flat in cpu_baseline
+    assert cb["train_pairs_per_s"] > 0 and cb["train_cores"] <= 16 and "2 steps" in cb["train_sample"], cb
     assert "workload" in d["config"] and d["value"] > 1e9 and d["bpr_pairs_per_s"] > 1e5
+    # the second half of the metric where the driver's record keeps it: scalars of `config` / `roofline`
+    assert d["config"]["bpr_pairs_per_s"] == d["bpr_pairs_per_s"] and d["config"]["train_ms_per_step"] == d["train_ms_per_step"]
     # the timed region: exactly `steps` steps of passes_per_step passes, sized to last about --target-seconds
     R = d["config"]["passes_per_step"]
     assert R >= 50 and d["timed_region_s"] > 0.3 and abs(d["ms_per_step"] - 1e3 * d["timed_region_s"] / 3) < 0.02 * d["ms_per_step"]
-    assert abs(d["value"] - d["config"]["edges_directed_per_step"] * 3 / d["timed_region_s"]) < 0.01 * d["value"]
+    assert abs(d["value"] - d["config"]["edges_directed_per_pass"] * R * 3 / d["timed_region_s"]) < 0.01 * d["value"]
     assert 0.7 < d["value_median_window"] / d["value"] < 1.3
     rf = d["roofline"]
-    # Gowalla scale: the 9 MB table never leaves L2 + Infinity Cache -- the roof is the cache row-gather blend and the fraction
-    # of it stays at or below 1; the HBM figure is kept apart under its own name
-    assert rf["regime"].startswith("cache-resident") and rf["bound"] == "l2+mall gather" and rf["launches_timed"] >= 300
-    assert 8600.0 <= rf["peak"] <= 17800.0 and 0.3 < rf["frac"] <= 1.0 and rf["frac_hbm_algorithmic"] > rf["frac"]
-    assert rf["traffic"] is None or "from_profile" in rf["traffic_source"]
+    # Gowalla scale: the 9 MB table never leaves L2 + Infinity Cache -- the roof is the MEASURED one (the kernel's own stripped
+    # instantiation over the same plan, timed in this run); the kernel cannot beat it by more than timing noise; the HBM figure
+    # is kept apart under its own name
+    assert rf["regime"].startswith("cache-resident") and rf["bound"] == "l2+mall gather (measured roof)" and rf["launches_timed"] >= 300
+    assert rf["peak"] == rf["measured_gather_roof_GBps"] and 8600.0 <= rf["peak"] <= 34500.0 and 0.3 < rf["frac"] <= 1.02
+    assert rf["measured_gather_roof_us"] <= rf["gather_roof_one_add_per_element_us"] * 1.05 and rf["frac_hbm_algorithmic"] > rf["frac"]
     # the kernels' own durations (dispatch timestamps): the pass cannot be shorter than its kernels
-    kern_us = sum(rf["per_stage_us"]) + rf.get("transform_launch_us", 0.0) * rf.get("transform_launches_per_pass", 0)
+    kern_us = sum(rf["per_stage_us"]) + rf.get("transform_launch_us", 0.0)
     assert 0.8 * kern_us < 1e3 * d["ms_per_pass"] < 1.25 * kern_us, (kern_us, d["ms_per_pass"])
     assert d["config"]["fused_next_stage_transform"] and d["config"]["launches_per_pass"] == 4
-    assert d["train_traversals_per_step"]["performed"] < d["train_traversals_per_step"]["if_every_stage_ran_in_full"]
-    assert rf["frac_of_guide_gather_blend"] is not None and rf["frac_of_l2_peak_blend"] is not None        # both fixed fields, whatever the dtype
-    # north_star's target configuration in the reference's precision (fp32), the same in bf16 storage, and the headline graph in fp32
+    assert d["train_traversals_per_step"] < 4 * d["config"]["edges_directed_per_pass"]
+    assert rf["frac_of_guide_gather_blend"] is not None and rf["frac_of_l2_peak_blend"] is not None        # secondary, whatever the dtype
+    # north_star's target configuration in the reference's precision (fp32), the same in bf16 storage, and the headline graph in fp32:
+    # all graded against their own measured roof (one yardstick)
     for key, dt, floor in (("yelp_probe", "fp32", 2.5e10), ("yelp_probe_bf16", "bf16", 3e10), ("gowalla_fp32_probe", "fp32", 2.5e10)):
         yp = d[key]
         assert "error" not in yp and yp["dtype"] == dt and yp["value"] > floor, (key, yp)
-        assert yp["roofline"]["bound"] == "l2+mall gather" and yp["roofline"]["frac"] <= 1.0 and yp["roofline"]["launches_timed"] >= 150, (key, yp)
+        assert yp["roofline"]["bound"] == "l2+mall gather (measured roof)" and yp["roofline"]["frac"] <= 1.02, (key, yp)
     tr = d["train_roofline"]                                             # the train leg's dominant kernel: the dense edge backward
-    assert tr["bound"] == "l2+mall gather" and 0.2 < tr["frac"] <= 1.0 and tr["launches_timed"] >= 40 and len(tr["per_stage_us"]) == 3, tr
+    assert tr["bound"] == "l2+mall gather (measured roof)" and 0.2 < tr["frac"] <= 1.02 and tr["launches_timed"] >= 40 and len(tr["per_stage_us"]) == 3, tr
     assert abs(tr["frac"] - tr["achieved"] / tr["peak"]) < 1e-3 and tr["bytes_per_launch"] > d["roofline"]["bytes_per_launch"]
+    assert rf["train_avg_launch_us"] == tr["avg_launch_us"] and rf["train_frac"] == tr["frac"]
     # an edge backward launched alone cannot last longer than its share of the two-chain step
     assert 4 * tr["avg_launch_us"] < 1e3 * d["train_ms_per_step"], (tr["avg_launch_us"], d["train_ms_per_step"])
     pr = d["scaling_probe"]                                              # the same forward on the 10^9-edge graph, one GPU

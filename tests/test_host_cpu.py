@@ -411,6 +411,17 @@ def test_grad_sink_parks_parameter_gradients_and_adam_refuses_what_it_cannot_ste
     (ya + yb).backward()
     assert p.grad is None
     assert torch.equal(sink_a[p], torch.full((2, 3), 2.0)) and torch.equal(sink_b[p], torch.full((2, 3), 4.0))
+    # a sink whose owner accepts gradients that are filled later (the chain's batched dW launch) is opt-in, and takes ONE piece
+    # per parameter: a second piece would be added to memory that may still be unwritten
+    assert not NF.sink_defers()
+    with NF.grad_sink({}):
+        assert NF.sink_active() and not NF.sink_defers()
+    sink_c = {}
+    with NF.grad_sink(sink_c, deferred_ok=True):
+        assert NF.sink_defers()
+        yc = (NF.through_sink(p) * 2.0).sum() + (NF.through_sink(p) * 1.0).sum()
+    with pytest.raises(RuntimeError, match="ONE gradient piece"):
+        yc.backward()
     # the optimizer: same defaults and state_dict keys as torch's, loud on what the kernel does not do
     opt = Adam([p], lr=1e-2, weight_decay=1e-4)
     ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone())], lr=1e-2, weight_decay=1e-4)
