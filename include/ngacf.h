@@ -370,6 +370,20 @@ int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const int64_t* i
 int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
                     const float* gscore, float* gF, int32_t* bad_index, int B, int U, int I, int d, void* stream);
 
+/* Node-partitioned scoring (replaces the reference's replicas, parallel.py:94-196, for SPUIGACF.py:49-52 on a table whose rows
+ * are spread over the ranks): the 2B rows a batch reads, contributed by their owners.
+ *   ngacf_shard_rows:   rows float[2B][d]: row b = the fp32 copy of user u[b]'s (b < B) / item i[b - B]'s row of this rank's local
+ *                       tables Tu [cu][d] / Ti [ci][d] when this rank owns it (internal id in [u_lo, u_lo + cu) / [i_lo, i_lo + ci)),
+ *                       zeros otherwise -- the all-reduce of `rows` over the ranks then holds every row once;
+ *                       pos int32[2B] = the local row (users first, an item's behind the cu user rows) or -1;
+ *                       perm_u int64[U] / perm_i int64[I]: data-set id -> internal id, or NULL (identity).
+ *   ngacf_rows_scatter: du [cu][d] / di [ci][d] (dtype; zero-filled by the caller): row pos[b] = sum of g[b'] (float[n][d]) over
+ *                       the b' with pos[b'] == pos[b], ascending b' -- no atomics, bit-reproducible; n <= 16384. */
+int ngacf_shard_rows(const void* Tu, const void* Ti, int dtype, const int64_t* u, const int64_t* i, const int64_t* perm_u,
+                     const int64_t* perm_i, float* rows, int32_t* pos, int32_t* bad_index, int B, int U, int I,
+                     int u_lo, int cu, int i_lo, int ci, int d, void* stream);
+int ngacf_rows_scatter(const int32_t* pos, const float* g, void* du, void* di, int dtype, int n, int cu, int d, void* stream);
+
 /* optim.step() of the train loop (train_eval_Gowalla.py:137-138; torch.optim.Adam with L2 weight decay, run_Gowalla.py:114)
  * for up to NGACF_ADAM_MAX_TENSORS fp32 tensors in ONE launch.  The five pointer tables and numel are HOST arrays of `count`
  * entries (copied into the kernel's arguments); steps[t] points at the DEVICE float holding tensor t's step count AFTER this

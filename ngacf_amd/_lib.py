@@ -58,6 +58,8 @@ SIGNATURES = {
     "ngacf_sample_pairs": [_p, ctypes.c_longlong, ctypes.c_longlong, _p, _p, _i, _p, _p, _i, _u64, _p, _p, _p, _p, _p, _i, _p],
     "ngacf_eval_topk": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
     "ngacf_dropout_bits": [_i, _u64, _p, _p, _p, _p, _i, _p],
+    "ngacf_shard_rows": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ngacf_rows_scatter": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ngacf_timing_begin": [],
     "ngacf_timing_end": [_p, _p, _i],
     "ngacf_peer_alloc": [_u64, _p], "ngacf_peer_alloc_ctrl": [_u64, _p], "ngacf_peer_free": [_p], "ngacf_peer_export": [_p, _p], "ngacf_peer_import": [_p, _p],

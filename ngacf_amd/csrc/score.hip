@@ -163,6 +163,98 @@ __global__ __launch_bounds__(256) void score_bwd_atomic_kernel(const T* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Node-partitioned scoring (ngacf_amd/dist.py _RowExchange): the 2B rows a batch reads of a table whose rows are spread over the
+// ranks.  Every rank contributes the rows it owns (zeros elsewhere), ONE all-reduce of [2B, d] sums them (one non-zero term per
+// row: exact).  These two kernels replace ~25 index / compare / gather launches of 5 us each per forward and the index_add_ of
+// the backward.
+//   shard_rows:  rows[b] = fp32 copy of the local row of pair side b (b < B: user u[b]; else item it[b - B]) when this rank owns
+//                it, zeros otherwise; pos[b] = its local row (users first, items behind the cu user rows) or -1.
+//                perm_u / perm_i: data-set id -> internal id (the degree-dealt numbering), or NULL (identity).
+//   rows_scatter: d[pos[b]] = sum of g[b'] over all b' with pos[b'] == pos[b], in ascending b' (the first such b does the sum
+//                and the one store: no atomics, bit-reproducible); rows nobody names are not written (the caller zero-fills).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void shard_rows_kernel(const T* __restrict__ Tu, const T* __restrict__ Ti, const int64_t* __restrict__ u,
+                                                         const int64_t* __restrict__ it, const int64_t* __restrict__ perm_u,
+                                                         const int64_t* __restrict__ perm_i, float* __restrict__ rows, int* __restrict__ pos,
+                                                         int* __restrict__ bad, int B, int U, int I, int u_lo, int cu, int i_lo, int ci) {
+    constexpr int LPR = D / 4;                                    // lanes per row: a float4 of the output each
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = (int)(t / LPR), q = (int)(t % LPR);
+    if (b >= 2 * B) return;
+    const bool user = b < B;
+    const int64_t id = user ? u[b] : it[b - B];
+    const bool in = id >= 0 && id < (user ? U : I);
+    int64_t internal = -1;
+    if (in) internal = user ? (perm_u ? perm_u[id] : id) : (perm_i ? perm_i[id] : id);
+    const int lo = user ? u_lo : i_lo, n = user ? cu : ci;
+    const bool mine = in && internal >= lo && internal < lo + n;
+    const int local = mine ? (int)(internal - lo) : 0;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mine) {
+        const T* src = (user ? Tu : Ti) + (size_t)local * D + 4 * q;
+        if constexpr (sizeof(T) == 4) v = *reinterpret_cast<const float4*>(src);
+        else {
+            const uint2 w = *reinterpret_cast<const uint2*>(src);
+            v = make_float4(bf16_to_f32(w.x & 0xffffu), bf16_to_f32(w.x >> 16), bf16_to_f32(w.y & 0xffffu), bf16_to_f32(w.y >> 16));
+        }
+    }
+    *reinterpret_cast<float4*>(rows + (size_t)b * D + 4 * q) = v;
+    if (q == 0) {
+        pos[b] = mine ? (user ? local : cu + local) : -1;
+        if (!in && bad) atomicAdd(bad, 1);
+    }
+}
+
+constexpr int ROWS_SCATTER_MAX_N = 16384;        // ids in 64 KB of LDS
+template <typename T, int D>
+__global__ __launch_bounds__(256) void rows_scatter_kernel(const int* __restrict__ pos, const float* __restrict__ g, T* __restrict__ du,
+                                                           T* __restrict__ di, int n, int cu) {
+    extern __shared__ int ids[];
+    for (int k = threadIdx.x; k < n; k += 256) ids[k] = pos[k];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int row = ids[b];
+    if (row < 0) return;
+    int cnt = 0, first = 0x7fffffff;
+    for (int k = lane; k < n; k += 64) {
+        const bool m = ids[k] == row;
+        cnt += m ? 1 : 0;
+        first = m ? min(first, k) : first;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        cnt += __shfl_xor(cnt, m, 64);
+        first = min(first, __shfl_xor(first, m, 64));
+    }
+    if (first != b) return;                      // an earlier entry names this row: its wave does the sum
+    constexpr int CPL = D / 64;
+    float acc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = g[(size_t)b * D + lane + 64 * c];
+    if (cnt > 1) {
+        for (int k0 = (b + 1) & ~63; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            unsigned long long m = __ballot(k < n && k > b && ids[k] == row);
+            while (m) {
+                const int kk = k0 + __builtin_ctzll(m);
+                m &= m - 1;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) acc[c] += g[(size_t)kk * D + lane + 64 * c];
+            }
+        }
+    }
+    T* dst = row < cu ? du + (size_t)row * D : di + (size_t)(row - cu) * D;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        if constexpr (sizeof(T) == 4) reinterpret_cast<float*>(dst)[lane + 64 * c] = acc[c];
+        else reinterpret_cast<uint16_t*>(dst)[lane + 64 * c] = (uint16_t)f32_to_bf16(acc[c]);
+    }
+}
+
 // bit u[b] and bit U + it[b] of `needed` set for the pairs of a batch, and the same rows as a list (rows[b] = u[b], rows[B + b] =
 // U + it[b]; -1 for an id out of range: the scoring kernels report those).  u == NULL: items only (rows[b] = U + it[b]).
 // gzero != NULL: rows u[b] and U + it[b] of that float [N][d] table are zeroed (where ngacf_score_bwd will add the batch's
@@ -369,4 +461,48 @@ extern "C" int ngacf_dropout_bits(int kind, uint64_t seed, const int32_t* a, con
                        kind, seed, a, b, c, bits, n);
     NGACF_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int ngacf_shard_rows(const void* Tu, const void* Ti, int dtype, const int64_t* u, const int64_t* i, const int64_t* perm_u,
+                                const int64_t* perm_i, float* rows, int32_t* pos, int32_t* bad_index, int B, int U, int I,
+                                int u_lo, int cu, int i_lo, int ci, int d, void* stream) {
+    if (B < 0 || U <= 0 || I <= 0 || cu < 0 || ci < 0 || u_lo < 0 || i_lo < 0) return NGACF_E_ARG;
+    if (B == 0) return 0;
+    if (!u || !i || !rows || !pos || (cu > 0 && !Tu) || (ci > 0 && !Ti)) return NGACF_E_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NGACF_CASE(T, D)                                                                                                       \
+    {                                                                                                                          \
+        const size_t threads = (size_t)2 * B * (D / 4);                                                                        \
+        hipLaunchKernelGGL((shard_rows_kernel<T, D>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,               \
+                           static_cast<const T*>(Tu), static_cast<const T*>(Ti), u, i, perm_u, perm_i, rows, pos, bad_index,   \
+                           B, U, I, u_lo, cu, i_lo, ci);                                                                       \
+        NGACF_CHECK_LAUNCH();                                                                                                  \
+        return 0;                                                                                                              \
+    }
+    if (dtype == NGACF_F32 && d == 64) NGACF_CASE(float, 64)
+    if (dtype == NGACF_F32 && d == 128) NGACF_CASE(float, 128)
+    if (dtype == NGACF_BF16 && d == 64) NGACF_CASE(bf16_t, 64)
+    if (dtype == NGACF_BF16 && d == 128) NGACF_CASE(bf16_t, 128)
+#undef NGACF_CASE
+    return NGACF_E_SHAPE;
+}
+
+extern "C" int ngacf_rows_scatter(const int32_t* pos, const float* g, void* du, void* di, int dtype, int n, int cu, int d, void* stream) {
+    if (n < 0 || cu < 0) return NGACF_E_ARG;
+    if (n == 0) return 0;
+    if (!pos || !g || n > ROWS_SCATTER_MAX_N) return NGACF_E_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NGACF_CASE(T, D)                                                                                                       \
+    {                                                                                                                          \
+        hipLaunchKernelGGL((rows_scatter_kernel<T, D>), dim3((n + 3) / 4), dim3(256), (size_t)n * sizeof(int), st,             \
+                           pos, g, static_cast<T*>(du), static_cast<T*>(di), n, cu);                                           \
+        NGACF_CHECK_LAUNCH();                                                                                                  \
+        return 0;                                                                                                              \
+    }
+    if (dtype == NGACF_F32 && d == 64) NGACF_CASE(float, 64)
+    if (dtype == NGACF_F32 && d == 128) NGACF_CASE(float, 128)
+    if (dtype == NGACF_BF16 && d == 64) NGACF_CASE(bf16_t, 64)
+    if (dtype == NGACF_BF16 && d == 128) NGACF_CASE(bf16_t, 128)
+#undef NGACF_CASE
+    return NGACF_E_SHAPE;
 }

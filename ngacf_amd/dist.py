@@ -158,8 +158,37 @@ class Comm:
         self.launches = 0                     # collective launches issued (for the tests / the bench line)
         self.timer = None                     # list -> (start event, end event, bytes received) per gather (bench, serial mode)
         self.dry_run = False                  # tools/shard_compute.py: one rank's kernels of a P-way partition, no collectives
+        self.inline = False                   # True: every gather synchronously in the caller's stream order (start_gather)
+        # A gather that brings this rank fewer bytes than this goes in the caller's stream order too: an asynchronous launch hides
+        # the transfer behind the other half's traversal but pays a fork and a join (~10 us each inside a replayed graph) -- about
+        # what 4 MiB take at the ~300 GB/s a rank receives over xGMI.  Gowalla-scale half tables stay below it; the 10^9-edge graph's
+        # 240 MB halves do not.  (NGACF_DIST_INLINE_BYTES=0: always asynchronous, the schedule of rounds 1-4.)
+        self.inline_below = int(os.environ.get("NGACF_DIST_INLINE_BYTES", str(4 << 20)))
 
     peer_store = False                        # (ngacf_amd.peer.PeerComm: gathers by stores into the peers' tables)
+
+    def twin(self):
+        """A SECOND communicator over the same ranks (its own process group = its own RCCL communicator and its own c10d stream),
+        with this one's switches: the two propagation chains of a train step run as concurrent branches, each on its own
+        communicator -- collectives of different communicators share nothing, so the order in which the GPU picks the two
+        branches' kernels need not agree between the ranks (one communicator driven from two streams would need exactly that).
+        dist.new_group is itself a collective call: every rank creates the twin at the same point (ShardedSPUIGACF.__init__)."""
+        if not dist.is_initialized():
+            return self
+        ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
+        t = Comm(self.part, dist.new_group(ranks=ranks, backend=dist.get_backend(self.group)))
+        t._primary = self
+        return t
+
+    _primary = None
+    _MIRRORED = ("force", "defer_weight_reduce", "overlap", "dry_run", "inline_below")
+
+    def sync_switches(self):
+        """(a twin takes the switches of its primary at every use: bench.py and the tests set them on model.comm after construction)"""
+        if self._primary is not None:
+            for k in self._MIRRORED:
+                setattr(self, k, getattr(self._primary, k))
+        return self
 
     @property
     def active(self):
@@ -194,7 +223,23 @@ class Comm:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
         self.launches += 1 if (self._coalesce or len(regions) == 1) else len(regions)
-        if self._base:
+        recv = sum(o.numel() * o.element_size() for o, _, _ in regions) * (self.world - 1) // max(self.world, 1)
+        if self.inline or (self.overlap and recv < self.inline_below):
+            # IN the caller's stream order (c10d runs a synchronous collective on the current stream): no communicator-side stream,
+            # no fork / join around the launch.  The graphed train step's two concurrent chains use this form -- the OTHER chain's
+            # work is what hides a gather then -- because a fork / join nested inside a forked branch crashes hipGraph
+            # instantiation on this runtime (segfault in capture_end: tools/graph_topology_probe.py).
+            if self._base:
+                ctx = dist.distributed_c10d._coalescing_manager(group=self.group) if (self._coalesce and len(regions) > 1) \
+                    else contextlib.nullcontext()
+                with ctx:
+                    for out, mine, _ in regions:
+                        dist.all_gather_into_tensor(out, mine, group=self.group)
+            else:
+                for out, mine, n in regions:
+                    dist.all_gather([out[r * n:(r + 1) * n] for r in range(self.world)], mine.clone(), group=self.group)
+            h = _Handle()
+        elif self._base:
             if self._coalesce and len(regions) > 1:
                 with dist.distributed_c10d._coalescing_manager(group=self.group, async_ops=True) as cm:
                     for out, mine, _ in regions:
@@ -395,7 +440,8 @@ class _RowExchange(torch.autograd.Function):
     """rows[b] = table row `idx[b]` (internal global row) on EVERY rank: each rank contributes the rows it owns, zeros
     elsewhere, one all-reduce of [B,d] sums them (one non-zero term per row: exact).  Replaces the all-gather of the
     whole [N,d] table for 3 x B rows.  Every rank computes the same loss, so the gradient of a row is identical on
-    all ranks and its owner adds it locally: no communication in the backward."""
+    all ranks and its owner adds it locally: no communication in the backward.  (The torch stand-in of the CPU tests;
+    the product runs _RowExchangeHIP.)"""
 
     @staticmethod
     def forward(ctx, out_u, out_i, idx, part, comm):
@@ -418,6 +464,31 @@ class _RowExchange(torch.autograd.Function):
         d = torch.zeros(cu + ci, g.shape[1], dtype=torch.float32, device=g.device)
         d.index_add_(0, pos, g.float() * mine[:, None].float())
         return d[:cu].to(dt), d[cu:].to(dt), None, None, None
+
+
+class _RowExchangeHIP(torch.autograd.Function):
+    """The same on the HIP library: ONE launch writes the rows this rank owns (and remembers where they sit: ngacf_shard_rows,
+    data-set ids -> internal ids -> local rows inside the kernel), the all-reduce, and in the backward ONE launch adds the
+    gradient rows into their owners' rows (ngacf_rows_scatter: no atomics).  The torch form above costs ~25 index / compare /
+    gather launches of 5 us per forward -- a quarter of the node-partitioned train step at Gowalla scale."""
+
+    @staticmethod
+    def forward(ctx, out_u, out_i, u, it, part, comm):
+        dev = out_u.device
+        pu = part._on("perm_u", dev) if part.perm_u is not None else None
+        pi = part._on("perm_i", dev) if part.perm_i is not None else None
+        rows, pos = _hip_ops.shard_rows(out_u.contiguous(), out_i.contiguous(), u, it, pu, pi, part.U, part.I, part.u_lo, part.i_lo)
+        comm.all_reduce_sum(rows)
+        ctx.save_for_backward(pos)
+        ctx.shape = (out_u.shape[0], out_i.shape[0], out_u.dtype)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        (pos,) = ctx.saved_tensors
+        cu, ci, dt = ctx.shape
+        du, di = _hip_ops.rows_scatter(pos, g.contiguous().float(), cu, ci, dt)
+        return du, di, None, None, None, None
 
 
 class ShardedSPUIGACF(nn.Module):
@@ -446,6 +517,12 @@ class ShardedSPUIGACF(nn.Module):
             self.comm = PeerComm(self.part, group, device=device)
         else:
             self.comm = Comm(self.part, group)
+        # the second propagation chain of a train step on its own communicator (Comm.twin; NGACF_DIST_TWO_COMMS=0: one chain after
+        # the other on the one communicator, the schedule of rounds 1-4).  Peer stores keep one chain at a time (shared tables).
+        self._comms = [self.comm, self.comm]
+        if not peer_store and dist.is_initialized() and os.environ.get("NGACF_DIST_TWO_COMMS", "1") != "0":
+            self._comms = [self.comm, self.comm.twin()]
+        self._chain = 0
         self.be = backend if backend is not None else _hip_ops
         p = self.part
         # Same values on every rank -- and at every world size -- as the unsharded model under the same torch seed: the random
@@ -517,12 +594,29 @@ class ShardedSPUIGACF(nn.Module):
         gu, gi = self.uEmbd.weight.grad, self.iEmbd.weight.grad
         return (ou[ou >= 0], gu[ou >= 0]), (oi[oi >= 0], gi[oi >= 0]), torch.cat([gu[ou < 0], gi[oi < 0]])
 
-    def reduce_grads(self):
+    def collective_launches(self, reset=False):
+        """collective launches issued so far on both communicators"""
+        cs = list({id(c): c for c in self._comms + [getattr(self, "_comm0_inline", None)] if c is not None}.values())
+        n = sum(c.launches for c in cs)
+        if reset:
+            for c in cs:
+                c.launches = 0
+        return n
+
+    def reduce_grads(self, sinks=None):
         """With comm.defer_weight_reduce: sum the stage-weight gradients over the ranks in ONE grouped all-reduce,
-        after backward() and before the optimizer step (embedding rows are owned, their gradients are local)."""
-        gs = [p.grad for p in self.gat.parameters() if p.grad is not None]
+        after backward() and before the optimizer step (embedding rows are owned, their gradients are local).
+        sinks: the gradient sinks of a step whose chains parked their pieces there (functional.grad_sink: .grad stays None) --
+        the stage weights' pieces of every sink travel in the one grouped launch."""
+        if sinks is None:
+            gs = [p.grad for p in self.gat.parameters() if p.grad is not None]
+        else:
+            mine = {id(p) for p in self.gat.parameters()}
+            gs = [g for sk in sinks for p, g in sk.items() if id(p) in mine and g is not None]
         if gs:
             self.comm.all_reduce_sum(*gs)
+
+    reduce_grads_takes_sinks = True
 
     # ---- graph ---------------------------------------------------------------------------------------------
     def attach_plan(self, plan):
@@ -555,6 +649,50 @@ class ShardedSPUIGACF(nn.Module):
             self._seed_ctr.add_(_CTR_STRIDE)
 
     # ---- forward ------------------------------------------------------------------------------------------
+    @property
+    def concurrent_chains(self):
+        """Should a CAPTURED train step run its two forwards as concurrent branches (each on its own communicator)?  The plumbing is
+        in place and tested (second communicator, in-order gathers: tests/test_dist_cpu.py; chain(k) in graphs.GraphedBPRStep), but
+        hipGraph instantiation of that step SEGFAULTS on this runtime (capture_end, one RCCL rank, with the collectives on the
+        communicators' own streams and with them in the branches' own order alike: profiles/README.md, r05 rehearsal) -- the
+        same failure tools/graph_topology_probe.py shows for cross-branch waits.  So: opt-in, NGACF_DIST_CONCURRENT_GRAPH=1."""
+        return self._comms[1] is not self._comms[0] and os.environ.get("NGACF_DIST_CONCURRENT_GRAPH", "0") == "1"
+
+    @contextlib.contextmanager
+    def chain(self, k, inline=False):
+        """with model.chain(k): forwards issued inside run on communicator k (0 / 1) -- graphs.GraphedBPRStep puts the two
+        propagations of a step on two streams and two communicators; their backwards follow (the autograd node holds its own).
+        inline: that chain's gathers in its stream's own order (Comm.inline): what a captured concurrent chain needs."""
+        was, self._chain = (self._chain, self._inline), int(k) & 1
+        self._inline = bool(inline)
+        try:
+            yield self
+        finally:
+            self._chain, self._inline = was
+
+    _inline = False
+
+    def _comm_now(self):
+        c = self._comms[self._chain].sync_switches()
+        if self._inline and c._primary is None and self._comms[1] is not self._comms[0]:
+            # (chain 0 of a concurrent pair: the primary communicator itself must not stay inline for its other users)
+            c = self._inline_view(c)
+        elif self._inline:
+            c.inline = True
+        else:
+            c.inline = False
+        return c
+
+    def _inline_view(self, c):
+        v = getattr(self, "_comm0_inline", None)
+        if v is None:
+            v = Comm(c.part, c.group)
+            v._primary = c
+            self._comm0_inline = v
+        v.sync_switches()
+        v.inline = True
+        return v
+
     def propagate_local(self, mask):
         """(out_u [cu,d], out_i [ci,d]): this rank's rows of the propagated embeddings."""
         plan = self._plan(mask)
@@ -569,12 +707,12 @@ class ShardedSPUIGACF(nn.Module):
         stages = self.gat._stages()
         params = []
         for s in range(len(stages)):
-            params.extend(self.gat.stage_params(s))
-        cfg = {"part": self.part, "plan": plan, "comm": self.comm, "be": self.be, "heads": [len(l) for l in stages],
+            params.extend(NF.through_sink(p_) for p_ in self.gat.stage_params(s))      # (behind the caller's gradient sink, if any)
+        cfg = {"part": self.part, "plan": plan, "comm": self._comm_now(), "be": self.be, "heads": [len(l) for l in stages],
                "alpha": stages[0][0].alpha, "drop": drop, "feat_drop": drop,
                "seeds": [NF.stage_seed(base, s) for s in range(len(stages))], "h_dtype": self.compute_dtype,
                "seed_dev": seed_dev, "grad_mode": torch.is_grad_enabled(), "fuse_next": NF.FUSE_NEXT}
-        return _ShardedStack.apply(self.uEmbd.weight, self.iEmbd.weight, *params, cfg)
+        return _ShardedStack.apply(NF.through_sink(self.uEmbd.weight), NF.through_sink(self.iEmbd.weight), *params, cfg)
 
     def propagate(self, mask):
         """The full [U+I, d] table of propagated embeddings in the data set's numbering, on every rank (evaluation)."""
@@ -585,8 +723,11 @@ class ShardedSPUIGACF(nn.Module):
         out_u, out_i = self.propagate_local(mask)
         p = self.part
         B = userIdx.numel()
-        idx = torch.cat([p.internal_users(userIdx.long()), p.internal_items(itemIdx.long()) + p.Up])
-        rows = _RowExchange.apply(out_u, out_i, idx, p, self.comm)                  # [2B, d]: user rows then item rows
+        if self.be is _hip_ops and 2 * B <= _hip_ops.ROWS_SCATTER_MAX_N:
+            rows = _RowExchangeHIP.apply(out_u, out_i, userIdx.long().contiguous(), itemIdx.long().contiguous(), p, self._comm_now())
+        else:
+            idx = torch.cat([p.internal_users(userIdx.long()), p.internal_items(itemIdx.long()) + p.Up])
+            rows = _RowExchange.apply(out_u, out_i, idx, p, self._comm_now())       # [2B, d]: user rows then item rows
         ar = torch.arange(B, device=rows.device)
         score = self.be.score if hasattr(self.be, "score") else NF.score
         return score(rows, ar, ar, B)                                                # SPUIGACF.py:49-52
@@ -904,9 +1045,9 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
             loss.backward()
             model.reduce_grads()                                          # one grouped all-reduce of the stage weights
             opt.step()
-        model.comm.launches = 0
+        model.collective_launches(reset=True)
         step()
-        per_step = model.comm.launches
+        per_step = model.collective_launches()
         sync()
         t0 = time.perf_counter()
         step()
@@ -1013,7 +1154,7 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
             from .graphs import GraphedBPRStep
             model.train()
             opt_g = _Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
-            gs = GraphedBPRStep(model, lossfn, opt_g, edge, B, concurrent_forwards=False, after_backward=model.reduce_grads)
+            gs = GraphedBPRStep(model, lossfn, opt_g, edge, B, concurrent_forwards=model.concurrent_chains, after_backward=model.reduce_grads)
             upn = torch.stack([ub, pb, nb])
             for _ in range(3):
                 gs(upn)
@@ -1025,7 +1166,9 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
             t_trg = allmax(time.perf_counter() - t0)
             if t_trg < t_tr:
                 extra = dict(extra, bpr_pairs_per_s=round(B * ksteps / t_trg, 1), train_ms_per_step=round(1e3 * t_trg / ksteps, 3),
-                             train_launch="hipGraph replay (kernels + RCCL launches + fused Adam)",
+                             train_launch="hipGraph replay (kernels + RCCL launches + fused Adam; %s)"
+                                          % ("the two propagation chains as concurrent branches on two communicators" if model.concurrent_chains
+                                             else "one chain after the other"),
                              train_ms_per_step_eager=round(1e3 * t_tr / ksteps, 3))
                 best = line(t_graph, win_graph, glaunch, extra, R_graph) if better else line(t_eager, win_eager, "eager", extra)
         except Exception as e:

@@ -45,6 +45,12 @@ def _gats(model):
     return [m for m in model.modules() if hasattr(m, "advance_device_seed") and hasattr(m, "use_device_seed")]
 
 
+def _chain(model, k):
+    """The node-partitioned model runs its two propagation chains on two communicators (ShardedSPUIGACF.chain); others: nothing."""
+    import contextlib
+    return model.chain(k, inline=True) if hasattr(model, "chain") else contextlib.nullcontext()
+
+
 class GraphedBPRStep:
     """step(users, pos, neg) -> loss (a device scalar, valid until the next call).
 
@@ -90,8 +96,10 @@ class GraphedBPRStep:
         fused_loss = (fuse_loss_node and isinstance(lossfn, BPRLoss) and isinstance(model, _CFBase)
                       and type(model).forward is _CFBase.forward)
         # after a step of this kind .grad of the sunk parameters is None (the pieces went straight to the optimizer)
+        # (with after_backward -- the node-partitioned model's weight-gradient all-reduce -- only when that hook takes the sinks)
+        hook_takes_sinks = after_backward is not None and getattr(getattr(after_backward, "__self__", None), "reduce_grads_takes_sinks", False)
         split_grads = (split_grads and concurrent_forwards and not shared_propagation and not fused_loss
-                       and getattr(optim, "supports_grad_pairs", False) and after_backward is None)
+                       and getattr(optim, "supports_grad_pairs", False) and (after_backward is None or hook_takes_sinks))
         sinks = ({}, {})
         direct_bpr = type(lossfn) is BPRLoss and split_grads           # this step owns its backward: see the join below
         own_steps = hasattr(optim, "step_counters")        # ngacf_amd.optim.Adam: its step counts join the step's one tick launch
@@ -131,9 +139,9 @@ class GraphedBPRStep:
                     # the two (ngacf_adam_step's grads2) -- autograd would run one accumulation kernel per parameter, eight
                     # launch-bound kernels at the very end of the slower branch
                     # (deferred_ok: this step reads its sinks after the whole backward and after both branch streams were joined)
-                    with torch.cuda.stream(sa), NF.grad_sink(sinks[0] if split_grads else None, deferred_ok=True):
+                    with torch.cuda.stream(sa), NF.grad_sink(sinks[0] if split_grads else None, deferred_ok=True), _chain(model, 0):
                         ps = model(self.u, self.p, adj)
-                    with torch.cuda.stream(sb), NF.grad_sink(sinks[1] if split_grads else None, deferred_ok=True):
+                    with torch.cuda.stream(sb), NF.grad_sink(sinks[1] if split_grads else None, deferred_ok=True), _chain(model, 1):
                         ns = model(self.u, self.n, adj)
                     cur.wait_stream(sa)
                     cur.wait_stream(sb)
@@ -148,12 +156,14 @@ class GraphedBPRStep:
                 loss = lossfn(model(self.u, self.p, adj), model(self.u, self.n, adj))
             if not (direct_bpr and concurrent_forwards and not shared_propagation and not fused_loss):
                 loss.backward()
-            if after_backward is not None:                  # e.g. the sharded model's grouped weight-gradient all-reduce
-                after_backward()
+            if after_backward is not None and not (sinks[0] or sinks[1]):
+                after_backward()                            # e.g. the sharded model's grouped weight-gradient all-reduce
             if sinks[0] or sinks[1]:
                 cur = torch.cuda.current_stream()           # the sinks were filled on the branch streams; no AccumulateGrad
                 cur.wait_stream(sa)                         # node synchronised them with this one
                 cur.wait_stream(sb)
+                if after_backward is not None:              # (the pieces of both chains in the hook's one grouped launch)
+                    after_backward(sinks)
                 keys = list(dict.fromkeys(list(sinks[0]) + list(sinks[1])))
                 optim.step(grad_pairs={k: (sinks[0].get(k), sinks[1].get(k)) for k in keys}, steps_incremented=own_steps)
                 sinks[0].clear()
@@ -249,5 +259,6 @@ def graphed_epoch_step(model, lossfn, optim, adj, batch_size, data, after_backwa
     if key not in cache:
         cache.clear()
         cache[key] = GraphedBPRStep(model, lossfn, optim, adj, batch_size, data=data, preserve_state=True,
-                                    concurrent_forwards=after_backward is None, after_backward=after_backward)
+                                    concurrent_forwards=after_backward is None or getattr(model, "concurrent_chains", False),
+                                    after_backward=after_backward)
     return cache[key]

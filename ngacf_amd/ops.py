@@ -578,6 +578,40 @@ def score_bwd(F, u, i, gscore, U, into=None):
     return gF
 
 
+ROWS_SCATTER_MAX_N = 16384
+
+
+def shard_rows(Tu, Ti, u, i, perm_u, perm_i, U, I, u_lo, i_lo):
+    """(rows float [2B, d], pos int32 [2B]) of ngacf_shard_rows: the batch's rows this rank owns (zeros elsewhere) and their local
+    row numbers (-1 elsewhere).  Tu [cu, d], Ti [ci, d]: the rank's local tables."""
+    dev, d, B = Tu.device, Tu.shape[1], u.numel()
+    cu, ci = Tu.shape[0], Ti.shape[0]
+    if d not in SUPPORTED_D or Tu.dtype not in _DT or Ti.dtype != Tu.dtype or Ti.shape[1] != d:
+        raise ValueError("shard_rows: tables [cu, d] / [ci, d] of one supported type, d in %s" % (SUPPORTED_D,))
+    rows = torch.empty(2 * B, d, dtype=torch.float32, device=dev)
+    pos = torch.empty(2 * B, dtype=torch.int32, device=dev)
+    if B:
+        _lib.check(lib.ngacf_shard_rows(_chk(Tu, "Tu", None, cu * d, dev) if cu else 0, _chk(Ti, "Ti", None, ci * d, dev) if ci else 0, _DT[Tu.dtype],
+                                        _idx(u, "userIdx", B, dev), _idx(i, "itemIdx", B, dev),
+                                        _chk(perm_u, "perm_u", torch.int64, U, dev, align=8) if perm_u is not None else 0,
+                                        _chk(perm_i, "perm_i", torch.int64, I, dev, align=8) if perm_i is not None else 0,
+                                        rows.data_ptr(), pos.data_ptr(), _bad_counter(dev).data_ptr(), B, U, I, int(u_lo), cu, int(i_lo), ci, d,
+                                        _stream()), "ngacf_shard_rows")
+    return rows, pos
+
+
+def rows_scatter(pos, g, cu, ci, dtype):
+    """(du [cu, d], di [ci, d]) in `dtype`: row pos[b] = the sum of the g[b'] naming it (ngacf_rows_scatter), zeros elsewhere."""
+    dev, (n, d) = g.device, g.shape
+    if n > ROWS_SCATTER_MAX_N or d not in SUPPORTED_D or dtype not in _DT:
+        raise ValueError("rows_scatter: at most %d rows of d in %s" % (ROWS_SCATTER_MAX_N, SUPPORTED_D))
+    du, di = torch.zeros(cu, d, dtype=dtype, device=dev), torch.zeros(ci, d, dtype=dtype, device=dev)
+    if n:
+        _lib.check(lib.ngacf_rows_scatter(_chk(pos, "pos", torch.int32, n, dev, align=4), _chk(g, "g", torch.float32, n * d, dev),
+                                          du.data_ptr(), di.data_ptr(), _DT[dtype], n, cu, d, _stream()), "ngacf_rows_scatter")
+    return du, di
+
+
 def bpr_fwd(pos, neg):
     dev, B = pos.device, pos.numel()
     loss = torch.empty((), dtype=torch.float32, device=dev)

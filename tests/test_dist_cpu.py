@@ -45,7 +45,14 @@ def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced
         m.comm.overlap = overlap
         m.train()
         u, pos, neg = (torch.from_numpy(g[k]) for k in ("u", "pos", "neg"))
-        ps, ns = m(u, pos, edge), m(u, neg, edge)
+        # the two propagations of a step on the model's TWO communicators (ShardedSPUIGACF.chain: what the graphed train step does
+        # with its two concurrent branches); the assertions below then cover the second communicator's forward and backward too
+        assert m._comms[1] is not m._comms[0] and m._comms[1].group is not m._comms[0].group and not m.concurrent_chains   # (captured concurrency: opt-in)
+        ps = m(u, pos, edge)
+        with m.chain(1, inline=not overlap):             # (inline: the gathers in the caller's own order, the captured step's form)
+            ns = m(u, neg, edge)
+        assert m._comms[1].launches > 0 and m._comms[1].overlap == overlap and m._comms[1].defer_weight_reduce == defer
+        assert m._comms[1].inline == (not overlap) and not m._comms[0].inline
         loss = -torch.log(torch.sigmoid(ps - ns)).mean()
         loss.backward()
         if defer:
