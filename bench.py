@@ -61,6 +61,8 @@ def parse(argv=None):
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: serial all-gather -> traversal schedule")
     ap.add_argument("--renumber", default="degree", choices=["degree", "none"],
                     help="node numbering at ingest (run_Gowalla.py --renumber): by degree, descending, or the generator's ids")
+    ap.add_argument("--no-roof", action="store_true", help="skip the measured gather roof (the stripped instantiations' launches): counter "
+                    "passes and kernel traces of the pass itself")
     ap.add_argument("--no-probe", action="store_true", help="skip the secondary legs: the Yelp / fp32 / 10^9-edge probes of the default "
                     "(gowalla) line and the two-passes-in-flight figure")
     a = ap.parse_args(argv)
@@ -416,7 +418,8 @@ def worker(args):
     med_ms = BK.median(windows)
     roofs = None
     try:
-        roofs = measure_roofs(torch, BK, ops, model, edge, U, I, args.seg_len, dims, args.dtype, 10 if big else 100)
+        if not args.no_roof:
+            roofs = measure_roofs(torch, BK, ops, model, edge, U, I, args.seg_len, dims, args.dtype, 10 if big else 100)
     except Exception as e:                        # (a secondary figure must not cost the line)
         print("[bench] gather roof failed: %r" % (e,), file=sys.stderr, flush=True)
     roofline = roofline_of(BK, D, wl, args.dtype, U, I, E, dims, elem, fm["prop_ms"], fm["n_timed"], fused, roofs)
@@ -479,7 +482,7 @@ def worker(args):
         t_tr, ksteps, loss = time_train(step)
         train_rl = None
         try:
-            broofs = None if big else measure_roofs(torch, BK, ops, model, edge, U, I, args.seg_len, dims, args.dtype, 100, bwd=True)
+            broofs = None if (big or args.no_roof) else measure_roofs(torch, BK, ops, model, edge, U, I, args.seg_len, dims, args.dtype, 100, bwd=True)
             train_rl = train_roofline_of(torch, BK, ops, eager_step, model, wl, args.dtype, U, I, E, dims, elem, roofs=broofs)
         except Exception as e:                        # (a secondary figure must not cost the line)
             print("[bench] train_roofline failed: %r" % (e,), file=sys.stderr, flush=True)

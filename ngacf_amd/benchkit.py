@@ -187,7 +187,7 @@ def cpu_model_name():
     return "unknown"
 
 
-_ROUNDS = ("r04", "r03", "r02", "r01")
+_ROUNDS = ("r05", "r04", "r03", "r02", "r01")
 
 
 def traffic_from_profile(root, workload, dtype, stages, d):
@@ -233,12 +233,13 @@ def bwd_hit_from_profile(root, workload, dtype):
     """(L2 hit rate of the dense edge backward, source): tools/traffic.py trainstep -- the kernels of the replayed train step under
     rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum, per workload and dtype.  (Only files of the round that wrote the current edge
     backward count: the split-sign kernel gathers other tables than rounds 1-3's.)"""
-    rel = os.path.join("profiles", "%s_traffic_trainstep%s.json" % (_ROUNDS[0], "" if workload == "gowalla" else "_" + workload))
-    p = os.path.join(root, rel)
-    if os.path.exists(p):
-        k = (json.load(open(p)).get("by_dtype", {}).get(dtype) or {}).get("kernels", {}).get("prop_bwd_kernel dense")
-        if k and k.get("l2_hit_rate") is not None:
-            return k["l2_hit_rate"], "from_profile: %s" % rel
+    for rnd in _ROUNDS[:2]:                                  # (r04 wrote the split-sign backward; r05 kept its gathers)
+        rel = os.path.join("profiles", "%s_traffic_trainstep%s.json" % (rnd, "" if workload == "gowalla" else "_" + workload))
+        p = os.path.join(root, rel)
+        if os.path.exists(p):
+            k = (json.load(open(p)).get("by_dtype", {}).get(dtype) or {}).get("kernels", {}).get("prop_bwd_kernel dense")
+            if k and k.get("l2_hit_rate") is not None:
+                return k["l2_hit_rate"], "from_profile: %s" % rel
     return None, None
 
 

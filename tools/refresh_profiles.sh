@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the round's bench / profile files under gpurun_out/refresh/ on the GPU box (copy what is wanted into profiles/).
-#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh [tag] [part]'      part: all | bench | pmc | train | aux
-tag=${1:-r04}
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh [tag] [part]'      part: all | bench | roof | pmc | train | aux
+tag=${1:-r05}
 part=${2:-all}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -10,7 +10,7 @@ mkdir -p $out
 say() { echo "[refresh] $(date +%H:%M:%S) $*"; }
 prof() {   # prof <name> <bench args...>: rocprofv3 kernel stats of a bench run
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -o k -- python3 bench.py "$@" > $out/${tag}_bench_${name}_under_rocprof.json 2> $out/prof_$name.err || return 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -o k -- python3 bench.py --no-roof "$@" > $out/${tag}_bench_${name}_under_rocprof.json 2> $out/prof_$name.err || return 1
   cp "$(find $out/prof_$name -name 'k_kernel_stats.csv' | head -1)" $out/${tag}_bench_${name}_kernel_stats.csv
   rm -rf $out/prof_$name $out/prof_$name.err
 }
@@ -27,8 +27,13 @@ done
 say "synthetic200m";                     timeout -k 10 500 python bench.py --workload synthetic200m --steps 10 --warmup 2 > $out/${tag}_bench_synthetic200m_bf16.json 2>> $out/err.log || exit 1
 say "synthetic200m under rocprof";       prof synthetic200m_bf16 --workload synthetic200m --steps 5 --warmup 1 --no-cpu-baseline || exit 1
 for w in gowalla_real yelp_real; do say "bench $w"; timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > $out/${tag}_bench_${w}_bf16.json 2>> $out/err.log || exit 1; done
+say "gowalla fp32 under rocprof";       prof gowalla_fp32 --dtype fp32 --steps 20 --warmup 5 --no-probe --no-train --no-cpu-baseline || exit 1
 say "hub-finish soak";                   timeout -k 10 600 python tools/hub_soak.py --launches 120000 > $out/${tag}_hub_soak.json 2>> $out/err.log || exit 1
 say "rehearsal (1 RCCL rank)";           NGACF_BENCH_FORCE_DIST=1 timeout -k 10 400 python bench.py --gpus 1 > $out/${tag}_bench_rehearsal_1rank_rccl.json 2>> $out/err.log || exit 1
+fi
+if [ "$part" = all ] || [ "$part" = roof ]; then
+say "measured gather roof: traversal kernels against their stripped instantiations (Gowalla, Yelp; bf16, fp32; 8 heads, 1 head)"
+timeout -k 10 600 python tools/gather_roof.py > $out/${tag}_gather_roof.jsonl 2>> $out/err.log || exit 1
 fi
 if [ "$part" = all ] || [ "$part" = pmc ]; then
 say "PMC traffic + L2 hit rate: gowalla"; timeout -k 10 600 python tools/traffic.py gowalla bf16,fp32 > $out/traffic_gowalla.log 2>&1 && cp gpurun_out/${tag}_traffic_gowalla.json $out/
@@ -53,6 +58,10 @@ NGACF_FUSE_SPARSE=1 timeout -k 10 200 python tools/train_profile.py >> $out/${ta
 NGACF_DEFER_DW=0 timeout -k 10 200 python tools/train_profile.py >> $out/${tag}_trainstep.jsonl 2>/dev/null
 timeout -k 10 200 python tools/bwd_probe.py > $out/${tag}_bwd_probe.log 2>&1; timeout -k 10 200 python tools/pair_probe.py > $out/${tag}_pair_probe.log 2>&1
 timeout -k 10 200 python tools/train_profile.py --torch-adam >> $out/${tag}_trainstep.jsonl 2>/dev/null
+say "the train step launched eagerly, one chain at a time: every kernel's stand-alone duration"
+timeout -k 10 300 python tools/train_profile.py --profile --eager --one-chain > $out/tp_eager.log 2>&1 && cp gpurun_out/trainprof_eager_kernel_stats.csv $out/${tag}_trainstep_eager_kernel_stats.csv && cp gpurun_out/trainprof_refsem_eager.txt $out/${tag}_trainstep_kernels_eager.txt
+say "node-partitioned train step on one RCCL rank (replayed)"
+timeout -k 10 200 python tools/shard_step_profile.py > $out/${tag}_shard_step_world1.json 2>> $out/err.log
 say "epoch + evaluation";                timeout -k 10 300 python tools/eval_bench.py --epochs 3 > $out/${tag}_epoch_eval_gowalla.log 2>&1
 rm -rf gpurun_out/trainprof
 fi

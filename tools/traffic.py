@@ -1,10 +1,10 @@
 """HBM-side traffic of the dominant kernel from PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
 WRITE_SIZE in SEPARATE rocprofv3 --pmc passes of the same bench command (kernel-trace only), units of KB, FETCH_SIZE
 doubled on gfx950; a third pass collects TCC_HIT_sum / TCC_MISS_sum (the L2 hit rate bench.py's cache-gather roof is built
-from).  Writes gpurun_out/r04_traffic_<workload>.json -- copy it to profiles/ (bench.py reads roofline.traffic and
+from).  Writes gpurun_out/r05_traffic_<workload>.json -- copy it to profiles/ (bench.py reads roofline.traffic and
 roofline.l2_hit_rate from there and labels them from_profile).
 Run on the GPU box:  python tools/traffic.py gowalla   (this process never touches the GPU itself).
-    python tools/traffic.py trainstep [bf16,fp32] [yelp]   -> gpurun_out/r04_traffic_trainstep[_yelp].json: the same three passes over the
+    python tools/traffic.py trainstep [bf16,fp32] [yelp]   -> gpurun_out/r05_traffic_trainstep[_yelp].json: the same three passes over the
     replayed reference-semantics TRAIN step (tools/train_profile.py), per kernel family of the backward (bench.py's train_roofline
     reads the dense edge backward's L2 hit rate from there).  Under --pmc every dispatch runs alone: these are the kernels' own
     figures, not those of two chains sharing the GPU."""
@@ -27,7 +27,7 @@ def one_pass(counters, workload, dtype, tag):
     steps = ["--steps", "3", "--warmup", "1", "--passes-per-step", "4"] if workload not in ("synthetic1b", "synthetic200m") else \
             ["--steps", "2", "--warmup", "1", "--passes-per-step", "1"]
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "bench.py")] + steps + ["--no-cpu-baseline", "--no-train", "--no-probe", "--workload", workload, "--dtype", dtype]
+           sys.executable, os.path.join(ROOT, "bench.py")] + steps + ["--no-cpu-baseline", "--no-train", "--no-probe", "--no-roof", "--workload", workload, "--dtype", dtype]
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     tot = {c: collections.defaultdict(float) for c in counters}
     n = {c: collections.defaultdict(int) for c in counters}
@@ -38,6 +38,8 @@ def one_pass(counters, workload, dtype, tag):
                     c = r["Counter_Name"]
                     if c not in tot:
                         continue
+                    if ", 1>(" in r["Kernel_Name"] or ", 2>(" in r["Kernel_Name"]:
+                        continue                            # (a measurement-only ROOF instantiation: never part of a pass)
                     for k in KERNELS:
                         if k + "<" in r["Kernel_Name"] or k + "(" in r["Kernel_Name"]:
                             tot[c][k] += float(r["Counter_Value"])
@@ -48,7 +50,7 @@ def one_pass(counters, workload, dtype, tag):
 
 
 KERNELS = ("prop_fwd_kernel", "prop_fwd_split_kernel", "transform_mfma_kernel", "transform_fwd_kernel")
-ROUND = "r04"
+ROUND = "r05"
 
 
 def train_pass(counters, dtype, workload="gowalla"):
@@ -118,7 +120,7 @@ def main():
         return main_train(dtypes, sys.argv[3] if len(sys.argv) > 3 else "gowalla")
     res = {"workload": wl, "stages": 3,
            "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum} -- python bench.py --steps 3 --warmup 1 "
-                      "--passes-per-step 4 --no-cpu-baseline --no-train --no-probe --workload %s [--dtype fp32]  (tools/traffic.py; "
+                      "--passes-per-step 4 --no-cpu-baseline --no-train --no-probe --no-roof --workload %s [--dtype fp32]  (tools/traffic.py; "
                       "three separate passes, the eval forward as benched: the fused traversals of a bf16 pass included)" % wl,
            "by_dtype": {}}
     for dt in dtypes:
