@@ -364,7 +364,7 @@ int ngacf_prop_bwd_node(const void* out, int dtype, const void* agg, const float
  * and each such pair adds 1 to *bad_index (int32 device counter, may be NULL) for the host to raise on. */
 int ngacf_score_fwd(const void* F, int dtype, const int64_t* u, const int64_t* i,
                     float* score, int32_t* bad_index, int B, int U, int I, int d, void* stream);
-/* gF[u[b]] += g[b] * F[U+i[b]],  gF[U+i[b]] += g[b] * F[u[b]]   (gF float[N][d]).  B <= 8192: NO atomics -- the first pair that
+/* gF[u[b]] += g[b] * F[U+i[b]],  gF[U+i[b]] += g[b] * F[u[b]]   (gF float[N][d]).  B <= 4096: NO atomics -- the first pair that
  * names a row adds the contributions of all the pairs naming it, in ascending pair order, and does the row's one read-modify-write
  * (bit-reproducible; the rows named by a batch must not be written by anything else in flight).  Larger batches: float atomics. */
 int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const int64_t* i,

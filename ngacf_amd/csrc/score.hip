@@ -33,98 +33,128 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const T* __restrict__ F,
 
 // gF[u] += g * F[i], gF[i] += g * F[u], WITHOUT atomics: bit-reproducible under a seed.
 // A row of gF collects the contributions of every pair of the batch that names it (a user drawn twice, an item that is one pair's
-// positive and another's negative).  Every (pair, side) is looked at by one wave: it scans the batch's row ids of that side (in LDS)
+// positive and another's negative).  Every (pair, side) is looked at by one wave: it scans the batch's ids of that side
 // in ascending pair order; the FIRST pair that names a row owns it -- its wave adds the contributions of all the pairs naming the
 // row, in ascending pair order, in registers, and performs the single read-modify-write of the row; the later pairs' waves find an
 // earlier match and leave.  O(B^2 / 64) compares per launch (B = 2048: 131 k wave-steps, ~2 us), no sort, no order that depends on
 // timing.  (Rounds 1-4 added the products with float atomics: two runs of a train step differed in the last bit.)
-constexpr int SCORE_BWD_DET_MAX_B = 8192;        // 2 B ids in 64 KB of LDS; beyond it score_bwd_atomic_kernel (order not fixed)
-constexpr int SIDES_PER_WAVE = 4;                // (pair, side) items per wave, all of ONE side: they share the scan of that side's ids
+constexpr int SCORE_BWD_DET_MAX_B = 4096;        // (64 scan rounds: a lane keeps its matches as one 64-bit mask per row) beyond it score_bwd_atomic_kernel
+constexpr int SIDES_PER_WAVE = 8;                // (pair, side) items per wave, all of ONE side: they share the scan of that side's ids
 template <typename T, int D>
 __global__ __launch_bounds__(256) void score_bwd_kernel(const T* __restrict__ F, const int64_t* __restrict__ u,
                                                         const int64_t* __restrict__ it, const float* __restrict__ g,
                                                         float* __restrict__ gF, int* __restrict__ bad, int B, int U, int I) {
-    extern __shared__ int ids[];                 // [2][B]: global row of the user side / of the item side; -1: pair out of range
-    for (int k = threadIdx.x; k < B; k += 256) {
-        const int64_t ub = u[k], ib = it[k];
-        const bool ok = ub >= 0 && ub < U && ib >= 0 && ib < I;
-        ids[k] = ok ? (int)ub : -1;
-        ids[B + k] = ok ? U + (int)ib : -1;
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wpl = (B + SIDES_PER_WAVE - 1) / SIDES_PER_WAVE;        // waves per list
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= 2 * wpl) return;
     const int side = w >= wpl;
     const int b0 = (side ? w - wpl : w) * SIDES_PER_WAVE;
-    const int* mine = ids + side * B;
-    const int* other = ids + (1 - side) * B;
+    const int64_t* mine = side ? it : u;                               // the ids this side's rows are named by
+    const int64_t* other = side ? u : it;
+    const int64_t nmine = side ? I : U, nother = side ? U : I;
     constexpr int CPL = D / 64;                  // columns per lane
-    // One scan of the list for the wave's four rows: per row the number of pairs naming it and the first of them.  (Almost always
-    // one pair, itself; the ordered walk below runs only for a row named more than once.)
-    int row[SIDES_PER_WAVE], cnt[SIDES_PER_WAVE], first[SIDES_PER_WAVE];
+    // One scan of the list (straight from the batch's id array: 16 KB that every wave of the launch reads, L2 / L1 resident) for
+    // the wave's rows: per row the number of pairs naming it and the first of them.  (Almost always one pair, itself; the
+    // ordered walk below runs only for a row named more than once.)
+    // Ids compare as 32-bit values: an id outside the table becomes a negative sentinel that equals no row of this wave (such a pair
+    // is skipped anyway) -- 64-bit compares and shifts issue at a fraction of the 32-bit rate, and this scan is pure vector work.
+    int id[SIDES_PER_WAVE];
+    unsigned long long mk[SIDES_PER_WAVE];       // bit i: pair lane + 64 i names row j (B <= 4096: 64 rounds)
 #pragma unroll
     for (int j = 0; j < SIDES_PER_WAVE; ++j) {
-        row[j] = b0 + j < B ? mine[b0 + j] : -1;
-        cnt[j] = 0;
-        first[j] = 0x7fffffff;
+        const int64_t v = b0 + j < B ? mine[b0 + j] : -1;
+        id[j] = (v >= 0 && v < nmine) ? (int)v : -1;
+        mk[j] = 0ull;
     }
-    for (int k = lane; k < B; k += 64) {
-        const int v = mine[k];
+    const int rounds = (B + 63) >> 6;
+    for (int i0 = 0; i0 < rounds; i0 += 16) {     // sixteen rounds' ids requested together: two round trips for B = 2048, not eight
+        int v[16];
 #pragma unroll
-        for (int j = 0; j < SIDES_PER_WAVE; ++j) {
-            const bool m = v == row[j];
-            cnt[j] += m ? 1 : 0;
-            first[j] = m ? min(first[j], k) : first[j];
+        for (int r = 0; r < 16; ++r) {
+            const int k = lane + 64 * (i0 + r);
+            const int64_t x = k < B ? mine[k] : -1;
+            v[r] = (x >= 0 && x < nmine) ? (int)x : -2;
         }
-    }
+        unsigned int blk[SIDES_PER_WAVE];
 #pragma unroll
-    for (int j = 0; j < SIDES_PER_WAVE; ++j) {
+        for (int j = 0; j < SIDES_PER_WAVE; ++j) blk[j] = 0u;
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            cnt[j] += __shfl_xor(cnt[j], m, 64);
-            first[j] = min(first[j], __shfl_xor(first[j], m, 64));
-        }
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < SIDES_PER_WAVE; ++j) blk[j] |= v[r] == id[j] ? (1u << r) : 0u;
+#pragma unroll
+        for (int j = 0; j < SIDES_PER_WAVE; ++j) mk[j] |= (unsigned long long)blk[j] << i0;
     }
+    // owner: no pair in front of b names the row (one ballot); dup: some pair behind b names it too (one ballot)
+    bool is_first[SIDES_PER_WAVE], has_more[SIDES_PER_WAVE];
 #pragma unroll
     for (int j = 0; j < SIDES_PER_WAVE; ++j) {
         const int b = b0 + j;
-        if (b >= B) break;
-        if (row[j] < 0) {                        // out-of-range pair: no write anywhere, counted once
-            if (side == 0 && lane == 0 && bad) atomicAdd(bad, 1);
-            continue;
-        }
-        if (first[j] != b) continue;             // an earlier pair names this row: its wave does the sum
-        float acc[CPL];
+        const int lim = min(64, max(0, (b - lane + 63) >> 6));            // rounds i with lane + 64 i < b
+        const unsigned long long before = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
+        const int own_i = b >> 6;
+        const unsigned long long self = (lane == (b & 63)) ? (1ull << own_i) : 0ull;
+        is_first[j] = __ballot((mk[j] & before) != 0ull) == 0ull;
+        has_more[j] = __ballot((mk[j] & ~before & ~self) != 0ull) != 0ull;
+    }
+    // The rows this wave owns, in PHASES over its eight items -- every phase's loads are independent of each other (one round trip
+    // per phase, not per item: done item by item the launch took 24 us, each item a chain of three dependent trips).
+    int64_t ob[SIDES_PER_WAVE];
+    float gk[SIDES_PER_WAVE];
+    bool owner[SIDES_PER_WAVE];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
-        auto add = [&](int kk) {
-            const float gk = g[kk];
-            const size_t orow = (size_t)other[kk];
+    for (int j = 0; j < SIDES_PER_WAVE; ++j) {
+        const int b = b0 + j < B ? b0 + j : B - 1;
+        ob[j] = other[b];
+        gk[j] = g[b];
+    }
+    auto other_row = [&](int64_t o) { return (size_t)(side ? o : o + U); };
+    auto f_at = [&](size_t row, int col) {
+        if constexpr (sizeof(T) == 4) return reinterpret_cast<const float*>(F)[row * D + col];
+        else return bf16_to_f32(reinterpret_cast<const uint16_t*>(F)[row * D + col]);
+    };
+    float acc[SIDES_PER_WAVE][CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const int col = lane + 64 * c;
-                float y;
-                if constexpr (sizeof(T) == 4) y = reinterpret_cast<const float*>(F)[orow * D + col];
-                else y = bf16_to_f32(reinterpret_cast<const uint16_t*>(F)[orow * D + col]);
-                acc[c] = fmaf(gk, y, acc[c]);
+    for (int j = 0; j < SIDES_PER_WAVE; ++j) {
+        const int b = b0 + j;
+        const bool in = b < B && id[j] >= 0 && ob[j] >= 0 && ob[j] < nother;
+        if (b < B && !in && side == 0 && lane == 0 && bad) atomicAdd(bad, 1);      // out-of-range pair: no write anywhere, counted once
+        owner[j] = in && is_first[j];            // (else an earlier pair names this row: its wave does the sum)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[j][c] = owner[j] ? gk[j] * f_at(other_row(ob[j]), lane + 64 * c) : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < SIDES_PER_WAVE; ++j) {
+        if (!owner[j] || !has_more[j]) continue; // (uniform) a row named more than once: the later pairs, ascending, from the scan's masks
+        const int b = b0 + j;
+        for (int i = b >> 6; i < rounds; ++i) {
+            unsigned long long m = __ballot((mk[j] >> i) & 1ull);
+            while (m) {
+                const int kk = 64 * i + __builtin_ctzll(m);
+                m &= m - 1;
+                if (kk == b) continue;
+                const int64_t o = other[kk];
+                if (o < 0 || o >= nother) continue;                     // (that pair is out of range: it contributes nothing)
+                const float gq = g[kk];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) acc[j][c] = fmaf(gq, f_at(other_row(o), lane + 64 * c), acc[j][c]);
             }
-        };
-        if (cnt[j] == 1) {
-            add(b);
-        } else {                                 // the pairs naming the row, in ascending order
-            for (int k0 = b & ~63; k0 < B; k0 += 64) {
-                const int k = k0 + lane;
-                unsigned long long m = __ballot(k < B && k >= b && mine[k] == row[j]);
-                while (m) {
-                    add(k0 + __builtin_ctzll(m));
-                    m &= m - 1;
-                }
-            }
         }
+    }
+    float old[SIDES_PER_WAVE][CPL];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) gF[(size_t)row[j] * D + lane + 64 * c] += acc[c];
+    for (int j = 0; j < SIDES_PER_WAVE; ++j) {
+        const size_t row = owner[j] ? (size_t)(side ? id[j] + U : id[j]) : 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) old[j][c] = owner[j] ? gF[row * D + lane + 64 * c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < SIDES_PER_WAVE; ++j) {
+        if (!owner[j]) continue;
+        const size_t row = (size_t)(side ? id[j] + U : id[j]);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) gF[row * D + lane + 64 * c] = old[j][c] + acc[j][c];
     }
 }
 
@@ -384,7 +414,7 @@ extern "C" int ngacf_score_bwd(const void* F, int dtype, const int64_t* u, const
     {                                                                                                      \
         if (B <= SCORE_BWD_DET_MAX_B) {                                                                    \
             const int waves = 2 * ((B + SIDES_PER_WAVE - 1) / SIDES_PER_WAVE);                             \
-            hipLaunchKernelGGL((score_bwd_kernel<T, D>), dim3((waves + 3) / 4), dim3(256), 2 * (size_t)B * sizeof(int), st, \
+            hipLaunchKernelGGL((score_bwd_kernel<T, D>), dim3((waves + 3) / 4), dim3(256), 0, st,          \
                                static_cast<const T*>(F), u, i, gscore, gF, bad_index, B, U, I);            \
         } else {                                                                                           \
             constexpr int PPB = 16;                                                                        \
