@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const T* __restrict__ F,
     unsigned long long mk[SIDES_PER_WAVE];       // bit i: pair lane + 64 i names row j (B <= 4096: 64 rounds)
 #pragma unroll
     for (int j = 0; j < SIDES_PER_WAVE; ++j) {
-        const int64_t v = b0 + j < B ? mine[b0 + j] : -1;
-        id[j] = (v >= 0 && v < nmine) ? (int)v : -1;
+        const int64_t v = b0 + j < B ? mine[b0 + j] : -1, y = b0 + j < B ? other[b0 + j] : -1;
+        id[j] = (v >= 0 && v < nmine && y >= 0 && y < nother) ? (int)v : -1;
         mk[j] = 0ull;
     }
     const int rounds = (B + 63) >> 6;
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const T* __restrict__ F,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = lane + 64 * (i0 + r);
-            const int64_t x = k < B ? mine[k] : -1;
-            v[r] = (x >= 0 && x < nmine) ? (int)x : -2;
+            const int64_t x = k < B ? mine[k] : -1, y = k < B ? other[k] : -1;
+            v[r] = (x >= 0 && x < nmine && y >= 0 && y < nother) ? (int)x : -2;      // (a pair out of range on either side names no row)
         }
         unsigned int blk[SIDES_PER_WAVE];
 #pragma unroll
