@@ -341,12 +341,12 @@ class BwdDx:
         self.dX = self.Gn = self.ST = self.dS = None
 
 
-# A/B switch of the backward's launch plan: 0 = dX and the node steps as their own launches; 1 = dX in the edge backward's tail;
-# 2 (default) = dX and the previous stage's step 1 in the tail.  Measured: stand-alone a dense stage's
-# backward goes from 88 to 82 us (98 to 79 for the first stage, whose dX is the fp32 table's gradient); inside the two-chain
-# train step all three plans land within 1 % of each other -- the step is bound by its six edge backwards, not by what runs
-# between them.
-FUSE_BWD = int(__import__("os").environ.get("NGACF_FUSE_BWD", "2"))
+# The backward's launch plan: 0 = dX and the node steps as their own launches; 1 (default) = the stage's dX in the edge backward's tail;
+# 2 = dX and the previous stage's step 1 in the tail.  Measured, three runs each of the replayed two-chain step (round 5, Gowalla bf16):
+# 0.6220 / 0.6180 / 0.6194 ms; Yelp 0.731 (1) against 0.743 (2).  Level 2's extra fusion buys nothing inside the step -- it is bound
+# by the sum of its traversal launches, DESIGN.md section 4 -- so the default is the simpler fastest plan; level 2 stays selectable
+# and tested (tests/test_gpu_fused_bwd.py), NGACF_FUSE_BWD=2.
+FUSE_BWD = int(__import__("os").environ.get("NGACF_FUSE_BWD", "1"))
 
 
 def can_fuse_bwd(plan, H_dtype, d, din, x_dtype, has_prev):
