@@ -313,7 +313,7 @@ def train_roofline_of(torch, BK, ops, eager_step, model, wl, dtype, U, I, E, dim
     n_dense = L - 1 if sparse_last else L
     tail = 0
     if fused and n_dense > 0:
-        later = N * d * elem + (N * (4 * d * elem + 24 * heads_dense) if ops.FUSE_BWD >= 2 else 0)
+        later = N * d * elem                              # a later dense stage's tail writes its bf16 dX rows
         tail = (N * d * 4 + (n_dense - 1) * later) / n_dense
     bytes_launch = bytes_edges + tail
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9

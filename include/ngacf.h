@@ -226,38 +226,24 @@ int ngacf_prop_bwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
                    int U, int N, int d, int heads, float alpha,
                    float drop_p, uint64_t seed, const uint64_t* seed_dev, int flags, void* stream);
 
-/* ngacf_prop_bwd whose launch ALSO runs the stage's transform backward for the rows it finishes, and step 1 of the PREVIOUS
- * stage's backward on the result -- the mirror image of ngacf_prop_fwd_next (autograd of SPUIGACF.py:356-357 chained through
- * :207-215; the reference's autograd runs these as separate ATen kernels):
+/* ngacf_prop_bwd whose launch ALSO runs the stage's transform backward for the rows it finishes -- the mirror image of
+ * ngacf_prop_fwd_next (autograd of SPUIGACF.py:356-357 chained through :207-215; the reference's autograd runs these as separate
+ * ATen kernels):
  *   dX[n, :] = mask * (dH[n, :] @ W[type(n)]^T)      what ngacf_transform_bwd's dX half computes from the stored dH, bit for bit
- *   and with prev_*: step 1 of the previous stage on gout = dX (prev_Gn, prev_ST, prev_dS = its Gn, ST and P1)
- *                                                    what ngacf_prop_bwd_node computes from the stored dX, bit for bit
- * so the previous stage's backward is then called with NGACF_SKIP_NODE, gout = dX, Gn = prev_Gn, ST = prev_ST, dS = prev_dS.
  *   panel   bf16 A fragments of W[type]^T: ngacf_transform_fwd_pack with pack_kind 1 (2 * din * d * 2 bytes)
- *   dX      [N][din], NGACF_BF16 or NGACF_F32 (X's type); with prev_* NGACF_BF16 (dX is the gradient of the previous stage's bf16
- *           output); NGACF_F32 e.g. for the first stage (the gradient of the fp32 embedding table)
+ *   dX      [N][din], NGACF_BF16 or NGACF_F32 (X's type; NGACF_F32 e.g. for the first stage: the gradient of the fp32 embedding table)
  *   feat_drop_p, seed: the stage's feature dropout (the mask of ngacf_transform_fwd)
- *   prev_out [N][din] bf16, prev_agg [2][N][din] bf16, prev_R float[2][N][din/8]: as the previous stage's forward saved them
- *   (8-column heads); prev_S float[N][din/8]: that stage's scores; prev_alpha: its leaky-relu slope;
- *   prev_Gn [N][din] bf16, prev_ST float[N][din/8][2], prev_dS float[N][din/8]: results;   prev_flags: NGACF_ELU of the previous stage
  * dH and dS are written as by ngacf_prop_bwd (the weights' gradient still needs them: ngacf_transform_bwd with dX == NULL).
  * Restrictions: dtype == NGACF_BF16, d == 64, din == 64, G == NULL, nhub == 0, hub rows finished in-kernel
- * (part_split + tickets) or absent.  dx == NULL: exactly ngacf_prop_bwd. */
+ * (part_split + tickets) or absent.  dx == NULL: exactly ngacf_prop_bwd.
+ * (Round 4's form also ran step 1 of the PREVIOUS stage's backward on the dX row in the same tail: worth nothing inside the
+ * two-chain train step, deleted in round 5.) */
 typedef struct ngacf_bwd_dx {
     const void* panel;
     void* dX;
     int32_t din, dx_dtype;
     float feat_drop_p;
     uint64_t seed;
-    const void* prev_out;
-    const void* prev_agg;
-    const float* prev_R;
-    const float* prev_S;
-    void* prev_Gn;
-    float* prev_ST;
-    float* prev_dS;
-    float prev_alpha;
-    int32_t prev_flags;
 } ngacf_bwd_dx;
 int ngacf_prop_bwd_dx(const int32_t* segs, int nseg, const int32_t* split, int nsplit,
                       const int32_t* srow, int nshort, int nseg_user, int nshort_user,

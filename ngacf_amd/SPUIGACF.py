@@ -335,8 +335,7 @@ class _GATBase(nn.Module):
         if NF.ops.FUSE_BWD and features.is_cuda and torch.is_grad_enabled() and self.compute_dtype == torch.bfloat16:
             for s in range(L):
                 x_dtype = features.dtype if s == 0 else self.compute_dtype
-                has_prev = NF.ops.FUSE_BWD >= 2 and s > 0 and shapes[s - 1][1] == 64 and shapes[s - 1][2] == 8
-                fuse_b[s] = NF.ops.can_fuse_bwd(plan, self.compute_dtype, shapes[s][1], shapes[s][0], x_dtype, has_prev)
+                fuse_b[s] = NF.ops.can_fuse_bwd(plan, self.compute_dtype, shapes[s][1], shapes[s][0], x_dtype)
         link = NF.StageLink() if any(fuse) or any(fuse_b) else None
         if link is not None:
             link.defer_dw = NF.sink_defers()

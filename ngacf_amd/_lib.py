@@ -91,9 +91,7 @@ class DxPrev(ctypes.Structure):
 
 class BwdDx(ctypes.Structure):
     """ngacf_bwd_dx of include/ngacf.h"""
-    _fields_ = [("panel", _p), ("dX", _p), ("din", ctypes.c_int32), ("dx_dtype", ctypes.c_int32), ("feat_drop_p", _f), ("seed", _u64),
-                ("prev_out", _p), ("prev_agg", _p), ("prev_R", _p), ("prev_S", _p), ("prev_Gn", _p), ("prev_ST", _p), ("prev_dS", _p),
-                ("prev_alpha", _f), ("prev_flags", ctypes.c_int32)]
+    _fields_ = [("panel", _p), ("dX", _p), ("din", ctypes.c_int32), ("dx_dtype", ctypes.c_int32), ("feat_drop_p", _f), ("seed", _u64)]
 
 
 MAX_PEERS, PEER_MAX_REGIONS, PEER_HANDLE_BYTES = 15, 2, 64       # NGACF_MAX_PEERS, NGACF_PEER_MAX_REGIONS, NGACF_PEER_HANDLE_BYTES

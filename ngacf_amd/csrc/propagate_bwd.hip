@@ -67,22 +67,13 @@ struct PropBwdArgs {
     const int* rows;               // with needed: the same rows as a list (duplicates allowed, -1 = skip): step 1 runs over it
     int nrows;
     // The fused tail (ngacf_prop_bwd_dx; fx_dX == nullptr: none): the stage's transform backward dX = mask * (dH @ W[type]^T) of the
-    // rows a workgroup has just finished, and on that dX row step 1 of the PREVIOUS stage's backward (pv_*: that stage's saved
-    // out / agg / R and its scores; its Gn, ST and dS (P1) tables are the results).
+    // rows a workgroup has just finished.  (Round 4 also ran the PREVIOUS stage's node step on that dX row in the tail: measured
+    // worth nothing inside the train step -- 0.6194 against 0.6180 ms -- and deleted in round 5)
     const void* fx_panel;          // [2][d/16][din/32][64] x 16 B: bf16 A fragments of W[type]^T (ngacf_transform_fwd_pack, kind 1)
-    void* fx_dX;                   // [N][din]: bf16 (with pv_*), or fp32 (the first stage: the embedding table's gradient)
+    void* fx_dX;                   // [N][din]: bf16, or fp32 (the first stage: the embedding table's gradient)
     uint32_t fx_drop_thr;          // the stage's feature dropout (0 = none)
     float fx_drop_scale;
     uint64_t fx_seed;
-    const void* pv_out;
-    const void* pv_agg;            // [2][N][din]
-    const float* pv_R;             // [2][N][din/8]
-    const float* pv_S;             // [N][din/8]
-    void* pv_Gn;
-    float2* pv_ST;
-    float* pv_dS;
-    float pv_alpha;
-    int pv_flags;                  // NGACF_ELU of the previous stage
 };
 
 template <typename T, int D, int HEADS>
@@ -406,40 +397,6 @@ struct RowDone {
     bool valid;
 };
 
-// The previous stage's rows of the fused tail (FUSE == 2) go global -> LDS by LDS-DMA when the wave learns its row(s): no VGPRs,
-// nobody waits, and the traversal hides the round trip.  (A finish that starts these loads itself adds a dependent trip to memory
-// to every wave's life -- with row flags most rows' finish has no load at all, and that launch went from 38 to 64 us.)
-// Tile layout: [32 rows][8 pieces of 16 B], no padding (a wave instruction writes 1 KB = the 8 rows of a wave, contiguous);
-// lane (slot, q) fetches piece q ^ slot, so position (row r, p) holds piece p ^ (r & 7) and the tail's reads of ONE piece over
-// 16 rows spread over all banks.  R, Rn, S: [32 rows][8 heads] floats each.
-template <typename T, int D, int VEC>
-struct PrevTiles {
-    uint4* otile;
-    uint4* atile;
-    uint4* ntile;
-    float* rtile;                  // [3][32 * 8]: R, Rn, S
-};
-
-template <typename T, int D, int VEC>
-__device__ __forceinline__ void dma_prev(const PropBwdArgs& a, const PrevTiles<T, D, VEC>& pt, int row, int slot, int q) {
-    static_assert(sizeof(T) == 2 && D == 64, "bf16 rows of 64 columns");
-    const int wave = threadIdx.x >> 6;
-    const size_t off = (size_t)row * D * sizeof(T) + (size_t)((q ^ slot) * 16);
-    const size_t plane = (size_t)a.N * D * sizeof(T);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.pv_out) + off),
-                                     (__attribute__((address_space(3))) void*)(pt.otile + wave * 64), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.pv_agg) + off),
-                                     (__attribute__((address_space(3))) void*)(pt.atile + wave * 64), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.pv_agg) + plane + off),
-                                     (__attribute__((address_space(3))) void*)(pt.ntile + wave * 64), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.pv_R + (size_t)row * 8 + q),
-                                     (__attribute__((address_space(3))) void*)(pt.rtile + wave * 64), 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.pv_R + ((size_t)a.N + row) * 8 + q),
-                                     (__attribute__((address_space(3))) void*)(pt.rtile + 256 + wave * 64), 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.pv_S + (size_t)row * 8 + q),
-                                     (__attribute__((address_space(3))) void*)(pt.rtile + 512 + wave * 64), 4, 0, 0);
-}
-
 template <typename T, int D, int HEADS, int FUSE, int VEC>
 __device__ __forceinline__ void finish_row_t(const PropBwdArgs& a, int row, int q, int head, const float (&acc)[VEC], float dsum, RowDone<VEC>& rd) {
     if constexpr (FUSE == 0) {
@@ -455,8 +412,7 @@ __device__ __forceinline__ void finish_row_t(const PropBwdArgs& a, int row, int 
 // The traversal of one wave's work item(s).  FUSE != 0 (ngacf_prop_bwd_dx): the row this lane's group finished is also handed
 // back in `rd` for the workgroup's tail, and no path leaves the KERNEL before that tail (the returns below leave this function).
 template <typename T, int D, int HEADS, bool DROP, bool SPARSE, int FUSE, int ROOF = 0>
-__device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, int widx, int wend, int* qmem, RowDone<Slice<T>::VEC>& rd,
-                                              const PrevTiles<T, D, Slice<T>::VEC>& pt) {
+__device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, int widx, int wend, int* qmem, RowDone<Slice<T>::VEC>& rd) {
     using SH = BShape<T, D, HEADS>;
     constexpr int UNR = UNROLL;
     constexpr int LPR = SH::LPR, EPI = SH::EPI, HW = SH::HW, VEC = SH::VEC;
@@ -529,7 +485,6 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
         const int deg = live ? rec.z : 0;
         const int maxdeg = uniform(deg);                     // rows are sorted: slot 0 holds the longest
         load_ctx<T, D, HEADS, DROP>(a, row, q, head, x);
-        if constexpr (FUSE == 2) dma_prev<T, D, VEC>(a, pt, row, slot, q);
         if (SPARSE) {                                        // only the edges out of the batch take part (the queue)
             sparse_edges_b<T, D, HEADS, DROP>(a, x, qbuf, row, beg, 1, deg, slot, q, head, sm);
             sm.get(acc, dsum);
@@ -572,7 +527,6 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
     const int4 sg = a.segs[w];
     const int row = uniform(sg.x), beg = uniform(sg.y), end = uniform(sg.z), part = uniform(sg.w);
     load_ctx<T, D, HEADS, DROP>(a, row, q, head, x);
-    if constexpr (FUSE == 2) dma_prev<T, D, VEC>(a, pt, row, slot, q);     // (a hub row's slices fetch it too: any of them may finish the row)
     if (SPARSE) {                                   // the lane group's edges: beg + slot, + EPI, ... (the dense loop's assignment)
         const int mine = end - beg - slot;
         sparse_edges_b<T, D, HEADS, DROP>(a, x, qbuf, row, beg + slot, EPI, mine > 0 ? (mine + EPI - 1) / EPI : 0, slot, q, head, sm);
@@ -657,16 +611,11 @@ __device__ __forceinline__ void prop_bwd_body(const PropBwdArgs& a, int kind, in
 // The fused tail (ngacf_prop_bwd_dx), the mirror image of the forward's next-stage transform (propagate.hip): the rows THIS
 // WORKGROUP has just finished go through the stage's transform backward while they are on chip,
 //     dX[n, :] = mask * (dH[n, :] @ W[type(n)]^T)                    (transform_bwd.hip: the dX half of transform_dw_mfma_kernel)
-// and, when dX is the gradient of the previous stage's output (FUSE == 2), that stage's step 1 runs on the finished dX row:
-//     g = dX * ELU'(out_prev);  Gn_prev = g / R_prev;  t_prev = (Gn_prev . agg_prev)_h;  ST_prev = (S_prev, t_prev);  dS_prev = P1
-//                                                                                                (prop_bwd_node_kernel)
 //   1. every wave writes its finished dH rows -- the bf16 values the dH table stores -- into the workgroup's 32-row LDS tile;
-//      the same rows of out_prev / agg_prev / R_prev (dma_prev, issued when the wave learnt its rows) and the weight panel
-//      (bf16 A fragments of W[type]^T, packed once per step: ngacf_transform_fwd_pack kind 1) have arrived by LDS-DMA meanwhile;
 //   2. ONE barrier; waves 1..3 leave;
 //   3. wave 0: DKS x DOT v_mfma_f32_32x32x16_bf16 with the node on the lane, k ascending -- the arithmetic, order and bits of
-//      transform_dw_mfma_kernel<WITH_DX> -- then mask, rounding, the half-waves' exchange (a lane then holds 8 consecutive
-//      columns = one head of the previous stage) and the node step in prop_bwd_node_kernel's own operation order.
+//      transform_dw_mfma_kernel<WITH_DX> -- then mask, rounding, the half-waves' exchange (bf16 rows: one 16-byte store per lane).
+// FUSE 1: fp32 dX rows (the first stage: the embedding table's gradient); FUSE 3: bf16 dX rows.
 // A launch's workgroups hold rows of one node type (work order), with row flags too: one panel per workgroup.
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bw_bf16x8;
@@ -674,8 +623,7 @@ typedef __attribute__((ext_vector_type(16))) float bw_f32x16;
 constexpr int GROW_U4 = 9;           // a staged row: 128 B of bf16 + 16 B pad (36-dword stride: 16 rows hit 64 distinct banks)
 
 template <typename T, int HEADS, int D, int DIN, int FUSE>
-__device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, int gwave, uint4* otile, uint4* atile, uint4* ntile, float* rtile,
-                                            int* xmeta, int primary, const RowDone<8>& rd, int slot, int q) {
+__device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, int gwave, int* xmeta, int primary, const RowDone<8>& rd, int slot, int q) {
     static_assert(D == 64 && DIN == 64, "fused dX: 64 -> 64 stages");
     constexpr int DKS = D / 16, DOT = DIN / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -687,10 +635,6 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
         gtile[wave * gwave + slot * GROW_U4 + q] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     if (q == 0) xmeta[tr] = rd.valid ? rd.row : -1;
-    // The previous stage's rows (FUSE 2) came global -> LDS by LDS-DMA (dma_prev): they are vector-memory operations of THIS wave,
-    // and a workgroup barrier does not drain them (no vmcnt in a workgroup-scope release) -- drain them explicitly before the
-    // barrier publishes the tiles (every wave has finished its traversal by now: nothing is waited for that was not needed).
-    if constexpr (FUSE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // The weight panel (8 KB of bf16 A fragments, L2-resident) goes straight into wave 0's registers, requested in front of the
     // wave's own stores: the MFMAs then wait for these loads only.  (As an LDS-DMA image it cost every workgroup 8 KB of LDS for
@@ -754,37 +698,6 @@ __device__ __forceinline__ void bwd_dx_tail(const PropBwdArgs& a, uint4* gtile, 
                     const uint32_t w[4] = {rx[0], ry[0], rx[1], ry[1]};
                     const int pc = 4 * t + gp + hh;
                     if (mine) *reinterpret_cast<uint4*>(static_cast<char*>(a.fx_dX) + (size_t)node * DIN * 2 + 16 * pc) = make_uint4(w[0], w[1], w[2], w[3]);
-                    if constexpr (FUSE == 3) continue;        // (bf16 dX only: the previous stage runs its own step 1)
-                    // step 1 of the previous stage's backward on this piece = head pc of that stage (prop_bwd_node_kernel, bf16, 8 heads)
-                    const uint4 ov = otile[r * 8 + (pc ^ (r & 7))], gv = atile[r * 8 + (pc ^ (r & 7))];   // (dma_prev's layout)
-                    const uint4 nv = ntile[r * 8 + (pc ^ (r & 7))];
-                    const float rr = rtile[r * 8 + pc], rn = rtile[256 + r * 8 + pc], sp = rtile[512 + r * 8 + pc];
-                    const uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w}, aw[4] = {gv.x, gv.y, gv.z, gv.w}, nw[4] = {nv.x, nv.y, nv.z, nv.w};
-                    float g[8], o[8], ag[8], an[8];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        g[2 * j] = __uint_as_float(w[j] << 16);   g[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
-                        o[2 * j] = __uint_as_float(ow[j] << 16);  o[2 * j + 1] = __uint_as_float(ow[j] & 0xffff0000u);
-                        ag[2 * j] = __uint_as_float(aw[j] << 16); ag[2 * j + 1] = __uint_as_float(aw[j] & 0xffff0000u);
-                        an[2 * j] = __uint_as_float(nw[j] << 16); an[2 * j + 1] = __uint_as_float(nw[j] & 0xffff0000u);
-                    }
-                    if (a.pv_flags & NGACF_ELU) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) g[j] *= o[j] > 0.f ? 1.f : o[j] + 1.f;
-                    }
-                    const float inv = rr > 0.f ? 1.f / rr : 0.f;
-                    float gn[8], p = 0.f, pn = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        gn[j] = Slice<bf16_t>::round(g[j] * inv);
-                        p = fmaf(gn[j], ag[j], p);
-                        pn = fmaf(gn[j], an[j], pn);
-                    }
-                    if (mine) {
-                        Slice<bf16_t>::store(static_cast<bf16_t*>(a.pv_Gn) + (size_t)node * DIN + 8 * pc, gn);
-                        a.pv_ST[(size_t)node * (DIN / 8) + pc] = make_float2(sp, p);
-                        a.pv_dS[(size_t)node * (DIN / 8) + pc] = own_term(a.pv_alpha, rr, rn, p, pn);
-                    }
                 }
             }
         }
@@ -815,18 +728,13 @@ __global__ __launch_bounds__(256, FUSE != 0 ? 4 : (SPARSE ? (DROP ? 5 : 4) : 1))
         __shared__ __attribute__((aligned(16))) uint4 gtile_own[SPARSE ? 1 : 32 * GROW_U4];
         uint4* gtile_lds = SPARSE ? reinterpret_cast<uint4*>(qmem) : gtile_own;
         constexpr int gwave = SPARSE ? QWAVE_U4 : 8 * GROW_U4;
-        __shared__ __attribute__((aligned(16))) uint4 otile_lds[FUSE == 2 ? 32 * 8 : 1];
-        __shared__ __attribute__((aligned(16))) uint4 atile_lds[FUSE == 2 ? 32 * 8 : 1];
-        __shared__ __attribute__((aligned(16))) uint4 ntile_lds[FUSE == 2 ? 32 * 8 : 1];
-        __shared__ __attribute__((aligned(16))) float rtile_lds[FUSE == 2 ? 3 * 32 * 8 : 4];
-        const PrevTiles<T, D, VEC> pt{otile_lds, atile_lds, ntile_lds, rtile_lds};
         __shared__ int xmeta_lds[32];
         const int lane = threadIdx.x & 63;
         const int primary = (int)blockIdx.x < a.order.b2 ? 0 : 1;       // (work order: user rows first)
-        prop_bwd_body<T, D, HEADS, DROP, SPARSE, FUSE>(a, kind, widx, wend, qmem, rd, pt);
-        bwd_dx_tail<T, HEADS, D, DIN, FUSE>(a, gtile_lds, gwave, otile_lds, atile_lds, ntile_lds, rtile_lds, xmeta_lds, primary, rd, lane / SH::LPR, lane % SH::LPR);
+        prop_bwd_body<T, D, HEADS, DROP, SPARSE, FUSE>(a, kind, widx, wend, qmem, rd);
+        bwd_dx_tail<T, HEADS, D, DIN, FUSE>(a, gtile_lds, gwave, xmeta_lds, primary, rd, lane / SH::LPR, lane % SH::LPR);
     } else {
-        prop_bwd_body<T, D, HEADS, DROP, SPARSE, 0, ROOF>(a, kind, widx, wend, qmem, rd, PrevTiles<T, D, VEC>{nullptr, nullptr, nullptr, nullptr});
+        prop_bwd_body<T, D, HEADS, DROP, SPARSE, 0, ROOF>(a, kind, widx, wend, qmem, rd);
     }
 }
 
@@ -881,7 +789,6 @@ static int launch_bwd(PropBwdArgs a, const int* split, int nsplit, bool drop, hi
                 else                  launch_k(NGACF_TAG_PROP_BWD, prop_bwd_kernel<T, D, HEADS, false, false, F>, grid, block, 0, st, a);  \
             } while (0)
             if (fuse == 1) NGACF_FX(1);
-            else if (fuse == 2) NGACF_FX(2);
             else NGACF_FX(3);
 #undef NGACF_FX
             NGACF_CHECK_LAUNCH();
@@ -968,8 +875,6 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
     const bool drop = drop_p > 0.f;
     hipStream_t st = static_cast<hipStream_t>(stream);
     a.fx_panel = nullptr; a.fx_dX = nullptr; a.fx_drop_thr = 0; a.fx_drop_scale = 1.f; a.fx_seed = 0;
-    a.pv_out = a.pv_agg = nullptr; a.pv_R = a.pv_S = nullptr; a.pv_Gn = nullptr; a.pv_ST = nullptr; a.pv_dS = nullptr; a.pv_flags = 0;
-    a.pv_alpha = alpha;
     int fuse = 0;
     if (dx) {
         if (!dx->panel || !dx->dX) return NGACF_E_ARG;
@@ -978,17 +883,11 @@ static int prop_bwd_impl(const int32_t* segs, int nseg, const int32_t* split, in
         if (dtype != NGACF_BF16 || d != 64 || dx->din != 64) return NGACF_E_SHAPE;
         if (nu_lo != 0 || nu_n != U || ni_lo != 0 || ni_n != N - U) return NGACF_E_ARG;
         if (!(dx->feat_drop_p >= 0.f && dx->feat_drop_p < 1.f)) return NGACF_E_ARG;
-        const bool prev = dx->prev_out || dx->prev_agg || dx->prev_R || dx->prev_S || dx->prev_Gn || dx->prev_ST || dx->prev_dS;
-        if (prev && !(dx->prev_out && dx->prev_agg && dx->prev_R && dx->prev_S && dx->prev_Gn && dx->prev_ST && dx->prev_dS)) return NGACF_E_ARG;
-        if (prev && !(dx->prev_alpha > 0.f && dx->prev_alpha < 1.f)) return NGACF_E_ARG;
-        if (dx->dx_dtype != NGACF_BF16 && (prev || dx->dx_dtype != NGACF_F32)) return NGACF_E_SHAPE;   // a previous stage's output is bf16
+        if (dx->dx_dtype != NGACF_BF16 && dx->dx_dtype != NGACF_F32) return NGACF_E_SHAPE;
         a.fx_panel = dx->panel; a.fx_dX = dx->dX;
         a.fx_drop_thr = dx->feat_drop_p > 0.f ? drop_threshold(dx->feat_drop_p) : 0u;
         a.fx_drop_scale = 1.f / (1.f - dx->feat_drop_p); a.fx_seed = dx->seed;
-        a.pv_out = dx->prev_out; a.pv_agg = dx->prev_agg; a.pv_R = dx->prev_R; a.pv_S = dx->prev_S; a.pv_Gn = dx->prev_Gn;
-        a.pv_ST = reinterpret_cast<float2*>(dx->prev_ST); a.pv_dS = dx->prev_dS; a.pv_alpha = dx->prev_alpha;
-        a.pv_flags = dx->prev_flags;
-        fuse = prev ? 2 : dx->dx_dtype == NGACF_F32 ? 1 : 3;
+        fuse = dx->dx_dtype == NGACF_F32 ? 1 : 3;
     }
 #define NGACF_CASE(T, D, HD) return launch_bwd<T, D, HD>(a, split, nsplit, drop, st, do_node, do_edges, fuse)
     if (dtype == NGACF_F32) {

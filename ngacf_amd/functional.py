@@ -21,8 +21,8 @@ class StageLink:
     def __init__(self):
         self.pack, self.panels, self.pre = None, {}, None
         # the backward's mirror image (ngacf_prop_bwd_dx): pack_t = {stage: W} whose dX fragments the first transform's launch
-        # packs too, panels_t = those panels; saved[s] = (out, agg, R, S, elu, alpha) of stage s's forward, read by stage s+1's
-        # backward, which runs stage s's step 1 on the dX it produces and parks (dX, Gn, ST, dS) in node_pre[s]
+        # packs too, panels_t = those panels.  fp32 storage: saved[s] = (out, agg, R, S, elu, alpha) of stage s's forward, read by
+        # stage s+1's dX kernel (ngacf_transform_dx_node), which runs stage s's step 1 on its dX and parks (dX, Gn, ST, dS) in node_pre[s]
         self.pack_t, self.panels_t, self.saved, self.node_pre = None, {}, {}, {}
         # defer_dw (a gradient sink is active: nobody reads a weight gradient before the stack's backward has finished): the stages
         # whose dX came out of the edge backward leave their dW / davec to ONE batched launch behind the stack's last backward
@@ -67,7 +67,7 @@ FUSE_SPARSE = __import__("os").environ.get("NGACF_FUSE_SPARSE", "0") != "0"
 
 def _bwd_links(bw, gout, X, H, plan, feat_drop_p, seed, want_dx, sparse=False):
     """backward of stage s: node = (Gn, ST, dS) when the next stage's backward already ran this stage's step 1 on exactly this gout;
-    dx = ops.BwdDx when this stage's launch can produce dX (and the previous stage's step 1) itself."""
+    dx = ops.BwdDx when this stage's launch can produce dX itself."""
     if bw is None or X is None:
         return None, None
     link, s = bw
@@ -76,11 +76,8 @@ def _bwd_links(bw, gout, X, H, plan, feat_drop_p, seed, want_dx, sparse=False):
     if pre is not None and pre[0] is not None and pre[0].data_ptr() == gout.data_ptr() and pre[0].dtype == gout.dtype and gout.is_contiguous():
         node = (pre[1], pre[2], pre[3])
     if want_dx and s in link.panels_t and (FUSE_SPARSE or not sparse):
-        prev = link.saved.get(s - 1) if X.dtype == torch.bfloat16 and ops.FUSE_BWD >= 2 else None
-        if prev is not None and (prev[0].data_ptr() != X.data_ptr() or prev[3].shape[1] != X.shape[1] // 8):
-            prev = None                                  # X is not the previous stage's output table (or not in 8-column heads)
-        if ops.can_fuse_bwd(plan, H.dtype, H.shape[1], X.shape[1], X.dtype, prev is not None):
-            dx = ops.BwdDx(link.panels_t[s], X.dtype, feat_drop_p, seed, prev)
+        if ops.can_fuse_bwd(plan, H.dtype, H.shape[1], X.shape[1], X.dtype):
+            dx = ops.BwdDx(link.panels_t[s], X.dtype, feat_drop_p, seed)
     return node, dx
 
 
@@ -150,8 +147,6 @@ def _transform_bwd_after(bw, dx, X, W, H, dH, dS, plan, heads, feat_drop_p, seed
         _flush_dw(bw, plan, seed_dev)
         return r
     link, s = bw
-    if dx.prev is not None:
-        link.node_pre[s - 1] = (dx.dX, dx.Gn, dx.ST, dx.dS)
     if link.defer_dw and DEFER_DW and tuple(W.shape) == (2, 64, 64) and H.dtype == torch.bfloat16:
         dW, da = torch.empty(2, 64, 64, dtype=torch.float32, device=H.device), torch.empty(2, 64, dtype=torch.float32, device=H.device)
         _defer_dw(link, (X, H, dH, dS, heads, feat_drop_p, seed, dW, da), plan, seed_dev)

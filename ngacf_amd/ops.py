@@ -331,30 +331,27 @@ def prop_fwd(plan, H, S_dst, S_src, avec, heads, alpha=0.2, elu=True, residual=T
 class BwdDx:
     """The stage's transform backward riding in its edge backward (ngacf_prop_bwd_dx): `panel` = the kind-1 fragments of the
     stage's W [2, 64, 64] (transform_fwd(pack=..., pack_kind=1) / pack_panels), x_dtype = the type of the stage's input X (dX's),
-    the stage's feature dropout and seed; prev = (out, agg, R, S, elu, alpha) of the PREVIOUS stage's forward when X is that
-    stage's output -- the launch then also runs that stage's step 1 on dX.  prop_bwd(dx=...) fills .dX (and, with prev, .Gn /
-    .ST / .dS = that stage's Gn, (S, t) pairs and P1: its prop_bwd takes them as node=(Gn, ST, dS))."""
-    __slots__ = ("panel", "x_dtype", "feat_drop_p", "seed", "prev", "dX", "Gn", "ST", "dS")
+    the stage's feature dropout and seed.  prop_bwd(dx=...) fills .dX."""
+    __slots__ = ("panel", "x_dtype", "feat_drop_p", "seed", "dX")
 
-    def __init__(self, panel, x_dtype, feat_drop_p=0.0, seed=0, prev=None):
-        self.panel, self.x_dtype, self.feat_drop_p, self.seed, self.prev = panel, x_dtype, float(feat_drop_p), int(seed), prev
-        self.dX = self.Gn = self.ST = self.dS = None
+    def __init__(self, panel, x_dtype, feat_drop_p=0.0, seed=0):
+        self.panel, self.x_dtype, self.feat_drop_p, self.seed = panel, x_dtype, float(feat_drop_p), int(seed)
+        self.dX = None
 
 
-# The backward's launch plan: 0 = dX and the node steps as their own launches; 1 (default) = the stage's dX in the edge backward's tail;
-# 2 = dX and the previous stage's step 1 in the tail.  Measured, three runs each of the replayed two-chain step (round 5, Gowalla bf16):
-# 0.6220 / 0.6180 / 0.6194 ms; Yelp 0.731 (1) against 0.743 (2).  Level 2's extra fusion buys nothing inside the step -- it is bound
-# by the sum of its traversal launches, DESIGN.md section 4 -- so the default is the simpler fastest plan; level 2 stays selectable
-# and tested (tests/test_gpu_fused_bwd.py), NGACF_FUSE_BWD=2.
-FUSE_BWD = int(__import__("os").environ.get("NGACF_FUSE_BWD", "1"))
+# The backward's launch plan: 0 = dX and the node steps as their own launches; 1 (default) = the stage's dX in the edge backward's tail.
+# Round 4 had a level 2 (+ the previous stage's step 1 in the same tail); three runs each of the replayed two-chain step (round 5,
+# Gowalla bf16): 0.6220 / 0.6180 / 0.6194 ms for 0 / 1 / 2, Yelp 0.731 (1) against 0.743 (2) -- the step is bound by the sum of its
+# traversal launches (DESIGN.md section 4), the extra fusion bought nothing, and level 2 was deleted (kernel tail, C struct, tests).
+FUSE_BWD = min(int(__import__("os").environ.get("NGACF_FUSE_BWD", "1")), 1)
 
 
-def can_fuse_bwd(plan, H_dtype, d, din, x_dtype, has_prev):
+def can_fuse_bwd(plan, H_dtype, d, din, x_dtype):
     """Can ngacf_prop_bwd_dx serve this stage's backward?  (bf16 rows, a 64 -> 64 stage, the whole graph in the plan, hub rows
-    finished in-kernel or absent; with a previous stage behind it its dX is bf16)"""
+    finished in-kernel or absent)"""
     return (bool(FUSE_BWD) and H_dtype == torch.bfloat16 and d == 64 and din == 64 and plan.nhub == 0 and plan.n_rows == plan.N
             and (plan.nsplit == 0 or (INKERNEL_HUB_FINISH and plan.nparts <= INKERNEL_MAX_PARTS))
-            and x_dtype in (torch.bfloat16, torch.float32) and not (has_prev and x_dtype != torch.bfloat16))
+            and x_dtype in (torch.bfloat16, torch.float32))
 
 
 def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, elu=True, residual=True,
@@ -364,7 +361,7 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
     node = (Gn [N,d] in H's dtype, ST float [N,heads,2], dS float [N,heads] holding P1): step 1 has been run elsewhere (a later
     stage's prop_bwd(dx=...)) on this gout; that dS is finished in place and returned.
     score_from_row: accepted for symmetry with prop_fwd and ignored -- the backward reads a neighbour's score from its (S, t) pair.
-    dx = BwdDx: the launch also writes the gradient of the stage's input (dx.dX) and, with dx.prev, the previous stage's step 1.
+    dx = BwdDx: the launch also writes the gradient of the stage's input (dx.dX).
     roof = 1 / 2: MEASUREMENT ONLY (tools/gather_roof.py): the edge step stripped to its gathers and stores (results meaningless)."""
     dev, N, d = H.device, plan.N, H.shape[1]
     if roof and (dx is not None or needed is not None or drop_p or d != 64 or roof not in (1, 2)):
@@ -397,19 +394,12 @@ def prop_bwd(plan, H, S_dst, S_src, avec, out, agg, R, gout, heads, alpha=0.2, e
              (_lib.FLAG_GOUT_F32 if gout_f32 else 0) | (_lib.FLAG_SKIP_NODE if node is not None else 0) | _lib.FLAG_ROOF[roof])
     if dx is not None:
         din = 64
-        if not can_fuse_bwd(plan, H.dtype, d, din, dx.x_dtype, dx.prev is not None):
+        if not can_fuse_bwd(plan, H.dtype, d, din, dx.x_dtype):
             raise ValueError("prop_bwd(dx=...): not available for this launch (ops.can_fuse_bwd)")
         dx.dX = torch.empty(N, din, dtype=dx.x_dtype, device=dev)
         panel = dx.panel.get() if hasattr(dx.panel, "get") else dx.panel
-        pv = [0, 0, 0, 0, 0, 0, 0, 0.2, 0]
-        if dx.prev is not None:
-            p_out, p_agg, p_R, p_S, p_elu, p_alpha = dx.prev
-            dx.Gn, dx.ST, dx.dS = torch.empty(N, din, dtype=H.dtype, device=dev), torch.empty(N, din // 8, 2, **f32), torch.empty(N, din // 8, **f32)
-            pv = [_chk(p_out, "prev out", H.dtype, N * din, dev), _chk(p_agg, "prev agg", H.dtype, 2 * N * din, dev),
-                  _chk(p_R, "prev R", torch.float32, 2 * N * (din // 8), dev), _chk(p_S, "prev S", torch.float32, N * (din // 8), dev),
-                  dx.Gn.data_ptr(), dx.ST.data_ptr(), dx.dS.data_ptr(), float(p_alpha), FLAG_ELU if p_elu else 0]
         st_ = _lib.BwdDx(_chk(panel, "dx.panel", torch.uint8, 2 * din * d * 2, dev), dx.dX.data_ptr(), din, _DT[dx.x_dtype],
-                         dx.feat_drop_p, dx.seed & 0xFFFFFFFFFFFFFFFF, *pv)
+                         dx.feat_drop_p, dx.seed & 0xFFFFFFFFFFFFFFFF)
         _lib.check(lib.ngacf_prop_bwd_dx(*pp, hp, _DT[H.dtype], sd, ss, ap,
                                          op, gp, rp, go, 0, Gn.data_ptr(), st.data_ptr(), dH.data_ptr(),
                                          dS.data_ptr(), pa.data_ptr(), pr.data_ptr(), *_hub(plan, dev), *_needed_args(needed, plan, N, dev)[:3], plan.U, N, d, heads, float(alpha),

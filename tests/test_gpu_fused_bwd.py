@@ -33,10 +33,11 @@ def _bits(t):
 @pytest.mark.parametrize("heads", [8, 1])
 @pytest.mark.parametrize("drop", [0.0, 0.2])
 @pytest.mark.parametrize("sparse", [False, True])
-def test_edge_backward_with_dx_and_previous_node_step_bitwise(dev, heads, drop, sparse):
-    """One stage: prop_bwd(dx=...) against prop_bwd + transform_bwd + prop_bwd_node on the same inputs: dH, dS, dX, and the
-    previous stage's Gn / (S, t) pairs / P1, every row class (short rows, long rows, hub rows finished in-kernel, isolated
-    items), with and without dropout, over all rows and over a scored batch's rows (the batch lists duplicates)."""
+def test_edge_backward_with_dx_bitwise(dev, heads, drop, sparse):
+    """One stage: prop_bwd(dx=...) against prop_bwd + transform_bwd on the same inputs: dH, dS, dX (bf16 and fp32 rows), dW, da,
+    every row class (short rows, long rows, hub rows finished in-kernel, isolated items), with and without dropout, over all rows
+    and over a scored batch's rows (the batch lists duplicates).  (Round 4's form with the previous stage's node step in the same
+    tail was deleted in round 5: worth nothing inside the train step.)"""
     from ngacf_amd import ops
     from ngacf_amd.plan import build_plan
     U, I = 1100, 901
@@ -65,56 +66,30 @@ def test_edge_backward_with_dx_and_previous_node_step_bitwise(dev, heads, drop, 
     else:
         gout = t(rs.randn(N, 64).astype(np.float32) * 0.1, bf)
     out, agg, R = ops.prop_fwd(plan, H, S, S, a, heads, drop_p=drop, seed=9, save=True, needed=rows)
-    p_out = t(rs.randn(N, 64).astype(np.float32) * 0.5, bf)
-    p_agg = t(rs.randn(2, N, 64).astype(np.float32) * 0.5, bf)          # (two planes, as the forward saves them: ops.prop_fwd)
-    p_R = t(np.abs(rs.randn(2, N, 8)).astype(np.float32) + 0.1)
-    p_S = t(rs.randn(N, 8).astype(np.float32) * 0.3)
-    p_R[0, 5, 3] = 0.0
-    p_R[0, U + 2] = 0.0                                                  # an isolated row of the previous stage: its Gn and t are 0
     kw = dict(drop_p=drop, seed=9, needed=rows, gout_f32=sparse)
     for x_dtype in (bf, torch.float32):
         Xs = X if x_dtype == bf else X.float()
         # the separate launches
         dH, dS = ops.prop_bwd(plan, H, S, S, a, out, agg, R, gout, heads, **kw)
         dX, dW, da = ops.transform_bwd(Xs, W, H, dH, dS, U, I, heads, drop, 5)
-        if x_dtype == bf:
-            G = torch.empty(N, 64, dtype=torch.float32, device=dev)
-            Gn = torch.empty(N, 64, dtype=bf, device=dev)
-            T = torch.empty(N, 8, 2, dtype=torch.float32, device=dev)
-            P1 = torch.empty(N, 8, dtype=torch.float32, device=dev)
-            ops.prop_bwd_node(p_out, p_agg, p_R, dX, p_S, G, Gn, T, P1, U, 8, (0, U, 0, I), False, elu=True, alpha=0.2)
         # the fused launch
         panel = ops.pack_panels([W], kinds=[1])[0]
-        dx = ops.BwdDx(panel, x_dtype, drop, 5, prev=(p_out, p_agg, p_R, p_S, True, 0.2) if x_dtype == bf else None)
+        dx = ops.BwdDx(panel, x_dtype, drop, 5)
         dH2, dS2 = ops.prop_bwd(plan, H, S, S, a, out, agg, R, gout, heads, dx=dx, **kw)
         _, dW2, da2 = ops.transform_bwd(Xs, W, H, dH2, dS2, U, I, heads, drop, 5, part="dw")
         torch.cuda.synchronize()
         assert torch.equal(_bits(dH), _bits(dH2)) and torch.equal(_bits(dS), _bits(dS2))
         assert torch.equal(_bits(dX), _bits(dx.dX)), (x_dtype, float((dX.float() - dx.dX.float()).abs().max()))
         assert torch.equal(_bits(dW), _bits(dW2)) and torch.equal(_bits(da), _bits(da2))
-        if x_dtype == bf:
-            assert torch.equal(_bits(Gn), _bits(dx.Gn)) and torch.equal(_bits(T), _bits(dx.ST)) and torch.equal(_bits(P1), _bits(dx.dS))
-            assert float(dx.Gn[U + 2].float().abs().max()) == 0.0 and float(dx.ST[5, 3, 1]) == 0.0
-            assert torch.equal(dx.ST[:, :, 0], p_S)
-            dx3 = ops.BwdDx(panel, bf, drop, 5)                          # bf16 dX alone (the previous stage runs its own step 1)
-            dH3, dS3 = ops.prop_bwd(plan, H, S, S, a, out, agg, R, gout, heads, dx=dx3, **kw)
-            torch.cuda.synchronize()
-            assert torch.equal(_bits(dH), _bits(dH3)) and torch.equal(_bits(dS), _bits(dS3)) and torch.equal(_bits(dX), _bits(dx3.dX))
-            # ... and an 8-head stage's edge backward fed with them (node=) equals the call that runs its own step 1 on that dX
-            if not sparse and heads == 8:
-                dHa, dSa = ops.prop_bwd(plan, H, p_S, p_S, a, p_out, p_agg, p_R, dx.dX, 8, drop_p=drop, seed=9)
-                dHb, dSb = ops.prop_bwd(plan, H, p_S, p_S, a, p_out, p_agg, p_R, dx.dX, 8, drop_p=drop, seed=9, node=(dx.Gn, dx.ST, dx.dS.clone()))
-                torch.cuda.synchronize()
-                assert torch.equal(_bits(dHa), _bits(dHb)) and torch.equal(_bits(dSa), _bits(dSb))
 
 
 @pytest.mark.parametrize("kind", ["spuigacf", "multi"])
 @pytest.mark.parametrize("sparse_last", [True, False])
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1])
 def test_fused_backward_stack_equals_unfused_backward_stack(dev, kind, sparse_last, level):
-    """The whole train step's gradients with NGACF_FUSE_BWD = 1 (dX in the edge backward's tail) / 2 (and the previous stage's
-    step 1) against 0 (separate launches), bf16 storage, dropout on (same seeds = same masks): the loss is bitwise the same;
-    gradients to 1e-5 (the score gradient's float atomics reorder a few sums in front of both plans alike)."""
+    """The whole train step's gradients with NGACF_FUSE_BWD = 1 (dX in the edge backward's tail) against 0 (separate launches),
+    bf16 storage, dropout on (same seeds = same masks): the loss is bitwise the same; gradients to 1e-5 (the batched and the
+    per-stage weight-gradient launches reduce in different orders)."""
     import ngacf_amd
     from ngacf_amd import ops
     U, I = 900, 700

@@ -61,8 +61,8 @@ def main():
             r["dW+dX (fp32 X)"] = timed(lambda: ops.transform_bwd(X.float(), W, H, dH, dS, U, I, heads, p, 3))
             dx1 = ops.BwdDx(panel, torch.float32, p, 3)
             r["edges+dX fp32 (fuse 1)"] = timed(lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, dx=dx1, **kw))
-            dx2 = ops.BwdDx(panel, bf, p, 3, prev=(p_out, p_agg, p_R, p_S, True, 0.2))
-            r["edges+dX+prev node (fuse 2)"] = timed(lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, dx=dx2, **kw))
+            dx3 = ops.BwdDx(panel, bf, p, 3)
+            r["edges+dX bf16 (fuse 1, later stages)"] = timed(lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, dx=dx3, **kw))
             res[tag] = {k: round(v, 1) for k, v in r.items()}
             print(tag, json.dumps(res[tag]), flush=True)
     G = torch.empty(N, d, device=dev)

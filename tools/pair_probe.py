@@ -78,13 +78,10 @@ def main():
         c["dW+dX"] = lambda: ops.transform_bwd(X, W, H, dH, dS, U, I, heads, p, 3)
         c["dW"] = lambda: ops.transform_bwd(X, W, H, dH, dS, U, I, heads, p, 3, part="dw")
         dx1, dx3 = ops.BwdDx(panel, torch.float32, p, 3), ops.BwdDx(panel, bf, p, 3)
-        dx2 = ops.BwdDx(panel, bf, p, 3, prev=(p_out, p_agg, p_R, p_S, True, 0.2))
         c["edges+dX f32"] = lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T, P1), dx=dx1, **kw)
         c["edges+dX bf16"] = lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T, P1), dx=dx3, **kw)
-        c["edges+dX+node"] = lambda: ops.prop_bwd(plan, H, S, S, avec, out, agg, R, gout, heads, node=(Gn, T, P1), dx=dx2, **kw)
         c["separate: node, edges, dW+dX"] = lambda: (c["node"](), c["edges"](), c["dW+dX"]())
         c["fused 3: node, edges+dX, dW"] = lambda: (c["node"](), c["edges+dX bf16"](), c["dW"]())
-        c["fused 2: edges+dX+node, dW"] = lambda: (c["edges+dX+node"](), c["dW"]())
         return c
 
     A, B = chain(), chain()
