@@ -18,6 +18,7 @@
 // Items stream in ascending id order inside a wave, so "score > tau" (strict) is exactly the stable descending
 // sort's tie rule; the cross-wave merge compares ids explicitly.
 #include <stdlib.h>
+#include <type_traits>
 #include "ngacf_common.hpp"
 
 namespace ngacf {
@@ -354,6 +355,358 @@ __global__ __launch_bounds__(64 * NW) void eval_topk_kernel(const TopkArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Second form (round 5), for user batches that fill the chip: 16 * NW users per workgroup, the ITEM rows staged once per
+// workgroup in LDS and read by all of its NW waves (the form above streams the whole item table through L2 once per
+// 32 users: 4.9 GB per Gowalla-scale evaluation, 0.66 ms at the L2's rate before any selection), and the score tile TRANSPOSED:
+//
+//   wave      = 16 users x all items on v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32 (exact products, fp32 accumulate),
+//               A operand = 16 item rows from LDS, B operand = the wave's 16 user rows (registers, loaded once)
+//   lane      = (user c = lane & 15, row group rg = lane >> 4): accumulator register e holds score(user c, item 4 rg + e) --
+//               a lane's scores all belong to ONE user, so that user's threshold is ONE register (the first form keeps 16),
+//               its list's entry count is a register (no LDS atomic, no returned slot to wait for) and a survivor is ONE
+//               ds_write_b64 behind a ballot: per accumulator register the steady state is v_cmp + s_cbranch
+//   list      = ONE per user (64 entries of (score, item) in LDS, K live + slack), written by the user's four lanes (slot =
+//               count + the hits of the lower row groups, from the ballot mask); a list that overflows is compacted by its
+//               wave exactly as in the first form (train positives out, rank by (score desc, item asc), K best kept, threshold
+//               raised); scores of the SAME 32-item step that were held back are retried with ">=" (an equal score of the same
+//               step may carry a lower item id than the list's K-th entry; a later step's never does: strict ">" is the
+//               stable sort's tie rule)
+//   stage     = 16 KB of item rows (128 bf16 / 64 fp32 rows of 64 columns), double buffered, one barrier per stage; the item
+//               pool's flags ride along, and a stage in which every item is a candidate (the usual case) takes the loop
+//               without the per-score flag test
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float tk_f32x4;
+constexpr int TL_STAGE_BYTES = 16384;
+
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(64 * NW) void eval_topk_lds_kernel(const TopkArgs a, const int tc) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int RB = D * (int)sizeof(T);          // bytes of a table row
+    constexpr int RP = RB + 16;                     // pitch of a staged row (16-byte fragment reads of 16 rows: no bank conflict)
+    constexpr int SI = TL_STAGE_BYTES / RB;         // items per stage: 128 / 64 / 64 / 32
+    constexpr int STEPS = SI / 32;                  // a step = 32 items = two 16 x 16 score tiles per wave
+    constexpr int NT = 64 * NW;
+    constexpr int CPR = RB / 16, CH = SI * CPR;     // 16-byte chunks per row / per stage (1024)
+    constexpr int NLD = (CH + NT - 1) / NT;
+    constexpr int UW = 16 * NW;                     // users per workgroup
+    constexpr int NF = RB / 64;                     // 16-byte operand fragments per row and lane
+    constexpr unsigned long long QUAD = 0x0001000100010001ull;
+    extern __shared__ __attribute__((aligned(16))) char tl_lds[];
+    char* const stage0 = tl_lds;                                                          // [2][SI][RP]
+    uint8_t* const pflag = reinterpret_cast<uint8_t*>(tl_lds + 2 * SI * RP);               // [2][SI]: 1 = candidate item inside the table
+    uint2* const lists = reinterpret_cast<uint2*>(tl_lds + 2 * SI * RP + 2 * SI);          // [UW][TK_CAP] (score bits, item)
+    int* const c_item = reinterpret_cast<int*>(lists + UW * TK_CAP);                       // [UW][tc] first train items of a user
+    int* const c_deg = c_item + UW * tc;                                                   // [UW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, rg = lane >> 4;
+    const int u0 = blockIdx.x * UW;
+    const int us = wave * 16 + c;                    // this lane's user slot in the workgroup
+    const int K = a.K;
+    const int nst = (a.I + SI - 1) / SI;
+    const char* const items = static_cast<const char*>(a.F) + (size_t)a.U * RB;
+
+    // ---- staging registers: this thread's chunks of the next stage -----------------------------------------------------------
+    uint4 sreg[NLD];
+    uint8_t pf_reg = 0;
+    auto load_regs = [&](int st) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int q = tid + k * NT;
+            const int j = st * SI + q / CPR;
+            sreg[k] = (q < CH && st < nst && j < a.I) ? *reinterpret_cast<const uint4*>(items + (size_t)j * RB + (q % CPR) * 16)
+                                                      : make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (tid < SI) {
+            const int j = st * SI + tid;
+            pf_reg = (st < nst && j < a.I) ? a.pool[j] : 0;           // (raw: normalised when written -- a compare here would wait for the load)
+        }
+    };
+    auto write_lds = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int q = tid + k * NT;
+            if (q < CH) *reinterpret_cast<uint4*>(stage0 + (size_t)b * SI * RP + (q / CPR) * RP + (q % CPR) * 16) = sreg[k];
+        }
+        if (tid < SI) pflag[b * SI + tid] = pf_reg != 0 ? 1 : 0;
+    };
+    load_regs(0);
+
+    // ---- per-user state: the first tc train items (wave-private: a wave fills and reads only its own users') ------------------
+    {
+        long long p0_l = 0;                                      // lane i < 16: row of the wave's user i (one round of loads for all 16)
+        int deg_l = 0;
+        if (lane < 16 && u0 + wave * 16 + lane < a.B) {
+            const int64_t u = tk_user(a, u0 + wave * 16 + lane);
+            p0_l = a.train_ptr[u];
+            deg_l = (int)(a.train_ptr[u + 1] - p0_l);
+        }
+        if (lane < 16) c_deg[wave * 16 + lane] = deg_l;
+        int got[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                           // 16 independent loads in flight, then 16 LDS writes
+            const int deg = __builtin_amdgcn_readlane(deg_l, i);
+            const long long p0 = (long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(p0_l >> 32), i) << 32) |
+                                             (unsigned int)__builtin_amdgcn_readlane((int)p0_l, i));
+            got[i] = (lane < deg && lane < tc) ? a.train_items[p0 + lane] : 0x7fffffff;      // (padding: beyond every item id)
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (lane < tc) c_item[(wave * 16 + i) * tc + lane] = got[i];
+    }
+    // ---- B operand: this lane's user row (users past the batch end take the last one and never select) -------------------------
+    uint4 ufrag[NF];
+    {
+        const int my_u = u0 + us < a.B ? u0 + us : a.B - 1;
+        const char* urow = static_cast<const char*>(a.F) + (size_t)tk_user(a, my_u) * RB + 16 * rg;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) ufrag[f] = *reinterpret_cast<const uint4*>(urow + 64 * f);
+    }
+    float tau = u0 + us < a.B ? TK_NEG : 3.402823466e38f;       // the user's threshold, the same in its four lanes
+    int cnt = 0;                                                  // entries appended to the user's list (> TK_CAP: some were held back)
+    unsigned int pend = 0u;                                       // bit (4 t + e): this lane's score of that register was held back
+    uint2* const mylist = lists + us * TK_CAP;
+    const unsigned long long lowmask = QUAD & ((1ull << (16 * rg)) - 1ull);
+
+    // The wave compacts the list of its user ui (0..15; n entries), one entry per lane.  All arguments wave-uniform.
+    //   * train positives out: the user's first tc train items sit in LDS, ascending, padded -- a 4-ary search (three round trips
+    //     for 64 entries; the first form's linear scan cost ~4 000 cycles per compaction); beyond them a binary search in memory
+    //   * (score desc, item asc) as ONE unsigned 64-bit key per entry (order-preserving score bits, ~item): no ties
+    //   * SORTED = false (in the stream): only the K best are wanted, in any order -> the wave finds the K-th largest key by
+    //     quickselect (pivot = a candidate lane's key, v_cmp_gt_u64 + ballot + popcount per round, ~8 rounds) and the keepers
+    //     move to the front by their position in the keep mask; SORTED = true (the end): every entry ranked against all others
+    // Returns the new entry count; `own` = the K-th best score when K entries remain.
+    auto compact = [&](int ui, int n, float& own, auto sorted) -> int {
+        constexpr bool SORTED = decltype(sorted)::value;
+        own = TK_NEG;
+        if (n == 0) return 0;
+        const int usl = wave * 16 + ui;
+        uint2* const L = lists + usl * TK_CAP;
+        const bool live = lane < n;
+        const uint2 en = live ? L[lane] : make_uint2(__float_as_uint(TK_NEG), 0x7fffffffu);
+        const int i_t = (int)en.y;
+        const int* const ci = c_item + usl * tc;
+        int lo = 0;
+        if (tc == 32) lo = ci[15] < i_t ? 16 : 0;
+        for (int q = tc == 32 ? 1 : 4; q >= 1; q >>= 2) {            // a span of 16 q entries -> 4 q
+            const int p1 = ci[lo + 4 * q - 1], p2 = ci[lo + 8 * q - 1], p3 = ci[lo + 12 * q - 1];
+            lo += 4 * q * ((p1 < i_t ? 1 : 0) + (p2 < i_t ? 1 : 0) + (p3 < i_t ? 1 : 0));
+        }
+        const int4 fin = *reinterpret_cast<const int4*>(ci + lo);
+        bool member = fin.x == i_t || fin.y == i_t || fin.z == i_t || fin.w == i_t;
+        const int deg = c_deg[usl];
+        if (deg > tc && live && !member && i_t > ci[tc - 1]) {
+            const int64_t p0 = a.train_ptr[tk_user(a, u0 + usl)];
+            int l2 = tc, h2 = deg;                                   // per-lane binary search over the uncached tail
+            while (l2 < h2) {
+                const int mid = (l2 + h2) >> 1;
+                if (a.train_items[p0 + mid] < i_t) l2 = mid + 1; else h2 = mid;
+            }
+            member = l2 < deg && a.train_items[p0 + l2] == i_t;
+        }
+        const bool valid = live && !member;
+        const unsigned long long vm = __ballot(valid);
+        const int nvalid = __popcll(vm);
+        const int ncnt = nvalid < K ? nvalid : K;
+        const unsigned int ob = en.x ^ ((unsigned int)((int)en.x >> 31) | 0x80000000u);       // float order -> unsigned order
+        const unsigned long long key = valid ? (((unsigned long long)ob << 32) | (unsigned int)~i_t) : 0ull;
+        if constexpr (SORTED) {
+            int rank = 0;
+#pragma unroll
+            for (int t = 0; t < TK_CAP; ++t) {
+                const unsigned long long k2 = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(key >> 32), t) << 32) |
+                                              (unsigned int)__builtin_amdgcn_readlane((int)key, t);
+                rank += k2 > key ? 1 : 0;
+            }
+            if (valid && rank < K) L[rank] = en;
+            if (ncnt == K) {
+                const unsigned long long last = __ballot(valid && rank == K - 1);
+                own = __int_as_float(__builtin_amdgcn_readlane((int)en.x, __builtin_ctzll(last)));
+            }
+        } else {
+            unsigned long long keep = vm;
+            if (nvalid > K) {
+                unsigned long long cand = vm;
+                int need = K;
+                unsigned long long pk;
+                for (;;) {                                               // cand shrinks every round: at most 64
+                    const int p = __builtin_ctzll(cand);
+                    pk = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(key >> 32), p) << 32) |
+                         (unsigned int)__builtin_amdgcn_readlane((int)key, p);
+                    const unsigned long long G = __ballot(key > pk) & cand;
+                    const int g = __popcll(G);
+                    if (g == need - 1) break;
+                    if (g >= need) cand = G;
+                    else { need -= g + 1; cand &= ~G & ~(1ull << p); }
+                }
+                keep = __ballot(key >= pk) & vm;                        // exactly K lanes
+                own = __uint_as_float((unsigned int)(pk >> 32) ^ (((unsigned int)(pk >> 32) >> 31) ? 0x80000000u : 0xffffffffu));
+            } else if (nvalid == K) {
+                float sm = valid ? __uint_as_float(en.x) : 3.402823466e38f;     // rare: exactly K left -> their smallest score
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) sm = fminf(sm, __shfl_xor(sm, o, 64));
+                own = sm;
+            }
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(keep >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)keep, 0u));
+            if ((keep >> lane) & 1ull) L[pos] = en;
+        }
+        return ncnt;
+    };
+
+    // One accumulator register of the wave: the lanes whose score passed append it to their user's list.
+    auto push = [&](bool hit, float sc, int j, unsigned int bit) {
+        const unsigned long long m = __ballot(hit);
+        if (m == 0ull) return;                                    // the steady state: nobody's did
+        const unsigned long long mu = (m >> c) & QUAD;            // the hits of this user's four lanes (bit 16 rg')
+        const int pos = cnt + __popcll(mu & lowmask);
+        if (hit) {
+            if (pos < TK_CAP) mylist[pos] = make_uint2(__float_as_uint(sc), (unsigned int)j);
+            else pend |= bit;
+        }
+        cnt += __popcll(mu);
+    };
+
+    // Three steps in flight per wave (a step = 32 items = two 16-item tiles): while step g is sifted (vector + LDS work),
+    // step g + 1 is on the matrix cores and the operand fragments (and pool flags) of step g + 2 are on their way from LDS.
+    // (Reading a step's fragments and multiplying them at once left every wave waiting a full LDS round trip per step with
+    // nothing else to issue: 0.86 ms of the kernel's 1.14 at two waves per SIMD.)  The steps run on across the stages; a stage
+    // is written, and the barrier passed, just before its first fragments are read -- by then every wave has the fragments of
+    // the stage two back in registers (its multiply precedes the barrier), so two buffers suffice.
+    uint4 frag[2][NF];                 // step g + 2
+    unsigned int fwr[2];
+    tk_f32x4 acc_n[2];                 // step g + 1
+    unsigned int fw_n[2] = {0u, 0u};
+    auto read_step = [&](int gs) {
+        const int sb = (gs / STEPS) & 1, step = gs % STEPS;
+        const char* rp = stage0 + (size_t)sb * SI * RP + (step * 32 + c) * RP + 16 * rg;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) frag[t][f] = *reinterpret_cast<const uint4*>(rp + t * 16 * RP + 64 * f);
+            fwr[t] = *reinterpret_cast<const unsigned int*>(pflag + sb * SI + step * 32 + 16 * t + 4 * rg);
+        }
+    };
+    // acc_n[t][e] in lane (c, rg) = score(user c, item 32 gs + 16 t + 4 rg + e)
+    auto multiply = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            tk_f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const uint4 v = frag[t][f];
+                if constexpr (BF) {
+                    r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tk_bf16x8, v), __builtin_bit_cast(tk_bf16x8, ufrag[f]), r, 0, 0, 0);
+                } else {
+                    r = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.x), __uint_as_float(ufrag[f].x), r, 0, 0, 0);
+                    r = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.y), __uint_as_float(ufrag[f].y), r, 0, 0, 0);
+                    r = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.z), __uint_as_float(ufrag[f].z), r, 0, 0, 0);
+                    r = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.w), __uint_as_float(ufrag[f].w), r, 0, 0, 0);
+                }
+            }
+            acc_n[t] = r;
+            fw_n[t] = fwr[t];
+        }
+    };
+
+    write_lds(0);
+    __syncthreads();
+    // The user rows must have ARRIVED here: left pending, their first use sits inside the loop, and the wait the compiler
+    // puts in front of it (vmcnt counts in order) also waits, on every turn, for the next stage's rows requested a moment ago.
+#pragma unroll
+    for (int f = 0; f < NF; ++f) asm volatile("" :: "v"(ufrag[f].x), "v"(ufrag[f].y), "v"(ufrag[f].z), "v"(ufrag[f].w));
+    load_regs(1);
+    read_step(0);
+    const int total = nst * STEPS;
+    tk_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    unsigned int fw[2] = {0u, 0u};
+#pragma unroll 1
+    for (int g = -1; g < total; ++g) {
+        if (g + 1 < total) multiply();                                  // step g + 1: its fragments were read a turn ago
+        if (g + 2 < total) {
+            if ((g + 2) % STEPS == 0) {                                 // step g + 2 opens a stage
+                const int s2 = (g + 2) / STEPS;
+                write_lds(s2 & 1);
+                __syncthreads();
+                load_regs(s2 + 1);
+            }
+            read_step(g + 2);
+        }
+        if (g >= 0) {
+            const int jb = g * 32 + 4 * rg;
+            if (__ballot((fw[0] & fw[1]) != 0x01010101u) == 0ull) {    // every item of the step a candidate: the usual case
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) push(acc[t][e] > tau, acc[t][e], jb + 16 * t + e, 1u << (4 * t + e));
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        push(acc[t][e] > tau && ((fw[t] >> (8 * e)) & 1u), acc[t][e], jb + 16 * t + e, 1u << (4 * t + e));
+            }
+            while (__ballot(pend != 0u) != 0ull) {                      // some list overflowed: compact it, raise tau, retry what was held back
+                unsigned int over = (unsigned int)__ballot(cnt > TK_CAP) & 0xffffu;
+                while (over) {
+                    const int ui = __builtin_ctz(over);
+                    over &= over - 1u;
+                    float own;
+                    const int n = compact(ui, TK_CAP, own, std::false_type{});
+                    if (c == ui) {
+                        cnt = n;
+                        if (n == K) tau = fmaxf(tau, own);
+                    }
+                }
+                const unsigned int p = pend;
+                pend = 0u;
+                const float tb = tk_below(tau);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        push(((p >> (4 * t + e)) & 1u) && acc[t][e] > tb, acc[t][e], jb + 16 * t + e, 1u << (4 * t + e));
+            }
+        }
+        acc[0] = acc_n[0]; acc[1] = acc_n[1];
+        fw[0] = fw_n[0]; fw[1] = fw_n[1];
+    }
+
+    // ---- every list compacted (valid entries only, best first, at most K) and written out ------------------------------------------
+    for (int ui = 0; ui < 16; ++ui) {
+        const int have = __builtin_amdgcn_readlane(cnt, ui);
+        float own;
+        const int n = compact(ui, have < TK_CAP ? have : TK_CAP, own, std::true_type{});
+        const int usl = wave * 16 + ui, ub = u0 + usl;
+        if (ub >= a.B) continue;
+        const int64_t uraw = a.users[ub];
+        const bool isuser = uraw >= 0 && uraw < a.U;
+        if (!isuser && lane == 0 && a.bad) atomicAdd(a.bad, 1);
+        if (lane < K) {
+            const uint2 en = (isuser && lane < n) ? lists[usl * TK_CAP + lane] : make_uint2(__float_as_uint(TK_NEG), 0xffffffffu);
+            a.top_items[(size_t)ub * K + lane] = (int)en.y;
+            a.top_scores[(size_t)ub * K + lane] = __uint_as_float(en.x);
+        }
+    }
+}
+
+template <typename T, int D, int NW>
+static int launch_topk_lds(const TopkArgs& a, hipStream_t st) {
+    constexpr int RB = D * (int)sizeof(T), SI = TL_STAGE_BYTES / RB, UW = 16 * NW;
+    const size_t fixed = (size_t)2 * SI * (RB + 16) + 2 * SI + (size_t)UW * TK_CAP * 8 + (size_t)UW * 4;
+    const int tc = fixed + (size_t)UW * TK_CACHE * 4 <= 160 * 1024 ? TK_CACHE : TK_CACHE / 2;
+    const size_t lds = fixed + (size_t)UW * tc * 4;
+    auto k = eval_topk_lds_kernel<T, D, NW>;
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return static_cast<int>(e);
+    }
+    hipLaunchKernelGGL(k, dim3((a.B + UW - 1) / UW), dim3(64 * NW), lds, st, a, tc);
+    NGACF_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace ngacf
 
 using namespace ngacf;
@@ -368,7 +721,28 @@ extern "C" int ngacf_eval_topk(const void* F, int dtype, const int64_t* users, i
     a.F = F; a.users = users; a.pool = pool_mask; a.train_ptr = train_ptr; a.train_items = train_items;
     a.top_items = top_items; a.top_scores = top_scores; a.bad = bad_index; a.B = B; a.U = U; a.I = I; a.K = K;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const int nw_env = getenv("NGACF_TOPK_WAVES") ? atoi(getenv("NGACF_TOPK_WAVES")) : 0;
+    // Which form: the LDS-shared one (16 * NW users per workgroup, item rows staged once per workgroup) when its workgroups
+    // fill a good part of the chip, else the wave-private one below.  NGACF_TOPK_FORM=lds|wave and NGACF_TOPK_LDS_WAVES=8|12
+    // force a choice (tests, A/B runs); read per call.
+    {
+        const char* form = getenv("NGACF_TOPK_FORM");
+        const char* lw = getenv("NGACF_TOPK_LDS_WAVES");
+        const bool use_lds = form ? (form[0] == 'l') : B >= 96 * 128;
+        if (use_lds) {
+            // 128 users per workgroup while those fit the 256 CUs in one round, 192 while THOSE do (a second, partly filled
+            // round would double the kernel's time), 128 beyond
+            int nwl = lw ? atoi(lw) : ((B + 127) / 128 <= 256 ? 8 : ((B + 191) / 192 <= 256 ? 12 : 8));
+            if (nwl != 8 && nwl != 12) nwl = 8;
+#define NGACF_TKL(T, D) return nwl == 8 ? launch_topk_lds<T, D, 8>(a, st) : launch_topk_lds<T, D, 12>(a, st)
+            if (dtype == NGACF_F32 && d == 64) NGACF_TKL(float, 64);
+            if (dtype == NGACF_F32 && d == 128) NGACF_TKL(float, 128);
+            if (dtype == NGACF_BF16 && d == 64) NGACF_TKL(bf16_t, 64);
+            if (dtype == NGACF_BF16 && d == 128) NGACF_TKL(bf16_t, 128);
+#undef NGACF_TKL
+            return NGACF_E_SHAPE;
+        }
+    }
+    const int nw_env = getenv("NGACF_TOPK_WAVES") ? atoi(getenv("NGACF_TOPK_WAVES")) : 0;
     // waves per group of 32 users: one list per user (1) as long as the groups alone fill the chip's 1024 SIMDs; small user
     // batches split every group's items over 2 or 4 waves instead
     const int groups = (B + 31) / 32;

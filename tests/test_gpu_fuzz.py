@@ -91,12 +91,17 @@ def test_random_stage_forward_backward_vs_oracle(seed):
 
 
 @pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("NGACF_FUZZ_ITERS", "12")) // 3)))
-def test_random_eval_topk_and_sampler_vs_host(seed):
+def test_random_eval_topk_and_sampler_vs_host(seed, monkeypatch):
     """ngacf_eval_topk against masked scores + stable sort (integer tables: exact, with ties), ngacf_sample_pairs against
-    its numpy statement, on random sizes: ragged user blocks, tiny pools, K from 1 to 32, users with few candidates."""
+    its numpy statement, on random sizes: ragged user blocks, tiny pools, K from 1 to 32, users with few candidates;
+    the kernel's form (wave-private / LDS-shared with 8 or 12 waves) drawn per case."""
     from ngacf_amd import ops, rng
     dev = torch.device("cuda:0")
     rs = np.random.RandomState(5000 + seed)
+    form = ["wave", "lds8", "lds12"][seed % 3]
+    monkeypatch.setenv("NGACF_TOPK_FORM", "wave" if form == "wave" else "lds")
+    if form != "wave":
+        monkeypatch.setenv("NGACF_TOPK_LDS_WAVES", form[3:])
     U, I = int(rs.randint(1, 300)), int(rs.randint(1, 900))
     d = int(rs.choice([64, 128]))
     K = int(rs.randint(1, 33))
@@ -124,7 +129,7 @@ def test_random_eval_topk_and_sampler_vs_host(seed):
     kk = min(K, I)
     want_i, want_s = order.indices[:, :kk], order.values[:, :kk]
     valid = want_s > neg
-    tag = (seed, U, I, d, K, str(dt))
+    tag = (seed, U, I, d, K, str(dt), form)
     assert torch.equal(top[:, :kk].long()[valid], want_i[valid]) and bool((top[:, :kk][~valid] == -1).all()), tag
     assert bool((top[:, kk:] == -1).all()) and torch.equal(top_s[:, :kk][valid], want_s[valid]), tag
     # sampler: only users with a train positive and a legal negative can be sampled

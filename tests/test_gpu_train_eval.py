@@ -216,12 +216,18 @@ def test_forward_pairs_equals_two_forwards_without_dropout_and_debug_asserts():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["wave", "lds8", "lds12"])
 @pytest.mark.parametrize("d,dt", [(64, "fp32"), (64, "bf16"), (128, "fp32"), (128, "bf16")])
-def test_eval_topk_kernel_matches_stable_sort_exactly(d, dt):
+def test_eval_topk_kernel_matches_stable_sort_exactly(d, dt, form, monkeypatch):
     """ngacf_eval_topk (MFMA scoring fused with top-K selection) against masked scores + stable descending sort.
     Integer-valued embeddings make every dot product exact in fp32 whatever the summation order, and produce
-    thousands of exact score ties, so the comparison is bit-for-bit including the tie rule (lower item id first)."""
+    thousands of exact score ties, so the comparison is bit-for-bit including the tie rule (lower item id first).
+    Both forms of the kernel: one wave per 32 users streaming the item table (small user batches), and 128 / 192 users
+    per workgroup sharing LDS-staged item rows (the form a whole evaluation takes)."""
     from ngacf_amd import ops
+    monkeypatch.setenv("NGACF_TOPK_FORM", "wave" if form == "wave" else "lds")
+    if form != "wave":
+        monkeypatch.setenv("NGACF_TOPK_LDS_WAVES", form[3:])
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(d)
     U, I, K = 333, 1777, 20
