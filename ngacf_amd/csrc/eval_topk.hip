@@ -378,26 +378,36 @@ __global__ __launch_bounds__(64 * NW) void eval_topk_kernel(const TopkArgs a) {
 //               without the per-score flag test
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) float tk_f32x4;
-constexpr int TL_STAGE_BYTES = 16384;
+constexpr int TL_NB = 4;             // stage buffers in the ring
+__host__ __device__ constexpr int tl_stage_bytes(int nw) { return nw == 8 ? 16384 : 8192; }
+constexpr int TL_SUB = 16;           // entries per quarter list (a user's list: four quarters, one per lane of the user)
 
 template <typename T, int D, int NW>
-__global__ __launch_bounds__(64 * NW) void eval_topk_lds_kernel(const TopkArgs a, const int tc) {
+__global__ __launch_bounds__(64 * (NW + 1)) void eval_topk_lds_kernel(const TopkArgs a, const int tc) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int RB = D * (int)sizeof(T);          // bytes of a table row
-    constexpr int RP = RB + 16;                     // pitch of a staged row (16-byte fragment reads of 16 rows: no bank conflict)
-    constexpr int SI = TL_STAGE_BYTES / RB;         // items per stage: 128 / 64 / 64 / 32
+    // Staged rows are NOT padded: their 16-byte chunks are swizzled, chunk k of stage row r at position k ^ sw(r), sw(r) =
+    // (r >> 1) & 7 for 128-byte rows, r & 15 for longer ones.  ds_read_b128 is served in four groups of 16 lanes -- lanes
+    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- each of which must touch 64 distinct banks; with lane =
+    // (c, rg) a group holds all 16 rows c, half of them with chunk 4 f + rg and half with 4 f + rg + 1, and no row pitch
+    // separates those (144 bytes: 39 % extra LDS cycles by SQ_LDS_BANK_CONFLICT); these two XOR patterns do.
+    constexpr int STAGE = tl_stage_bytes(NW);       // bytes of a stage
+    constexpr int SI = STAGE / RB;                  // items per stage
     constexpr int STEPS = SI / 32;                  // a step = 32 items = two 16 x 16 score tiles per wave
-    constexpr int NT = 64 * NW;
-    constexpr int CPR = RB / 16, CH = SI * CPR;     // 16-byte chunks per row / per stage (1024)
-    constexpr int NLD = (CH + NT - 1) / NT;
+    constexpr int NB = TL_NB, FR = TL_NB + 4;       // stage buffers; slots of the flag ring (a stage's flags outlive its rows: the sift runs two steps behind the reads)
+    constexpr int CPR = RB / 16;                    // 16-byte chunks per row
+    constexpr int PIECES = STAGE / 1024;            // 1 KB LDS-DMA pieces per stage
+    constexpr int FL = (SI + 63) / 64;              // flag requests per stage (64 items each)
+    constexpr int FSLOT = FL * 64;                  // dwords of a stage's flag slot (one dword per item: what a byte-sized LDS-DMA writes)
     constexpr int UW = 16 * NW;                     // users per workgroup
     constexpr int NF = RB / 64;                     // 16-byte operand fragments per row and lane
-    constexpr unsigned long long QUAD = 0x0001000100010001ull;
+    static_assert(SI >= 32 && SI % 32 == 0, "a stage holds whole steps");
     extern __shared__ __attribute__((aligned(16))) char tl_lds[];
-    char* const stage0 = tl_lds;                                                          // [2][SI][RP]
-    uint8_t* const pflag = reinterpret_cast<uint8_t*>(tl_lds + 2 * SI * RP);               // [2][SI]: 1 = candidate item inside the table
-    uint2* const lists = reinterpret_cast<uint2*>(tl_lds + 2 * SI * RP + 2 * SI);          // [UW][TK_CAP] (score bits, item)
-    int* const c_item = reinterpret_cast<int*>(lists + UW * TK_CAP);                       // [UW][tc] first train items of a user
+    char* const stage0 = tl_lds;                                                          // [NB][SI][RB], chunks swizzled
+    unsigned int* const pflag = reinterpret_cast<unsigned int*>(tl_lds + NB * STAGE);      // [FR][FSLOT]: the pool's byte of an item, one dword each (stage s in slot s % FR)
+    int* const ctr = reinterpret_cast<int*>(pflag + FR * FSLOT);                           // full[NB]: times buffer b was filled; done[NB]: waves that left it, summed
+    uint2* const lists = reinterpret_cast<uint2*>(ctr + 2 * NB);                           // [UW][4][TL_SUB + 1] (score bits, item)
+    int* const c_item = reinterpret_cast<int*>(lists + UW * 4 * (TL_SUB + 1));             // [UW][tc] first train items of a user
     int* const c_deg = c_item + UW * tc;                                                   // [UW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -407,32 +417,63 @@ __global__ __launch_bounds__(64 * NW) void eval_topk_lds_kernel(const TopkArgs a
     const int K = a.K;
     const int nst = (a.I + SI - 1) / SI;
     const char* const items = static_cast<const char*>(a.F) + (size_t)a.U * RB;
+    // LDS byte addresses of the counters (polled / bumped with explicit ds_ instructions: a plain load could be kept in a register)
+    const unsigned int ctr_at = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(ctr);
+    auto lds_peek = [&](unsigned int at) -> int {
+        int v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(at) : "memory");
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    if (tid < 2 * NB) ctr[tid] = 0;
+    __syncthreads();                                  // (the only barrier: from here on the waves run on their own)
 
-    // ---- staging registers: this thread's chunks of the next stage -----------------------------------------------------------
-    uint4 sreg[NLD];
-    uint8_t pf_reg = 0;
-    auto load_regs = [&](int st) {
+    // ---- the producer wave: item rows global -> LDS by LDS-DMA, NB - 1 stages ahead of the slowest consumer ---------------------
+    // buffer b = s % NB is refilled once all NW consumer waves have bumped done[b] for its previous stage (a wave bumps it right
+    // behind the LAST fragment reads of that stage: LDS executes a wave's instructions in order); a stage is published (full[b] =
+    // its round) once this wave's vmcnt says its pieces and flags have landed.  The consumers never meet at a barrier: one of
+    // them compacting a list (~2 000 cycles) used to hold the other seven at the next stage's barrier -- 0.4 ms of the kernel.
+    if (wave == NW) {
+        // One stage's turn: request stage s -- rows AND pool flags by LDS-DMA, so that this wave holds no loaded register and
+        // the compiler has no reason to put a vmcnt(0) of its own anywhere in the loop (it did, in front of every use of a
+        // flag byte: the producer then ran one stage at a time) -- then, vmcnt counting in order: at most this stage's
+        // PIECES + FL requests outstanding = the previous stage has landed -> its round number goes up.
+        // (A flag byte lands as one zero-extended dword per lane; rows and flags past the table's end are clamped copies of
+        // its last item and are never believed: the consumers check j < I wherever a stage reaches beyond it.)
+#pragma unroll 1
+        for (int s = 0; s <= nst; ++s) {
+            if (s < nst) {
+                const int b = s % NB;
+                if (s >= NB) {
+                    const int want = NW * (s / NB);
+                    while (lds_peek(ctr_at + 4 * (NB + b)) < want) __builtin_amdgcn_s_sleep(2);
+                }
+                const int j0 = s * SI;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int q = tid + k * NT;
-            const int j = st * SI + q / CPR;
-            sreg[k] = (q < CH && st < nst && j < a.I) ? *reinterpret_cast<const uint4*>(items + (size_t)j * RB + (q % CPR) * 16)
-                                                      : make_uint4(0u, 0u, 0u, 0u);
-        }
-        if (tid < SI) {
-            const int j = st * SI + tid;
-            pf_reg = (st < nst && j < a.I) ? a.pool[j] : 0;           // (raw: normalised when written -- a compare here would wait for the load)
-        }
-    };
-    auto write_lds = [&](int b) {
+                for (int p = 0; p < PIECES; ++p) {
+                    const int r = p * (1024 / RB) + lane / CPR;                     // stage row of this lane's chunk
+                    const int pc = lane % CPR;                                      // its place in the row as stored
+                    const int k = RB == 128 ? pc ^ ((r >> 1) & 7) : pc ^ (r & 15);  // the chunk that belongs there
+                    const int j = j0 + r < a.I ? j0 + r : a.I - 1;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(items + (size_t)j * RB + 16 * k),
+                                                     (__attribute__((address_space(3))) void*)(stage0 + b * STAGE + p * 1024), 16, 0, 0);
+                }
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int q = tid + k * NT;
-            if (q < CH) *reinterpret_cast<uint4*>(stage0 + (size_t)b * SI * RP + (q / CPR) * RP + (q % CPR) * 16) = sreg[k];
+                for (int k = 0; k < FL; ++k) {
+                    const int j = j0 + lane + 64 * k;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.pool + (j < a.I ? j : a.I - 1)),
+                                                     (__attribute__((address_space(3))) void*)(pflag + (s % FR) * FSLOT + 64 * k), 1, 0, 0);
+                }
+            }
+            if (s > 0) {
+                if (s < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES + FL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned int at = ctr_at + 4 * ((s - 1) % NB);
+                const int rnd = (s - 1) / NB + 1;
+                asm volatile("ds_write_b32 %0, %1" :: "v"(at), "v"(rnd) : "memory");
+            }
         }
-        if (tid < SI) pflag[b * SI + tid] = pf_reg != 0 ? 1 : 0;
-    };
-    load_regs(0);
+        return;
+    }
 
     // ---- per-user state: the first tc train items (wave-private: a wave fills and reads only its own users') ------------------
     {
@@ -464,11 +505,14 @@ __global__ __launch_bounds__(64 * NW) void eval_topk_lds_kernel(const TopkArgs a
 #pragma unroll
         for (int f = 0; f < NF; ++f) ufrag[f] = *reinterpret_cast<const uint4*>(urow + 64 * f);
     }
+    // (The user rows must have ARRIVED before the loop: left pending, the wait the compiler puts in front of their first use
+    // would sit inside it.)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) asm volatile("" :: "v"(ufrag[f].x), "v"(ufrag[f].y), "v"(ufrag[f].z), "v"(ufrag[f].w));
     float tau = u0 + us < a.B ? TK_NEG : 3.402823466e38f;       // the user's threshold, the same in its four lanes
-    int cnt = 0;                                                  // entries appended to the user's list (> TK_CAP: some were held back)
+    int cnt = 0;                                                  // appends to THIS LANE's quarter of the user's list (> TL_SUB: some were held back)
     unsigned int pend = 0u;                                       // bit (4 t + e): this lane's score of that register was held back
-    uint2* const mylist = lists + us * TK_CAP;
-    const unsigned long long lowmask = QUAD & ((1ull << (16 * rg)) - 1ull);
+    uint2* const mysub = lists + (us * 4 + rg) * (TL_SUB + 1);    // (entry TL_SUB: where a held-back score is dumped)
 
     // The wave compacts the list of its user ui (0..15; n entries), one entry per lane.  All arguments wave-uniform.
     //   * train positives out: the user's first tc train items sit in LDS, ascending, padded -- a 4-ary search (three round trips
@@ -478,19 +522,22 @@ __global__ __launch_bounds__(64 * NW) void eval_topk_lds_kernel(const TopkArgs a
     //     quickselect (pivot = a candidate lane's key, v_cmp_gt_u64 + ballot + popcount per round, ~8 rounds) and the keepers
     //     move to the front by their position in the keep mask; SORTED = true (the end): every entry ranked against all others
     // Returns the new entry count; `own` = the K-th best score when K entries remain.
-    auto compact = [&](int ui, int n, float& own, auto sorted) -> int {
+    auto compact = [&](int ui, float& own, auto sorted) -> int {
         constexpr bool SORTED = decltype(sorted)::value;
         own = TK_NEG;
-        if (n == 0) return 0;
         const int usl = wave * 16 + ui;
-        uint2* const L = lists + usl * TK_CAP;
-        const bool live = lane < n;
-        const uint2 en = live ? L[lane] : make_uint2(__float_as_uint(TK_NEG), 0x7fffffffu);
+        uint2* const L = lists + usl * 4 * (TL_SUB + 1);
+        // lane i looks at entry (i & 15) of quarter (i >> 4); the quarters' counts sit in the user's four lanes
+        const int n0 = __builtin_amdgcn_readlane(cnt, ui), n1 = __builtin_amdgcn_readlane(cnt, ui + 16),
+                  n2 = __builtin_amdgcn_readlane(cnt, ui + 32), n3 = __builtin_amdgcn_readlane(cnt, ui + 48);
+        const int nq = rg == 0 ? n0 : (rg == 1 ? n1 : (rg == 2 ? n2 : n3));
+        const bool live = c < (nq < TL_SUB ? nq : TL_SUB);
+        const uint2 en = live ? L[rg * (TL_SUB + 1) + c] : make_uint2(__float_as_uint(TK_NEG), 0x7fffffffu);
         const int i_t = (int)en.y;
         const int* const ci = c_item + usl * tc;
         int lo = 0;
         if (tc == 32) lo = ci[15] < i_t ? 16 : 0;
-        for (int q = tc == 32 ? 1 : 4; q >= 1; q >>= 2) {            // a span of 16 q entries -> 4 q
+        for (int q = tc == 64 ? 4 : 1; q >= 1; q >>= 2) {            // a span of 16 q entries -> 4 q
             const int p1 = ci[lo + 4 * q - 1], p2 = ci[lo + 8 * q - 1], p3 = ci[lo + 12 * q - 1];
             lo += 4 * q * ((p1 < i_t ? 1 : 0) + (p2 < i_t ? 1 : 0) + (p3 < i_t ? 1 : 0));
         }
@@ -520,7 +567,7 @@ __global__ __launch_bounds__(64 * NW) void eval_topk_lds_kernel(const TopkArgs a
                                               (unsigned int)__builtin_amdgcn_readlane((int)key, t);
                 rank += k2 > key ? 1 : 0;
             }
-            if (valid && rank < K) L[rank] = en;
+            if (valid && rank < K) L[(rank & 3) * (TL_SUB + 1) + (rank >> 2)] = en;      // entry r of the ranking: quarter r & 3, place r >> 2
             if (ncnt == K) {
                 const unsigned long long last = __ballot(valid && rank == K - 1);
                 own = __int_as_float(__builtin_amdgcn_readlane((int)en.x, __builtin_ctzll(last)));
@@ -550,141 +597,158 @@ __global__ __launch_bounds__(64 * NW) void eval_topk_lds_kernel(const TopkArgs a
                 own = sm;
             }
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned int)(keep >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)keep, 0u));
-            if ((keep >> lane) & 1ull) L[pos] = en;
+            if ((keep >> lane) & 1ull) L[(pos & 3) * (TL_SUB + 1) + (pos >> 2)] = en;    // dealt round the four quarters
         }
         return ncnt;
     };
 
     // One accumulator register of the wave: the lanes whose score passed append it to their user's list.
+    // (Each of a user's four lanes appends to its OWN quarter of the list: the first build kept one count per user and found a
+    // lane's slot from the ballot mask -- 15 vector + 11 scalar instructions per survivor, three quarters of the kernel's
+    // issue slots at ~310 survivors per user.)
     auto push = [&](bool hit, float sc, int j, unsigned int bit) {
-        const unsigned long long m = __ballot(hit);
-        if (m == 0ull) return;                                    // the steady state: nobody's did
-        const unsigned long long mu = (m >> c) & QUAD;            // the hits of this user's four lanes (bit 16 rg')
-        const int pos = cnt + __popcll(mu & lowmask);
+        if (__ballot(hit) == 0ull) return;                        // nobody's did
         if (hit) {
-            if (pos < TK_CAP) mylist[pos] = make_uint2(__float_as_uint(sc), (unsigned int)j);
-            else pend |= bit;
+            mysub[cnt < TL_SUB ? cnt : TL_SUB] = make_uint2(__float_as_uint(sc), (unsigned int)j);
+            pend |= cnt >= TL_SUB ? bit : 0u;
+            ++cnt;
         }
-        cnt += __popcll(mu);
     };
 
-    // Three steps in flight per wave (a step = 32 items = two 16-item tiles): while step g is sifted (vector + LDS work),
-    // step g + 1 is on the matrix cores and the operand fragments (and pool flags) of step g + 2 are on their way from LDS.
-    // (Reading a step's fragments and multiplying them at once left every wave waiting a full LDS round trip per step with
-    // nothing else to issue: 0.86 ms of the kernel's 1.14 at two waves per SIMD.)  The steps run on across the stages; a stage
-    // is written, and the barrier passed, just before its first fragments are read -- by then every wave has the fragments of
-    // the stage two back in registers (its multiply precedes the barrier), so two buffers suffice.
+    // Three steps in flight per wave (a step = 32 items = two 16-item tiles): while step g is sifted, step g + 1 is on the
+    // matrix cores and the operand fragments of step g + 2 are on their way from LDS.  The steps run on across the stages; a
+    // stage is written, and the barrier passed, just before its first fragments are read -- by then every wave has the
+    // fragments of the stage two back in registers (its multiply precedes the barrier), so two buffers suffice.
+    // The loop is ISSUE-bound (SQ counters of the first build: 52 vector + 23 scalar + 19 branch instructions per wave and
+    // step, 0.62 ms with nothing ever selected), so the steady state is pared down: the turn is unrolled by two (the two
+    // accumulator sets swap roles by name, no copies), the eight scores of a lane are folded to their maximum (v_max3) and
+    // ONE compare + ONE never-taken branch decides whether anybody in the wave has anything to do (the per-register
+    // compares, item numbers, pool flags live behind it), addresses are a per-lane constant + a scalar.
     uint4 frag[2][NF];                 // step g + 2
-    unsigned int fwr[2];
-    tk_f32x4 acc_n[2];                 // step g + 1
-    unsigned int fw_n[2] = {0u, 0u};
-    auto read_step = [&](int gs) {
-        const int sb = (gs / STEPS) & 1, step = gs % STEPS;
-        const char* rp = stage0 + (size_t)sb * SI * RP + (step * 32 + c) * RP + 16 * rg;
+    int foff[NF];                      // this lane's byte offsets into a stage row block: row c, chunk (4 f + rg) ^ sw(c)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int f = 0; f < NF; ++f) frag[t][f] = *reinterpret_cast<const uint4*>(rp + t * 16 * RP + 64 * f);
-            fwr[t] = *reinterpret_cast<const unsigned int*>(pflag + sb * SI + step * 32 + 16 * t + 4 * rg);
+    for (int f = 0; f < NF; ++f) foff[f] = c * RB + 16 * ((4 * f + rg) ^ (RB == 128 ? (c >> 1) & 7 : c));
+    unsigned int okbits = 0u;          // bit (s & 31): every item of stage s is a candidate inside the table (wave-uniform)
+    // The wave moves on to stage st: the previous stage's buffer is released (every fragment read of it has been ISSUED, and LDS
+    // executes this wave's instructions in order), then the wave waits for the producer's word on st.
+    auto enter_stage = [&](int st) {
+        if (st > 0 && lane == 0) {
+            const unsigned int at = ctr_at + 4 * (NB + (st - 1) % NB);
+            const int one = 1;
+            asm volatile("ds_add_u32 %0, %1" :: "v"(at), "v"(one) : "memory");
         }
+        const int want = st / NB + 1;
+        while (lds_peek(ctr_at + 4 * (st % NB)) < want) __builtin_amdgcn_s_sleep(1);
+        bool zero = false;
+#pragma unroll
+        for (int k = 0; k < FL; ++k) zero |= lane + 64 * k < SI && pflag[(st % FR) * FSLOT + lane + 64 * k] == 0u;
+        const bool ok = __ballot(zero) == 0ull && (st + 1) * SI <= a.I;
+        okbits = (okbits & ~(1u << (st & 31))) | ((ok ? 1u : 0u) << (st & 31));
     };
-    // acc_n[t][e] in lane (c, rg) = score(user c, item 32 gs + 16 t + 4 rg + e)
-    auto multiply = [&]() {
+    auto read_step = [&](int gs) {
+        const int sbase = (((gs / STEPS) % NB) * SI + (gs % STEPS) * 32) * RB;        // scalar
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) frag[t][f] = *reinterpret_cast<const uint4*>(stage0 + sbase + foff[f] + t * 16 * RB);
+    };
+    // r[t][e] in lane (c, rg) = score(user c, item 32 gs + 16 t + 4 rg + e)
+    auto multiply = [&](tk_f32x4 (&r)[2]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            tk_f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            r[t] = tk_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const uint4 v = frag[t][f];
                 if constexpr (BF) {
-                    r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tk_bf16x8, v), __builtin_bit_cast(tk_bf16x8, ufrag[f]), r, 0, 0, 0);
+                    r[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tk_bf16x8, v), __builtin_bit_cast(tk_bf16x8, ufrag[f]), r[t], 0, 0, 0);
                 } else {
-                    r = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.x), __uint_as_float(ufrag[f].x), r, 0, 0, 0);
-                    r = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.y), __uint_as_float(ufrag[f].y), r, 0, 0, 0);
-                    r = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.z), __uint_as_float(ufrag[f].z), r, 0, 0, 0);
-                    r = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.w), __uint_as_float(ufrag[f].w), r, 0, 0, 0);
+                    r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.x), __uint_as_float(ufrag[f].x), r[t], 0, 0, 0);
+                    r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.y), __uint_as_float(ufrag[f].y), r[t], 0, 0, 0);
+                    r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.z), __uint_as_float(ufrag[f].z), r[t], 0, 0, 0);
+                    r[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v.w), __uint_as_float(ufrag[f].w), r[t], 0, 0, 0);
                 }
             }
-            acc_n[t] = r;
-            fw_n[t] = fwr[t];
+        }
+    };
+    // Somebody in the wave has a score above its threshold (or the stage holds non-candidates): the registers one by one.
+    auto sift_slow = [&](const tk_f32x4 (&acc)[2], int g, bool sok) {
+        int jb = g * 32 + 4 * rg;
+        asm volatile("" : "+v"(jb));                                    // (item numbers are computed HERE, not in the steady state)
+        if (sok) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) push(acc[t][e] > tau, acc[t][e], jb + 16 * t + e, 1u << (4 * t + e));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint4 fw = *reinterpret_cast<const uint4*>(pflag + ((g / STEPS) % FR) * FSLOT + (g % STEPS) * 32 + 16 * t + 4 * rg);
+                const unsigned int fwe[4] = {fw.x, fw.y, fw.z, fw.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    push(acc[t][e] > tau && fwe[e] != 0u && jb + 16 * t + e < a.I, acc[t][e], jb + 16 * t + e, 1u << (4 * t + e));
+            }
+        }
+        while (__ballot(pend != 0u) != 0ull) {                          // some list overflowed: compact it, raise tau, retry what was held back
+            const unsigned long long om = __ballot(cnt > TL_SUB);
+            unsigned int over = (unsigned int)(om | (om >> 16) | (om >> 32) | (om >> 48)) & 0xffffu;      // users with a full quarter
+            while (over) {
+                const int ui = __builtin_ctz(over);
+                over &= over - 1u;
+                float own;
+                const int n = compact(ui, own, std::false_type{});
+                if (c == ui) {
+                    cnt = (n + 3 - rg) >> 2;
+                    if (n == K) tau = fmaxf(tau, own);
+                }
+            }
+            const unsigned int p = pend;
+            pend = 0u;
+            const float tb = tk_below(tau);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    push(((p >> (4 * t + e)) & 1u) && acc[t][e] > tb, acc[t][e], jb + 16 * t + e, 1u << (4 * t + e));
+        }
+    };
+    const int total = nst * STEPS;
+    // one turn: `cur` holds step g (sifted now), `nxt` receives step g + 1
+    auto turn = [&](tk_f32x4 (&cur)[2], tk_f32x4 (&nxt)[2], int g) {
+        if (g + 1 < total) multiply(nxt);                               // its fragments were read a turn ago
+        if (g + 2 < total) {
+            if ((g + 2) % STEPS == 0) enter_stage((g + 2) / STEPS);     // step g + 2 opens a stage
+            read_step(g + 2);
+        }
+        if (g >= 0 && g < total) {
+            const float m = fmaxf(fmaxf(fmaxf(fmaxf(cur[0][0], cur[0][1]), cur[0][2]), fmaxf(fmaxf(cur[0][3], cur[1][0]), cur[1][1])),
+                                  fmaxf(fmaxf(cur[1][2], cur[1][3]), TK_NEG));
+            const bool sok = (okbits >> ((g / STEPS) & 31)) & 1u;
+            if (__builtin_expect(__ballot(m > tau) != 0ull || !sok, 0)) sift_slow(cur, g, sok);
         }
     };
 
-    write_lds(0);
-    __syncthreads();
-    // The user rows must have ARRIVED here: left pending, their first use sits inside the loop, and the wait the compiler
-    // puts in front of it (vmcnt counts in order) also waits, on every turn, for the next stage's rows requested a moment ago.
-#pragma unroll
-    for (int f = 0; f < NF; ++f) asm volatile("" :: "v"(ufrag[f].x), "v"(ufrag[f].y), "v"(ufrag[f].z), "v"(ufrag[f].w));
-    load_regs(1);
+    enter_stage(0);
     read_step(0);
-    const int total = nst * STEPS;
-    tk_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    unsigned int fw[2] = {0u, 0u};
+    tk_f32x4 accA[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accB[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
-    for (int g = -1; g < total; ++g) {
-        if (g + 1 < total) multiply();                                  // step g + 1: its fragments were read a turn ago
-        if (g + 2 < total) {
-            if ((g + 2) % STEPS == 0) {                                 // step g + 2 opens a stage
-                const int s2 = (g + 2) / STEPS;
-                write_lds(s2 & 1);
-                __syncthreads();
-                load_regs(s2 + 1);
-            }
-            read_step(g + 2);
-        }
-        if (g >= 0) {
-            const int jb = g * 32 + 4 * rg;
-            if (__ballot((fw[0] & fw[1]) != 0x01010101u) == 0ull) {    // every item of the step a candidate: the usual case
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) push(acc[t][e] > tau, acc[t][e], jb + 16 * t + e, 1u << (4 * t + e));
-            } else {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        push(acc[t][e] > tau && ((fw[t] >> (8 * e)) & 1u), acc[t][e], jb + 16 * t + e, 1u << (4 * t + e));
-            }
-            while (__ballot(pend != 0u) != 0ull) {                      // some list overflowed: compact it, raise tau, retry what was held back
-                unsigned int over = (unsigned int)__ballot(cnt > TK_CAP) & 0xffffu;
-                while (over) {
-                    const int ui = __builtin_ctz(over);
-                    over &= over - 1u;
-                    float own;
-                    const int n = compact(ui, TK_CAP, own, std::false_type{});
-                    if (c == ui) {
-                        cnt = n;
-                        if (n == K) tau = fmaxf(tau, own);
-                    }
-                }
-                const unsigned int p = pend;
-                pend = 0u;
-                const float tb = tk_below(tau);
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        push(((p >> (4 * t + e)) & 1u) && acc[t][e] > tb, acc[t][e], jb + 16 * t + e, 1u << (4 * t + e));
-            }
-        }
-        acc[0] = acc_n[0]; acc[1] = acc_n[1];
-        fw[0] = fw_n[0]; fw[1] = fw_n[1];
+    for (int g = -1; g < total; g += 2) {
+        turn(accA, accB, g);
+        turn(accB, accA, g + 1);
     }
 
     // ---- every list compacted (valid entries only, best first, at most K) and written out ------------------------------------------
     for (int ui = 0; ui < 16; ++ui) {
-        const int have = __builtin_amdgcn_readlane(cnt, ui);
         float own;
-        const int n = compact(ui, have < TK_CAP ? have : TK_CAP, own, std::true_type{});
+        const int n = compact(ui, own, std::true_type{});
         const int usl = wave * 16 + ui, ub = u0 + usl;
         if (ub >= a.B) continue;
         const int64_t uraw = a.users[ub];
         const bool isuser = uraw >= 0 && uraw < a.U;
         if (!isuser && lane == 0 && a.bad) atomicAdd(a.bad, 1);
         if (lane < K) {
-            const uint2 en = (isuser && lane < n) ? lists[usl * TK_CAP + lane] : make_uint2(__float_as_uint(TK_NEG), 0xffffffffu);
+            const uint2 en = (isuser && lane < n) ? lists[(usl * 4 + (lane & 3)) * (TL_SUB + 1) + (lane >> 2)] : make_uint2(__float_as_uint(TK_NEG), 0xffffffffu);
             a.top_items[(size_t)ub * K + lane] = (int)en.y;
             a.top_scores[(size_t)ub * K + lane] = __uint_as_float(en.x);
         }
@@ -693,18 +757,22 @@ __global__ __launch_bounds__(64 * NW) void eval_topk_lds_kernel(const TopkArgs a
 
 template <typename T, int D, int NW>
 static int launch_topk_lds(const TopkArgs& a, hipStream_t st) {
-    constexpr int RB = D * (int)sizeof(T), SI = TL_STAGE_BYTES / RB, UW = 16 * NW;
-    const size_t fixed = (size_t)2 * SI * (RB + 16) + 2 * SI + (size_t)UW * TK_CAP * 8 + (size_t)UW * 4;
-    const int tc = fixed + (size_t)UW * TK_CACHE * 4 <= 160 * 1024 ? TK_CACHE : TK_CACHE / 2;
-    const size_t lds = fixed + (size_t)UW * tc * 4;
-    auto k = eval_topk_lds_kernel<T, D, NW>;
-    if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return static_cast<int>(e);
+    constexpr int RB = D * (int)sizeof(T), STAGE = tl_stage_bytes(NW), SI = STAGE / RB, UW = 16 * NW;
+    if constexpr (SI < 32) {
+        return NGACF_E_SHAPE;                                   // (512-byte rows take the 16 KB stages of the 8-wave form)
+    } else {
+        const int tc = NW == 12 ? 16 : 32;                      // train items of a user cached in LDS (what the ring and the lists leave)
+        const size_t lds = (size_t)TL_NB * STAGE + (size_t)(TL_NB + 4) * ((SI + 63) / 64) * 64 * 4 + 2 * TL_NB * 4 + (size_t)UW * 4 * (TL_SUB + 1) * 8 +
+                           (size_t)UW * tc * 4 + (size_t)UW * 4;
+        auto k = eval_topk_lds_kernel<T, D, NW>;
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return static_cast<int>(e);
+        }
+        hipLaunchKernelGGL(k, dim3((a.B + UW - 1) / UW), dim3(64 * (NW + 1)), lds, st, a, tc);
+        NGACF_CHECK_LAUNCH();
+        return 0;
     }
-    hipLaunchKernelGGL(k, dim3((a.B + UW - 1) / UW), dim3(64 * NW), lds, st, a, tc);
-    NGACF_CHECK_LAUNCH();
-    return 0;
 }
 
 }  // namespace ngacf
@@ -732,8 +800,9 @@ extern "C" int ngacf_eval_topk(const void* F, int dtype, const int64_t* users, i
             // 128 users per workgroup while those fit the 256 CUs in one round, 192 while THOSE do (a second, partly filled
             // round would double the kernel's time), 128 beyond
             int nwl = lw ? atoi(lw) : ((B + 127) / 128 <= 256 ? 8 : ((B + 191) / 192 <= 256 ? 12 : 8));
-            if (nwl != 8 && nwl != 12) nwl = 8;
-#define NGACF_TKL(T, D) return nwl == 8 ? launch_topk_lds<T, D, 8>(a, st) : launch_topk_lds<T, D, 12>(a, st)
+            if (nwl != 4 && nwl != 8 && nwl != 12) nwl = 8;
+            if (d * (dtype == NGACF_F32 ? 4 : 2) >= 512) nwl = 8;
+#define NGACF_TKL(T, D) return nwl == 4 ? launch_topk_lds<T, D, 4>(a, st) : (nwl == 8 ? launch_topk_lds<T, D, 8>(a, st) : launch_topk_lds<T, D, 12>(a, st))
             if (dtype == NGACF_F32 && d == 64) NGACF_TKL(float, 64);
             if (dtype == NGACF_F32 && d == 128) NGACF_TKL(float, 128);
             if (dtype == NGACF_BF16 && d == 64) NGACF_TKL(bf16_t, 64);

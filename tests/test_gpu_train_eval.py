@@ -216,7 +216,7 @@ def test_forward_pairs_equals_two_forwards_without_dropout_and_debug_asserts():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["wave", "lds8", "lds12"])
+@pytest.mark.parametrize("form", ["wave", "lds4", "lds8", "lds12"])
 @pytest.mark.parametrize("d,dt", [(64, "fp32"), (64, "bf16"), (128, "fp32"), (128, "bf16")])
 def test_eval_topk_kernel_matches_stable_sort_exactly(d, dt, form, monkeypatch):
     """ngacf_eval_topk (MFMA scoring fused with top-K selection) against masked scores + stable descending sort.
