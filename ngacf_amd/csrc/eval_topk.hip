@@ -512,7 +512,10 @@ __global__ __launch_bounds__(64 * (NW + 1)) void eval_topk_lds_kernel(const Topk
     float tau = u0 + us < a.B ? TK_NEG : 3.402823466e38f;       // the user's threshold, the same in its four lanes
     int cnt = 0;                                                  // appends to THIS LANE's quarter of the user's list (> TL_SUB: some were held back)
     unsigned int pend = 0u;                                       // bit (4 t + e): this lane's score of that register was held back
-    uint2* const mysub = lists + (us * 4 + rg) * (TL_SUB + 1);    // (entry TL_SUB: where a held-back score is dumped)
+    // LDS byte address of this lane's quarter (entry TL_SUB: where a held-back score is dumped).  Appends go out as ds_write2_b32
+    // with the score and the item number in two UNRELATED registers: a 64-bit store wants them in a register pair, and to have
+    // one the compiler copied half of every accumulator right behind its MFMAs -- four moves and a full matrix-core drain per turn.
+    const unsigned int mysub_at = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(lists + (us * 4 + rg) * (TL_SUB + 1));
 
     // The wave compacts the list of its user ui (0..15; n entries), one entry per lane.  All arguments wave-uniform.
     //   * train positives out: the user's first tc train items sit in LDS, ascending, padded -- a 4-ary search (three round trips
@@ -609,7 +612,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void eval_topk_lds_kernel(const Topk
     auto push = [&](bool hit, float sc, int j, unsigned int bit) {
         if (__ballot(hit) == 0ull) return;                        // nobody's did
         if (hit) {
-            mysub[cnt < TL_SUB ? cnt : TL_SUB] = make_uint2(__float_as_uint(sc), (unsigned int)j);
+            const unsigned int at = mysub_at + 8u * (unsigned int)(cnt < TL_SUB ? cnt : TL_SUB);
+            asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(at), "v"(sc), "v"(j) : "memory");
             pend |= cnt >= TL_SUB ? bit : 0u;
             ++cnt;
         }
@@ -714,6 +718,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void eval_topk_lds_kernel(const Topk
         }
     };
     const int total = nst * STEPS;
+    bool sok_cur = false;
+    float taue = TK_NEG;
     // one turn: `cur` holds step g (sifted now), `nxt` receives step g + 1
     auto turn = [&](tk_f32x4 (&cur)[2], tk_f32x4 (&nxt)[2], int g) {
         if (g + 1 < total) multiply(nxt);                               // its fragments were read a turn ago
@@ -722,10 +728,16 @@ __global__ __launch_bounds__(64 * (NW + 1)) void eval_topk_lds_kernel(const Topk
             read_step(g + 2);
         }
         if (g >= 0 && g < total) {
+            if (g % STEPS == 0) {                                       // the sift enters a stage: may its scores skip the flag test?
+                sok_cur = (okbits >> ((g / STEPS) & 31)) & 1u;
+                taue = sok_cur ? tau : TK_NEG;                          // (a stage with non-candidates always takes the slow path)
+            }
             const float m = fmaxf(fmaxf(fmaxf(fmaxf(cur[0][0], cur[0][1]), cur[0][2]), fmaxf(fmaxf(cur[0][3], cur[1][0]), cur[1][1])),
                                   fmaxf(fmaxf(cur[1][2], cur[1][3]), TK_NEG));
-            const bool sok = (okbits >> ((g / STEPS) & 31)) & 1u;
-            if (__builtin_expect(__ballot(m > tau) != 0ull || !sok, 0)) sift_slow(cur, g, sok);
+            if (__builtin_expect(__ballot(m > taue) != 0ull, 0)) {
+                sift_slow(cur, g, sok_cur);
+                taue = sok_cur ? tau : TK_NEG;
+            }
         }
     };
 
