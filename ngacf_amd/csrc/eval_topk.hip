@@ -649,12 +649,18 @@ __global__ __launch_bounds__(64 * (NW + 1)) void eval_topk_lds_kernel(const Topk
         const bool ok = __ballot(zero) == 0ull && (st + 1) * SI <= a.I;
         okbits = (okbits & ~(1u << (st & 31))) | ((ok ? 1u : 0u) << (st & 31));
     };
-    auto read_step = [&](int gs) {
-        const int sbase = (((gs / STEPS) % NB) * SI + (gs % STEPS) * 32) * RB;        // scalar
+    // (what the loop keeps per turn is counted in scalar instructions: the ring offset of the step being read and the two
+    // steps-into-their-stage counters run along instead of being divided out of g)
+    int rd_off = 0;                    // byte offset in the ring of the step that is read next
+    int rd_in = 0, sf_in = 0, sf_stage = 0;   // steps into its stage of the step read next / sifted next; the sifted step's stage
+    auto read_step = [&]() {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int f = 0; f < NF; ++f) frag[t][f] = *reinterpret_cast<const uint4*>(stage0 + sbase + foff[f] + t * 16 * RB);
+            for (int f = 0; f < NF; ++f) frag[t][f] = *reinterpret_cast<const uint4*>(stage0 + rd_off + foff[f] + t * 16 * RB);
+        rd_off += 32 * RB;
+        if (rd_off == NB * STAGE) rd_off = 0;
+        if (++rd_in == STEPS) rd_in = 0;
     };
     // r[t][e] in lane (c, rg) = score(user c, item 32 gs + 16 t + 4 rg + e)
     auto multiply = [&](tk_f32x4 (&r)[2]) {
@@ -687,7 +693,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void eval_topk_lds_kernel(const Topk
         } else {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const uint4 fw = *reinterpret_cast<const uint4*>(pflag + ((g / STEPS) % FR) * FSLOT + (g % STEPS) * 32 + 16 * t + 4 * rg);
+                const uint4 fw = *reinterpret_cast<const uint4*>(pflag + (sf_stage % FR) * FSLOT + sf_in * 32 + 16 * t + 4 * rg);
                 const unsigned int fwe[4] = {fw.x, fw.y, fw.z, fw.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -720,16 +726,17 @@ __global__ __launch_bounds__(64 * (NW + 1)) void eval_topk_lds_kernel(const Topk
     const int total = nst * STEPS;
     bool sok_cur = false;
     float taue = TK_NEG;
-    // one turn: `cur` holds step g (sifted now), `nxt` receives step g + 1
-    auto turn = [&](tk_f32x4 (&cur)[2], tk_f32x4 (&nxt)[2], int g) {
-        if (g + 1 < total) multiply(nxt);                               // its fragments were read a turn ago
-        if (g + 2 < total) {
-            if ((g + 2) % STEPS == 0) enter_stage((g + 2) / STEPS);     // step g + 2 opens a stage
-            read_step(g + 2);
+    // one turn: `cur` holds step g (sifted now), `nxt` receives step g + 1, the fragments of step g + 2 are requested.
+    // MUL / RD / SIFT: which of the three the turn has (all of them between the loop's head and its last two turns)
+    auto turn = [&](auto mul, auto rd, auto sift, tk_f32x4 (&cur)[2], tk_f32x4 (&nxt)[2], int g) {
+        if constexpr (decltype(mul)::value) multiply(nxt);              // its fragments were read a turn ago
+        if constexpr (decltype(rd)::value) {
+            if (rd_in == 0) enter_stage((g + 2) / STEPS);               // step g + 2 opens a stage
+            read_step();
         }
-        if (g >= 0 && g < total) {
-            if (g % STEPS == 0) {                                       // the sift enters a stage: may its scores skip the flag test?
-                sok_cur = (okbits >> ((g / STEPS) & 31)) & 1u;
+        if constexpr (decltype(sift)::value) {
+            if (sf_in == 0) {                                           // the sift enters a stage: may its scores skip the flag test?
+                sok_cur = (okbits >> (sf_stage & 31)) & 1u;
                 taue = sok_cur ? tau : TK_NEG;                          // (a stage with non-candidates always takes the slow path)
             }
             const float m = fmaxf(fmaxf(fmaxf(fmaxf(cur[0][0], cur[0][1]), cur[0][2]), fmaxf(fmaxf(cur[0][3], cur[1][0]), cur[1][1])),
@@ -738,16 +745,33 @@ __global__ __launch_bounds__(64 * (NW + 1)) void eval_topk_lds_kernel(const Topk
                 sift_slow(cur, g, sok_cur);
                 taue = sok_cur ? tau : TK_NEG;
             }
+            if (++sf_in == STEPS) { sf_in = 0; ++sf_stage; }
         }
     };
+    constexpr std::true_type Y{};
+    constexpr std::false_type N_{};
 
     enter_stage(0);
-    read_step(0);
+    read_step();                                                        // step 0
     tk_f32x4 accA[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accB[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // g = -1: multiply step 0 into B, request step 1 (when there is one); then turns 0 .. total - 1 with A / B swapping roles:
+    // even g sifts B and fills A.  The last two turns have nothing left to request, the last one nothing to multiply.
+    multiply(accB);
+    if (total > 1) {
+        if (rd_in == 0) enter_stage(1 / STEPS);
+        read_step();
+    }
+    int g = 0;
 #pragma unroll 1
-    for (int g = -1; g < total; g += 2) {
-        turn(accA, accB, g);
-        turn(accB, accA, g + 1);
+    for (; g + 3 < total; g += 2) {                                      // both turns complete: g + 1 + 2 < total
+        turn(Y, Y, Y, accB, accA, g);
+        turn(Y, Y, Y, accA, accB, g + 1);
+    }
+    for (; g < total; ++g) {                                            // at most three turns, each with what is left
+        const bool even = (g & 1) == 0;
+        if (g + 2 < total) { if (even) turn(Y, Y, Y, accB, accA, g); else turn(Y, Y, Y, accA, accB, g); }
+        else if (g + 1 < total) { if (even) turn(Y, N_, Y, accB, accA, g); else turn(Y, N_, Y, accA, accB, g); }
+        else { if (even) turn(N_, N_, Y, accB, accA, g); else turn(N_, N_, Y, accA, accB, g); }
     }
 
     // ---- every list compacted (valid entries only, best first, at most K) and written out ------------------------------------------
