@@ -501,6 +501,14 @@ def worker(args):
             train["shared_propagation_optin"] = {"bpr_pairs_per_s": round(B * n_sh / t_sh, 1),
                                                  "train_ms_per_step": round(1e3 * t_sh / n_sh, 3)}
 
+    # ---------------- the evaluation's ranking: every user against every item, top 20 ----------------
+    evl = None
+    if not args.no_probe and U * I <= 10 ** 10:
+        try:
+            evl = eval_leg(torch, ops, model, edge, U, I)
+        except Exception as e:                            # (a secondary figure must not cost the line)
+            print("[bench] eval leg failed: %r" % (e,), file=sys.stderr, flush=True)
+
     # ---------------- CPU baseline: reference operator order on the host cores (checker code) -------------
     cpu = None
     if not args.no_cpu_baseline:
@@ -521,6 +529,8 @@ def worker(args):
               "launch": "eager" if args.eager else "hipGraph replay", "launches_per_pass": (L + 1 if fused else 2 * L),
               "fused_next_stage_transform": bool(fused), "node_numbering": args.renumber,
               "graph": graph_law(torch, model, edge, U, I, args.seg_len)}
+    if evl:
+        config.update(evl)
     if train:
         config.update({"bpr_pairs_per_s": train["bpr_pairs_per_s"], "train_ms_per_step": train["train_ms_per_step"], "batch": train["batch"],
                        "droprate": train["droprate"]})
@@ -562,6 +572,34 @@ def worker(args):
             print("[bench] scaling probe failed: %r" % (e,), file=sys.stderr, flush=True)
             out["scaling_probe"] = {"error": repr(e)}
     emit(json.dumps(out))
+
+
+def eval_leg(torch, ops, model, edge, U, I, K=20, reps=5):
+    """ngacf_eval_topk over the model's propagated table: all U users against all I items, the graph's own interactions as
+    the train positives to leave out, top K -- the launch train_eval.eval_neg_all makes once per evaluation
+    (train_eval_Gowalla.py:274-385).  Kernel time from events around single launches (min and mean of `reps`)."""
+    dev = edge.device
+    model.eval()
+    with torch.no_grad():
+        F = model.score_table(edge).contiguous()
+    ptr = torch.zeros(U + 1, dtype=torch.long, device=dev)
+    ptr[1:] = torch.cumsum(torch.bincount(edge[0], minlength=U), 0)
+    order = torch.argsort(edge[0] * I + edge[1])                          # (user, item) ascending: the CSR's row order
+    items = edge[1][order].to(torch.int32).contiguous()
+    pool = (torch.bincount(edge[1], minlength=I) > 0).to(torch.uint8)
+    users = torch.arange(U, device=dev)
+    ops.eval_topk(F, users, U, I, pool, ptr, items, K)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ops.eval_topk(F, users, U, I, pool, ptr, items, K)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return {"eval_topk_ms": round(min(ts), 4), "eval_topk_ms_mean": round(sum(ts) / len(ts), 4), "eval_topk_K": K,
+            "eval_topk_scores_per_s": round(U * I / (min(ts) * 1e-3), 1)}
 
 
 def two_in_flight(torch, model, edge, E, L, seconds=0.3):

@@ -367,14 +367,15 @@ __global__ __launch_bounds__(64 * NW) void eval_topk_kernel(const TopkArgs a) {
 //               a lane's scores all belong to ONE user, so that user's threshold is ONE register (the first form keeps 16),
 //               its list's entry count is a register (no LDS atomic, no returned slot to wait for) and a survivor is ONE
 //               ds_write_b64 behind a ballot: per accumulator register the steady state is v_cmp + s_cbranch
-//   list      = ONE per user (64 entries of (score, item) in LDS, K live + slack), written by the user's four lanes (slot =
-//               count + the hits of the lower row groups, from the ballot mask); a list that overflows is compacted by its
-//               wave exactly as in the first form (train positives out, rank by (score desc, item asc), K best kept, threshold
-//               raised); scores of the SAME 32-item step that were held back are retried with ">=" (an equal score of the same
-//               step may carry a lower item id than the list's K-th entry; a later step's never does: strict ">" is the
-//               stable sort's tie rule)
-//   stage     = 16 KB of item rows (128 bf16 / 64 fp32 rows of 64 columns), double buffered, one barrier per stage; the item
-//               pool's flags ride along, and a stage in which every item is a candidate (the usual case) takes the loop
+//   list      = ONE per user (64 entries of (score, item) in LDS, K live + slack) in four quarters, one per lane of the user, each
+//               with its own fill count in a register; a user with a full quarter is compacted by its wave (train positives out,
+//               the K best by quickselect on 64-bit (score, ~item) keys, dealt round the quarters, threshold raised); scores of
+//               the SAME 32-item step that were held back are retried with ">=" (an equal score of the same step may carry a
+//               lower item id than the list's K-th entry; a later step's never does: strict ">" is the stable sort's tie rule)
+//   stage     = 16 KB of item rows (8 KB with 4 or 12 consumer waves), a ring of TL_NB of them filled by the workgroup's LAST wave,
+//               the producer: LDS-DMA for rows and pool flags, a `full` word per buffer published when vmcnt says the stage landed,
+//               a `done` word per buffer that every consumer bumps behind its last fragment read -- no barrier after the first
+//               (details at the producer's loop); a stage in which every item is a candidate (the usual case) takes the sift
 //               without the per-score flag test
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) float tk_f32x4;
