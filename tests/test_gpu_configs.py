@@ -458,3 +458,33 @@ def test_synthetic1b_sampled_rows_in_float64(dev):
     if os.environ.get("NGACF_SKIP_1B") == "1":
         pytest.skip("NGACF_SKIP_1B=1")
     _log("bigcheck_synthetic1b.log", _big_graph_check(dev, "synthetic1b", [torch.bfloat16, torch.float32]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,dt", [("gowalla", "bf16"), ("gowalla", "fp32"), ("yelp", "bf16")])
+def test_full_size_ranking_equals_masked_stable_sort_exactly(dev, workload, dt):
+    """The evaluation's ranking at BASELINE size (every user of a Gowalla / Yelp-scale graph against every item, K = 20, the form a
+    whole evaluation takes: item rows streamed through LDS by a producer wave; 8 consumer waves at Gowalla scale, 12 at Yelp scale)
+    against torch's statement of the contract -- scores, pool mask, train positives out, STABLE descending sort -- on an
+    integer-valued table: every dot product is exact whatever the summation order, thousands of exact ties per user, so items and
+    scores must agree bit for bit (train_eval_Gowalla.py:274-385)."""
+    from ngacf_amd import data as D, ops
+    from ngacf_amd.train_eval import topk_torch
+    U, I, E = D.SHAPES[workload]
+    g = torch.Generator(device=dev).manual_seed(11)
+    edge = D.synthetic_bipartite(U, I, E, seed=2019, device=dev)
+    keep = torch.rand(edge.shape[1], device=dev, generator=g) < 0.8
+    tu, ti = edge[0, keep], edge[1, keep]
+    ptr = torch.zeros(U + 1, dtype=torch.long, device=dev)
+    ptr[1:] = torch.cumsum(torch.bincount(tu, minlength=U), 0)
+    items = ti.to(torch.int32).contiguous()                                  # (the edge list is sorted by (user, item))
+    pool = (torch.bincount(edge[1], minlength=I) > 0).to(torch.uint8)
+    pool[torch.randperm(I, device=dev, generator=g)[:I // 50]] = 0           # + 2 % of the items outside the pool, scattered
+    F = torch.randint(-2, 3, (U + I, 64), device=dev, generator=g).float()
+    F = F.to(torch.bfloat16) if dt == "bf16" else F
+    users = torch.arange(U, device=dev)
+    top, top_s = ops.eval_topk(F, users, U, I, pool, ptr, items, 20)
+    want, want_s = topk_torch(F, users, U, I, pool, ptr, items, 20, chunk=1024)
+    assert torch.equal(top, want)
+    ok = want >= 0
+    assert torch.equal(top_s[ok], want_s[ok])

@@ -63,6 +63,10 @@ timeout -k 10 300 python tools/train_profile.py --profile --eager --one-chain > 
 say "node-partitioned train step on one RCCL rank (replayed)"
 timeout -k 10 200 python tools/shard_step_profile.py > $out/${tag}_shard_step_world1.json 2>> $out/err.log
 say "epoch + evaluation";                timeout -k 10 300 python tools/eval_bench.py --epochs 3 > $out/${tag}_epoch_eval_gowalla.log 2>&1
+say "the ranking kernel alone, both forms (Gowalla, Yelp) + its SQ counters"
+timeout -k 10 200 python tools/topk_bench.py --dtype bf16,fp32 --forms wave,lds4,lds8,lds12 > $out/${tag}_topk_bench_gowalla.jsonl 2>> $out/err.log
+timeout -k 10 200 python tools/topk_bench.py --workload yelp --dtype bf16 --forms wave,lds8,lds12 > $out/${tag}_topk_bench_yelp.jsonl 2>> $out/err.log
+bash tools/topk_pmc.sh > /dev/null 2>&1 && cp gpurun_out/topk_pmc.txt $out/${tag}_topk_pmc_sq_counters.txt
 rm -rf gpurun_out/trainprof
 fi
 if [ "$part" = all ] || [ "$part" = aux ]; then

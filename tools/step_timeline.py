@@ -16,7 +16,7 @@ def main(path):
     def short(n):
         n = re.sub(r"void |ngacf::", "", n)
         m = re.match(r"([a-z_A-Z0-9:]+)(<[^>]*>)?", n)
-        return (m.group(1) + (m.group(2) or ""))[:70]
+        return (m.group(1) + (m.group(2) or ""))[:70] if m else n[:70]      # (RCCL's kernels: names of another shape)
     busy = 0.0
     for r in rows[i0 + 1:i1 + 1]:
         s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
