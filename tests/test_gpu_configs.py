@@ -488,3 +488,6 @@ def test_full_size_ranking_equals_masked_stable_sort_exactly(dev, workload, dt):
     assert torch.equal(top, want)
     ok = want >= 0
     assert torch.equal(top_s[ok], want_s[ok])
+    for _ in range(20):                                                      # the producer / consumer hand-offs: the same bits every time
+        again, again_s = ops.eval_topk(F, users, U, I, pool, ptr, items, 20)
+        assert torch.equal(again, top) and torch.equal(again_s, top_s)
