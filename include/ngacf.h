@@ -414,9 +414,9 @@ int ngacf_spmm_fwd(const int32_t* segs, int nseg, const int32_t* split, int nspl
  * Replaces the host-side ranking of train_eval_Gowalla.py:274-354 (per-block score transfer) and :370-385
  * (heapq.nlargest(K, ...) per user in a process pool); the [B][I] score matrix is never materialised.
  * top_items[b][r] = -1 (top_scores = -FLT_MAX) when user b has fewer than r+1 candidates.  d in {64, 128}.
- * Two forms with the same results (bit for bit on tables whose dot products are exact): B >= 12 288 users take 128 / 192 users
- * per workgroup on item rows that a producer wave streams through an LDS ring; smaller batches a wave per 32 users that streams
- * the item table itself.  NGACF_TOPK_FORM=lds|wave, NGACF_TOPK_LDS_WAVES=4|8|12 (read per call) force a choice: tests, A/B runs.
+ * Two forms with the same results (bit for bit on tables whose dot products are exact): 64 / 128 / 192 users per workgroup on
+ * item rows that a producer wave streams through an LDS ring (128-byte rows always; longer rows from 12 288 users on), or a wave
+ * per 32 users that streams the item table itself.  NGACF_TOPK_FORM=lds|wave, NGACF_TOPK_LDS_WAVES=4|8|12 (read per call) force a choice: tests, A/B runs.
  * A users[b] outside [0,U) is never dereferenced: its row comes back all -1 and *bad_index (may be NULL) is bumped. */
 int ngacf_eval_topk(const void* F, int dtype, const int64_t* users, int B, int U, int I, int d,
                     const uint8_t* pool_mask, const int64_t* train_ptr, const int32_t* train_items,

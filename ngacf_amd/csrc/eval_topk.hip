@@ -826,17 +826,20 @@ extern "C" int ngacf_eval_topk(const void* F, int dtype, const int64_t* users, i
     a.F = F; a.users = users; a.pool = pool_mask; a.train_ptr = train_ptr; a.train_items = train_items;
     a.top_items = top_items; a.top_scores = top_scores; a.bad = bad_index; a.B = B; a.U = U; a.I = I; a.K = K;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // Which form: the LDS-shared one (16 * NW users per workgroup, item rows staged once per workgroup) when its workgroups
-    // fill a good part of the chip, else the wave-private one below.  NGACF_TOPK_FORM=lds|wave and NGACF_TOPK_LDS_WAVES=8|12
-    // force a choice (tests, A/B runs); read per call.
+    // Which form, how many consumer waves (measured, 40 981 items, iid table, ms for 64 / 1 024 / 16 384 / 29 858 users): 128-byte rows
+    // (bf16, d = 64) -- wave-private 1.00 / 1.02 / 1.14 / 1.91, LDS-shared with 4 waves 0.80 / 0.84 / 0.84 / 0.93, with 8 waves
+    // 0.89 (2 048 users) / 0.89 / 0.90: the LDS-shared form always, 64 users per workgroup while those fit one per CU, 128 while
+    // THOSE fit the chip in one round, 192 while those do (a second, partly filled round doubles the time: Yelp's 45 919 users
+    // 1.16 ms against 1.89), 128 beyond.  Longer rows (fp32, d = 128: the matrix cores bound the kernel; fp32 d = 64 at 64 / 1 024
+    // users: wave-private 1.26, LDS-shared 1.44 / 1.49; at 29 858: 3.05 against 1.96): the wave-private form below 12 288 users.
+    // NGACF_TOPK_FORM=lds|wave and NGACF_TOPK_LDS_WAVES=4|8|12 force a choice (tests, A/B runs); read per call.
     {
         const char* form = getenv("NGACF_TOPK_FORM");
         const char* lw = getenv("NGACF_TOPK_LDS_WAVES");
-        const bool use_lds = form ? (form[0] == 'l') : B >= 96 * 128;
+        const int rb = d * (dtype == NGACF_F32 ? 4 : 2);
+        const bool use_lds = form ? (form[0] == 'l') : (rb == 128 || B >= 96 * 128);
         if (use_lds) {
-            // 128 users per workgroup while those fit the 256 CUs in one round, 192 while THOSE do (a second, partly filled
-            // round would double the kernel's time), 128 beyond
-            int nwl = lw ? atoi(lw) : ((B + 127) / 128 <= 256 ? 8 : ((B + 191) / 192 <= 256 ? 12 : 8));
+            int nwl = lw ? atoi(lw) : (rb == 128 && B <= 64 * 256 ? 4 : ((B + 127) / 128 <= 256 ? 8 : ((B + 191) / 192 <= 256 ? 12 : 8)));
             if (nwl != 4 && nwl != 8 && nwl != 12) nwl = 8;
             if (d * (dtype == NGACF_F32 ? 4 : 2) >= 512) nwl = 8;
 #define NGACF_TKL(T, D) return nwl == 4 ? launch_topk_lds<T, D, 4>(a, st) : (nwl == 8 ? launch_topk_lds<T, D, 8>(a, st) : launch_topk_lds<T, D, 12>(a, st))
