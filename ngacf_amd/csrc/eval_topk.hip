@@ -357,16 +357,16 @@ __global__ __launch_bounds__(64 * NW) void eval_topk_kernel(const TopkArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Second form (round 5), for user batches that fill the chip: 16 * NW users per workgroup, the ITEM rows staged once per
-// workgroup in LDS and read by all of its NW waves (the form above streams the whole item table through L2 once per
-// 32 users: 4.9 GB per Gowalla-scale evaluation, 0.66 ms at the L2's rate before any selection), and the score tile TRANSPOSED:
+// Second form (round 5; which call takes which form: ngacf_eval_topk below): 16 * NW users per workgroup, the ITEM rows staged
+// once per workgroup in LDS and read by all of its NW consumer waves (the form above streams the whole item table through L2 once
+// per 32 users: 4.9 GB per Gowalla-scale evaluation, 0.66 ms at the L2's rate before any selection), and the score tile TRANSPOSED:
 //
 //   wave      = 16 users x all items on v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32 (exact products, fp32 accumulate),
 //               A operand = 16 item rows from LDS, B operand = the wave's 16 user rows (registers, loaded once)
 //   lane      = (user c = lane & 15, row group rg = lane >> 4): accumulator register e holds score(user c, item 4 rg + e) --
 //               a lane's scores all belong to ONE user, so that user's threshold is ONE register (the first form keeps 16),
 //               its list's entry count is a register (no LDS atomic, no returned slot to wait for) and a survivor is ONE
-//               ds_write_b64 behind a ballot: per accumulator register the steady state is v_cmp + s_cbranch
+//               ds_write2_b32; the steady state of a step is v_max3 over the lane's eight scores, one compare, one branch
 //   list      = ONE per user (64 entries of (score, item) in LDS, K live + slack) in four quarters, one per lane of the user, each
 //               with its own fill count in a register; a user with a full quarter is compacted by its wave (train positives out,
 //               the K best by quickselect on 64-bit (score, ~item) keys, dealt round the quarters, threshold raised); scores of
@@ -802,7 +802,7 @@ static int launch_topk_lds(const TopkArgs& a, hipStream_t st) {
         const size_t lds = (size_t)TL_NB * STAGE + (size_t)(TL_NB + 4) * ((SI + 63) / 64) * 64 * 4 + 2 * TL_NB * 4 + (size_t)UW * 4 * (TL_SUB + 1) * 8 +
                            (size_t)UW * tc * 4 + (size_t)UW * 4;
         auto k = eval_topk_lds_kernel<T, D, NW>;
-        if (lds > 64 * 1024) {
+        if (lds > 64 * 1024) {                                 // (every call: the attribute belongs to the current device)
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return static_cast<int>(e);
         }
