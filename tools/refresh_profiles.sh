@@ -67,6 +67,7 @@ say "the ranking kernel alone, both forms (Gowalla, Yelp) + its SQ counters"
 timeout -k 10 200 python tools/topk_bench.py --dtype bf16,fp32 --forms wave,lds4,lds8,lds12 > $out/${tag}_topk_bench_gowalla.jsonl 2>> $out/err.log
 timeout -k 10 200 python tools/topk_bench.py --workload yelp --dtype bf16 --forms wave,lds8,lds12 > $out/${tag}_topk_bench_yelp.jsonl 2>> $out/err.log
 bash tools/topk_pmc.sh > /dev/null 2>&1 && cp gpurun_out/topk_pmc.txt $out/${tag}_topk_pmc_sq_counters.txt
+say "ranking kernel hand-off soak (120 000 launches, ~5 min)"; timeout -k 10 900 python tools/topk_soak.py --launches 20000 > $out/${tag}_topk_soak.json 2>> $out/err.log
 rm -rf gpurun_out/trainprof
 fi
 if [ "$part" = all ] || [ "$part" = aux ]; then
