@@ -28,6 +28,10 @@ wait, not a host wait), two tables of one half as ONE grouped launch.  `overlap=
 the serial schedule of round 1, kept for A/B timing.  Scoring exchanges 2B rows (one small all-reduce per forward),
 not the [N,d] table.  No reduce-scatter, no atomics; results are bitwise independent of the schedule.
 
+Small tables (Comm.whole_below: a stage's table brings a rank < 32 MiB) take the WHOLE-STAGE schedule instead: T(s, both halves),
+one grouped all-gather of the stage's table, one traversal launch over all local rows (a gather is latency there, not bytes: hiding
+it behind a half-launch buys nothing; two collective launches and two launches' ramps per stage cost).  Same kernels, same bits.
+
 `backend` is the module that runs the local compute (default: ngacf_amd.ops = the HIP library).  The CPU tests inject a
 torch stand-in to exercise partition + collectives + schedule under gloo; the product never does.
 """
@@ -164,6 +168,12 @@ class Comm:
         # what 4 MiB take at the ~300 GB/s a rank receives over xGMI.  Gowalla-scale half tables stay below it; the 10^9-edge graph's
         # 240 MB halves do not.  (NGACF_DIST_INLINE_BYTES=0: always asynchronous, the schedule of rounds 1-4.)
         self.inline_below = int(os.environ.get("NGACF_DIST_INLINE_BYTES", str(4 << 20)))
+        # A stage whose whole table brings this rank fewer bytes than this runs as ONE collective + ONE traversal launch (the
+        # whole-stage schedule of _ShardedStack) instead of two half-table gathers hidden behind two half-launches: where a gather is
+        # latency, not bytes (Gowalla / Yelp-scale tables: 9-36 MB in all), hiding it behind a 5-25 us half-launch buys nothing and the
+        # second collective launch and the second launch's ramp and tail are pure cost (one RCCL rank, Gowalla scale: forward 0.120
+        # -> see DESIGN.md section 6).  The 10^9-edge graph's 1.9 GB tables stay on the pipelined halves.  0: never.
+        self.whole_below = int(os.environ.get("NGACF_DIST_WHOLE_BYTES", str(32 << 20)))
 
     peer_store = False                        # (ngacf_amd.peer.PeerComm: gathers by stores into the peers' tables)
 
@@ -181,7 +191,7 @@ class Comm:
         return t
 
     _primary = None
-    _MIRRORED = ("force", "defer_weight_reduce", "overlap", "dry_run", "inline_below")
+    _MIRRORED = ("force", "defer_weight_reduce", "overlap", "dry_run", "inline_below", "whole_below")
 
     def sync_switches(self):
         """(a twin takes the switches of its primary at every use: bench.py and the tests set them on model.comm after construction)"""
@@ -213,13 +223,25 @@ class Comm:
         lo, n, tot = (0, p.cu, p.Up) if t == "user" else (p.Up, p.ci, p.Ip)
         return full[lo:lo + tot], full[lo + p.rank * n: lo + (p.rank + 1) * n], n
 
+    def whole_stage(self, table_bytes):
+        """Should a stage whose global-row table(s) hold `table_bytes` run as one collective + one launch?  (Comm.whole_below)"""
+        return (not self.peer_store) and table_bytes * (self.world - 1) // max(self.world, 1) < self.whole_below
+
     def start_gather(self, t, *fulls):
         """All-gather the half `t` ('user' / 'item') of every global-row table in `fulls`; returns a handle to wait on."""
         if not self.active:
             return _Handle()
-        regions = [self._region(f, t) for f in fulls]
+        return self._gather([self._region(f, t) for f in fulls], fulls[0].is_cuda)
+
+    def start_gather2(self, *fulls):
+        """BOTH halves of every table in `fulls` as one grouped launch (the whole-stage schedule)."""
+        if not self.active:
+            return _Handle()
+        return self._gather([self._region(f, t) for f in fulls for t in ("user", "item")], fulls[0].is_cuda)
+
+    def _gather(self, regions, on_gpu):
         ev = None
-        if self.timer is not None and fulls[0].is_cuda:
+        if self.timer is not None and on_gpu:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
         self.launches += 1 if (self._coalesce or len(regions) == 1) else len(regions)
@@ -332,11 +354,51 @@ class _ShardedStack(torch.autograd.Function):
             else:
                 panels = {s: Ws[s] for s in idx}
 
-        first = "user"
-        T(0, OTHER[first])
-        T(0, first)
+        # Whole-stage schedule (Comm.whole_below): T(s, both halves), ONE grouped all-gather of the stage's table, ONE traversal launch
+        # over all local rows.  Same kernels on the same rows as the half schedule: the same bits.
+        whole = bool(cfg.get("whole"))
         out = None
-        for s in range(L):
+        if whole:
+            new_H(0)
+            for t in ("user", "item"):
+                be.transform_fwd_rows(X[t], Ws[0], As[0], Hs[0], Ss[0], part.Up, part.Ip, cfg["heads"][0], part.half_win(t), True,
+                                      cfg["feat_drop"], cfg["seeds"][0], **sd)
+            h = comm.start_gather2(Hs[0])
+            for s in range(L):
+                H, S, heads = Hs[s], Ss[s], cfg["heads"][s]
+                dout = H.shape[1]
+                fused_next = s + 1 < L and fuse[s + 1]
+                keep_out = need or not fused_next
+                out = torch.empty(N, dout, dtype=H.dtype, device=dev) if keep_out else None
+                agg = torch.empty(2, N, dout, dtype=H.dtype, device=dev) if need else None
+                R = torch.empty(2, N, heads, dtype=torch.float32, device=dev) if need else None
+                if s + 1 < L and Hs[s + 1] is None:
+                    new_H(s + 1)
+                Xs = dict(X)
+                h.wait()
+                if fused_next:
+                    nxt = be.NextStage(panels[s + 1], As[s + 1], cfg["heads"][s + 1], cfg["feat_drop"], cfg["seeds"][s + 1],
+                                       H=Hs[s + 1], S=Ss[s + 1])
+                    be.prop_fwd(plan, H, S, S, As[s], heads, cfg["alpha"], True, True, True, cfg["drop"], cfg["seeds"][s],
+                                save=need, out=out, agg=agg, R=R, next=nxt, want_out=keep_out, **sd)
+                else:
+                    be.prop_fwd(plan, H, S, S, As[s], heads, cfg["alpha"], True, True, True, cfg["drop"], cfg["seeds"][s],
+                                save=need, out=out, agg=agg, R=R, **sd)
+                if keep_out:
+                    X = {t: part.block(out, t) for t in ("user", "item")}
+                if s + 1 < L:
+                    if not fused_next:
+                        for t in ("user", "item"):
+                            be.transform_fwd_rows(X[t], Ws[s + 1], As[s + 1], Hs[s + 1], Ss[s + 1], part.Up, part.Ip, cfg["heads"][s + 1],
+                                                  part.half_win(t), True, cfg["feat_drop"], cfg["seeds"][s + 1], **sd)
+                    h = comm.start_gather2(Hs[s + 1])
+                if need:
+                    saved.append((Xs["user"], Xs["item"], Ws[s], As[s], H, S, out, agg, R))
+        first = "user"
+        if not whole:
+            T(0, OTHER[first])
+            T(0, first)
+        for s in range(0 if not whole else L, L):
             A, B = first, OTHER[first]
             H, S, heads = Hs[s], Ss[s], cfg["heads"][s]
             dout = H.shape[1]
@@ -389,7 +451,9 @@ class _ShardedStack(torch.autograd.Function):
         tabs, pending = [None] * L, {}
         lease = comm.new_lease()
 
-        def Nstep(s, t):
+        whole = bool(cfg.get("whole"))
+
+        def Nstep(s, t, gather=True):
             _, _, _, _, H, S, out, agg, R = saved[s]
             if tabs[s] is None:
                 d, heads = H.shape[1], cfg["heads"][s]
@@ -399,11 +463,20 @@ class _ShardedStack(torch.autograd.Function):
             G, Gn, ST, _, dS = tabs[s]
             # (step 1 leaves the rows' own half of dS -- P1 -- in dS; the edge step of the same half finishes it in place)
             be.prop_bwd_node(out, agg, R, g[t], S, G, Gn, ST, dS, part.Up, cfg["heads"][s], part.half_win(t), True, True, cfg["alpha"])
-            pending[(s, t)] = comm.start_gather(t, Gn, ST)          # one grouped launch
+            if gather:
+                pending[(s, t)] = comm.start_gather(t, Gn, ST)      # one grouped launch
+
+        def Nboth(s):                                               # whole-stage schedule: both halves' node steps, ONE gather
+            Nstep(s, "user", False)
+            Nstep(s, "item", False)
+            pending[(s, "both")] = comm.start_gather2(tabs[s][1], tabs[s][2])
 
         first = "user"
-        Nstep(L - 1, OTHER[first])
-        Nstep(L - 1, first)
+        if whole:
+            Nboth(L - 1)
+        else:
+            Nstep(L - 1, OTHER[first])
+            Nstep(L - 1, first)
         grads = [None] * (2 * L)
         for s in range(L - 1, -1, -1):
             Xu, Xi, W, a, H, S, out, agg, R = saved[s]
@@ -411,16 +484,23 @@ class _ShardedStack(torch.autograd.Function):
             G, Gn, ST, dH, dS = tabs[s]
             heads = cfg["heads"][s]
             parts = {}
-            for t in (first, OTHER[first]):
-                pending.pop((s, OTHER[t])).wait()
+            if whole:
+                pending.pop((s, "both")).wait()
                 be.prop_bwd_edges(plan, H, S, a, G, Gn, ST, heads, cfg["alpha"], True, True, cfg["drop"], cfg["seeds"][s],
-                                  half=t, dH=dH, dS=dS, **sd)
+                                  dH=dH, dS=dS, **sd)
+            for t in (first, OTHER[first]):
+                if not whole:
+                    pending.pop((s, OTHER[t])).wait()
+                    be.prop_bwd_edges(plan, H, S, a, G, Gn, ST, heads, cfg["alpha"], True, True, cfg["drop"], cfg["seeds"][s],
+                                      half=t, dH=dH, dS=dS, **sd)
                 dX, dW, da = be.transform_bwd_rows(Xs[t], W, H, dH, dS, part.Up, part.Ip, heads, part.half_win(t), True,
                                                    cfg["feat_drop"], cfg["seeds"][s], **sd)
                 parts[t] = (dW, da)
                 g[t] = dX if s == 0 else dX.to(h_dtype)
-                if s > 0:
+                if s > 0 and not whole:
                     Nstep(s - 1, t)
+            if s > 0 and whole:
+                Nboth(s - 1)
             dW = torch.stack([parts["user"][0][0], parts["item"][0][1]])         # each half owns its weight panel
             da = torch.stack([parts["user"][1][0], parts["item"][1][1]])
             if not comm.defer_weight_reduce:
@@ -708,7 +788,11 @@ class ShardedSPUIGACF(nn.Module):
         params = []
         for s in range(len(stages)):
             params.extend(NF.through_sink(p_) for p_ in self.gat.stage_params(s))      # (behind the caller's gradient sink, if any)
-        cfg = {"part": self.part, "plan": plan, "comm": self._comm_now(), "be": self.be, "heads": [len(l) for l in stages],
+        comm = self._comm_now()
+        elem = 2 if self.compute_dtype == torch.bfloat16 else 4
+        widest = max(int(self.gat.stage_params(s)[0].shape[-1]) for s in range(len(stages)))
+        cfg = {"part": self.part, "plan": plan, "comm": comm, "be": self.be, "heads": [len(l) for l in stages],
+               "whole": comm.whole_stage(self.part.N * widest * elem),
                "alpha": stages[0][0].alpha, "drop": drop, "feat_drop": drop,
                "seeds": [NF.stage_seed(base, s) for s in range(len(stages))], "h_dtype": self.compute_dtype,
                "seed_dev": seed_dev, "grad_mode": torch.is_grad_enabled(), "fuse_next": NF.FUSE_NEXT}
@@ -984,15 +1068,17 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
             torch.cuda.synchronize()
         durs = kt.durations_ms()
         ag = allgather_timing(model, fwd, n_probe, not args.no_overlap)
-    n_launch = len(durs) // n_probe                                          # 2 half-launches per stage
-    stage_ms = sum(durs) / n_probe / L                                       # both halves of a stage
+    n_launch = len(durs) // n_probe                                          # 2 half-launches per stage, or 1 launch (whole-stage schedule)
+    whole = model.comm.whole_stage(part.N * d * elem)
+    stage_ms = sum(durs) / n_probe / L                                       # the launch(es) of a stage
     local_edges = plan.n_edges_directed
     bytes_stage = local_edges * (4 + d * elem) + part.n_local * (2 * d * elem + 8)
     achieved = -allmax(-bytes_stage / (stage_ms * 1e-3) / 1e9)               # the slowest rank's rate (min over ranks)
     regime = BK.gather_regime(part.N * d * elem, max(part.Up, part.Ip) * d * elem)
     ag_ms = sum(x for x, _ in ag) / max(len(ag), 1)
     ag_bytes = sum(nb for _, nb in ag) / max(len(ag), 1)
-    roofline = {"bound": "hbm", "kernel": "prop_fwd_kernel (ngacf_prop_fwd: 2 half-launches per stage), slowest rank",
+    roofline = {"bound": "hbm", "kernel": "prop_fwd_kernel (ngacf_prop_fwd: %s), slowest rank"
+                                          % ("one launch per stage over the rank's rows" if whole else "2 half-launches per stage"),
                 "achieved": round(achieved, 1), "peak": BK.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / BK.HBM_PEAK_GBS, 4),
                 "traffic": None, "regime": regime["regime"],
                 "applicable_roof_GBps": regime["roof_GBps"], "frac_of_applicable_roof": round(achieved / regime["roof_GBps"], 4),
@@ -1017,9 +1103,10 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
                           "passes_per_step": R, "edges_directed_per_pass": trav, "edges_directed_per_step": trav * R,
                           "launch": launch,
                           "parallelism": "degree-balanced node partition x%d, sharded plan (%d of %d directed edges on rank 0), "
-                                         "%d async half-table all-gathers per forward, %s"
-                                         % (world, local_edges, 2 * E, launches_fwd,
-                                            "overlapped with the traversal of the other half" if model.comm.overlap else "serial")},
+                                         "%d %s all-gathers per forward, %s"
+                                         % (world, local_edges, 2 * E, launches_fwd, "whole-table" if whole else "async half-table",
+                                            "one gather + one launch per stage (small table: Comm.whole_below)" if whole else
+                                            ("overlapped with the traversal of the other half" if model.comm.overlap else "serial"))},
                "ms_per_pass": round(1e3 * t_fwd / args.steps / R, 5), "timed_region_s": round(t_fwd, 4),
                "value_median_window": round(trav * R / (med * 1e-3), 1) if med > 0 else None,
                "roofline": None, "cpu_baseline": None}

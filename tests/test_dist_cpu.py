@@ -26,11 +26,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced=True, overlap=True):
+def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced=True, overlap=True, halves=True):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, HERE)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # halves: the pipelined schedule of big graphs (two half-table gathers behind two half-launches per stage); otherwise what a
+        # table this small takes by default: one grouped gather + one launch per stage (Comm.whole_below)
+        os.environ["NGACF_DIST_WHOLE_BYTES"] = "0" if halves else str(32 << 20)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import fake_backend
         from ngacf_amd.dist import ShardedSPUIGACF
@@ -44,6 +47,7 @@ def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced
         m.comm.defer_weight_reduce = defer
         m.comm.overlap = overlap
         m.train()
+        assert m.comm.whole_stage(m.part.N * 64 * 4) == (not halves)
         u, pos, neg = (torch.from_numpy(g[k]) for k in ("u", "pos", "neg"))
         # the two propagations of a step on the model's TWO communicators (ShardedSPUIGACF.chain: what the graphed train step does
         # with its two concurrent branches); the assertions below then cover the second communicator's forward and backward too
@@ -58,7 +62,7 @@ def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced
         if defer:
             m.reduce_grads()                  # one all-reduce per step instead of one per stage
         p = m.part
-        err = {}
+        err = {"gathers": m._comms[0].launches + m._comms[1].launches}
         smax = float(np.abs(g["pos_f64"]).max())
         err["scores"] = max(float((ps.detach().double() - torch.from_numpy(g["pos_f64"])).abs().max()),
                             float((ns.detach().double() - torch.from_numpy(g["neg_f64"])).abs().max())) / smax
@@ -90,17 +94,19 @@ def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced
         q.put((rank, {"exception": "%s\n%s" % (e, traceback.format_exc())}))
 
 
-@pytest.mark.parametrize("world,tag,multi,defer,balanced,overlap", [
-    (2, "spuigacf", False, False, True, True), (2, "spuimultigacf", True, True, True, True),
-    (3, "spuigacf", False, True, True, True), (3, "spuimultigacf", True, False, False, True),
-    (2, "spuimultigacf", True, True, True, False)])
-def test_sharded_model_matches_reference_under_gloo(world, tag, multi, defer, balanced, overlap):
+@pytest.mark.parametrize("world,tag,multi,defer,balanced,overlap,halves", [
+    (2, "spuigacf", False, False, True, True, True), (2, "spuimultigacf", True, True, True, True, True),
+    (3, "spuigacf", False, True, True, True, True), (3, "spuimultigacf", True, False, False, True, True),
+    (2, "spuimultigacf", True, True, True, False, True),
+    (2, "spuimultigacf", True, True, True, True, False), (3, "spuigacf", False, False, False, True, False)])
+def test_sharded_model_matches_reference_under_gloo(world, tag, multi, defer, balanced, overlap, halves):
     """Forward, loss and every gradient of the node-partitioned model (degree-balanced renumbering or plain id blocks,
-    pipelined or serial schedule, sharded plans, 2B-row score exchange) against the reference's float64 run."""
+    pipelined or serial schedule of half-table gathers, or the whole-stage schedule a small table takes -- one grouped gather and
+    one launch per stage; sharded plans, 2B-row score exchange) against the reference's float64 run."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tag, multi, defer, q, 64, None, balanced, overlap)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tag, multi, defer, q, 64, None, balanced, overlap, halves)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]

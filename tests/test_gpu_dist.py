@@ -146,17 +146,19 @@ def test_bench_distributed_path_rehearsal_on_one_rank():
     d = json.loads(lines[0])
     assert "torch.distributed.run" in r.stderr and "graph_fallback" not in d, (r.stderr[-2000:], d.get("graph_fallback"))
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 1e9
-    assert "6 async half-table all-gathers per forward" in d["config"]["parallelism"]
+    # (a Gowalla-scale table is small: one grouped all-gather + one launch per stage, Comm.whole_below; the 10^9-edge probe below
+    # runs the pipelined half-table schedule)
+    assert "3 whole-table all-gathers per forward" in d["config"]["parallelism"]
     assert d["config"]["passes_per_step"] >= 1 and d["timed_region_s"] > 0.1
     rf = d["roofline"]
-    assert rf and rf["frac"] > 0 and rf["allgather"]["per_forward"] == 6 and rf["allgather"]["avg_us_serial"] > 0
+    assert rf and rf["frac"] > 0 and rf["allgather"]["per_forward"] == 3 and rf["launches_per_forward"] == 3 and rf["allgather"]["avg_us_serial"] > 0
     assert d["cpu_baseline"] and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     pr = d["scaling_probe"]                                              # the 10^9-edge forward through the same N>1 code path
     assert "error" not in pr and pr["n_gpus"] == 1 and pr["value"] > 1e10 and 0.5 < pr["prop_fwd_frac_of_hbm_peak"] < 1.2, pr
     assert d["ms_per_pass_eager"] > 0 and d["bpr_pairs_per_s"] > 1e5 and d["collective_launches_per_train_step"] > 0
 
 
-def _gloo_gpu_worker(rank, world, port, q, bf16, overlap):
+def _gloo_gpu_worker(rank, world, port, q, bf16, overlap, halves=True):
     """One rank of a world-`world` run whose ranks all use cuda:0 (gloo moves the collectives through the host; RCCL refuses
     two ranks per GPU).  Everything else is the product path: HIP kernels, sharded plans, pipelined schedule."""
     try:
@@ -165,6 +167,7 @@ def _gloo_gpu_worker(rank, world, port, q, bf16, overlap):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         sys.path.insert(0, root)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        os.environ["NGACF_DIST_WHOLE_BYTES"] = "0" if halves else str(32 << 20)      # (the pipelined halves / what a table this small takes by default)
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import ngacf_amd
@@ -204,11 +207,13 @@ def _gloo_gpu_worker(rank, world, port, q, bf16, overlap):
         q.put((rank, {"exception": "%s\n%s" % (e, traceback.format_exc())}))
 
 
-@pytest.mark.parametrize("world,bf16,overlap", [(2, False, True), (3, False, True), (2, True, True), (2, False, False)])
-def test_ranks_sharing_one_gpu_under_gloo_match_the_single_gpu_model(world, bf16, overlap):
+@pytest.mark.parametrize("world,bf16,overlap,halves", [(2, False, True, True), (3, False, True, True), (2, True, True, True), (2, False, False, True),
+                                                       (2, False, True, False), (3, True, True, False)])
+def test_ranks_sharing_one_gpu_under_gloo_match_the_single_gpu_model(world, bf16, overlap, halves):
     """The node-partitioned path END TO END with the real kernels and MORE THAN ONE RANK: `world` processes, all on cuda:0, gloo
     for the collectives -- degree-balanced partition, each rank's sharded plan, the pipelined half-table all-gathers in
-    forward and backward, the 2B-row score exchange, the weight-gradient all-reduce -- against the plain single-GPU model
+    forward and backward (or, halves = False, the whole-stage schedule a small table takes: one grouped gather + one launch per
+    stage), the 2B-row score exchange, the weight-gradient all-reduce -- against the plain single-GPU model
     (scores, every gradient, the propagated table).  fp32: 1e-5 / 2e-4; bf16 storage: both sides round alike up to summation
     order, 2e-2."""
     import socket
@@ -216,7 +221,7 @@ def test_ranks_sharing_one_gpu_under_gloo_match_the_single_gpu_model(world, bf16
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gloo_gpu_worker, args=(r, world, port, q, bf16, overlap)) for r in range(world)]
+    procs = [ctx.Process(target=_gloo_gpu_worker, args=(r, world, port, q, bf16, overlap, halves)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
