@@ -598,8 +598,7 @@ def eval_leg(torch, ops, model, edge, U, I, K=20, reps=5):
         b.record()
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
-    return {"eval_topk_ms": round(min(ts), 4), "eval_topk_ms_mean": round(sum(ts) / len(ts), 4), "eval_topk_K": K,
-            "eval_topk_scores_per_s": round(U * I / (min(ts) * 1e-3), 1)}
+    return {"eval_topk_ms": round(min(ts), 4), "eval_topk_K": K}          # (the line must stay under 6 KB: two scalars)
 
 
 def two_in_flight(torch, model, edge, E, L, seconds=0.3):

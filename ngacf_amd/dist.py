@@ -237,16 +237,17 @@ class Comm:
         """BOTH halves of every table in `fulls` as one grouped launch (the whole-stage schedule)."""
         if not self.active:
             return _Handle()
-        return self._gather([self._region(f, t) for f in fulls for t in ("user", "item")], fulls[0].is_cuda)
+        return self._gather([self._region(f, t) for f in fulls for t in ("user", "item")], fulls[0].is_cuda, inline=True)
 
-    def _gather(self, regions, on_gpu):
+    def _gather(self, regions, on_gpu, inline=False):
+        """inline: in the caller's stream order whatever the size (the whole-stage schedule has nothing to run beside its gather)"""
         ev = None
         if self.timer is not None and on_gpu:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
         self.launches += 1 if (self._coalesce or len(regions) == 1) else len(regions)
         recv = sum(o.numel() * o.element_size() for o, _, _ in regions) * (self.world - 1) // max(self.world, 1)
-        if self.inline or (self.overlap and recv < self.inline_below):
+        if inline or self.inline or (self.overlap and recv < self.inline_below):
             # IN the caller's stream order (c10d runs a synchronous collective on the current stream): no communicator-side stream,
             # no fork / join around the launch.  The graphed train step's two concurrent chains use this form -- the OTHER chain's
             # work is what hides a gather then -- because a fork / join nested inside a forked branch crashes hipGraph
@@ -358,11 +359,19 @@ class _ShardedStack(torch.autograd.Function):
         # over all local rows.  Same kernels on the same rows as the half schedule: the same bits.
         whole = bool(cfg.get("whole"))
         out = None
+        xflat = cfg.get("x_flat")
+        if xflat is not None and not (xflat.data_ptr() == Xu.data_ptr() and Xu.is_contiguous() and Xi.is_contiguous()
+                                      and Xi.data_ptr() == xflat.data_ptr() + Xu.numel() * Xu.element_size()):
+            xflat = None                                             # (the inputs are not the model's linked tables)
         if whole:
             new_H(0)
-            for t in ("user", "item"):
-                be.transform_fwd_rows(X[t], Ws[0], As[0], Hs[0], Ss[0], part.Up, part.Ip, cfg["heads"][0], part.half_win(t), True,
+            if xflat is not None:
+                be.transform_fwd_rows(xflat, Ws[0], As[0], Hs[0], Ss[0], part.Up, part.Ip, cfg["heads"][0], part.win, True,
                                       cfg["feat_drop"], cfg["seeds"][0], **sd)
+            else:
+                for t in ("user", "item"):
+                    be.transform_fwd_rows(X[t], Ws[0], As[0], Hs[0], Ss[0], part.Up, part.Ip, cfg["heads"][0], part.half_win(t), True,
+                                          cfg["feat_drop"], cfg["seeds"][0], **sd)
             h = comm.start_gather2(Hs[0])
             for s in range(L):
                 H, S, heads = Hs[s], Ss[s], cfg["heads"][s]
@@ -431,6 +440,7 @@ class _ShardedStack(torch.autograd.Function):
             first = B                                                # the next stage starts with the other half
         comm.join()
         if need:
+            ctx.xflat = xflat if whole else None
             ctx.cfg, ctx.L = cfg, L
             ctx.saved_stages = saved                                 # (held on ctx: views of the stage tables)
             ctx.lease = lease                                        # (the H tables go back to the pool with the node)
@@ -452,55 +462,104 @@ class _ShardedStack(torch.autograd.Function):
         lease = comm.new_lease()
 
         whole = bool(cfg.get("whole"))
+        zeroed = None
+        if whole:
+            # every stage's dH and dS out of ONE zeroed buffer (one fill per backward instead of two per stage: a launch is ~5 us on
+            # the step's one queue, where the whole-stage schedule runs)
+            sizes = []
+            for s in range(L):
+                d, heads = saved[s][4].shape[1], cfg["heads"][s]
+                sizes += [(N * d * saved[s][4].element_size() + 255) // 256 * 256, (N * heads * 4 + 255) // 256 * 256]
+            zeroed, zoff = torch.zeros(sum(sizes), dtype=torch.uint8, device=dev), [0]
+            for z in sizes:
+                zoff.append(zoff[-1] + z)
+
+        def alloc(s):
+            H = saved[s][4]
+            if tabs[s] is None:
+                d, heads = H.shape[1], cfg["heads"][s]
+                if zeroed is not None:
+                    dH0 = zeroed[zoff[2 * s]:zoff[2 * s] + N * d * H.element_size()].view(H.dtype).view(N, d)
+                    dS0 = zeroed[zoff[2 * s + 1]:zoff[2 * s + 1] + N * heads * 4].view(torch.float32).view(N, heads)
+                else:
+                    dH0, dS0 = torch.zeros(N, d, dtype=H.dtype, device=dev), torch.zeros(N, heads, dtype=torch.float32, device=dev)
+                tabs[s] = (torch.empty(N, d, dtype=torch.float32, device=dev), comm.table(("Gn", s), (N, d), H.dtype, dev, lease),
+                           comm.table(("t", s), (N, 2 * heads), torch.float32, dev, lease),     # pairs (S, t) per head
+                           dH0, dS0)
+            return tabs[s]
 
         def Nstep(s, t, gather=True):
             _, _, _, _, H, S, out, agg, R = saved[s]
-            if tabs[s] is None:
-                d, heads = H.shape[1], cfg["heads"][s]
-                tabs[s] = (torch.empty(N, d, dtype=torch.float32, device=dev), comm.table(("Gn", s), (N, d), H.dtype, dev, lease),
-                           comm.table(("t", s), (N, 2 * heads), torch.float32, dev, lease),     # pairs (S, t) per head
-                           torch.zeros(N, d, dtype=H.dtype, device=dev), torch.zeros(N, heads, dtype=torch.float32, device=dev))
-            G, Gn, ST, _, dS = tabs[s]
+            G, Gn, ST, _, dS = alloc(s)
             # (step 1 leaves the rows' own half of dS -- P1 -- in dS; the edge step of the same half finishes it in place)
             be.prop_bwd_node(out, agg, R, g[t], S, G, Gn, ST, dS, part.Up, cfg["heads"][s], part.half_win(t), True, True, cfg["alpha"])
             if gather:
                 pending[(s, t)] = comm.start_gather(t, Gn, ST)      # one grouped launch
 
-        def Nboth(s):                                               # whole-stage schedule: both halves' node steps, ONE gather
-            Nstep(s, "user", False)
-            Nstep(s, "item", False)
+        def Nboth(s, gfull=None):
+            """whole-stage schedule: the node step of all local rows, ONE gather.  gfull: the incoming gradient as a global-row
+            table (what the next stage's transform backward leaves) -> one launch; None: g's two local halves -> two."""
+            if gfull is None:
+                Nstep(s, "user", False)
+                Nstep(s, "item", False)
+            else:
+                _, _, _, _, H, S, out, agg, R = saved[s]
+                G, Gn, ST, _, dS = alloc(s)
+                be.prop_bwd_node(out, agg, R, gfull, S, G, Gn, ST, dS, part.Up, cfg["heads"][s], part.win, False, True, cfg["alpha"])
             pending[(s, "both")] = comm.start_gather2(tabs[s][1], tabs[s][2])
 
         first = "user"
+        grads = [None] * (2 * L)
         if whole:
             Nboth(L - 1)
+            for s in range(L - 1, -1, -1):
+                Xu, Xi, W, a, H, S, out, agg, R = saved[s]
+                G, Gn, ST, dH, dS = tabs[s]
+                heads = cfg["heads"][s]
+                pending.pop((s, "both")).wait()
+                be.prop_bwd_edges(plan, H, S, a, G, Gn, ST, heads, cfg["alpha"], True, True, cfg["drop"], cfg["seeds"][s],
+                                  dH=dH, dS=dS, **sd)
+                if s > 0:
+                    # this stage's input rows ARE the previous stage's output table (global rows): the transform backward of all local
+                    # rows as one launch, its dX a global-row table that the previous stage's node step reads in place
+                    dX, dW, da = be.transform_bwd_rows(saved[s - 1][6], W, H, dH, dS, part.Up, part.Ip, heads, part.win, False,
+                                                       cfg["feat_drop"], cfg["seeds"][s], **sd)
+                    Nboth(s - 1, dX if dX.dtype == h_dtype else dX.to(h_dtype))
+                elif getattr(ctx, "xflat", None) is not None:
+                    dX, dW, da = be.transform_bwd_rows(ctx.xflat, W, H, dH, dS, part.Up, part.Ip, heads, part.win, True,
+                                                       cfg["feat_drop"], cfg["seeds"][s], **sd)
+                    g["user"], g["item"] = dX[:part.cu], dX[part.cu:]
+                else:
+                    parts = {}
+                    for t, Xt in (("user", Xu), ("item", Xi)):
+                        dX, dW_, da_ = be.transform_bwd_rows(Xt, W, H, dH, dS, part.Up, part.Ip, heads, part.half_win(t), True,
+                                                             cfg["feat_drop"], cfg["seeds"][s], **sd)
+                        parts[t] = (dW_, da_)
+                        g[t] = dX
+                    dW = torch.stack([parts["user"][0][0], parts["item"][0][1]])
+                    da = torch.stack([parts["user"][1][0], parts["item"][1][1]])
+                if not comm.defer_weight_reduce:
+                    comm.all_reduce_sum(dW, da)
+                grads[2 * s], grads[2 * s + 1] = dW, da
         else:
             Nstep(L - 1, OTHER[first])
             Nstep(L - 1, first)
-        grads = [None] * (2 * L)
-        for s in range(L - 1, -1, -1):
+        for s in range(L - 1, -1, -1) if not whole else ():
             Xu, Xi, W, a, H, S, out, agg, R = saved[s]
             Xs = {"user": Xu, "item": Xi}
             G, Gn, ST, dH, dS = tabs[s]
             heads = cfg["heads"][s]
             parts = {}
-            if whole:
-                pending.pop((s, "both")).wait()
-                be.prop_bwd_edges(plan, H, S, a, G, Gn, ST, heads, cfg["alpha"], True, True, cfg["drop"], cfg["seeds"][s],
-                                  dH=dH, dS=dS, **sd)
             for t in (first, OTHER[first]):
-                if not whole:
-                    pending.pop((s, OTHER[t])).wait()
-                    be.prop_bwd_edges(plan, H, S, a, G, Gn, ST, heads, cfg["alpha"], True, True, cfg["drop"], cfg["seeds"][s],
-                                      half=t, dH=dH, dS=dS, **sd)
+                pending.pop((s, OTHER[t])).wait()
+                be.prop_bwd_edges(plan, H, S, a, G, Gn, ST, heads, cfg["alpha"], True, True, cfg["drop"], cfg["seeds"][s],
+                                  half=t, dH=dH, dS=dS, **sd)
                 dX, dW, da = be.transform_bwd_rows(Xs[t], W, H, dH, dS, part.Up, part.Ip, heads, part.half_win(t), True,
                                                    cfg["feat_drop"], cfg["seeds"][s], **sd)
                 parts[t] = (dW, da)
                 g[t] = dX if s == 0 else dX.to(h_dtype)
-                if s > 0 and not whole:
+                if s > 0:
                     Nstep(s - 1, t)
-            if s > 0 and whole:
-                Nboth(s - 1)
             dW = torch.stack([parts["user"][0][0], parts["item"][0][1]])         # each half owns its weight panel
             da = torch.stack([parts["user"][1][0], parts["item"][1][1]])
             if not comm.defer_weight_reduce:
@@ -509,6 +568,7 @@ class _ShardedStack(torch.autograd.Function):
             first = OTHER[first]
         comm.join()
         ctx.saved_stages = None
+        ctx.xflat = None
         for ls in (lease, getattr(ctx, "lease", None)):
             if ls is not None:
                 ls.release()
@@ -639,6 +699,31 @@ class ShardedSPUIGACF(nn.Module):
         self.seg_len = 256
 
     # ---- parameter plumbing -------------------------------------------------------------------------------
+    def _link_tables(self):
+        """uEmbd.weight and iEmbd.weight as views of ONE contiguous [cu + ci, d] table (same Parameter objects, same values:
+        SPUIGACF._CFBase._link_tables): the whole-stage schedule transforms all local rows of the first stage, forward and
+        backward, in one launch each."""
+        wu, wi = self.uEmbd.weight, self.iEmbd.weight
+        flat = torch.empty(wu.shape[0] + wi.shape[0], wu.shape[1], device=wu.device, dtype=wu.dtype)
+        flat[:wu.shape[0]] = wu.data
+        flat[wu.shape[0]:] = wi.data
+        wu.data, wi.data = flat[:wu.shape[0]], flat[wu.shape[0]:]
+        object.__setattr__(self, "_flat", flat)
+
+    def _apply(self, fn, recurse=True):
+        r = super()._apply(fn, recurse)                               # .to() / .cuda() move the halves apart
+        if "uEmbd" in self._modules and "iEmbd" in self._modules:
+            self._link_tables()
+        return r
+
+    def _flat_local(self):
+        wu, wi, flat = self.uEmbd.weight, self.iEmbd.weight, self.__dict__.get("_flat")
+        if flat is None or flat.device != wu.device or flat.dtype != wu.dtype or wu.data_ptr() != flat.data_ptr() \
+                or wi.data_ptr() != flat.data_ptr() + wu.numel() * wu.element_size():
+            self._link_tables()                                       # somebody re-assigned .data: alias again
+            flat = self._flat
+        return flat
+
     def load_full_embeddings(self, full_u, full_i):
         ou, oi = self.part.local_original_ids(full_u.device)
         with torch.no_grad():
@@ -793,6 +878,7 @@ class ShardedSPUIGACF(nn.Module):
         widest = max(int(self.gat.stage_params(s)[0].shape[-1]) for s in range(len(stages)))
         cfg = {"part": self.part, "plan": plan, "comm": comm, "be": self.be, "heads": [len(l) for l in stages],
                "whole": comm.whole_stage(self.part.N * widest * elem),
+               "x_flat": self._flat_local(),            # (the two local tables as one: the whole-stage schedule's first stage)
                "alpha": stages[0][0].alpha, "drop": drop, "feat_drop": drop,
                "seeds": [NF.stage_seed(base, s) for s in range(len(stages))], "h_dtype": self.compute_dtype,
                "seed_dev": seed_dev, "grad_mode": torch.is_grad_enabled(), "fuse_next": NF.FUSE_NEXT}
@@ -812,7 +898,10 @@ class ShardedSPUIGACF(nn.Module):
         else:
             idx = torch.cat([p.internal_users(userIdx.long()), p.internal_items(itemIdx.long()) + p.Up])
             rows = _RowExchange.apply(out_u, out_i, idx, p, self._comm_now())       # [2B, d]: user rows then item rows
-        ar = torch.arange(B, device=rows.device)
+        ar = self.__dict__.get("_arange")                                            # (built once per batch size, not per forward)
+        if ar is None or ar.numel() != B or ar.device != rows.device:
+            ar = torch.arange(B, device=rows.device)
+            self.__dict__["_arange"] = ar
         score = self.be.score if hasattr(self.be, "score") else NF.score
         return score(rows, ar, ar, B)                                                # SPUIGACF.py:49-52
 

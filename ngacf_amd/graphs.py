@@ -98,7 +98,10 @@ class GraphedBPRStep:
         # after a step of this kind .grad of the sunk parameters is None (the pieces went straight to the optimizer)
         # (with after_backward -- the node-partitioned model's weight-gradient all-reduce -- only when that hook takes the sinks)
         hook_takes_sinks = after_backward is not None and getattr(getattr(after_backward, "__self__", None), "reduce_grads_takes_sinks", False)
-        split_grads = (split_grads and concurrent_forwards and not shared_propagation and not fused_loss
+        # (the node-partitioned model's step runs its two chains one after the other -- concurrent branches do not capture there --
+        # but parks their gradients the same way: eight accumulation kernels and three loss kernels less on its one queue)
+        one_queue = not concurrent_forwards and hasattr(model, "chain")
+        split_grads = (split_grads and (concurrent_forwards or one_queue) and not shared_propagation and not fused_loss
                        and getattr(optim, "supports_grad_pairs", False) and (after_backward is None or hook_takes_sinks))
         sinks = ({}, {})
         direct_bpr = type(lossfn) is BPRLoss and split_grads           # this step owns its backward: see the join below
@@ -119,13 +122,19 @@ class GraphedBPRStep:
             optim.zero_grad(set_to_none=True)
             if shared_propagation:                          # opt-in: one propagation per step (model.forward_pairs)
                 loss = lossfn(*model.forward_pairs(self.u, self.p, self.n, adj))
-            elif concurrent_forwards:
+            elif concurrent_forwards or (one_queue and split_grads):
                 # reference semantics (two forwards, two propagations) as two parallel branches of the graph: the
                 # chains are independent until the loss, and autograd replays each branch's backward on the stream
                 # of its forward, so the many small launch-bound kernels of one chain fill the gaps of the other
+                # (one_queue: the same step with both chains on the current stream)
+                import contextlib
                 cur = torch.cuda.current_stream()
-                sa.wait_stream(cur)
-                sb.wait_stream(cur)
+                if concurrent_forwards:
+                    sa.wait_stream(cur)
+                    sb.wait_stream(cur)
+                on_a = (lambda: torch.cuda.stream(sa)) if concurrent_forwards else contextlib.nullcontext
+                on_b = (lambda: torch.cuda.stream(sb)) if concurrent_forwards else contextlib.nullcontext
+                chain = _chain if concurrent_forwards else (lambda m, k: contextlib.nullcontext())
                 if fused_loss:
                     with torch.cuda.stream(sa):
                         fa = model.propagate(adj)
@@ -139,12 +148,13 @@ class GraphedBPRStep:
                     # the two (ngacf_adam_step's grads2) -- autograd would run one accumulation kernel per parameter, eight
                     # launch-bound kernels at the very end of the slower branch
                     # (deferred_ok: this step reads its sinks after the whole backward and after both branch streams were joined)
-                    with torch.cuda.stream(sa), NF.grad_sink(sinks[0] if split_grads else None, deferred_ok=True), _chain(model, 0):
+                    with on_a(), NF.grad_sink(sinks[0] if split_grads else None, deferred_ok=True), chain(model, 0):
                         ps = model(self.u, self.p, adj)
-                    with torch.cuda.stream(sb), NF.grad_sink(sinks[1] if split_grads else None, deferred_ok=True), _chain(model, 1):
+                    with on_b(), NF.grad_sink(sinks[1] if split_grads else None, deferred_ok=True), chain(model, 1):
                         ns = model(self.u, self.n, adj)
-                    cur.wait_stream(sa)
-                    cur.wait_stream(sb)
+                    if concurrent_forwards:
+                        cur.wait_stream(sa)
+                        cur.wait_stream(sb)
                     if direct_bpr:
                         # BPRLoss and the start of its backward as ONE launch: the scores' gradients go straight into the two
                         # branches (the loss node, autograd's ones-like fill and the second BPR kernel sat on the serial join)
@@ -154,14 +164,15 @@ class GraphedBPRStep:
                         loss = lossfn(ps, ns)
             else:                                           # reference semantics: two forwards, two propagations
                 loss = lossfn(model(self.u, self.p, adj), model(self.u, self.n, adj))
-            if not (direct_bpr and concurrent_forwards and not shared_propagation and not fused_loss):
+            if not (direct_bpr and (concurrent_forwards or one_queue) and not shared_propagation and not fused_loss):
                 loss.backward()
             if after_backward is not None and not (sinks[0] or sinks[1]):
                 after_backward()                            # e.g. the sharded model's grouped weight-gradient all-reduce
             if sinks[0] or sinks[1]:
                 cur = torch.cuda.current_stream()           # the sinks were filled on the branch streams; no AccumulateGrad
-                cur.wait_stream(sa)                         # node synchronised them with this one
-                cur.wait_stream(sb)
+                if concurrent_forwards:                     # node synchronised them with this one
+                    cur.wait_stream(sa)
+                    cur.wait_stream(sb)
                 if after_backward is not None:              # (the pieces of both chains in the hook's one grouped launch)
                     after_backward(sinks)
                 keys = list(dict.fromkeys(list(sinks[0]) + list(sinks[1])))
