@@ -496,22 +496,29 @@ class _ShardedStack(torch.autograd.Function):
             if gather:
                 pending[(s, t)] = comm.start_gather(t, Gn, ST)      # one grouped launch
 
-        def Nboth(s, gfull=None):
+        def Nboth(s, gfull=None, glocal=None):
             """whole-stage schedule: the node step of all local rows, ONE gather.  gfull: the incoming gradient as a global-row
-            table (what the next stage's transform backward leaves) -> one launch; None: g's two local halves -> two."""
-            if gfull is None:
+            table (what the next stage's transform backward leaves), glocal: as one [cu + ci, d] table of the local rows (what the
+            scores' row exchange leaves) -> one launch; neither: g's two local halves -> two."""
+            if gfull is None and glocal is None:
                 Nstep(s, "user", False)
                 Nstep(s, "item", False)
             else:
                 _, _, _, _, H, S, out, agg, R = saved[s]
                 G, Gn, ST, _, dS = alloc(s)
-                be.prop_bwd_node(out, agg, R, gfull, S, G, Gn, ST, dS, part.Up, cfg["heads"][s], part.win, False, True, cfg["alpha"])
+                be.prop_bwd_node(out, agg, R, gfull if gfull is not None else glocal, S, G, Gn, ST, dS, part.Up, cfg["heads"][s],
+                                 part.win, gfull is None, True, cfg["alpha"])
             pending[(s, "both")] = comm.start_gather2(tabs[s][1], tabs[s][2])
 
         first = "user"
         grads = [None] * (2 * L)
         if whole:
-            Nboth(L - 1)
+            base = g["user"]._base                                      # the two incoming halves as views of ONE table?
+            if not (base is not None and base is g["item"]._base and base.dim() == 2 and base.is_contiguous() and base.dtype == h_dtype
+                    and base.shape[0] == part.cu + part.ci and g["user"].data_ptr() == base.data_ptr()
+                    and g["item"].data_ptr() == base.data_ptr() + part.cu * base.shape[1] * base.element_size()):
+                base = None
+            Nboth(L - 1, glocal=base)
             for s in range(L - 1, -1, -1):
                 Xu, Xi, W, a, H, S, out, agg, R = saved[s]
                 G, Gn, ST, dH, dS = tabs[s]

@@ -595,7 +595,8 @@ def rows_scatter(pos, g, cu, ci, dtype):
     dev, (n, d) = g.device, g.shape
     if n > ROWS_SCATTER_MAX_N or d not in SUPPORTED_D or dtype not in _DT:
         raise ValueError("rows_scatter: at most %d rows of d in %s" % (ROWS_SCATTER_MAX_N, SUPPORTED_D))
-    du, di = torch.zeros(cu, d, dtype=dtype, device=dev), torch.zeros(ci, d, dtype=dtype, device=dev)
+    flat = torch.zeros(cu + ci, d, dtype=dtype, device=dev)           # (one table, one fill; the halves are views of it)
+    du, di = flat[:cu], flat[cu:]
     if n:
         _lib.check(lib.ngacf_rows_scatter(_chk(pos, "pos", torch.int32, n, dev, align=4), _chk(g, "g", torch.float32, n * d, dev),
                                           du.data_ptr(), di.data_ptr(), _DT[dtype], n, cu, d, _stream()), "ngacf_rows_scatter")
