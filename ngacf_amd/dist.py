@@ -160,6 +160,7 @@ class Comm:
         self.defer_weight_reduce = False      # True: the caller sums weight gradients once per step (reduce_grads)
         self.overlap = True                   # False: wait right after every start (serial schedule)
         self.launches = 0                     # collective launches issued (for the tests / the bench line)
+        self.whole_gathers = 0                # ... of them whole-table gathers (start_gather2: the whole-stage schedule)
         self.timer = None                     # list -> (start event, end event, bytes received) per gather (bench, serial mode)
         self.dry_run = False                  # tools/shard_compute.py: one rank's kernels of a P-way partition, no collectives
         self.inline = False                   # True: every gather synchronously in the caller's stream order (start_gather)
@@ -237,6 +238,7 @@ class Comm:
         """BOTH halves of every table in `fulls` as one grouped launch (the whole-stage schedule)."""
         if not self.active:
             return _Handle()
+        self.whole_gathers += 1
         return self._gather([self._region(f, t) for f in fulls for t in ("user", "item")], fulls[0].is_cuda, inline=True)
 
     def _gather(self, regions, on_gpu, inline=False):

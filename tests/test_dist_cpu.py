@@ -62,7 +62,7 @@ def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced
         if defer:
             m.reduce_grads()                  # one all-reduce per step instead of one per stage
         p = m.part
-        err = {"gathers": m._comms[0].launches + m._comms[1].launches}
+        err = {"whole_gathers": m._comms[0].whole_gathers + m._comms[1].whole_gathers}
         smax = float(np.abs(g["pos_f64"]).max())
         err["scores"] = max(float((ps.detach().double() - torch.from_numpy(g["pos_f64"])).abs().max()),
                             float((ns.detach().double() - torch.from_numpy(g["neg_f64"])).abs().max())) / smax
@@ -117,6 +117,8 @@ def test_sharded_model_matches_reference_under_gloo(world, tag, multi, defer, ba
         assert err["scores"] < 1e-5 and err["loss"] < 1e-5, (rank, err)
         assert err["emb"] < 2e-4 and err["gat"] < 2e-4, (rank, err)          # fp32 stand-in vs float64 reference
         assert err["pad"] == 0.0 and err["sd"] == 0.0 and err["keys"] and err["propagate_shape"], (rank, err)
+        # the schedule that ran: no whole-table gather on the pipelined one; L per forward and L per backward, two chains, on the other
+        assert err["whole_gathers"] == (0 if halves else 4 * (3 if multi else 2)), (rank, halves, err["whole_gathers"])
     total = sum(err["plan_edges"][0] for _, err in res)
     assert total == res[0][1]["plan_edges"][1], "the ranks' plans together hold every directed edge exactly once"
     assert all(err["plan_edges"][0] < 0.75 * err["plan_edges"][1] for _, err in res)
