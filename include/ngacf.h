@@ -370,6 +370,13 @@ int ngacf_shard_rows(const void* Tu, const void* Ti, int dtype, const int64_t* u
                      int u_lo, int cu, int i_lo, int ci, int d, void* stream);
 int ngacf_rows_scatter(const int32_t* pos, const float* g, void* du, void* di, int dtype, int n, int cu, int d, void* stream);
 
+/* The same scatter for a SCORED batch, with the scores' backward inside it: rows = the 2B exchanged rows of ngacf_shard_rows (after the
+ * all-reduce: rows[b] the user row of pair b, rows[B + b] its item row; score[b] = rows[b] . rows[B + b], SPUIGACF.py:49-52), gscore[b] =
+ * d loss / d score[b]; entry k's gradient row gscore[k mod B] * rows[(k + B) mod 2B] is formed on the fly.  The same bits as
+ * ngacf_score_bwd over the row table followed by ngacf_rows_scatter, one launch.  n = 2B. */
+int ngacf_rows_scatter_scored(const int32_t* pos, const float* rows, const float* gscore, void* du, void* di, int dtype,
+                              int n, int cu, int d, void* stream);
+
 /* optim.step() of the train loop (train_eval_Gowalla.py:137-138; torch.optim.Adam with L2 weight decay, run_Gowalla.py:114)
  * for up to NGACF_ADAM_MAX_TENSORS fp32 tensors in ONE launch.  The five pointer tables and numel are HOST arrays of `count`
  * entries (copied into the kernel's arguments); steps[t] points at the DEVICE float holding tensor t's step count AFTER this

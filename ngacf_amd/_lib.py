@@ -60,6 +60,7 @@ SIGNATURES = {
     "ngacf_dropout_bits": [_i, _u64, _p, _p, _p, _p, _i, _p],
     "ngacf_shard_rows": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "ngacf_rows_scatter": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ngacf_rows_scatter_scored": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ngacf_timing_begin": [],
     "ngacf_timing_end": [_p, _p, _i],
     "ngacf_peer_alloc": [_u64, _p], "ngacf_peer_alloc_ctrl": [_u64, _p], "ngacf_peer_free": [_p], "ngacf_peer_export": [_p, _p], "ngacf_peer_import": [_p, _p],

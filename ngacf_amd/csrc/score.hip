@@ -238,10 +238,19 @@ __global__ __launch_bounds__(256) void shard_rows_kernel(const T* __restrict__ T
 }
 
 constexpr int ROWS_SCATTER_MAX_N = 16384;        // ids in 64 KB of LDS
-template <typename T, int D>
+// SCORED: g is not given; the n = 2B rows are an exchanged batch (rows[b] = the user row of pair b, rows[B + b] = its item row, score
+// of pair b = rows[b] . rows[B + b]) and gs[b] the gradient of that score: g[k] = gs[k mod B] * rows[(k + B) mod 2B] is formed on the
+// fly -- the products and the order of the sums of ngacf_score_bwd followed by the plain scatter, one launch instead of two.
+template <typename T, int D, bool SCORED = false>
 __global__ __launch_bounds__(256) void rows_scatter_kernel(const int* __restrict__ pos, const float* __restrict__ g, T* __restrict__ du,
-                                                           T* __restrict__ di, int n, int cu) {
+                                                           T* __restrict__ di, int n, int cu, const float* __restrict__ gs = nullptr) {
+#pragma clang fp contract(off)                    // (SCORED: a product is rounded on its own, as the two-launch form stores it -- never fused into the sums)
     extern __shared__ int ids[];
+    const int B = n >> 1;
+    auto gval = [&](int k, int col) -> float {
+        if constexpr (SCORED) return gs[k < B ? k : k - B] * g[(size_t)(k < B ? k + B : k - B) * D + col];
+        else return g[(size_t)k * D + col];
+    };
     for (int k = threadIdx.x; k < n; k += 256) ids[k] = pos[k];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256) void rows_scatter_kernel(const int* __restrict
     constexpr int CPL = D / 64;
     float acc[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) acc[c] = g[(size_t)b * D + lane + 64 * c];
+    for (int c = 0; c < CPL; ++c) acc[c] = gval(b, lane + 64 * c);
     if (cnt > 1) {
         for (int k0 = (b + 1) & ~63; k0 < n; k0 += 64) {
             const int k = k0 + lane;
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(256) void rows_scatter_kernel(const int* __restrict
                 const int kk = k0 + __builtin_ctzll(m);
                 m &= m - 1;
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) acc[c] += g[(size_t)kk * D + lane + 64 * c];
+                for (int c = 0; c < CPL; ++c) acc[c] += gval(kk, lane + 64 * c);
             }
         }
     }
@@ -517,6 +526,27 @@ extern "C" int ngacf_shard_rows(const void* Tu, const void* Ti, int dtype, const
     return NGACF_E_SHAPE;
 }
 
+extern "C" int ngacf_rows_scatter_scored(const int32_t* pos, const float* rows, const float* gscore, void* du, void* di, int dtype,
+                                         int n, int cu, int d, void* stream) {
+    if (n < 0 || cu < 0 || (n & 1)) return NGACF_E_ARG;
+    if (n == 0) return 0;
+    if (!pos || !rows || !gscore || n > ROWS_SCATTER_MAX_N) return NGACF_E_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NGACF_CASE(T, D)                                                                                                       \
+    {                                                                                                                          \
+        hipLaunchKernelGGL((rows_scatter_kernel<T, D, true>), dim3((n + 3) / 4), dim3(256), (size_t)n * sizeof(int), st,       \
+                           pos, rows, static_cast<T*>(du), static_cast<T*>(di), n, cu, gscore);                                \
+        NGACF_CHECK_LAUNCH();                                                                                                  \
+        return 0;                                                                                                              \
+    }
+    if (dtype == NGACF_F32 && d == 64) NGACF_CASE(float, 64)
+    if (dtype == NGACF_F32 && d == 128) NGACF_CASE(float, 128)
+    if (dtype == NGACF_BF16 && d == 64) NGACF_CASE(bf16_t, 64)
+    if (dtype == NGACF_BF16 && d == 128) NGACF_CASE(bf16_t, 128)
+#undef NGACF_CASE
+    return NGACF_E_SHAPE;
+}
+
 extern "C" int ngacf_rows_scatter(const int32_t* pos, const float* g, void* du, void* di, int dtype, int n, int cu, int d, void* stream) {
     if (n < 0 || cu < 0) return NGACF_E_ARG;
     if (n == 0) return 0;
@@ -524,8 +554,8 @@ extern "C" int ngacf_rows_scatter(const int32_t* pos, const float* g, void* du, 
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define NGACF_CASE(T, D)                                                                                                       \
     {                                                                                                                          \
-        hipLaunchKernelGGL((rows_scatter_kernel<T, D>), dim3((n + 3) / 4), dim3(256), (size_t)n * sizeof(int), st,             \
-                           pos, g, static_cast<T*>(du), static_cast<T*>(di), n, cu);                                           \
+        hipLaunchKernelGGL((rows_scatter_kernel<T, D, false>), dim3((n + 3) / 4), dim3(256), (size_t)n * sizeof(int), st,      \
+                           pos, g, static_cast<T*>(du), static_cast<T*>(di), n, cu, nullptr);                                  \
         NGACF_CHECK_LAUNCH();                                                                                                  \
         return 0;                                                                                                              \
     }

@@ -640,6 +640,30 @@ class _RowExchangeHIP(torch.autograd.Function):
         return du, di, None, None, None, None
 
 
+class _ExchangeScoreHIP(torch.autograd.Function):
+    """scores [B] of the batch = _RowExchangeHIP + the pair scoring as ONE autograd node: the backward forms the gradient rows of
+    the 2B exchanged rows from the scores' gradient inside the scatter launch (ngacf_rows_scatter_scored) -- the score kernel's own
+    backward over the [2B, d] row table (a duplicate scan over row numbers that are all distinct: 13 us) and its launch are gone."""
+
+    @staticmethod
+    def forward(ctx, out_u, out_i, u, it, part, comm, ar):
+        dev = out_u.device
+        pu = part._on("perm_u", dev) if part.perm_u is not None else None
+        pi = part._on("perm_i", dev) if part.perm_i is not None else None
+        rows, pos = _hip_ops.shard_rows(out_u.contiguous(), out_i.contiguous(), u, it, pu, pi, part.U, part.I, part.u_lo, part.i_lo)
+        comm.all_reduce_sum(rows)
+        ctx.save_for_backward(pos, rows)
+        ctx.shape = (out_u.shape[0], out_i.shape[0], out_u.dtype)
+        return _hip_ops.score_fwd(rows, ar, ar, ar.numel())
+
+    @staticmethod
+    def backward(ctx, gs):
+        pos, rows = ctx.saved_tensors
+        cu, ci, dt = ctx.shape
+        du, di = _hip_ops.rows_scatter_scored(pos, rows, gs.contiguous().float(), cu, ci, dt)
+        return du, di, None, None, None, None, None
+
+
 class ShardedSPUIGACF(nn.Module):
     """SPUIGACF / SPUIMultiGACF / SPUIStackedGACF with the embedding tables sharded by node blocks.
     forward(userIdx, itemIdx, mask) has the reference signature (SPUIGACF.py:41) and returns the scores of the
@@ -902,6 +926,13 @@ class ShardedSPUIGACF(nn.Module):
         out_u, out_i = self.propagate_local(mask)
         p = self.part
         B = userIdx.numel()
+        if self.be is _hip_ops and 2 * B <= _hip_ops.ROWS_SCATTER_MAX_N and out_u.shape[1] in _hip_ops.SUPPORTED_D \
+                and os.environ.get("NGACF_DIST_FUSED_SCORE", "1") != "0":
+            ar = self.__dict__.get("_arange")
+            if ar is None or ar.numel() != B or ar.device != out_u.device:
+                ar = torch.arange(B, device=out_u.device)
+                self.__dict__["_arange"] = ar
+            return _ExchangeScoreHIP.apply(out_u, out_i, userIdx.long().contiguous(), itemIdx.long().contiguous(), p, self._comm_now(), ar)
         if self.be is _hip_ops and 2 * B <= _hip_ops.ROWS_SCATTER_MAX_N:
             rows = _RowExchangeHIP.apply(out_u, out_i, userIdx.long().contiguous(), itemIdx.long().contiguous(), p, self._comm_now())
         else:

@@ -603,6 +603,21 @@ def rows_scatter(pos, g, cu, ci, dtype):
     return du, di
 
 
+def rows_scatter_scored(pos, rows, gscore, cu, ci, dtype):
+    """rows_scatter of the gradient rows of a scored batch, formed on the fly from the exchanged rows [2B, d] (fp32) and the scores'
+    gradient [B] (ngacf_rows_scatter_scored): what score_bwd over the row table + rows_scatter leave, in one launch."""
+    dev, (n, d) = rows.device, rows.shape
+    if n > ROWS_SCATTER_MAX_N or n % 2 or d not in SUPPORTED_D or dtype not in _DT:
+        raise ValueError("rows_scatter_scored: 2B <= %d rows of d in %s" % (ROWS_SCATTER_MAX_N, SUPPORTED_D))
+    flat = torch.zeros(cu + ci, d, dtype=dtype, device=dev)
+    du, di = flat[:cu], flat[cu:]
+    if n:
+        _lib.check(lib.ngacf_rows_scatter_scored(_chk(pos, "pos", torch.int32, n, dev, align=4), _chk(rows, "rows", torch.float32, n * d, dev),
+                                                 _chk(gscore, "gscore", torch.float32, n // 2, dev, align=4), du.data_ptr(), di.data_ptr(),
+                                                 _DT[dtype], n, cu, d, _stream()), "ngacf_rows_scatter_scored")
+    return du, di
+
+
 def bpr_fwd(pos, neg):
     dev, B = pos.device, pos.numel()
     loss = torch.empty((), dtype=torch.float32, device=dev)

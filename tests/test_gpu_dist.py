@@ -125,6 +125,36 @@ def test_sharded_model_world1_equals_plain_model(balanced):
     assert all(torch.equal(sd[k], v) for k, v in ref.state_dict().items())
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_fused_score_exchange_equals_the_two_launch_form_bitwise(bf16, monkeypatch):
+    """ngacf_rows_scatter_scored (the scores' backward formed inside the scatter of the exchanged rows' gradient) against
+    ngacf_score_bwd over the row table + ngacf_rows_scatter: scores and every embedding gradient bit for bit; a batch with users and
+    items named many times (the scatter sums them in one fixed order)."""
+    import ngacf_amd
+    from ngacf_amd.dist import ShardedSPUIGACF
+    dev = torch.device("cuda:0")
+    U, I = 333, 251
+    edge = _graph(U, I, 7000, 3).to(dev)
+    torch.manual_seed(3)
+    m = ShardedSPUIGACF(U, I, 64, [64, 64], 0.0, world=1, rank=0, stages=3, adj=edge).to(dev).train()
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30); m.iEmbd.weight.mul_(30)
+    if bf16:
+        m.compute_dtype = torch.bfloat16
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    u = torch.randint(0, 40, (512,), device=dev, generator=g); it = torch.randint(0, 50, (512,), device=dev, generator=g)
+    res = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("NGACF_DIST_FUSED_SCORE", fused)
+        m.zero_grad(set_to_none=True)
+        sc = m(u, it, edge)
+        (sc * torch.linspace(-1, 1, sc.numel(), device=dev)).sum().backward()
+        res.append((sc.detach().clone(), m.uEmbd.weight.grad.clone(), m.iEmbd.weight.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[0][1].abs().max()) > 0
+
+
 def test_bench_distributed_path_rehearsal_on_one_rank():
     """bench.py's N>1 code path on a one-rank RCCL group, reached the way the driver reaches it: `python bench.py --gpus 1`
     with NGACF_BENCH_FORCE_DIST=1 and NO torchrun environment -- the parent (no GPU call) launches torch.distributed.run as
