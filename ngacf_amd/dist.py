@@ -585,6 +585,185 @@ class _ShardedStack(torch.autograd.Function):
         return (g["user"], g["item"]) + tuple(grads) + (None,)
 
 
+class _ShardedStackTwo(torch.autograd.Function):
+    """The TWO propagations of a BPR step (train_eval_Gowalla.py:128-129: independent dropout masks, the same parameters) on the
+    whole-stage schedule, in lock-step: stage s of chain A, stage s of chain B, then ONE grouped all-gather that carries both
+    chains' tables -- half the collective launches of two _ShardedStack calls (where a gather is latency, the regime of this
+    schedule, that is half the exposed latency), and the weight panels packed once.  Same kernels, same rows, same seeds per
+    chain: the same bits as two calls.
+    apply(Xu, Xi, W_0, a_0, ..., (chain A's inputs)  Xu, Xi, W_0, a_0, ..., (chain B's: the same parameters, their own autograd slots)  cfg)
+    -> (out_u, out_i) of chain A, (out_u, out_i) of chain B."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        cfg = args[-1]
+        L = cfg["L"]
+        n_in = 2 + 2 * L
+        ins = [args[k * n_in:(k + 1) * n_in] for k in range(2)]
+        part, plan, comm, be = cfg["part"], cfg["plan"], cfg["comm"], cfg["be"]
+        N, dev = part.N, ins[0][0].device
+        need = cfg["grad_mode"] and any(ctx.needs_input_grad[:2 * n_in])
+        sd = {} if cfg["seed_dev"] is None else {"seed_dev": cfg["seed_dev"]}
+        Ws = [ins[0][2 + 2 * s].contiguous().float() for s in range(L)]          # (both chains read the same parameters)
+        As = [ins[0][3 + 2 * s].contiguous().float() for s in range(L)]
+        heads, seeds = cfg["heads"], cfg["seeds2"]                                # seeds2[k][s]: chain k, stage s
+        fuse = [False] * L
+        if cfg.get("fuse_next") and hasattr(be, "can_fuse_next"):
+            for s in range(1, L):
+                fuse[s] = (be.can_fuse_next(plan, cfg["h_dtype"], Ws[s - 1].shape[2], heads[s - 1])
+                           and Ws[s].shape[1] == 64 and Ws[s].shape[2] in (64, 128))
+        panels = {}
+        if any(fuse):
+            idx = [s for s in range(1, L) if fuse[s]]
+            panels = dict(zip(idx, be.pack_panels([Ws[s] for s in idx]))) if cfg["h_dtype"] == torch.bfloat16 else {s: Ws[s] for s in idx}
+        xflat = cfg.get("x_flat")
+        Xu0, Xi0 = ins[0][0], ins[0][1]
+        if xflat is not None and not (xflat.data_ptr() == Xu0.data_ptr() and Xu0.is_contiguous() and Xi0.is_contiguous()
+                                      and Xi0.data_ptr() == xflat.data_ptr() + Xu0.numel() * Xu0.element_size()):
+            xflat = None
+        st = [{"X": {"user": i_[0].contiguous(), "item": i_[1].contiguous()}, "H": [None] * L, "S": [None] * L, "saved": [], "out": None}
+              for i_ in ins]
+
+        def new_H(c, s):
+            c["H"][s] = torch.empty(N, Ws[s].shape[2], dtype=cfg["h_dtype"], device=dev)
+            c["S"][s] = torch.empty(N, heads[s], dtype=torch.float32, device=dev)
+
+        def transform(c, k, s):                                                    # all local rows of stage s, chain k
+            if s == 0 and xflat is not None:
+                be.transform_fwd_rows(xflat, Ws[0], As[0], c["H"][0], c["S"][0], part.Up, part.Ip, heads[0], part.win, True,
+                                      cfg["feat_drop"], seeds[k][0], **sd)
+            else:
+                for t in ("user", "item"):
+                    be.transform_fwd_rows(c["X"][t], Ws[s], As[s], c["H"][s], c["S"][s], part.Up, part.Ip, heads[s], part.half_win(t), True,
+                                          cfg["feat_drop"], seeds[k][s], **sd)
+
+        for k, c in enumerate(st):
+            new_H(c, 0)
+            transform(c, k, 0)
+        h = comm.start_gather2(st[0]["H"][0], st[1]["H"][0])
+        for s in range(L):
+            fused_next = s + 1 < L and fuse[s + 1]
+            keep_out = need or not fused_next
+            h.wait()
+            for k, c in enumerate(st):
+                H, S = c["H"][s], c["S"][s]
+                dout = H.shape[1]
+                out = torch.empty(N, dout, dtype=H.dtype, device=dev) if keep_out else None
+                agg = torch.empty(2, N, dout, dtype=H.dtype, device=dev) if need else None
+                R = torch.empty(2, N, heads[s], dtype=torch.float32, device=dev) if need else None
+                if s + 1 < L:
+                    new_H(c, s + 1)
+                Xs = dict(c["X"])
+                if fused_next:
+                    nxt = be.NextStage(panels[s + 1], As[s + 1], heads[s + 1], cfg["feat_drop"], seeds[k][s + 1], H=c["H"][s + 1], S=c["S"][s + 1])
+                    be.prop_fwd(plan, H, S, S, As[s], heads[s], cfg["alpha"], True, True, True, cfg["drop"], seeds[k][s],
+                                save=need, out=out, agg=agg, R=R, next=nxt, want_out=keep_out, **sd)
+                else:
+                    be.prop_fwd(plan, H, S, S, As[s], heads[s], cfg["alpha"], True, True, True, cfg["drop"], seeds[k][s],
+                                save=need, out=out, agg=agg, R=R, **sd)
+                if keep_out:
+                    c["X"] = {t: part.block(out, t) for t in ("user", "item")}
+                    c["out"] = out
+                if s + 1 < L and not fused_next:
+                    transform(c, k, s + 1)
+                if need:
+                    c["saved"].append((Xs["user"], Xs["item"], H, S, out, agg, R))
+            if s + 1 < L:
+                h = comm.start_gather2(st[0]["H"][s + 1], st[1]["H"][s + 1])
+        if need:
+            ctx.cfg, ctx.L, ctx.xflat = cfg, L, xflat
+            ctx.Ws, ctx.As = Ws, As
+            ctx.saved2 = [c["saved"] for c in st]
+        return tuple(part.block(c["out"], t) for c in st for t in ("user", "item"))
+
+    @staticmethod
+    def backward(ctx, gUA, gIA, gUB, gIB):
+        cfg, L = ctx.cfg, ctx.L
+        part, plan, comm, be = cfg["part"], cfg["plan"], cfg["comm"], cfg["be"]
+        sd = {} if cfg["seed_dev"] is None else {"seed_dev": cfg["seed_dev"]}
+        N, heads, seeds, Ws, As = part.N, cfg["heads"], cfg["seeds2"], ctx.Ws, ctx.As
+        saved2 = ctx.saved2
+        h_dtype = saved2[0][0][2].dtype
+        dev = gUA.device
+        gin = [{"user": gUA.contiguous().to(h_dtype), "item": gIA.contiguous().to(h_dtype)},
+               {"user": gUB.contiguous().to(h_dtype), "item": gIB.contiguous().to(h_dtype)}]
+        # every stage's dH and dS of both chains out of ONE zeroed buffer
+        sizes = []
+        for k in range(2):
+            for s in range(L):
+                H = saved2[k][s][2]
+                sizes += [(N * H.shape[1] * H.element_size() + 255) // 256 * 256, (N * heads[s] * 4 + 255) // 256 * 256]
+        zeroed, zoff = torch.zeros(sum(sizes), dtype=torch.uint8, device=dev), [0]
+        for z in sizes:
+            zoff.append(zoff[-1] + z)
+        tabs = [[None] * L, [None] * L]
+
+        def alloc(k, s):
+            H = saved2[k][s][2]
+            d, j = H.shape[1], 2 * (k * L + s)
+            if tabs[k][s] is None:
+                tabs[k][s] = (torch.empty(N, d, dtype=torch.float32, device=dev), torch.empty(N, d, dtype=H.dtype, device=dev),
+                              torch.empty(N, 2 * heads[s], dtype=torch.float32, device=dev),
+                              zeroed[zoff[j]:zoff[j] + N * d * H.element_size()].view(H.dtype).view(N, d),
+                              zeroed[zoff[j + 1]:zoff[j + 1] + N * heads[s] * 4].view(torch.float32).view(N, heads[s]))
+            return tabs[k][s]
+
+        def node(k, s, gfull=None, glocal=None):
+            _, _, H, S, out, agg, R = saved2[k][s]
+            G, Gn, ST, _, dS = alloc(k, s)
+            if gfull is None and glocal is None:
+                for t in ("user", "item"):
+                    be.prop_bwd_node(out, agg, R, gin[k][t], S, G, Gn, ST, dS, part.Up, heads[s], part.half_win(t), True, True, cfg["alpha"])
+            else:
+                be.prop_bwd_node(out, agg, R, gfull if gfull is not None else glocal, S, G, Gn, ST, dS, part.Up, heads[s], part.win,
+                                 gfull is None, True, cfg["alpha"])
+
+        def one_table(gd):                                                        # the two incoming halves as views of ONE [cu + ci, d] table?
+            base = gd["user"]._base
+            ok = (base is not None and base is gd["item"]._base and base.dim() == 2 and base.is_contiguous() and base.dtype == h_dtype
+                  and base.shape[0] == part.cu + part.ci and gd["user"].data_ptr() == base.data_ptr()
+                  and gd["item"].data_ptr() == base.data_ptr() + part.cu * base.shape[1] * base.element_size())
+            return base if ok else None
+
+        for k in range(2):
+            node(k, L - 1, glocal=one_table(gin[k]))
+        h = comm.start_gather2(tabs[0][L - 1][1], tabs[0][L - 1][2], tabs[1][L - 1][1], tabs[1][L - 1][2])
+        grads = [[None] * (2 * L), [None] * (2 * L)]
+        gx = [None, None]
+        for s in range(L - 1, -1, -1):
+            h.wait()
+            for k in range(2):
+                Xu, Xi, H, S, out, agg, R = saved2[k][s]
+                G, Gn, ST, dH, dS = tabs[k][s]
+                W, a = Ws[s], As[s]
+                be.prop_bwd_edges(plan, H, S, a, G, Gn, ST, heads[s], cfg["alpha"], True, True, cfg["drop"], seeds[k][s], dH=dH, dS=dS, **sd)
+                if s > 0:
+                    dX, dW, da = be.transform_bwd_rows(saved2[k][s - 1][4], W, H, dH, dS, part.Up, part.Ip, heads[s], part.win, False,
+                                                       cfg["feat_drop"], seeds[k][s], **sd)
+                    node(k, s - 1, gfull=dX if dX.dtype == h_dtype else dX.to(h_dtype))
+                elif ctx.xflat is not None:
+                    dX, dW, da = be.transform_bwd_rows(ctx.xflat, W, H, dH, dS, part.Up, part.Ip, heads[s], part.win, True,
+                                                       cfg["feat_drop"], seeds[k][s], **sd)
+                    gx[k] = (dX[:part.cu], dX[part.cu:])
+                else:
+                    parts = {}
+                    for t, Xt in (("user", Xu), ("item", Xi)):
+                        dXt, dW_, da_ = be.transform_bwd_rows(Xt, W, H, dH, dS, part.Up, part.Ip, heads[s], part.half_win(t), True,
+                                                              cfg["feat_drop"], seeds[k][s], **sd)
+                        parts[t] = (dXt, dW_, da_)
+                    gx[k] = (parts["user"][0], parts["item"][0])
+                    dW = torch.stack([parts["user"][1][0], parts["item"][1][1]])
+                    da = torch.stack([parts["user"][2][0], parts["item"][2][1]])
+                grads[k][2 * s], grads[k][2 * s + 1] = dW, da
+            if s > 0:
+                h = comm.start_gather2(tabs[0][s - 1][1], tabs[0][s - 1][2], tabs[1][s - 1][1], tabs[1][s - 1][2])
+            if not comm.defer_weight_reduce:
+                comm.all_reduce_sum(grads[0][2 * s], grads[0][2 * s + 1], grads[1][2 * s], grads[1][2 * s + 1])
+        ctx.saved2 = None
+        ctx.xflat = None
+        return tuple(gx[0]) + tuple(grads[0]) + tuple(gx[1]) + tuple(grads[1]) + (None,)
+
+
 class _RowExchange(torch.autograd.Function):
     """rows[b] = table row `idx[b]` (internal global row) on EVERY rank: each rank contributes the rows it owns, zeros
     elsewhere, one all-reduce of [B,d] sums them (one non-zero term per row: exact).  Replaces the all-gather of the
@@ -917,6 +1096,49 @@ class ShardedSPUIGACF(nn.Module):
                "seed_dev": seed_dev, "grad_mode": torch.is_grad_enabled(), "fuse_next": NF.FUSE_NEXT}
         return _ShardedStack.apply(NF.through_sink(self.uEmbd.weight), NF.through_sink(self.iEmbd.weight), *params, cfg)
 
+    def forward_two(self, userIdx, posIdx, negIdx, mask, sinks=None):
+        """(scores of (userIdx, posIdx), scores of (userIdx, negIdx)) = forward(userIdx, posIdx, mask), forward(userIdx, negIdx, mask)
+        of the reference's BPR step (train_eval_Gowalla.py:128-129: two propagations, independent dropout) -- as ONE lock-step pass
+        where the whole-stage schedule applies (_ShardedStackTwo: one grouped all-gather per stage for both chains), else the two
+        calls.  sinks: (sink of the first forward, sink of the second) -- functional.grad_sink of each chain's parameter reads."""
+        import contextlib
+        comm = self._comm_now()
+        elem = 2 if self.compute_dtype == torch.bfloat16 else 4
+        stages = self.gat._stages()
+        widest = max(int(self.gat.stage_params(s)[0].shape[-1]) for s in range(len(stages)))
+        sk = sinks if sinks is not None else (None, None)
+        ctxs = [(NF.grad_sink(sk[k], deferred_ok=True) if sinks is not None else contextlib.nullcontext()) for k in range(2)]
+        if not (self.be is _hip_ops or hasattr(self.be, "prop_fwd")) or not comm.whole_stage(self.part.N * widest * elem) \
+                or os.environ.get("NGACF_DIST_LOCKSTEP", "1") == "0":
+            with ctxs[0]:
+                ps = self.forward(userIdx, posIdx, mask)
+            with ctxs[1]:
+                ns = self.forward(userIdx, negIdx, mask)
+            return ps, ns
+        plan = self._plan(mask)
+        drop = self.droprate if self.training else 0.0
+        bases, seed_dev = [], None
+        for k in range(2):                                           # the seeds two forward() calls would draw, in their order
+            if drop > 0 and getattr(self, "_seed_ctr", None) is not None:
+                self._seed_call += 1
+                bases.append((self._seed_base + self._seed_call * _SEED_STRIDE) & 0x3FFFFFFFFFFFFFFF)
+                seed_dev = self._seed_ctr
+            else:
+                bases.append(_fresh_seed() if drop > 0 else 0)
+        L = len(stages)
+        ins = []
+        for k in range(2):
+            with ctxs[k]:
+                ins += [NF.through_sink(self.uEmbd.weight), NF.through_sink(self.iEmbd.weight)]
+                for s in range(L):
+                    ins.extend(NF.through_sink(p_) for p_ in self.gat.stage_params(s))
+        cfg = {"part": self.part, "plan": plan, "comm": comm, "be": self.be, "heads": [len(l) for l in stages], "L": L,
+               "x_flat": self._flat_local(), "alpha": stages[0][0].alpha, "drop": drop, "feat_drop": drop,
+               "seeds2": [[NF.stage_seed(b, s) for s in range(L)] for b in bases], "h_dtype": self.compute_dtype,
+               "seed_dev": seed_dev, "grad_mode": torch.is_grad_enabled(), "fuse_next": NF.FUSE_NEXT}
+        outs = _ShardedStackTwo.apply(*ins, cfg)
+        return self._scores(outs[0], outs[1], userIdx, posIdx), self._scores(outs[2], outs[3], userIdx, negIdx)
+
     def propagate(self, mask):
         """The full [U+I, d] table of propagated embeddings in the data set's numbering, on every rank (evaluation)."""
         out_u, out_i = self.propagate_local(mask)
@@ -924,6 +1146,10 @@ class ShardedSPUIGACF(nn.Module):
 
     def forward(self, userIdx, itemIdx, mask):
         out_u, out_i = self.propagate_local(mask)
+        return self._scores(out_u, out_i, userIdx, itemIdx)
+
+    def _scores(self, out_u, out_i, userIdx, itemIdx):
+        """the batch's scores from this rank's rows of the propagated table: the 2B scored rows exchanged, then SPUIGACF.py:49-52"""
         p = self.part
         B = userIdx.numel()
         if self.be is _hip_ops and 2 * B <= _hip_ops.ROWS_SCATTER_MAX_N and out_u.shape[1] in _hip_ops.SUPPORTED_D \
@@ -1257,7 +1483,7 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
 
         def step():
             opt.zero_grad(set_to_none=True)
-            loss = lossfn(model(ub, pb, edge), model(ub, nb, edge))
+            loss = lossfn(*model.forward_two(ub, pb, nb, edge))            # the step's two propagations (lock-step where the whole-stage schedule applies)
             loss.backward()
             model.reduce_grads()                                          # one grouped all-reduce of the stage weights
             opt.step()
@@ -1384,7 +1610,8 @@ def bench_main(args, ng, rank, world, dev, wl, d, elem, emit, cpu_baseline_leg):
                 extra = dict(extra, bpr_pairs_per_s=round(B * ksteps / t_trg, 1), train_ms_per_step=round(1e3 * t_trg / ksteps, 3),
                              train_launch="hipGraph replay (kernels + RCCL launches + fused Adam; %s)"
                                           % ("the two propagation chains as concurrent branches on two communicators" if model.concurrent_chains
-                                             else "one chain after the other"),
+                                             else ("both chains in lock-step on one queue, one grouped all-gather per stage for the two"
+                                                   if model.comm.whole_stage(part.N * d * elem) else "one chain after the other")),
                              train_ms_per_step_eager=round(1e3 * t_tr / ksteps, 3))
                 best = line(t_graph, win_graph, glaunch, extra, R_graph) if better else line(t_eager, win_eager, "eager", extra)
         except Exception as e:

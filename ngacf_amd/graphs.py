@@ -148,10 +148,14 @@ class GraphedBPRStep:
                     # the two (ngacf_adam_step's grads2) -- autograd would run one accumulation kernel per parameter, eight
                     # launch-bound kernels at the very end of the slower branch
                     # (deferred_ok: this step reads its sinks after the whole backward and after both branch streams were joined)
-                    with on_a(), NF.grad_sink(sinks[0] if split_grads else None, deferred_ok=True), chain(model, 0):
-                        ps = model(self.u, self.p, adj)
-                    with on_b(), NF.grad_sink(sinks[1] if split_grads else None, deferred_ok=True), chain(model, 1):
-                        ns = model(self.u, self.n, adj)
+                    if one_queue and hasattr(model, "forward_two"):
+                        # (the node-partitioned model: both propagations in lock-step, one grouped all-gather per stage for the two)
+                        ps, ns = model.forward_two(self.u, self.p, self.n, adj, sinks=sinks if split_grads else None)
+                    else:
+                        with on_a(), NF.grad_sink(sinks[0] if split_grads else None, deferred_ok=True), chain(model, 0):
+                            ps = model(self.u, self.p, adj)
+                        with on_b(), NF.grad_sink(sinks[1] if split_grads else None, deferred_ok=True), chain(model, 1):
+                            ns = model(self.u, self.n, adj)
                     if concurrent_forwards:
                         cur.wait_stream(sa)
                         cur.wait_stream(sb)

@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced=True, overlap=True, halves=True):
+def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced=True, overlap=True, halves=True, two=False):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, HERE)
@@ -52,11 +52,14 @@ def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced
         # the two propagations of a step on the model's TWO communicators (ShardedSPUIGACF.chain: what the graphed train step does
         # with its two concurrent branches); the assertions below then cover the second communicator's forward and backward too
         assert m._comms[1] is not m._comms[0] and m._comms[1].group is not m._comms[0].group and not m.concurrent_chains   # (captured concurrency: opt-in)
-        ps = m(u, pos, edge)
-        with m.chain(1, inline=not overlap):             # (inline: the gathers in the caller's own order, the captured step's form)
-            ns = m(u, neg, edge)
-        assert m._comms[1].launches > 0 and m._comms[1].overlap == overlap and m._comms[1].defer_weight_reduce == defer
-        assert m._comms[1].inline == (not overlap) and not m._comms[0].inline
+        if two:                                          # both propagations in lock-step (what the captured one-queue step runs)
+            ps, ns = m.forward_two(u, pos, neg, edge)
+        else:
+            ps = m(u, pos, edge)
+            with m.chain(1, inline=not overlap):         # (inline: the gathers in the caller's own order, the captured step's form)
+                ns = m(u, neg, edge)
+            assert m._comms[1].launches > 0 and m._comms[1].overlap == overlap and m._comms[1].defer_weight_reduce == defer
+            assert m._comms[1].inline == (not overlap) and not m._comms[0].inline
         loss = -torch.log(torch.sigmoid(ps - ns)).mean()
         loss.backward()
         if defer:
@@ -94,19 +97,23 @@ def _worker(rank, world, port, tag, multi, defer, q, d=64, stages=None, balanced
         q.put((rank, {"exception": "%s\n%s" % (e, traceback.format_exc())}))
 
 
-@pytest.mark.parametrize("world,tag,multi,defer,balanced,overlap,halves", [
-    (2, "spuigacf", False, False, True, True, True), (2, "spuimultigacf", True, True, True, True, True),
-    (3, "spuigacf", False, True, True, True, True), (3, "spuimultigacf", True, False, False, True, True),
-    (2, "spuimultigacf", True, True, True, False, True),
-    (2, "spuimultigacf", True, True, True, True, False), (3, "spuigacf", False, False, False, True, False)])
-def test_sharded_model_matches_reference_under_gloo(world, tag, multi, defer, balanced, overlap, halves):
+@pytest.mark.parametrize("world,tag,multi,defer,balanced,overlap,halves,two", [
+    (2, "spuigacf", False, False, True, True, True, False), (2, "spuimultigacf", True, True, True, True, True, False),
+    (3, "spuigacf", False, True, True, True, True, False), (3, "spuimultigacf", True, False, False, True, True, False),
+    (2, "spuimultigacf", True, True, True, False, True, False),
+    (2, "spuimultigacf", True, True, True, True, False, False), (3, "spuigacf", False, False, False, True, False, False),
+    (2, "spuimultigacf", True, True, True, True, False, True), (3, "spuigacf", False, False, True, True, False, True),
+    (2, "spuigacf", False, True, True, True, True, True)])
+def test_sharded_model_matches_reference_under_gloo(world, tag, multi, defer, balanced, overlap, halves, two):
     """Forward, loss and every gradient of the node-partitioned model (degree-balanced renumbering or plain id blocks,
     pipelined or serial schedule of half-table gathers, or the whole-stage schedule a small table takes -- one grouped gather and
-    one launch per stage; sharded plans, 2B-row score exchange) against the reference's float64 run."""
+    one launch per stage -- for one chain at a time or, two = True, both propagations of the step in lock-step with one grouped gather
+    per stage for the two (forward_two; on the half schedule it falls back to the two calls); sharded plans, 2B-row score exchange)
+    against the reference's float64 run."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tag, multi, defer, q, 64, None, balanced, overlap, halves)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tag, multi, defer, q, 64, None, balanced, overlap, halves, two)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -118,7 +125,7 @@ def test_sharded_model_matches_reference_under_gloo(world, tag, multi, defer, ba
         assert err["emb"] < 2e-4 and err["gat"] < 2e-4, (rank, err)          # fp32 stand-in vs float64 reference
         assert err["pad"] == 0.0 and err["sd"] == 0.0 and err["keys"] and err["propagate_shape"], (rank, err)
         # the schedule that ran: no whole-table gather on the pipelined one; L per forward and L per backward, two chains, on the other
-        assert err["whole_gathers"] == (0 if halves else 4 * (3 if multi else 2)), (rank, halves, err["whole_gathers"])
+        assert err["whole_gathers"] == (0 if halves else (2 if two else 4) * (3 if multi else 2)), (rank, halves, two, err["whole_gathers"])
     total = sum(err["plan_edges"][0] for _, err in res)
     assert total == res[0][1]["plan_edges"][1], "the ranks' plans together hold every directed edge exactly once"
     assert all(err["plan_edges"][0] < 0.75 * err["plan_edges"][1] for _, err in res)

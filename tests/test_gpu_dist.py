@@ -155,6 +155,38 @@ def test_fused_score_exchange_equals_the_two_launch_form_bitwise(bf16, monkeypat
     assert float(res[0][1].abs().max()) > 0
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_lockstep_two_chains_equal_the_two_calls_bitwise(bf16, monkeypatch):
+    """forward_two (both propagations of a BPR step in lock-step, one grouped all-gather per stage for the two: _ShardedStackTwo)
+    against forward(u, pos), forward(u, neg) one after the other: with dropout, the same seeds in the same order -- scores and
+    every gradient bit for bit."""
+    import ngacf_amd
+    from ngacf_amd.dist import ShardedSPUIGACF
+    dev = torch.device("cuda:0")
+    U, I = 333, 251
+    edge = _graph(U, I, 7000, 3).to(dev)
+    torch.manual_seed(3)
+    m = ShardedSPUIGACF(U, I, 64, [64, 64], 0.1, world=1, rank=0, stages=3, adj=edge).to(dev).train()
+    with torch.no_grad():
+        m.uEmbd.weight.mul_(30); m.iEmbd.weight.mul_(30)
+    if bf16:
+        m.compute_dtype = torch.bfloat16
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    u = torch.randint(0, U, (256,), device=dev, generator=g)
+    p = torch.randint(0, I, (256,), device=dev, generator=g); n = torch.randint(0, I, (256,), device=dev, generator=g)
+    res = []
+    for lock in ("1", "0"):
+        monkeypatch.setenv("NGACF_DIST_LOCKSTEP", lock)
+        torch.manual_seed(11)                                        # (dropout seeds come from torch's CPU generator)
+        m.zero_grad(set_to_none=True)
+        ps, ns = m.forward_two(u, p, n, edge)
+        (-torch.nn.functional.logsigmoid(ps - ns)).mean().backward()
+        res.append([ps.detach().clone(), ns.detach().clone()] + [q.grad.clone() for q in m.parameters()])
+    assert len(res[0]) == len(res[1]) and float(res[0][2].abs().max()) > 0
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_bench_distributed_path_rehearsal_on_one_rank():
     """bench.py's N>1 code path on a one-rank RCCL group, reached the way the driver reaches it: `python bench.py --gpus 1`
     with NGACF_BENCH_FORCE_DIST=1 and NO torchrun environment -- the parent (no GPU call) launches torch.distributed.run as
