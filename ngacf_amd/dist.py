@@ -843,6 +843,31 @@ class _ExchangeScoreHIP(torch.autograd.Function):
         return du, di, None, None, None, None, None
 
 
+class _ExchangeScoreTwoHIP(torch.autograd.Function):
+    """_ExchangeScoreHIP for the two propagations of a step at once: (scores of (u, pos) on chain A's table, scores of (u, neg) on chain
+    B's), the two row exchanges as ONE grouped all-reduce."""
+
+    @staticmethod
+    def forward(ctx, ua, ia, ub, ib, u, pos, neg, part, comm, ar):
+        dev = ua.device
+        pu = part._on("perm_u", dev) if part.perm_u is not None else None
+        pi = part._on("perm_i", dev) if part.perm_i is not None else None
+        ra, pa = _hip_ops.shard_rows(ua.contiguous(), ia.contiguous(), u, pos, pu, pi, part.U, part.I, part.u_lo, part.i_lo)
+        rb, pb = _hip_ops.shard_rows(ub.contiguous(), ib.contiguous(), u, neg, pu, pi, part.U, part.I, part.u_lo, part.i_lo)
+        comm.all_reduce_sum(ra, rb)
+        ctx.save_for_backward(pa, ra, pb, rb)
+        ctx.shape = (ua.shape[0], ia.shape[0], ua.dtype)
+        return _hip_ops.score_fwd(ra, ar, ar, ar.numel()), _hip_ops.score_fwd(rb, ar, ar, ar.numel())
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        pa, ra, pb, rb = ctx.saved_tensors
+        cu, ci, dt = ctx.shape
+        dua, dia = _hip_ops.rows_scatter_scored(pa, ra, ga.contiguous().float(), cu, ci, dt)
+        dub, dib = _hip_ops.rows_scatter_scored(pb, rb, gb.contiguous().float(), cu, ci, dt)
+        return dua, dia, dub, dib, None, None, None, None, None, None
+
+
 class ShardedSPUIGACF(nn.Module):
     """SPUIGACF / SPUIMultiGACF / SPUIStackedGACF with the embedding tables sharded by node blocks.
     forward(userIdx, itemIdx, mask) has the reference signature (SPUIGACF.py:41) and returns the scores of the
@@ -1137,7 +1162,19 @@ class ShardedSPUIGACF(nn.Module):
                "seeds2": [[NF.stage_seed(b, s) for s in range(L)] for b in bases], "h_dtype": self.compute_dtype,
                "seed_dev": seed_dev, "grad_mode": torch.is_grad_enabled(), "fuse_next": NF.FUSE_NEXT}
         outs = _ShardedStackTwo.apply(*ins, cfg)
+        B = userIdx.numel()
+        if self.be is _hip_ops and 2 * B <= _hip_ops.ROWS_SCATTER_MAX_N and outs[0].shape[1] in _hip_ops.SUPPORTED_D \
+                and os.environ.get("NGACF_DIST_FUSED_SCORE", "1") != "0":
+            return _ExchangeScoreTwoHIP.apply(*outs, userIdx.long().contiguous(), posIdx.long().contiguous(), negIdx.long().contiguous(),
+                                              self.part, comm, self._arange_of(B, outs[0].device))
         return self._scores(outs[0], outs[1], userIdx, posIdx), self._scores(outs[2], outs[3], userIdx, negIdx)
+
+    def _arange_of(self, B, dev):
+        ar = self.__dict__.get("_arange")                                            # (built once per batch size, not per forward)
+        if ar is None or ar.numel() != B or ar.device != dev:
+            ar = torch.arange(B, device=dev)
+            self.__dict__["_arange"] = ar
+        return ar
 
     def propagate(self, mask):
         """The full [U+I, d] table of propagated embeddings in the data set's numbering, on every rank (evaluation)."""
