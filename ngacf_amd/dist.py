@@ -409,7 +409,7 @@ class _ShardedStack(torch.autograd.Function):
         if not whole:
             T(0, OTHER[first])
             T(0, first)
-        for s in range(0 if not whole else L, L):
+        for s in (range(L) if not whole else ()):                    # the pipelined half-table schedule
             A, B = first, OTHER[first]
             H, S, heads = Hs[s], Ss[s], cfg["heads"][s]
             dout = H.shape[1]
@@ -553,7 +553,7 @@ class _ShardedStack(torch.autograd.Function):
         else:
             Nstep(L - 1, OTHER[first])
             Nstep(L - 1, first)
-        for s in range(L - 1, -1, -1) if not whole else ():
+        for s in (range(L - 1, -1, -1) if not whole else ()):        # the pipelined half-table schedule
             Xu, Xi, W, a, H, S, out, agg, R = saved[s]
             Xs = {"user": Xu, "item": Xi}
             G, Gn, ST, dH, dS = tabs[s]
