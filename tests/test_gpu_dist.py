@@ -94,20 +94,25 @@ def test_partitioned_stage_equals_single_gpu(P, dt):
     assert rel(dX, dX0.float()) < 1e-5 and rel(dW, dW0) < 1e-4 and rel(da, da0) < 1e-4
 
 
-@pytest.mark.parametrize("balanced", [False, True])
-def test_sharded_model_world1_equals_plain_model(balanced):
-    """world size 1: the pipelined stack (half launches, row exchange, renumbering when `balanced`) equals the plain
-    model -- scores, every gradient, the state_dict round trip, the propagated table in the data set's numbering."""
+@pytest.mark.parametrize("balanced,d,stages,halves", [(False, 64, 3, False), (True, 64, 3, False), (True, 64, 3, True), (True, 128, 4, False),
+                                                       (False, 128, 4, True)])
+def test_sharded_model_world1_equals_plain_model(balanced, d, stages, halves, monkeypatch):
+    """world size 1: the node-partitioned stack (whole-stage schedule, or the pipelined half launches; row exchange, renumbering
+    when `balanced`; d = 64 L = 3 and BASELINE config 4's d = 128 L = 4) equals the plain model -- scores, every gradient, the
+    state_dict round trip, the propagated table in the data set's numbering."""
     import ngacf_amd
     from ngacf_amd.dist import ShardedSPUIGACF
+    monkeypatch.setenv("NGACF_DIST_WHOLE_BYTES", "0" if halves else str(32 << 20))
     dev = torch.device("cuda:0")
     U, I = 333, 251
     edge = _graph(U, I, 7000, 3).to(dev)
     torch.manual_seed(1)
-    ref = ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0).to(dev).train()
+    ref = (ngacf_amd.SPUIMultiGACF(U, I, 64, [64, 64], 0.0) if (d, stages) == (64, 3)
+           else ngacf_amd.SPUIStackedGACF(U, I, d, [64, 64], 0.0, stages=stages)).to(dev).train()
     with torch.no_grad():
         ref.uEmbd.weight.mul_(30); ref.iEmbd.weight.mul_(30)
-    m = ShardedSPUIGACF(U, I, 64, [64, 64], 0.0, world=1, rank=0, stages=3, adj=edge if balanced else None).to(dev).train()
+    m = ShardedSPUIGACF(U, I, d, [64, 64], 0.0, world=1, rank=0, stages=stages, adj=edge if balanced else None).to(dev).train()
+    assert m.comm.whole_stage(m.part.N * 128 * 4) == (not halves)
     m.load_full_state_dict(ref.state_dict())
     u = torch.randint(0, U, (128,), device=dev); it = torch.randint(0, I, (128,), device=dev)
     a, b = ref(u, it, edge), m(u, it, edge)
