@@ -425,6 +425,10 @@ __global__ __launch_bounds__(64 * (NW + 1)) void eval_topk_lds_kernel(const Topk
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(at) : "memory");
         return __builtin_amdgcn_readfirstlane(v);
     };
+    // A wait that never ends would hang the GPU, not fail a launch.  Every cycle of waits in this kernel runs through the
+    // PRODUCER (consumers wait only for it, it waits only for them), so its poll loop carries the guard: after ~2^22 sleeps (seconds;
+    // a stage takes microseconds) it traps and the launch ends in an error the host sees.  (The same guard in the consumers' loop
+    // cost 2.5 % of the kernel by its code placement alone.)
     if (tid < 2 * NB) ctr[tid] = 0;
     __syncthreads();                                  // (the only barrier: from here on the waves run on their own)
 
@@ -446,7 +450,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void eval_topk_lds_kernel(const Topk
                 const int b = s % NB;
                 if (s >= NB) {
                     const int want = NW * (s / NB);
-                    while (lds_peek(ctr_at + 4 * (NB + b)) < want) __builtin_amdgcn_s_sleep(2);
+                    int spins = 0;
+                    while (lds_peek(ctr_at + 4 * (NB + b)) < want) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1 << 22)) __builtin_trap();
+                    }
                 }
                 const int j0 = s * SI;
 #pragma unroll
